@@ -1,0 +1,46 @@
+"""vision_amd — MI355X (gfx950) native implementation of torchvision's custom operator hot
+path (nms, roi_align, roi_pool, ps_roi_*, deform_conv2d, rotated box_iou, resize) behind the
+reference's own `torchvision::` dispatcher schemas.  See DESIGN.md / INTEGRATION.md."""
+import os as _os
+
+from . import _loader
+
+__version__ = "0.1.0"
+
+
+def load(register_python: bool = True):
+    """Load the native libraries and (optionally) the python-level fake/autograd/autocast
+    registrations.  Pass register_python=False when the reference `torchvision` python
+    package is going to be imported over this library: it brings its own
+    _meta_registrations / _autograd_registrations for the same schemas."""
+    _loader.load()
+    if register_python:
+        from . import _registrations
+
+        _registrations.register_all()
+
+
+try:
+    load(register_python=_os.environ.get("TVMI_NO_PY_REGISTRATIONS", "0") != "1")
+except _loader.ExtensionMissing:
+    if _os.environ.get("TVMI_ALLOW_MISSING", "0") != "1":
+        raise
+
+from .boxes import (  # noqa: E402,F401
+    batched_nms,
+    box_area,
+    box_iou,
+    clip_boxes_to_image,
+    nms,
+    remove_small_boxes,
+)
+from .roi_ops import (  # noqa: E402,F401
+    PSRoIAlign,
+    PSRoIPool,
+    RoIAlign,
+    RoIPool,
+    ps_roi_align,
+    ps_roi_pool,
+    roi_align,
+    roi_pool,
+)

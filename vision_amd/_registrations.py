@@ -1,0 +1,248 @@
+"""Python-level dispatcher registrations for the `torchvision::` ops that our library owns:
+fake (meta) kernels, autograd formulas and autocast wrappers.
+
+Role of torchvision/_meta_registrations.py and torchvision/_autograd_registrations.py in
+the reference (which are reused UNCHANGED when the reference python package is laid over
+this library, see INTEGRATION.md — call `vision_amd.load(register_python=False)` then).
+Everything here is table-driven; shapes/dtypes follow the reference fake kernels
+(_meta_registrations.py:25-231) and the backward op argument orders follow
+_autograd_registrations.py:14-205.
+"""
+import torch
+import torch.library
+
+_done = {"v": False}
+
+
+def _same_type(a, b, an, bn):
+    torch._check(
+        a.dtype == b.dtype,
+        lambda: f"Expected tensor for {an} to have the same type as tensor for {bn}; "
+        f"but type {a.dtype} does not equal {b.dtype}",
+    )
+
+
+def _rois_ok(rois):
+    torch._check(rois.size(1) == 5, lambda: "rois must have shape as Tensor[K, 5]")
+
+
+# --------------------------------------------------------------------- fake kernels
+def _fake_nms(dets, scores, iou_threshold):
+    torch._check(dets.dim() == 2, lambda: f"boxes should be a 2d tensor, got {dets.dim()}D")
+    torch._check(dets.size(1) == 4, lambda: f"boxes should have 4 elements in dimension 1, got {dets.size(1)}")
+    torch._check(scores.dim() == 1, lambda: f"scores should be a 1d tensor, got {scores.dim()}")
+    torch._check(
+        dets.size(0) == scores.size(0),
+        lambda: "boxes and scores should have same number of elements in dimension 0, "
+        f"got {dets.size(0)} and {scores.size(0)}",
+    )
+    n = torch.library.get_ctx().new_dynamic_size()
+    return dets.new_empty(n, dtype=torch.long)
+
+
+def _fake_nms_segmented(dets, scores, idxs, iou_threshold):
+    return _fake_nms(dets, scores, iou_threshold)
+
+
+def _fake_roi_align(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, aligned):
+    _rois_ok(rois)
+    _same_type(input, rois, "input", "rois")
+    return input.new_empty((rois.size(0), input.size(1), pooled_height, pooled_width))
+
+
+def _fake_roi_align_bwd(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height,
+                        width, sampling_ratio, aligned):
+    _same_type(grad, rois, "grad", "rois")
+    return grad.new_empty((batch_size, channels, height, width))
+
+
+def _fake_roi_pool(input, rois, spatial_scale, pooled_height, pooled_width):
+    _rois_ok(rois)
+    _same_type(input, rois, "input", "rois")
+    size = (rois.size(0), input.size(1), pooled_height, pooled_width)
+    return input.new_empty(size), torch.empty(size, device=input.device, dtype=torch.int32)
+
+
+def _fake_roi_pool_bwd(grad, rois, argmax, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                       height, width):
+    _same_type(grad, rois, "grad", "rois")
+    return grad.new_empty((batch_size, channels, height, width))
+
+
+def _fake_ps_roi_align(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    _rois_ok(rois)
+    _same_type(input, rois, "input", "rois")
+    c = input.size(1)
+    torch._check(c % (pooled_height * pooled_width) == 0,
+                 lambda: "input channels must be a multiple of pooling height * pooling width")
+    size = (rois.size(0), c // (pooled_height * pooled_width), pooled_height, pooled_width)
+    return input.new_empty(size), torch.empty(size, device=input.device, dtype=torch.int32)
+
+
+def _fake_ps_roi_align_bwd(grad, rois, channel_mapping, spatial_scale, pooled_height, pooled_width,
+                           sampling_ratio, batch_size, channels, height, width):
+    _same_type(grad, rois, "grad", "rois")
+    return grad.new_empty((batch_size, channels, height, width))
+
+
+def _fake_ps_roi_pool(input, rois, spatial_scale, pooled_height, pooled_width):
+    return _fake_ps_roi_align(input, rois, spatial_scale, pooled_height, pooled_width, 0)
+
+
+def _fake_ps_roi_pool_bwd(grad, rois, channel_mapping, spatial_scale, pooled_height, pooled_width, batch_size,
+                          channels, height, width):
+    _same_type(grad, rois, "grad", "rois")
+    return grad.new_empty((batch_size, channels, height, width))
+
+
+def _conv_out(size, pad, dil, k, stride):
+    return (size + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+
+
+def _fake_deform_conv2d(input, weight, offset, mask, bias, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                        n_weight_grps, n_offset_grps, use_mask):
+    out_h = _conv_out(input.size(2), pad_h, dil_h, weight.size(2), stride_h)
+    out_w = _conv_out(input.size(3), pad_w, dil_w, weight.size(3), stride_w)
+    return input.new_empty((input.size(0), weight.size(0), out_h, out_w))
+
+
+def _fake_deform_conv2d_bwd(grad, input, weight, offset, mask, bias, stride_h, stride_w, pad_h, pad_w, dil_h,
+                            dil_w, n_weight_grps, n_offset_grps, use_mask):
+    return (input.new_empty(input.shape), weight.new_empty(weight.shape), offset.new_empty(offset.shape),
+            mask.new_empty(mask.shape), bias.new_empty(bias.shape))
+
+
+def _fake_box_iou_rotated(boxes1, boxes2):
+    return boxes1.new_empty((boxes1.size(0), boxes2.size(0)), dtype=torch.float32)
+
+
+_FAKES = {
+    "torchvision::nms": _fake_nms,
+    "tvmi::nms_segmented": _fake_nms_segmented,
+    "torchvision::roi_align": _fake_roi_align,
+    "torchvision::_roi_align_backward": _fake_roi_align_bwd,
+    "torchvision::roi_pool": _fake_roi_pool,
+    "torchvision::_roi_pool_backward": _fake_roi_pool_bwd,
+    "torchvision::ps_roi_align": _fake_ps_roi_align,
+    "torchvision::_ps_roi_align_backward": _fake_ps_roi_align_bwd,
+    "torchvision::ps_roi_pool": _fake_ps_roi_pool,
+    "torchvision::_ps_roi_pool_backward": _fake_ps_roi_pool_bwd,
+    "torchvision::deform_conv2d": _fake_deform_conv2d,
+    "torchvision::_deform_conv2d_backward": _fake_deform_conv2d_bwd,
+    "torchvision::box_iou_rotated": _fake_box_iou_rotated,
+}
+
+
+# --------------------------------------------------------------------- autograd formulas
+# name -> (backward op, indices of scalar forward args appended to the backward call in the
+#          order the backward schema wants them, saved-output index or None)
+def _make_roi_autograd(fwd_name, bwd_name, n_scalar_before_shape, tail_idx, save_aux):
+    """Builds (setup_context, backward) for the RoI pooling family.
+
+    Forward args are (input, rois, *scalars); the backward op takes
+    (grad, rois, [aux], *scalars[:n_scalar_before_shape], N, C, H, W, *scalars[tail_idx]).
+    """
+    bwd_op = getattr(torch.ops.torchvision, bwd_name)
+
+    def setup_context(ctx, inputs, output):
+        inp, rois = inputs[0], inputs[1]
+        ctx.scalars = tuple(inputs[2:])
+        ctx.in_shape = tuple(inp.shape)
+        if save_aux:
+            ctx.save_for_backward(rois, output[1])
+        else:
+            ctx.save_for_backward(rois)
+
+    def backward(ctx, grad, *unused):
+        saved = ctx.saved_tensors
+        sc = ctx.scalars
+        args = [grad, saved[0]]
+        if save_aux:
+            args.append(saved[1])
+        args += list(sc[:n_scalar_before_shape])
+        args += list(ctx.in_shape)
+        args += [sc[i] for i in tail_idx]
+        return (bwd_op(*args),) + (None,) * (1 + len(sc))
+
+    return setup_context, backward
+
+
+def _deform_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:5])
+    ctx.params = tuple(inputs[5:])
+
+
+def _deform_backward(ctx, grad):
+    inp, weight, offset, mask, bias = ctx.saved_tensors
+    grads = torch.ops.torchvision._deform_conv2d_backward(grad, inp, weight, offset, mask, bias, *ctx.params)
+    return tuple(grads) + (None,) * len(ctx.params)
+
+
+def _no_double_backward(name):
+    def backward(ctx, *grads):
+        raise RuntimeError(f"double backwards on {name} not supported")
+
+    return backward
+
+
+# --------------------------------------------------------------------- autocast
+_AUTOCAST_KEYS = None
+
+
+def _fp32(t):
+    # at::autocast::cached_cast(kFloat, ...): only lower-precision floating tensors are cast
+    if isinstance(t, torch.Tensor) and t.is_floating_point() and t.dtype is not torch.float64:
+        return t.float()
+    return t
+
+
+def _make_autocast(op_name, n_tensor_args, restore):
+    op = getattr(torch.ops.torchvision, op_name)
+
+    def wrapper(*args):
+        orig = args[0].dtype
+        with torch._C._ExcludeDispatchKeyGuard(_AUTOCAST_KEYS):
+            out = op(*[_fp32(a) for a in args[:n_tensor_args]], *args[n_tensor_args:])
+        if not restore:
+            return out
+        if isinstance(out, tuple):
+            return tuple(o.to(orig) for o in out)
+        return out.to(orig)
+
+    return wrapper
+
+
+def register_all():
+    """Idempotent; skipped entirely if another package already registered these ops."""
+    global _AUTOCAST_KEYS
+    if _done["v"]:
+        return
+    _done["v"] = True
+    for name, fn in _FAKES.items():
+        torch.library.register_fake(name, fn)
+
+    tv = "torchvision::"
+    for fwd, bwd, nb, tail, aux in (
+        ("roi_align", "_roi_align_backward", 3, (3, 4), False),
+        ("roi_pool", "_roi_pool_backward", 3, (), True),
+        ("ps_roi_align", "_ps_roi_align_backward", 4, (), True),
+        ("ps_roi_pool", "_ps_roi_pool_backward", 3, (), True),
+    ):
+        setup, backward = _make_roi_autograd(fwd, bwd, nb, tail, aux)
+        torch.library.register_autograd(tv + fwd, backward, setup_context=setup)
+        torch.library.register_autograd(tv + bwd, _no_double_backward(fwd))
+    torch.library.register_autograd(tv + "deform_conv2d", _deform_backward, setup_context=_deform_setup)
+    torch.library.register_autograd(tv + "_deform_conv2d_backward", _no_double_backward("deform_conv2d"))
+
+    _AUTOCAST_KEYS = torch._C.DispatchKeySet(torch._C.DispatchKey.AutocastCUDA) | torch._C.DispatchKeySet(
+        torch._C.DispatchKey.AutocastCPU
+    )
+    lib = torch.library.Library("torchvision", "IMPL")
+    _done["lib"] = lib  # keep alive
+    for key in ("AutocastCUDA", "AutocastCPU"):
+        lib.impl("nms", _make_autocast("nms", 2, restore=False), key)
+        lib.impl("roi_align", _make_autocast("roi_align", 2, restore=True), key)
+    lib.impl("roi_pool", _make_autocast("roi_pool", 2, restore=True), "AutocastCUDA")
+    lib.impl("ps_roi_align", _make_autocast("ps_roi_align", 2, restore=True), "AutocastCUDA")
+    lib.impl("ps_roi_pool", _make_autocast("ps_roi_pool", 2, restore=True), "AutocastCUDA")
+    lib.impl("deform_conv2d", _make_autocast("deform_conv2d", 5, restore=True), "AutocastCUDA")

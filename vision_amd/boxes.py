@@ -1,0 +1,99 @@
+"""Box operators — host-side mirror of torchvision/ops/boxes.py (nms :20-54, batched_nms
+:57-126, box helpers :129-391) on top of the gfx950 kernels.  Same names, argument meaning,
+return conventions and error behaviour as the reference; no CPU/eager fallback for CUDA
+tensors (CPU tensors go wherever the dispatcher has a CPU kernel registered — in this repo
+that is only the reference oracle, loaded by tests)."""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from ._loader import assert_has_ops
+
+
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+    """Greedy NMS; int64 indices of kept boxes in decreasing score order
+    (torchvision.ops.nms, ops/boxes.py:20-54)."""
+    assert_has_ops()
+    return torch.ops.torchvision.nms(boxes, scores, iou_threshold)
+
+
+def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
+    """NMS that never suppresses across categories (ops/boxes.py:57-91).
+
+    Same strategy switch as the reference: up to 100k box elements on the GPU (4k on CPU)
+    the boxes are shifted per category and a single nms() is run ("coordinate trick",
+    :93-109); above that the reference loops over categories in python (:113-126).  On CUDA
+    tensors that loop is replaced by ONE segmented launch (`tvmi::nms_segmented`, identical
+    result: IoU is evaluated on the unshifted boxes and category-mismatched pairs never
+    suppress), so there is no torch.unique / torch.where host round trip per category.
+    """
+    if boxes.numel() > (4000 if boxes.device.type == "cpu" else 100_000):
+        return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)
+    return _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold)
+
+
+def _batched_nms_coordinate_trick(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+def _batched_nms_vanilla(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
+    if boxes.is_cuda:
+        assert_has_ops()
+        return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold)
+    keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+    for class_id in torch.unique(idxs):
+        curr = torch.where(idxs == class_id)[0]
+        keep_mask[curr[nms(boxes[curr], scores[curr], iou_threshold)]] = True
+    keep = torch.where(keep_mask)[0]
+    return keep[scores[keep].sort(descending=True)[1]]
+
+
+def _upcast(t: Tensor) -> Tensor:
+    # ops/_utils.py:72-84: protect products from overflow
+    if t.is_floating_point():
+        return t if t.dtype in (torch.float32, torch.float64) else t.float()
+    return t if t.dtype in (torch.int32, torch.int64) else t.int()
+
+
+def box_area(boxes: Tensor) -> Tensor:
+    boxes = _upcast(boxes)
+    return (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])
+
+
+def _box_inter_union(boxes1: Tensor, boxes2: Tensor) -> Tuple[Tensor, Tensor]:
+    area1, area2 = box_area(boxes1), box_area(boxes2)
+    lt = torch.max(boxes1[..., :, None, :2], boxes2[..., None, :, :2])
+    rb = torch.min(boxes1[..., :, None, 2:], boxes2[..., None, :, 2:])
+    wh = _upcast(rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter, area1[..., :, None] + area2[..., None, :] - inter
+
+
+def box_iou(boxes1: Tensor, boxes2: Tensor, fmt: str = "xyxy") -> Tensor:
+    """Pairwise IoU [N, M].  Axis-aligned formats are plain tensor math exactly as in the
+    reference (ops/boxes.py:314-391); rotated `cxcywhr` boxes go to the
+    `torchvision::box_iou_rotated` kernel (:393-399)."""
+    if fmt == "cxcywhr":
+        assert_has_ops()
+        return torch.ops.torchvision.box_iou_rotated(boxes1, boxes2)
+    if fmt != "xyxy":
+        raise ValueError(f"Unsupported box format {fmt!r}; convert to xyxy or cxcywhr first")
+    inter, union = _box_inter_union(boxes1, boxes2)
+    return inter / union
+
+
+def clip_boxes_to_image(boxes: Tensor, size: Tuple[int, int]) -> Tensor:
+    height, width = size
+    x = boxes[..., 0::2].clamp(min=0, max=width)
+    y = boxes[..., 1::2].clamp(min=0, max=height)
+    return torch.stack((x, y), dim=boxes.dim()).reshape(boxes.shape)
+
+
+def remove_small_boxes(boxes: Tensor, min_size: float) -> Tensor:
+    ws, hs = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    return torch.where((ws >= min_size) & (hs >= min_size))[0]
