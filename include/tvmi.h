@@ -78,6 +78,103 @@ int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input
                             int64_t sampling_ratio, int aligned, int64_t n_stride,
                             int64_t c_stride, int64_t h_stride, int64_t w_stride, void* stream);
 
+/* ----------------------------------------------- RoIPool / PSRoIAlign / PSRoIPool ------
+ * Replaces: cuda/roi_pool_kernel.cu:15-125,127-260, cuda/ps_roi_align_kernel.cu,
+ * cuda/ps_roi_pool_kernel.cu:14-140; arithmetic follows cpu/roi_pool_kernel.cpp:24-134,
+ * cpu/ps_roi_align_kernel.cpp:73-151,219-313, cpu/ps_roi_pool_kernel.cpp:22-155.
+ * Side outputs (argmax, channel_mapping) are int32 [K, C_out, PH, PW]; PS variants need
+ * C % (PH*PW) == 0 and produce C_out = C / (PH*PW) channels.  Backward launchers
+ * accumulate into a caller-zeroed grad_input; PS backward reads a contiguous grad.
+ */
+int tvmi_roi_pool_forward(const void* input, const void* rois, void* output, int32_t* argmax,
+                          tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                          int64_t pooled_h, int64_t pooled_w, double spatial_scale, void* stream);
+int tvmi_roi_pool_backward(const void* grad, const void* rois, const int32_t* argmax, void* grad_input,
+                           tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                           int64_t pooled_h, int64_t pooled_w, int64_t n_stride, int64_t c_stride,
+                           int64_t h_stride, int64_t w_stride, void* stream);
+int tvmi_ps_roi_align_forward(const void* input, const void* rois, void* output,
+                              int32_t* channel_mapping, tvmi_dtype dt, int64_t N, int64_t C, int64_t H,
+                              int64_t W, int64_t K, int64_t pooled_h, int64_t pooled_w,
+                              double spatial_scale, int64_t sampling_ratio, void* stream);
+int tvmi_ps_roi_align_backward(const void* grad, const void* rois, const int32_t* channel_mapping,
+                               void* grad_input, tvmi_dtype dt, int64_t N, int64_t C, int64_t H,
+                               int64_t W, int64_t K, int64_t pooled_h, int64_t pooled_w,
+                               double spatial_scale, int64_t sampling_ratio, void* stream);
+int tvmi_ps_roi_pool_forward(const void* input, const void* rois, void* output, int32_t* channel_mapping,
+                             tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                             int64_t pooled_h, int64_t pooled_w, double spatial_scale, void* stream);
+int tvmi_ps_roi_pool_backward(const void* grad, const void* rois, const int32_t* channel_mapping,
+                              void* grad_input, tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W,
+                              int64_t K, int64_t pooled_h, int64_t pooled_w, double spatial_scale,
+                              void* stream);
+
+/* ------------------------------------------------------------ deform_conv2d ------------
+ * Replaces: cuda/deform_conv2d_kernel.cu:136-209 (deformable_im2col) + the per-group
+ * addmm_ loop at :1035-1255 with ONE fused offset-gather -> LDS -> fp32-MFMA kernel (fp32),
+ * or a direct kernel (other dtypes / tiny channel counts); semantics of
+ * cpu/deform_conv2d_kernel.cpp:95-209,921-1151.  Tensors: input [B,C,H,W],
+ * weight [OC,C/groups,kh,kw], offset [B,2*og*kh*kw,oh,ow], mask [B,og*kh*kw,oh,ow]
+ * (ignored unless use_mask), bias [OC], output [B,OC,oh,ow] (fully overwritten).
+ * `workspace` holds the re-laid-out weights (tvmi_deform_conv2d_workspace_bytes).
+ * The three deformable_* launchers are the building blocks of the backward pass
+ * (cuda/deform_conv2d_kernel.cu:319-750): columns is [C*kh*kw, B*oh*ow]; col2im accumulates
+ * into a caller-zeroed grad_input; col2im_coord overwrites grad_offset (and grad_mask).
+ */
+size_t tvmi_deform_conv2d_workspace_bytes(tvmi_dtype dt, int64_t C, int64_t OC, int64_t kh, int64_t kw,
+                                          int64_t groups);
+int tvmi_deform_conv2d_forward(const void* input, const void* weight, const void* offset, const void* mask,
+                               const void* bias, void* output, tvmi_dtype dt, int64_t B, int64_t C,
+                               int64_t H, int64_t W, int64_t OC, int64_t kh, int64_t kw, int64_t stride_h,
+                               int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w,
+                               int64_t groups, int64_t offset_groups, int use_mask, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int tvmi_deformable_im2col(const void* input, const void* offset, const void* mask, void* columns,
+                           tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw,
+                           int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h,
+                           int64_t dil_w, int64_t offset_groups, int use_mask, void* stream);
+int tvmi_deformable_col2im(const void* columns, const void* offset, const void* mask, void* grad_input,
+                           tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw,
+                           int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h,
+                           int64_t dil_w, int64_t offset_groups, int use_mask, void* stream);
+int tvmi_deformable_col2im_coord(const void* columns, const void* input, const void* offset, const void* mask,
+                                 void* grad_offset, void* grad_mask, tvmi_dtype dt, int64_t B, int64_t C,
+                                 int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t stride_h,
+                                 int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w,
+                                 int64_t offset_groups, int use_mask, void* stream);
+
+/* ---------------------------------------------------------- box_iou_rotated ------------
+ * Replaces: cuda/box_iou_rotated_kernel.cu:41-188; semantics of box_iou_rotated_utils.h:67-383
+ * and cpu/box_iou_rotated_kernel.cpp:29-115.  boxes [N,5]/[M,5] = (cx,cy,w,h,angle_deg),
+ * F32 or F64; ious [N,M] is always float32.
+ */
+int tvmi_box_iou_rotated(const void* boxes1, const void* boxes2, float* ious, tvmi_dtype dt, int64_t N,
+                         int64_t M, void* stream);
+
+/* ------------------------------------------------------------------- resize ------------
+ * The reference's resize path (transforms/v2/functional/_geometry.py:283-362,
+ * transforms/_functional_tensor.py:441-474, models/detection/transform.py:65-72) ends in
+ * aten::upsample_{bilinear2d,bicubic2d,nearest2d}, _upsample_nearest_exact2d and
+ * _upsample_{bilinear2d,bicubic2d}_aa; these launchers implement that arithmetic
+ * (ATen/native/UpSample.h, ATen/native/cuda/UpSample.cuh of torch 2.10) for contiguous
+ * planes: input [NC,IH,IW] -> output [NC,OH,OW].  scale_h/scale_w <= 0 mean "not given"
+ * (scale = in/out), otherwise they are the user scale factors exactly like the aten ops'
+ * optional `scales_*` arguments.  mode for the anti-aliased entry: 0 bilinear, 1 bicubic.
+ */
+int tvmi_upsample_bilinear2d(const void* input, void* output, tvmi_dtype dt, int64_t NC, int64_t IH, int64_t IW,
+                             int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
+                             void* stream);
+int tvmi_upsample_bicubic2d(const void* input, void* output, tvmi_dtype dt, int64_t NC, int64_t IH, int64_t IW,
+                            int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
+                            void* stream);
+int tvmi_upsample_nearest2d(const void* input, void* output, tvmi_dtype dt, int64_t NC, int64_t IH, int64_t IW,
+                            int64_t OH, int64_t OW, int exact, double scale_h, double scale_w, void* stream);
+size_t tvmi_upsample_aa2d_workspace_bytes(int mode, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                                          int align_corners, double scale_h, double scale_w);
+int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt, int mode, int64_t NC, int64_t IH,
+                       int64_t IW, int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,226 @@
+// box_iou_rotated.hip — pairwise IoU of rotated boxes (cx, cy, w, h, angle in degrees).
+//
+// Semantics: torchvision/csrc/ops/box_iou_rotated_utils.h:67-383 (single_box_iou_rotated:
+// rectangle corners -> up to 24 candidate points (16 edge/edge intersections + 8 contained
+// corners) -> Graham scan -> triangle-fan area) as driven by
+// cpu/box_iou_rotated_kernel.cpp:29-115; output is float32 whatever the input dtype
+// (:102-103).  The double-precision promotions of the reference (angle, EPS comparisons,
+// centre shift, area/2.0) are kept.
+//
+// Layout: a 16x16 thread tile per workgroup; the 16 row boxes and 16 column boxes of the
+// tile are staged once in LDS, each lane then works on its own pair with the 24-point
+// scratch arrays held per lane.  Pairs whose circumscribed circles do not touch skip the
+// polygon clipping altogether (the IoU is exactly 0 there: no candidate point can exist).
+#include "tvmi_common.h"
+
+namespace tvmi {
+namespace {
+
+constexpr int kTile = 16;
+
+template <typename T>
+struct P2 {
+  T x, y;
+};
+
+template <typename T>
+__device__ __forceinline__ T cross2(const P2<T>& a, const P2<T>& b) {
+  return a.x * b.y - b.x * a.y;
+}
+template <typename T>
+__device__ __forceinline__ T dot2(const P2<T>& a, const P2<T>& b) {
+  return a.x * b.x + a.y * b.y;
+}
+template <typename T>
+__device__ __forceinline__ P2<T> sub(const P2<T>& a, const P2<T>& b) {
+  return {a.x - b.x, a.y - b.y};
+}
+
+// box_iou_rotated_utils.h:67-87
+template <typename T>
+__device__ __forceinline__ void corners(T cx, T cy, T w, T h, T angle, P2<T> (&pt)[4]) {
+  const double theta = (double)angle * 0.01745329251;
+  const T c2 = (T)cos(theta) * 0.5f;
+  const T s2 = (T)sin(theta) * 0.5f;
+  pt[0].x = cx + s2 * h + c2 * w;
+  pt[0].y = cy + c2 * h - s2 * w;
+  pt[1].x = cx - s2 * h + c2 * w;
+  pt[1].y = cy - c2 * h - s2 * w;
+  pt[2].x = 2 * cx - pt[0].x;
+  pt[2].y = 2 * cy - pt[0].y;
+  pt[3].x = 2 * cx - pt[1].x;
+  pt[3].y = 2 * cy - pt[1].y;
+}
+
+// :89-171 — candidate vertices of the intersection polygon
+template <typename T>
+__device__ int candidates(const P2<T> (&a)[4], const P2<T> (&b)[4], P2<T> (&out)[24]) {
+  P2<T> ea[4], eb[4];
+  for (int i = 0; i < 4; ++i) {
+    ea[i] = sub(a[(i + 1) & 3], a[i]);
+    eb[i] = sub(b[(i + 1) & 3], b[i]);
+  }
+  const double EPS = 1e-5;
+  int n = 0;
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      const T det = cross2(eb[j], ea[i]);
+      if (fabs((double)det) <= 1e-14) continue;  // parallel edges
+      const P2<T> d = sub(b[j], a[i]);
+      const T t1 = cross2(eb[j], d) / det;
+      const T t2 = cross2(ea[i], d) / det;
+      if ((double)t1 > -EPS && (double)t1 < 1.0f + EPS && (double)t2 > -EPS && (double)t2 < 1.0f + EPS) {
+        out[n].x = a[i].x + ea[i].x * t1;
+        out[n].y = a[i].y + ea[i].y * t1;
+        ++n;
+      }
+    }
+  }
+  // corners of `a` inside `b`, then corners of `b` inside `a` (projection test)
+  for (int pass = 0; pass < 2; ++pass) {
+    const P2<T>(&q)[4] = pass == 0 ? a : b;
+    const P2<T>(&r)[4] = pass == 0 ? b : a;
+    const P2<T>& AB = pass == 0 ? eb[0] : ea[0];
+    const P2<T>& DA = pass == 0 ? eb[3] : ea[3];
+    const T ABAB = dot2(AB, AB), ADAD = dot2(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const P2<T> AP = sub(q[i], r[0]);
+      const T pAB = dot2(AP, AB);
+      const T pAD = -dot2(AP, DA);
+      if (((double)pAB > -EPS) && ((double)pAD > -EPS) && ((double)pAB < (double)ABAB + EPS) &&
+          ((double)pAD < (double)ADAD + EPS)) {
+        out[n++] = q[i];
+      }
+    }
+  }
+  return n;
+}
+
+// :173-305 (device branch) — Graham scan on points shifted to the lowest-leftmost one
+template <typename T>
+__device__ int hull(const P2<T> (&p)[24], int n, P2<T> (&q)[24]) {
+  int t = 0;
+  for (int i = 1; i < n; ++i)
+    if (p[i].y < p[t].y || (p[i].y == p[t].y && p[i].x < p[t].x)) t = i;
+  const P2<T> start = p[t];
+  for (int i = 0; i < n; ++i) q[i] = sub(p[i], start);
+  {
+    const P2<T> tmp = q[0];
+    q[0] = q[t];
+    q[t] = tmp;
+  }
+  T dist[24];
+  for (int i = 0; i < n; ++i) dist[i] = dot2(q[i], q[i]);
+  for (int i = 1; i < n - 1; ++i) {
+    for (int j = i + 1; j < n; ++j) {
+      const T cp = cross2(q[i], q[j]);
+      if (((double)cp < -1e-6) || (fabs((double)cp) < 1e-6 && dist[i] > dist[j])) {
+        const P2<T> tq = q[i];
+        q[i] = q[j];
+        q[j] = tq;
+        const T td = dist[i];
+        dist[i] = dist[j];
+        dist[j] = td;
+      }
+    }
+  }
+  int k = 1;
+  for (; k < n; ++k)
+    if ((double)dist[k] > 1e-8) break;
+  if (k == n) {
+    q[0] = p[t];
+    return 1;
+  }
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < n; ++i) {
+    while (m > 1) {
+      const P2<T> q1 = sub(q[i], q[m - 2]), q2 = sub(q[m - 1], q[m - 2]);
+      if (q1.x * q2.y >= q2.x * q1.y)
+        --m;
+      else
+        break;
+    }
+    q[m++] = q[i];
+  }
+  return m;  // left shifted to `start`: only the area is needed
+}
+
+template <typename T>
+__device__ float pair_iou(const T* b1, const T* b2) {
+  const double sx = ((double)b1[0] + (double)b2[0]) / 2.0;
+  const double sy = ((double)b1[1] + (double)b2[1]) / 2.0;
+  const T x1 = (T)((double)b1[0] - sx), y1 = (T)((double)b1[1] - sy);
+  const T x2 = (T)((double)b2[0] - sx), y2 = (T)((double)b2[1] - sy);
+  const T area1 = b1[2] * b1[3], area2 = b2[2] * b2[3];
+  if ((double)area1 < 1e-14 || (double)area2 < 1e-14) return 0.f;
+  // Quick reject: circumscribed circles (slightly inflated) do not touch -> no candidate
+  // point can pass the 1e-5-relaxed tests above, the reference returns exactly 0.
+  {
+    const double r1 = 0.5 * sqrt((double)b1[2] * b1[2] + (double)b1[3] * b1[3]);
+    const double r2 = 0.5 * sqrt((double)b2[2] * b2[2] + (double)b2[3] * b2[3]);
+    const double dx = (double)b1[0] - (double)b2[0], dy = (double)b1[1] - (double)b2[1];
+    const double rr = (r1 + r2) * 1.001 + 1e-3;
+    if (dx * dx + dy * dy > rr * rr && b1[2] >= 0 && b1[3] >= 0 && b2[2] >= 0 && b2[3] >= 0) return 0.f;
+  }
+  P2<T> pa[4], pb[4], cand[24], ord[24];
+  corners<T>(x1, y1, b1[2], b1[3], b1[4], pa);
+  corners<T>(x2, y2, b2[2], b2[3], b2[4], pb);
+  const int n = candidates<T>(pa, pb, cand);
+  T inter = 0;
+  if (n > 2) {
+    const int m = hull<T>(cand, n, ord);
+    if (m > 2) {
+      T area = 0;
+      for (int i = 1; i < m - 1; ++i) area += fabs(cross2(sub(ord[i], ord[0]), sub(ord[i + 1], ord[0])));
+      inter = (T)((double)area / 2.0);
+    }
+  }
+  T iou = inter / (area1 + area2 - inter);
+  iou = (iou < 0) ? 0 : (iou > 1 ? 1 : iou);
+  return (float)iou;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kTile* kTile) void box_iou_rotated_kernel(const T* __restrict__ boxes1,
+                                                                       const T* __restrict__ boxes2,
+                                                                       float* __restrict__ out, int N, int M) {
+  __shared__ T s1[kTile][5];
+  __shared__ T s2[kTile][5];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * kTile + tx;
+  const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
+  if (tid < kTile * 5) {
+    const int r = tid / 5, c = tid - r * 5;
+    s1[r][c] = row0 + r < N ? boxes1[(int64_t)(row0 + r) * 5 + c] : (T)0;
+  } else if (tid >= 128 && tid < 128 + kTile * 5) {
+    const int t2 = tid - 128;
+    const int r = t2 / 5, c = t2 - r * 5;
+    s2[r][c] = col0 + r < M ? boxes2[(int64_t)(col0 + r) * 5 + c] : (T)0;
+  }
+  __syncthreads();
+  const int i = row0 + ty, j = col0 + tx;
+  if (i < N && j < M) out[(int64_t)i * M + j] = pair_iou<T>(s1[ty], s2[tx]);
+}
+
+}  // namespace
+}  // namespace tvmi
+
+extern "C" int tvmi_box_iou_rotated(const void* boxes1, const void* boxes2, float* ious, tvmi_dtype dt,
+                                    int64_t N, int64_t M, void* stream) {
+  if (N == 0 || M == 0) return 0;
+  TVMI_CHECK_ARG(boxes1 && boxes2 && ious, "box_iou_rotated: null pointer");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "box_iou_rotated: boxes must be float32 or float64");
+  TVMI_CHECK_ARG(N < (1ll << 31) && M < (1ll << 31), "box_iou_rotated: too many boxes");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 block(tvmi::kTile, tvmi::kTile);
+  const dim3 grid((unsigned)tvmi::ceil_div(M, tvmi::kTile), (unsigned)tvmi::ceil_div(N, tvmi::kTile));
+  TVMI_CHECK_ARG(grid.y <= 65535u * 1024u, "box_iou_rotated: grid too large");
+  if (dt == TVMI_F32)
+    tvmi::box_iou_rotated_kernel<float><<<grid, block, 0, s>>>((const float*)boxes1, (const float*)boxes2, ious,
+                                                               (int)N, (int)M);
+  else
+    tvmi::box_iou_rotated_kernel<double><<<grid, block, 0, s>>>((const double*)boxes1, (const double*)boxes2,
+                                                                 ious, (int)N, (int)M);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_box_iou_rotated");
+}

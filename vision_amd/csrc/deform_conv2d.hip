@@ -1,0 +1,596 @@
+// deform_conv2d.hip — deformable convolution v1/v2 for gfx950 (MI355X).
+//
+// Semantics: torchvision/csrc/ops/cpu/deform_conv2d_kernel.cpp
+//   bilinear_interpolate :95-132 (zero outside (-1,H)x(-1,W), per-corner validity),
+//   deformable_im2col_kernel :134-209, deformable_col2im_kernel :274-348,
+//   get_coordinate_weight :407-438, deformable_col2im_coord_kernel :440-551,
+//   forward host :921-1151.
+//
+// Forward, fp32 (the hot path): ONE fused kernel — the reference materialises
+// columns[C*kh*kw, B*oh*ow] in memory (250 MB at 2x256x100x136, k=3) and then calls one GEMM
+// per weight group (cuda/deform_conv2d_kernel.cu:1035-1255).  Here a 256-thread workgroup
+// owns an (out-channel tile x pixel tile) of the output and walks K = (tap, in-channel) in
+// slabs of 16: the offset-gather + bilinear "im2col" values of a slab are produced straight
+// into LDS (they never touch HBM), the matching weight slab comes from a [tap][ic][oc]
+// re-layout of the weights (coalesced, L2 resident), and the contraction runs on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate).  Sampling
+// coordinates / bilinear weights are computed once per (pixel, tap, offset group) and reused
+// for every input channel of the group.  Global gathers for slab s+1 are issued before the
+// MFMAs of slab s (register staging, double-buffered LDS, one barrier per slab); bias is
+// added in the epilogue and the result is stored coalesced along the pixel dimension.
+// Other dtypes / tiny channel counts use a direct (non-MFMA) kernel with the same maths.
+// Backward pieces (im2col, col2im, col2im_coord) are separate kernels combined with plain
+// library GEMMs by the dispatcher glue.
+#include <algorithm>
+#include <type_traits>
+
+#include "tvmi_common.h"
+
+namespace tvmi {
+namespace {
+
+struct DcnParams {
+  int B, C, H, W;        // input
+  int OC, kh, kw;        // weight [OC, C/groups, kh, kw]
+  int oh, ow;            // output spatial
+  int sh, sw, ph, pw, dh, dw;
+  int groups, ogroups;   // weight groups, offset groups
+  int use_mask;
+  int ICg, OCg;          // channels per weight group
+  int cpog;              // channels per offset group
+};
+
+// One sampling location: 4 corner offsets (clamped to a valid address) and 4 weights
+// (zeroed for corners outside the image), per cpu/deform_conv2d_kernel.cpp:95-132.
+template <typename A>
+struct Tap {
+  int o1, o2, o3, o4;
+  A w1, w2, w3, w4;
+  A m;  // modulation mask (1 when unused)
+};
+
+template <typename A>
+__device__ __forceinline__ void make_tap(Tap<A>& t, int H, int W, A h, A w, A mask) {
+  t.m = mask;
+  if (h <= (A)-1 || (A)H <= h || w <= (A)-1 || (A)W <= w) {
+    t.o1 = t.o2 = t.o3 = t.o4 = 0;
+    t.w1 = t.w2 = t.w3 = t.w4 = (A)0;
+    return;
+  }
+  const int hl = (int)floor(h), wl = (int)floor(w);
+  const int hh_ = hl + 1, wh_ = wl + 1;
+  const A lh = h - (A)hl, lw = w - (A)wl;
+  const A hh = (A)1 - lh, hw = (A)1 - lw;
+  const bool v_hl = hl >= 0, v_wl = wl >= 0, v_hh = hh_ <= H - 1, v_wh = wh_ <= W - 1;
+  const int chl = v_hl ? hl : 0, cwl = v_wl ? wl : 0, chh = v_hh ? hh_ : H - 1, cwh = v_wh ? wh_ : W - 1;
+  t.o1 = chl * W + cwl;
+  t.o2 = chl * W + cwh;
+  t.o3 = chh * W + cwl;
+  t.o4 = chh * W + cwh;
+  t.w1 = (v_hl && v_wl) ? hh * hw : (A)0;
+  t.w2 = (v_hl && v_wh) ? hh * lw : (A)0;
+  t.w3 = (v_hh && v_wl) ? lh * hw : (A)0;
+  t.w4 = (v_hh && v_wh) ? lh * lw : (A)0;
+}
+
+template <typename T, typename A>
+__device__ __forceinline__ void load_tap(Tap<A>& t, const DcnParams& p, const T* __restrict__ offset,
+                                         const T* __restrict__ mask, int b, int og, int tap, int oy, int ox) {
+  const int i = tap / p.kw, j = tap - i * p.kw;
+  const int64_t plane = (int64_t)p.oh * p.ow;
+  const int64_t pix = (int64_t)oy * p.ow + ox;
+  const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * p.kh * p.kw) * plane;
+  const A off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
+  const A off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
+  A mval = (A)1;
+  if (p.use_mask) mval = ld(mask + ((int64_t)(b * p.ogroups + og) * p.kh * p.kw + tap) * plane + pix);
+  const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + off_h;
+  const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + off_w;
+  make_tap<A>(t, p.H, p.W, y, x, mval);
+}
+
+template <typename T, typename A>
+__device__ __forceinline__ A sample_tap(const Tap<A>& t, const T* __restrict__ plane) {
+  const A v1 = ld(plane + t.o1), v2 = ld(plane + t.o2), v3 = ld(plane + t.o3), v4 = ld(plane + t.o4);
+  return t.m * (t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4);
+}
+
+// ------------------------------------------------------------------ direct forward
+// One thread per output element; taps outer, channels inner (coordinates reused).
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ input, const T* __restrict__ weight,
+                                                      const T* __restrict__ offset, const T* __restrict__ mask,
+                                                      const T* __restrict__ bias, T* __restrict__ out,
+                                                      DcnParams p, int64_t total) {
+  using A = typename Acc<T>::type;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % p.ow);
+    const int oy = (int)((idx / p.ow) % p.oh);
+    const int oc = (int)((idx / ((int64_t)p.ow * p.oh)) % p.OC);
+    const int b = (int)(idx / ((int64_t)p.ow * p.oh * p.OC));
+    const int g = oc / p.OCg;
+    const int64_t plane = (int64_t)p.H * p.W;
+    const int KK = p.kh * p.kw;
+    A acc = (A)0;
+    for (int tap = 0; tap < KK; ++tap) {
+      int ic = 0;
+      while (ic < p.ICg) {
+        const int c_abs = g * p.ICg + ic;
+        const int og = c_abs / p.cpog;
+        const int seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
+        Tap<A> t;
+        load_tap<T, A>(t, p, offset, mask, b, og, tap, oy, ox);
+        for (; ic < seg_end; ++ic) {
+          const T* pl = input + ((int64_t)b * p.C + g * p.ICg + ic) * plane;
+          const A wv = ld(weight + ((int64_t)oc * p.ICg + ic) * KK + tap);
+          acc += wv * sample_tap<T, A>(t, pl);
+        }
+      }
+    }
+    st(out + idx, acc + ld(bias + oc));
+  }
+}
+
+// ------------------------------------------------------------------ fused MFMA forward (fp32)
+constexpr int kBK = 16;
+
+// weight [OC, ICg, kh, kw] -> wt [groups][tap][ICg_pad][OCg_pad] (zero padded)
+__global__ void dcn_weight_relayout(const float* __restrict__ w, float* __restrict__ wt, DcnParams p,
+                                    int ICg_pad, int OCg_pad) {
+  const int KK = p.kh * p.kw;
+  const int64_t total = (int64_t)p.groups * KK * ICg_pad * OCg_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int oc = (int)(idx % OCg_pad);
+    const int ic = (int)((idx / OCg_pad) % ICg_pad);
+    const int tap = (int)((idx / ((int64_t)OCg_pad * ICg_pad)) % KK);
+    const int g = (int)(idx / ((int64_t)OCg_pad * ICg_pad * KK));
+    float v = 0.f;
+    if (oc < p.OCg && ic < p.ICg) v = w[(((int64_t)(g * p.OCg + oc)) * p.ICg + ic) * KK + tap];
+    wt[idx] = v;
+  }
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int WM, int WN>  // waves along M (out channels) and N (pixels); WM*WN == 4
+__global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict__ input,
+                                                        const float* __restrict__ wt,
+                                                        const float* __restrict__ offset,
+                                                        const float* __restrict__ mask,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        DcnParams p, int ICg_pad, int OCg_pad) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int NSUB = 256 / BN;        // channel subsets among the B-tile producers
+  constexpr int BPT = kBK / NSUB;       // B elements per thread per slab
+  constexpr int APT = kBK * BM / 256;   // A elements per thread per slab (multiple of 4)
+  __shared__ __attribute__((aligned(16))) float As[2][kBK][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kBK][BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = blockIdx.z;
+  const int oc0 = blockIdx.y * BM;  // within group
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+  const int KK = p.kh * p.kw;
+  const int64_t in_plane = (int64_t)p.H * p.W;
+
+  // this thread's producer pixel
+  const int pn = tid % BN, csub = tid / BN;
+  const int64_t my_pix = pix0 + pn;
+  const bool pix_ok = my_pix < npix;
+  int pb = 0, poy = 0, pox = 0;
+  if (pix_ok) {
+    pox = (int)(my_pix % p.ow);
+    poy = (int)((my_pix / p.ow) % p.oh);
+    pb = (int)(my_pix / ((int64_t)p.ow * p.oh));
+  }
+  const float* in_b = input + ((int64_t)pb * p.C + (int64_t)g * p.ICg) * in_plane;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  float bv[BPT][4];   // staged corner values of the next slab
+  float4 av[APT / 4]; // staged weights of the next slab
+  Tap<float> tap_cur;
+  tap_cur.o1 = tap_cur.o2 = tap_cur.o3 = tap_cur.o4 = 0;
+  tap_cur.w1 = tap_cur.w2 = tap_cur.w3 = tap_cur.w4 = 0.f;
+  tap_cur.m = 0.f;
+
+  // Slab iteration space: tap (outer) x offset-group segment x ic0 (inner).
+  int s_tap = 0, s_ic = 0, s_seg_end = 0;
+  bool have = KK > 0 && p.ICg > 0;
+  auto begin_segment = [&](int tap, int ic) {
+    const int og = (g * p.ICg + ic) / p.cpog;
+    s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
+    if (pix_ok) load_tap<float, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+  };
+  auto issue_loads = [&](int tap, int ic0, int kmax) {
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      const int kk = csub + e * NSUB;
+      if (kk < kmax && pix_ok) {
+        const float* pl = in_b + (int64_t)(ic0 + kk) * in_plane;
+        bv[e][0] = pl[tap_cur.o1];
+        bv[e][1] = pl[tap_cur.o2];
+        bv[e][2] = pl[tap_cur.o3];
+        bv[e][3] = pl[tap_cur.o4];
+      } else {
+        bv[e][0] = bv[e][1] = bv[e][2] = bv[e][3] = 0.f;
+      }
+    }
+    const float* wsrc = wt + (((int64_t)g * KK + tap) * ICg_pad + ic0) * OCg_pad + oc0;
+#pragma unroll
+    for (int e = 0; e < APT / 4; ++e) {
+      const int lin = (tid + e * 256) * 4;
+      const int kk = lin / BM, m = lin - kk * BM;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kk < kmax && oc0 + m < OCg_pad) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)kk * OCg_pad + m);
+      av[e] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      const int kk = csub + e * NSUB;
+      Bs[buf][kk][pn] =
+          tap_cur.m * (tap_cur.w1 * bv[e][0] + tap_cur.w2 * bv[e][1] + tap_cur.w3 * bv[e][2] + tap_cur.w4 * bv[e][3]);
+    }
+#pragma unroll
+    for (int e = 0; e < APT / 4; ++e) {
+      const int lin = (tid + e * 256) * 4;
+      const int kk = lin / BM, m = lin - kk * BM;
+      *reinterpret_cast<float4*>(&As[buf][kk][m]) = av[e];
+    }
+  };
+
+  int buf = 0;
+  if (have) {
+    begin_segment(0, 0);
+    issue_loads(0, 0, min(kBK, s_seg_end));
+  }
+  while (have) {
+    commit(buf);  // uses tap_cur of the slab that was loaded
+    __syncthreads();
+    // advance to the next slab and start its loads before the MFMAs
+    int n_tap = s_tap, n_ic = s_ic + kBK;
+    bool n_have = true;
+    if (n_ic >= s_seg_end) {
+      n_ic = s_seg_end;
+      if (n_ic >= p.ICg) {
+        n_ic = 0;
+        n_tap = s_tap + 1;
+        if (n_tap >= KK) n_have = false;
+      }
+      if (n_have) begin_segment(n_tap, n_ic);
+    }
+    if (n_have) issue_loads(n_tap, n_ic, min(kBK, s_seg_end - n_ic));
+    // MFMA over this slab
+    const int kq = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < kBK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = As[buf][kk + kq][wm * 64 + mi * 32 + l31];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) b[ni] = Bs[buf][kk + kq][wn * 64 + ni * 32 + l31];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    s_tap = n_tap;
+    s_ic = n_ic;
+    have = n_have;
+    buf ^= 1;
+  }
+
+  // epilogue: D[row][col], col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (oc)
+  const int l31 = lane & 31, kq = lane >> 5;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t pix = pix0 + wn * 64 + ni * 32 + l31;
+    if (pix >= npix) continue;
+    const int ox = (int)(pix % p.ow);
+    const int oy = (int)((pix / p.ow) % p.oh);
+    const int b = (int)(pix / ((int64_t)p.ow * p.oh));
+    float* obase = out + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * p.oh * p.ow + (int64_t)oy * p.ow + ox;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = oc0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (oc < p.OCg) obase[(int64_t)oc * p.oh * p.ow] = acc[mi][ni][r] + bias[g * p.OCg + oc];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward building blocks
+// columns layout: [C*kh*kw][B*oh*ow]  (k = (c*kh + i)*kw + j ; n = (b*oh + y)*ow + x)
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_im2col(const T* __restrict__ input, const T* __restrict__ offset,
+                                                  const T* __restrict__ mask, T* __restrict__ columns,
+                                                  DcnParams p, int64_t total) {
+  using A = typename Acc<T>::type;
+  const int KK = p.kh * p.kw;
+  const int64_t ncols = (int64_t)p.B * p.oh * p.ow;
+  // one thread per (c, b, y, x); writes KK column entries
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % p.ow);
+    const int oy = (int)((idx / p.ow) % p.oh);
+    const int b = (int)((idx / ((int64_t)p.ow * p.oh)) % p.B);
+    const int c = (int)(idx / ((int64_t)p.ow * p.oh * p.B));
+    const int og = c / p.cpog;
+    const T* pl = input + ((int64_t)b * p.C + c) * p.H * p.W;
+    const int64_t n = ((int64_t)b * p.oh + oy) * p.ow + ox;
+    for (int tap = 0; tap < KK; ++tap) {
+      Tap<A> t;
+      load_tap<T, A>(t, p, offset, mask, b, og, tap, oy, ox);
+      st(columns + ((int64_t)c * KK + tap) * ncols + n, sample_tap<T, A>(t, pl));
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_col2im(const T* __restrict__ col, const T* __restrict__ offset,
+                                                  const T* __restrict__ mask, T* __restrict__ grad_im,
+                                                  DcnParams p, int64_t total) {
+  using A = typename Acc<T>::type;
+  const int KK = p.kh * p.kw;
+  const int64_t plane = (int64_t)p.oh * p.ow;
+  const int64_t ncols = (int64_t)p.B * plane;
+  // idx enumerates the columns buffer: (c, i, j, b, y, x)
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t n = idx % ncols;
+    const int k = (int)(idx / ncols);
+    const int ox = (int)(n % p.ow);
+    const int oy = (int)((n / p.ow) % p.oh);
+    const int b = (int)(n / plane);
+    const int tap = k % KK, c = k / KK;
+    const int i = tap / p.kw, j = tap - i * p.kw;
+    const int og = c / p.cpog;
+    const int64_t pix = (int64_t)oy * p.ow + ox;
+    const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * plane;
+    const A off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
+    const A off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
+    A mval = (A)1;
+    if (p.use_mask) mval = ld(mask + ((int64_t)(b * p.ogroups + og) * KK + tap) * plane + pix);
+    const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + off_h;
+    const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + off_w;
+    const A cv = ld(col + idx);
+    T* gi = grad_im + ((int64_t)b * p.C + c) * p.H * p.W;
+    for (int dy = -1; dy <= 1; ++dy) {
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yp = (int)y + dy, xp = (int)x + dx;
+        const A ay = fabs(y - (A)yp), ax = fabs(x - (A)xp);
+        if (0 <= yp && yp < p.H && 0 <= xp && xp < p.W && ay < (A)1 && ax < (A)1) {
+          const A wgt = ((A)1 - ay) * ((A)1 - ax);
+          atomic_accum(gi + (int64_t)yp * p.W + xp, mval * wgt * cv);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename A>
+__device__ __forceinline__ A coord_weight(const T* __restrict__ im, int H, int W, A y, A x, bool ydir) {
+  const int yl = (int)floor(y), xl = (int)floor(x);
+  const int yh = yl + 1, xh = xl + 1;
+  const bool vyl = 0 <= yl && yl < H, vyh = 0 <= yh && yh < H;
+  const bool vxl = 0 <= xl && xl < W, vxh = 0 <= xh && xh < W;
+  const A v_yx = (vyl && vxl) ? ld(im + yl * W + xl) : (A)0;
+  const A v_yX = (vyl && vxh) ? ld(im + yl * W + xh) : (A)0;
+  const A v_Yx = (vyh && vxl) ? ld(im + yh * W + xl) : (A)0;
+  const A v_YX = (vyh && vxh) ? ld(im + yh * W + xh) : (A)0;
+  if (ydir) {
+    const A dx = x - (A)xl;
+    return dx * (v_YX - v_yX) + ((A)1 - dx) * (v_Yx - v_yx);
+  }
+  const A dy = y - (A)yl;
+  return dy * (v_YX - v_Yx) + ((A)1 - dy) * (v_yX - v_yx);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_col2im_coord(const T* __restrict__ col, const T* __restrict__ im,
+                                                        const T* __restrict__ offset,
+                                                        const T* __restrict__ mask, T* __restrict__ grad_offset,
+                                                        T* __restrict__ grad_mask, DcnParams p, int64_t total) {
+  using A = typename Acc<T>::type;
+  const int KK = p.kh * p.kw;
+  const int64_t plane = (int64_t)p.oh * p.ow;
+  const int64_t ncols = (int64_t)p.B * plane;
+  const int off_ch = 2 * KK * p.ogroups;
+  // one thread per grad_offset element (b, c_off, y, x)
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % p.ow);
+    const int oy = (int)((idx / p.ow) % p.oh);
+    const int c = (int)((idx / plane) % off_ch);
+    const int b = (int)(idx / (plane * off_ch));
+    const int og = c / (2 * KK);
+    const int oc_in = c - og * 2 * KK;
+    const bool ydir = (oc_in % 2) == 0;
+    const int tap = oc_in / 2;
+    const int i = tap / p.kw, j = tap - i * p.kw;
+    const int64_t pix = (int64_t)oy * p.ow + ox;
+    const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * plane;
+    const A off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
+    const A off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
+    A mval = (A)1;
+    if (p.use_mask) mval = ld(mask + ((int64_t)(b * p.ogroups + og) * KK + tap) * plane + pix);
+    const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + off_h;
+    const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + off_w;
+    Tap<A> t;
+    make_tap<A>(t, p.H, p.W, y, x, (A)1);
+    const int64_t n = (int64_t)b * plane + pix;
+    A g_off = (A)0, g_mask = (A)0;
+    for (int cc = 0; cc < p.cpog; ++cc) {
+      const int ch = og * p.cpog + cc;
+      const T* im_c = im + ((int64_t)b * p.C + ch) * p.H * p.W;
+      const A cv = ld(col + ((int64_t)ch * KK + tap) * ncols + n);
+      g_off += mval * coord_weight<T, A>(im_c, p.H, p.W, y, x, ydir) * cv;
+      if (p.use_mask && ydir) g_mask += cv * sample_tap<T, A>(t, im_c);
+    }
+    st(grad_offset + idx, g_off);
+    if (p.use_mask && ydir) st(grad_mask + ((int64_t)(b * p.ogroups + og) * KK + tap) * plane + pix, g_mask);
+  }
+}
+
+int fill_params(DcnParams& p, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC, int64_t kh, int64_t kw,
+                int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, int64_t groups,
+                int64_t ogroups, int use_mask) {
+  TVMI_CHECK_ARG(kh > 0 && kw > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && ph >= 0 && pw >= 0,
+                 "deform_conv2d: invalid kernel/stride/pad/dilation");
+  TVMI_CHECK_ARG(groups > 0 && ogroups > 0 && C % groups == 0 && OC % groups == 0 && C % ogroups == 0,
+                 "deform_conv2d: channels not divisible by groups");
+  p.B = (int)B;
+  p.C = (int)C;
+  p.H = (int)H;
+  p.W = (int)W;
+  p.OC = (int)OC;
+  p.kh = (int)kh;
+  p.kw = (int)kw;
+  p.sh = (int)sh;
+  p.sw = (int)sw;
+  p.ph = (int)ph;
+  p.pw = (int)pw;
+  p.dh = (int)dh;
+  p.dw = (int)dw;
+  p.groups = (int)groups;
+  p.ogroups = (int)ogroups;
+  p.use_mask = use_mask;
+  p.oh = (int)((H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1);
+  p.ow = (int)((W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1);
+  p.ICg = (int)(C / groups);
+  p.OCg = (int)(OC / groups);
+  p.cpog = (int)(C / ogroups);
+  TVMI_CHECK_ARG(p.oh > 0 && p.ow > 0, "deform_conv2d: calculated output size too small");
+  TVMI_CHECK_ARG(H * W < (1ll << 31), "deform_conv2d: plane too large");
+  return 0;
+}
+
+inline bool use_mfma(const DcnParams& p, tvmi_dtype dt) { return dt == TVMI_F32 && p.OCg >= 16 && p.ICg >= 4; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline dim3 grid1d(int64_t total) { return dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1 << 20)); }
+
+}  // namespace
+}  // namespace tvmi
+
+using namespace tvmi;
+
+extern "C" size_t tvmi_deform_conv2d_workspace_bytes(tvmi_dtype dt, int64_t C, int64_t OC, int64_t kh, int64_t kw,
+                                                     int64_t groups) {
+  if (dt != TVMI_F32 || groups <= 0 || C <= 0 || OC <= 0) return 0;
+  const int ICg_pad = round_up((int)(C / groups), kBK), OCg_pad = round_up((int)(OC / groups), 64);
+  return (size_t)groups * kh * kw * ICg_pad * OCg_pad * sizeof(float);
+}
+
+extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight, const void* offset,
+                                          const void* mask, const void* bias, void* output, tvmi_dtype dt,
+                                          int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC, int64_t kh,
+                                          int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                                          int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t groups,
+                                          int64_t offset_groups, int use_mask, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  DcnParams p;
+  if (int e = fill_params(p, B, C, H, W, OC, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups,
+                          offset_groups, use_mask))
+    return e;
+  const int64_t total = (int64_t)B * OC * p.oh * p.ow;
+  if (total == 0) return 0;
+  TVMI_CHECK_ARG(input && weight && offset && bias && output && (!use_mask || mask), "deform_conv2d: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (use_mfma(p, dt)) {
+    const int ICg_pad = round_up(p.ICg, kBK), OCg_pad = round_up(p.OCg, 64);
+    TVMI_CHECK_ARG(workspace && workspace_bytes >= tvmi_deform_conv2d_workspace_bytes(dt, C, OC, kh, kw, groups),
+                   "deform_conv2d: workspace too small");
+    float* wt = static_cast<float*>(workspace);
+    const int64_t wtotal = (int64_t)p.groups * kh * kw * ICg_pad * OCg_pad;
+    dcn_weight_relayout<<<grid1d(wtotal), dim3(256), 0, s>>>((const float*)weight, wt, p, ICg_pad, OCg_pad);
+    const int64_t npix = (int64_t)B * p.oh * p.ow;
+#define TVMI_DCN(WM, WN)                                                                               \
+  dcn_fwd_mfma_f32<WM, WN>                                                                             \
+      <<<dim3((unsigned)ceil_div(npix, 64 * WN), (unsigned)ceil_div(p.OCg, 64 * WM), (unsigned)p.groups), \
+         dim3(256), 0, s>>>((const float*)input, wt, (const float*)offset, (const float*)mask,            \
+                            (const float*)bias, (float*)output, p, ICg_pad, OCg_pad)
+    if (p.OCg > 128) {
+      TVMI_DCN(4, 1);
+    } else if (p.OCg > 64) {
+      TVMI_DCN(2, 2);
+    } else {
+      TVMI_DCN(1, 4);
+    }
+#undef TVMI_DCN
+  } else {
+    TVMI_DISPATCH_FLOAT(dt, "deform_conv2d_forward",
+                        dcn_fwd_direct<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
+                            (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset,
+                            (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, total));
+  }
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_deform_conv2d_forward");
+}
+
+extern "C" int tvmi_deformable_im2col(const void* input, const void* offset, const void* mask, void* columns,
+                                      tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+                                      int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                                      int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t offset_groups,
+                                      int use_mask, void* stream) {
+  DcnParams p;
+  if (int e = fill_params(p, B, C, H, W, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1,
+                          offset_groups, use_mask))
+    return e;
+  const int64_t total = (int64_t)C * B * p.oh * p.ow;
+  if (total == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_DISPATCH_FLOAT(dt, "deformable_im2col",
+                      dcn_im2col<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
+                          (const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,
+                          (scalar_t*)columns, p, total));
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_deformable_im2col");
+}
+
+extern "C" int tvmi_deformable_col2im(const void* columns, const void* offset, const void* mask, void* grad_input,
+                                      tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+                                      int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                                      int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t offset_groups,
+                                      int use_mask, void* stream) {
+  DcnParams p;
+  if (int e = fill_params(p, B, C, H, W, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1,
+                          offset_groups, use_mask))
+    return e;
+  const int64_t total = (int64_t)C * kh * kw * B * p.oh * p.ow;
+  if (total == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_DISPATCH_FLOAT(dt, "deformable_col2im",
+                      dcn_col2im<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
+                          (const scalar_t*)columns, (const scalar_t*)offset, (const scalar_t*)mask,
+                          (scalar_t*)grad_input, p, total));
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_deformable_col2im");
+}
+
+extern "C" int tvmi_deformable_col2im_coord(const void* columns, const void* input, const void* offset,
+                                            const void* mask, void* grad_offset, void* grad_mask, tvmi_dtype dt,
+                                            int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw,
+                                            int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                                            int64_t dil_h, int64_t dil_w, int64_t offset_groups, int use_mask,
+                                            void* stream) {
+  DcnParams p;
+  if (int e = fill_params(p, B, C, H, W, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1,
+                          offset_groups, use_mask))
+    return e;
+  const int64_t total = (int64_t)B * 2 * kh * kw * offset_groups * p.oh * p.ow;
+  if (total == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_DISPATCH_FLOAT(dt, "deformable_col2im_coord",
+                      dcn_col2im_coord<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
+                          (const scalar_t*)columns, (const scalar_t*)input, (const scalar_t*)offset,
+                          (const scalar_t*)mask, (scalar_t*)grad_offset, (scalar_t*)grad_mask, p, total));
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_deformable_col2im_coord");
+}

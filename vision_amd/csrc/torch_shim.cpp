@@ -145,6 +145,325 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
   return grad_input;
 }
 
+// ---- roi_pool: cuda/roi_pool_kernel.cu:127-260
+std::tuple<at::Tensor, at::Tensor> roi_pool_forward(const at::Tensor& input, const at::Tensor& rois,
+                                                    double spatial_scale, int64_t pooled_height,
+                                                    int64_t pooled_width) {
+  TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+  TORCH_CHECK(rois.is_cuda(), "rois must be a CUDA tensor");
+  TORCH_CHECK(rois.dim() == 2 && rois.size(1) == 5, "Tensor rois should have shape as Tensor[K, 5]");
+  TORCH_CHECK(input.dim() == 4, "input must be a 4d tensor [N, C, H, W]");
+  TORCH_CHECK(input.device() == rois.device(), "roi_pool_forward_kernel: input and rois must be on the same GPU");
+  TORCH_CHECK(input.scalar_type() == rois.scalar_type(), "roi_pool_forward_kernel: input and rois must have the same type");
+  c10::DeviceGuard guard(input.device());
+  const int64_t K = rois.size(0), C = input.size(1), H = input.size(2), W = input.size(3);
+  at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, input.options());
+  at::Tensor argmax = at::empty({K, C, pooled_height, pooled_width}, input.options().dtype(at::kInt));
+  if (output.numel() == 0) return std::make_tuple(output, argmax);
+  at::Tensor input_ = input.contiguous(), rois_ = rois.contiguous();
+  check_status(tvmi_roi_pool_forward(input_.const_data_ptr(), rois_.const_data_ptr(), output.mutable_data_ptr(),
+                                     argmax.mutable_data_ptr<int32_t>(), dtype_of(input, "roi_pool"), input.size(0),
+                                     C, H, W, K, pooled_height, pooled_width, spatial_scale, current_stream(input)),
+               "roi_pool");
+  return std::make_tuple(output, argmax);
+}
+
+at::Tensor roi_pool_backward(const at::Tensor& grad, const at::Tensor& rois, const at::Tensor& argmax,
+                             double spatial_scale, int64_t pooled_height, int64_t pooled_width,
+                             int64_t batch_size, int64_t channels, int64_t height, int64_t width) {
+  TORCH_CHECK(grad.is_cuda(), "grad must be a CUDA tensor");
+  TORCH_CHECK(rois.is_cuda(), "rois must be a CUDA tensor");
+  TORCH_CHECK(argmax.is_cuda(), "argmax must be a CUDA tensor");
+  TORCH_CHECK(grad.scalar_type() == rois.scalar_type(), "roi_pool_backward_kernel: grad and rois must have the same type");
+  c10::DeviceGuard guard(grad.device());
+  at::Tensor grad_input = at::zeros({batch_size, channels, height, width}, grad.options());
+  if (grad.numel() == 0) return grad_input;
+  at::globalContext().alertNotDeterministic("roi_pool_backward_kernel");
+  at::Tensor argmax_ = argmax.to(at::kInt).contiguous(), rois_ = rois.contiguous();
+  check_status(tvmi_roi_pool_backward(grad.const_data_ptr(), rois_.const_data_ptr(), argmax_.const_data_ptr<int32_t>(),
+                                      grad_input.mutable_data_ptr(), dtype_of(grad, "_roi_pool_backward"), batch_size,
+                                      channels, height, width, rois.size(0), pooled_height, pooled_width,
+                                      grad.stride(0), grad.stride(1), grad.stride(2), grad.stride(3),
+                                      current_stream(grad)),
+               "_roi_pool_backward");
+  return grad_input;
+}
+
+// ---- ps_roi_align / ps_roi_pool: cuda/ps_roi_align_kernel.cu, cuda/ps_roi_pool_kernel.cu host parts
+std::tuple<at::Tensor, at::Tensor> ps_roi_common_forward(const char* name, bool align, const at::Tensor& input,
+                                                         const at::Tensor& rois, double spatial_scale,
+                                                         int64_t pooled_height, int64_t pooled_width,
+                                                         int64_t sampling_ratio) {
+  TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+  TORCH_CHECK(rois.is_cuda(), "rois must be a CUDA tensor");
+  TORCH_CHECK(rois.dim() == 2 && rois.size(1) == 5, "Tensor rois should have shape as Tensor[K, 5]");
+  TORCH_CHECK(input.dim() == 4, "input must be a 4d tensor [N, C, H, W]");
+  TORCH_CHECK(input.device() == rois.device(), name, ": input and rois must be on the same GPU");
+  TORCH_CHECK(input.scalar_type() == rois.scalar_type(), name, ": input and rois must have the same type");
+  c10::DeviceGuard guard(input.device());
+  const int64_t K = rois.size(0), C = input.size(1), H = input.size(2), W = input.size(3);
+  TORCH_CHECK(C % (pooled_height * pooled_width) == 0,
+              "input channels must be a multiple of pooling height * pooling width");
+  const int64_t C_out = C / (pooled_height * pooled_width);
+  at::Tensor output = at::empty({K, C_out, pooled_height, pooled_width}, input.options());
+  at::Tensor mapping = at::empty({K, C_out, pooled_height, pooled_width}, input.options().dtype(at::kInt));
+  if (output.numel() == 0) return std::make_tuple(output, mapping);
+  at::Tensor input_ = input.contiguous(), rois_ = rois.contiguous();
+  int st = align ? tvmi_ps_roi_align_forward(input_.const_data_ptr(), rois_.const_data_ptr(), output.mutable_data_ptr(),
+                                             mapping.mutable_data_ptr<int32_t>(), dtype_of(input, name), input.size(0),
+                                             C, H, W, K, pooled_height, pooled_width, spatial_scale, sampling_ratio,
+                                             current_stream(input))
+                 : tvmi_ps_roi_pool_forward(input_.const_data_ptr(), rois_.const_data_ptr(), output.mutable_data_ptr(),
+                                            mapping.mutable_data_ptr<int32_t>(), dtype_of(input, name), input.size(0),
+                                            C, H, W, K, pooled_height, pooled_width, spatial_scale,
+                                            current_stream(input));
+  check_status(st, name);
+  return std::make_tuple(output, mapping);
+}
+
+at::Tensor ps_roi_common_backward(const char* name, bool align, const at::Tensor& grad, const at::Tensor& rois,
+                                  const at::Tensor& channel_mapping, double spatial_scale, int64_t pooled_height,
+                                  int64_t pooled_width, int64_t sampling_ratio, int64_t batch_size,
+                                  int64_t channels, int64_t height, int64_t width) {
+  TORCH_CHECK(grad.is_cuda(), "grad must be a CUDA tensor");
+  TORCH_CHECK(rois.is_cuda(), "rois must be a CUDA tensor");
+  TORCH_CHECK(channel_mapping.is_cuda(), "channel_mapping must be a CUDA tensor");
+  TORCH_CHECK(grad.scalar_type() == rois.scalar_type(), name, ": grad and rois must have the same type");
+  c10::DeviceGuard guard(grad.device());
+  at::Tensor grad_input = at::zeros({batch_size, channels, height, width}, grad.options());
+  if (grad.numel() == 0) return grad_input;
+  at::globalContext().alertNotDeterministic(name);
+  at::Tensor grad_ = grad.contiguous(), rois_ = rois.contiguous(), map_ = channel_mapping.to(at::kInt).contiguous();
+  int st = align ? tvmi_ps_roi_align_backward(grad_.const_data_ptr(), rois_.const_data_ptr(),
+                                              map_.const_data_ptr<int32_t>(), grad_input.mutable_data_ptr(),
+                                              dtype_of(grad, name), batch_size, channels, height, width, rois.size(0),
+                                              pooled_height, pooled_width, spatial_scale, sampling_ratio,
+                                              current_stream(grad))
+                 : tvmi_ps_roi_pool_backward(grad_.const_data_ptr(), rois_.const_data_ptr(),
+                                             map_.const_data_ptr<int32_t>(), grad_input.mutable_data_ptr(),
+                                             dtype_of(grad, name), batch_size, channels, height, width, rois.size(0),
+                                             pooled_height, pooled_width, spatial_scale, current_stream(grad));
+  check_status(st, name);
+  return grad_input;
+}
+
+std::tuple<at::Tensor, at::Tensor> ps_roi_align_forward(const at::Tensor& input, const at::Tensor& rois,
+                                                        double spatial_scale, int64_t pooled_height,
+                                                        int64_t pooled_width, int64_t sampling_ratio) {
+  return ps_roi_common_forward("ps_roi_align_forward_kernel", true, input, rois, spatial_scale, pooled_height,
+                               pooled_width, sampling_ratio);
+}
+at::Tensor ps_roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, const at::Tensor& channel_mapping,
+                                 double spatial_scale, int64_t pooled_height, int64_t pooled_width,
+                                 int64_t sampling_ratio, int64_t batch_size, int64_t channels, int64_t height,
+                                 int64_t width) {
+  return ps_roi_common_backward("ps_roi_align_backward_kernel", true, grad, rois, channel_mapping, spatial_scale,
+                                pooled_height, pooled_width, sampling_ratio, batch_size, channels, height, width);
+}
+std::tuple<at::Tensor, at::Tensor> ps_roi_pool_forward(const at::Tensor& input, const at::Tensor& rois,
+                                                       double spatial_scale, int64_t pooled_height,
+                                                       int64_t pooled_width) {
+  return ps_roi_common_forward("ps_roi_pool_forward_kernel", false, input, rois, spatial_scale, pooled_height,
+                               pooled_width, 0);
+}
+at::Tensor ps_roi_pool_backward(const at::Tensor& grad, const at::Tensor& rois, const at::Tensor& channel_mapping,
+                                double spatial_scale, int64_t pooled_height, int64_t pooled_width,
+                                int64_t batch_size, int64_t channels, int64_t height, int64_t width) {
+  return ps_roi_common_backward("ps_roi_pool_backward_kernel", false, grad, rois, channel_mapping, spatial_scale,
+                                pooled_height, pooled_width, 0, batch_size, channels, height, width);
+}
+
+// ---- deform_conv2d: checks/messages of cpu/deform_conv2d_kernel.cpp:921-1046 (= cuda :1035-1160)
+struct DcnShape {
+  int64_t B, C, H, W, OC, kh, kw, oh, ow;
+};
+
+DcnShape dcn_check(const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
+                   const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h, int64_t stride_w,
+                   int64_t pad_h, int64_t pad_w, int64_t dilation_h, int64_t dilation_w, int64_t n_weight_grps,
+                   int64_t n_offset_grps, bool use_mask) {
+  TORCH_CHECK(input.dim() == 4);
+  TORCH_CHECK(offset.dim() == 4);
+  TORCH_CHECK(!use_mask || mask.dim() == 4);
+  TORCH_CHECK(weight.dim() == 4);
+  TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+  DcnShape s;
+  s.B = input.size(0);
+  s.C = input.size(1);
+  s.H = input.size(2);
+  s.W = input.size(3);
+  s.OC = weight.size(0);
+  s.kh = weight.size(2);
+  s.kw = weight.size(3);
+  const int64_t ker_h = dilation_h * (s.kh - 1) + 1, ker_w = dilation_w * (s.kw - 1) + 1;
+  s.oh = ((s.H + 2 * pad_h - ker_h) / stride_h) + 1;
+  s.ow = ((s.W + 2 * pad_w - ker_w) / stride_w) + 1;
+  TORCH_CHECK(s.kh > 0 && s.kw > 0, "weight_h: ", s.kh, " weight_w: ", s.kw);
+  TORCH_CHECK(stride_h > 0 && stride_w > 0, "stride_h: ", stride_h, " stride_w: ", stride_w);
+  TORCH_CHECK(pad_h >= 0 && pad_w >= 0, "pad_h: ", pad_h, " pad_w: ", pad_w);
+  TORCH_CHECK(dilation_h > 0 && dilation_w > 0, "dilation_h: ", dilation_h, " dilation_w: ", dilation_w);
+  TORCH_CHECK(weight.size(1) * n_weight_grps == input.size(1));
+  TORCH_CHECK(weight.size(0) % n_weight_grps == 0);
+  TORCH_CHECK((offset.size(1) == n_offset_grps * 2 * s.kh * s.kw), "offset.shape[1] is not valid: got: ",
+              offset.size(1), " expected: ", n_offset_grps * 2 * s.kh * s.kw);
+  TORCH_CHECK((!use_mask || mask.size(1) == n_offset_grps * s.kh * s.kw), "mask.shape[1] is not valid: got: ",
+              mask.size(1), " expected: ", n_offset_grps * s.kh * s.kw);
+  TORCH_CHECK(input.size(1) % n_offset_grps == 0);
+  TORCH_CHECK((offset.size(0) == input.size(0)), "invalid batch size of offset");
+  TORCH_CHECK((offset.size(2) == s.oh && offset.size(3) == s.ow), "offset output dims: (", offset.size(2), ", ",
+              offset.size(3), ") - ", "computed output dims: (", s.oh, ", ", s.ow, ")");
+  TORCH_CHECK((mask.size(0) == input.size(0)), "invalid batch size of mask");
+  TORCH_CHECK((!use_mask || (mask.size(2) == s.oh && mask.size(3) == s.ow)), "mask output dims: (", mask.size(2),
+              ", ", mask.size(3), ") - ", "computed output dims: (", s.oh, ", ", s.ow, ")");
+  TORCH_CHECK(s.oh > 0 && s.ow > 0, "Calculated output size too small - out_h: ", s.oh, " out_w: ", s.ow);
+  return s;
+}
+
+at::Tensor deform_conv2d_forward(const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
+                                 const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h,
+                                 int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dilation_h,
+                                 int64_t dilation_w, int64_t n_weight_grps, int64_t n_offset_grps, bool use_mask) {
+  at::Tensor input_c = input.contiguous(), offset_c = offset.contiguous(), weight_c = weight.contiguous();
+  at::Tensor mask_c = mask.contiguous(), bias_c = bias.contiguous();
+  const DcnShape s = dcn_check(input_c, weight_c, offset_c, mask_c, bias_c, stride_h, stride_w, pad_h, pad_w,
+                               dilation_h, dilation_w, n_weight_grps, n_offset_grps, use_mask);
+  c10::DeviceGuard guard(input.device());
+  at::Tensor out = at::empty({s.B, s.OC, s.oh, s.ow}, input_c.options());
+  if (out.numel() == 0) return out;
+  const tvmi_dtype dt = dtype_of(input_c, "deform_conv2d");
+  const size_t ws_bytes = tvmi_deform_conv2d_workspace_bytes(dt, s.C, s.OC, s.kh, s.kw, n_weight_grps);
+  at::Tensor ws = at::empty({(int64_t)ws_bytes}, input_c.options().dtype(at::kByte));
+  check_status(tvmi_deform_conv2d_forward(input_c.const_data_ptr(), weight_c.const_data_ptr(),
+                                          offset_c.const_data_ptr(), mask_c.const_data_ptr(), bias_c.const_data_ptr(),
+                                          out.mutable_data_ptr(), dt, s.B, s.C, s.H, s.W, s.OC, s.kh, s.kw, stride_h,
+                                          stride_w, pad_h, pad_w, dilation_h, dilation_w, n_weight_grps, n_offset_grps,
+                                          use_mask ? 1 : 0, ws.mutable_data_ptr(), ws_bytes, current_stream(input)),
+               "deform_conv2d");
+  return out;
+}
+
+// Backward (cuda/deform_conv2d_kernel.cu:752-1033,1257-1330): the gather/scatter kernels are
+// ours; the two plain GEMMs per weight group go to the BLAS library through ATen.  Images
+// are processed in chunks so that the materialised columns stay below ~1 GiB.
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_conv2d_backward(
+    const at::Tensor& grad, const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
+    const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+    int64_t dilation_h, int64_t dilation_w, int64_t n_weight_grps, int64_t n_offset_grps, bool use_mask) {
+  at::Tensor grad_c = grad.contiguous(), input_c = input.contiguous(), offset_c = offset.contiguous();
+  at::Tensor weight_c = weight.contiguous(), mask_c = mask.contiguous(), bias_c = bias.contiguous();
+  const DcnShape s = dcn_check(input_c, weight_c, offset_c, mask_c, bias_c, stride_h, stride_w, pad_h, pad_w,
+                               dilation_h, dilation_w, n_weight_grps, n_offset_grps, use_mask);
+  c10::DeviceGuard guard(input.device());
+  at::globalContext().alertNotDeterministic("deform_conv2d_backward_kernel");
+  at::Tensor grad_input = at::zeros_like(input_c);
+  at::Tensor grad_offset = at::zeros_like(offset_c);
+  at::Tensor grad_mask = at::zeros_like(mask_c);
+  at::Tensor grad_weight = at::zeros_like(weight_c);
+  at::Tensor grad_bias = at::ones_like(bias_c);
+  if (s.B == 0) return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
+  grad_bias = grad_c.sum({0, 2, 3});
+  const tvmi_dtype dt = dtype_of(input_c, "_deform_conv2d_backward");
+  void* stream = current_stream(input);
+  const int64_t G = n_weight_grps, ICg = s.C / G, OCg = s.OC / G, KK = s.kh * s.kw, plane = s.oh * s.ow;
+  const int64_t col_rows = s.C * KK;
+  const int64_t bytes_per_img = col_rows * plane * (int64_t)input_c.element_size();
+  int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(s.B, (int64_t(1) << 30) / std::max<int64_t>(bytes_per_img, 1)));
+  at::Tensor wg = weight_c.view({G, OCg, ICg * KK});
+  at::Tensor gw = grad_weight.view({G, OCg, ICg * KK});
+  for (int64_t b0 = 0; b0 < s.B; b0 += chunk) {
+    const int64_t nb = std::min(chunk, s.B - b0);
+    at::Tensor in_b = input_c.narrow(0, b0, nb), off_b = offset_c.narrow(0, b0, nb);
+    at::Tensor mask_b = use_mask ? mask_c.narrow(0, b0, nb) : mask_c;
+    at::Tensor go_b = grad_c.narrow(0, b0, nb);                       // [nb, OC, oh, ow]
+    // [G, OCg, nb*plane] with column index n = b*plane + pix
+    at::Tensor go_g = go_b.view({nb, G, OCg, plane}).permute({1, 2, 0, 3}).reshape({G, OCg, nb * plane});
+    // (1) columns = W^T * grad_out  -> grad_input, grad_offset, grad_mask
+    at::Tensor columns = at::bmm(wg.transpose(1, 2), go_g).view({col_rows, nb * plane});
+    at::Tensor gi_b = grad_input.narrow(0, b0, nb), goff_b = grad_offset.narrow(0, b0, nb);
+    at::Tensor gmask_b = use_mask ? grad_mask.narrow(0, b0, nb) : grad_mask;
+    check_status(tvmi_deformable_col2im_coord(columns.const_data_ptr(), in_b.const_data_ptr(), off_b.const_data_ptr(),
+                                              mask_b.const_data_ptr(), goff_b.mutable_data_ptr(),
+                                              gmask_b.mutable_data_ptr(), dt, nb, s.C, s.H, s.W, s.kh, s.kw, stride_h,
+                                              stride_w, pad_h, pad_w, dilation_h, dilation_w, n_offset_grps,
+                                              use_mask ? 1 : 0, stream),
+                 "_deform_conv2d_backward(col2im_coord)");
+    check_status(tvmi_deformable_col2im(columns.const_data_ptr(), off_b.const_data_ptr(), mask_b.const_data_ptr(),
+                                        gi_b.mutable_data_ptr(), dt, nb, s.C, s.H, s.W, s.kh, s.kw, stride_h, stride_w,
+                                        pad_h, pad_w, dilation_h, dilation_w, n_offset_grps, use_mask ? 1 : 0, stream),
+                 "_deform_conv2d_backward(col2im)");
+    // (2) grad_weight += grad_out * im2col(input)^T
+    check_status(tvmi_deformable_im2col(in_b.const_data_ptr(), off_b.const_data_ptr(), mask_b.const_data_ptr(),
+                                        columns.mutable_data_ptr(), dt, nb, s.C, s.H, s.W, s.kh, s.kw, stride_h,
+                                        stride_w, pad_h, pad_w, dilation_h, dilation_w, n_offset_grps,
+                                        use_mask ? 1 : 0, stream),
+                 "_deform_conv2d_backward(im2col)");
+    at::Tensor col_g = columns.view({G, ICg * KK, nb * plane});
+    gw.baddbmm_(go_g, col_g.transpose(1, 2));
+  }
+  return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
+}
+
+// ---- box_iou_rotated: cuda/box_iou_rotated_kernel.cu:92-188
+at::Tensor box_iou_rotated(const at::Tensor& boxes1, const at::Tensor& boxes2) {
+  TORCH_CHECK(boxes1.is_cuda(), "boxes1 must be a CUDA tensor");
+  TORCH_CHECK(boxes2.is_cuda(), "boxes2 must be a CUDA tensor");
+  TORCH_CHECK(boxes1.dim() == 2 && boxes1.size(1) == 5, "boxes1 must have shape (N, 5)");
+  TORCH_CHECK(boxes2.dim() == 2 && boxes2.size(1) == 5, "boxes2 must have shape (M, 5)");
+  TORCH_CHECK(boxes1.scalar_type() == boxes2.scalar_type(), "boxes1 and boxes2 must have the same dtype");
+  c10::DeviceGuard guard(boxes1.device());
+  at::Tensor b1 = boxes1.contiguous(), b2 = boxes2.contiguous();
+  if (b1.scalar_type() == at::kHalf || b1.scalar_type() == at::kBFloat16) {
+    b1 = b1.to(at::kFloat);
+    b2 = b2.to(at::kFloat);
+  }
+  const int64_t N = b1.size(0), M = b2.size(0);
+  at::Tensor ious = at::empty({N, M}, b1.options().dtype(at::kFloat));
+  if (N > 0 && M > 0)
+    check_status(tvmi_box_iou_rotated(b1.const_data_ptr(), b2.const_data_ptr(), ious.mutable_data_ptr<float>(),
+                                      dtype_of(b1, "box_iou_rotated"), N, M, current_stream(boxes1)),
+                 "box_iou_rotated");
+  return ious;
+}
+
+// ---- resize (aten::upsample_* arithmetic; see include/tvmi.h).  mode: 0 nearest, 1 nearest-exact,
+// 2 bilinear, 3 bicubic.  Input [N,C,H,W] (any strides; made contiguous), output [N,C,OH,OW].
+at::Tensor interpolate2d(const at::Tensor& input, int64_t out_h, int64_t out_w, int64_t mode, bool align_corners,
+                         bool antialias, double scale_h, double scale_w) {
+  TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+  TORCH_CHECK(input.dim() == 4, "interpolate2d expects a 4d tensor [N, C, H, W]");
+  TORCH_CHECK(out_h >= 0 && out_w >= 0, "output size must be non-negative");
+  TORCH_CHECK(mode >= 0 && mode <= 3, "unknown interpolation mode ", mode);
+  TORCH_CHECK(!antialias || mode >= 2, "Anti-alias option is restricted to bilinear and bicubic modes");
+  TORCH_CHECK((input.size(2) > 0 && input.size(3) > 0) || input.numel() == 0,
+              "Input and output sizes should be greater than 0");
+  c10::DeviceGuard guard(input.device());
+  at::Tensor in_c = input.contiguous();
+  const int64_t N = input.size(0), C = input.size(1), IH = input.size(2), IW = input.size(3);
+  at::Tensor out = at::empty({N, C, out_h, out_w}, in_c.options());
+  if (out.numel() == 0) return out;
+  const tvmi_dtype dt = dtype_of(in_c, "interpolate2d");
+  void* stream = current_stream(input);
+  int st = 0;
+  if (mode <= 1) {
+    st = tvmi_upsample_nearest2d(in_c.const_data_ptr(), out.mutable_data_ptr(), dt, N * C, IH, IW, out_h, out_w,
+                                 mode == 1, scale_h, scale_w, stream);
+  } else if (antialias) {
+    const size_t wb = tvmi_upsample_aa2d_workspace_bytes((int)mode - 2, IH, IW, out_h, out_w, align_corners, scale_h,
+                                                         scale_w);
+    at::Tensor ws = at::empty({(int64_t)wb}, in_c.options().dtype(at::kByte));
+    st = tvmi_upsample_aa2d(in_c.const_data_ptr(), out.mutable_data_ptr(), dt, (int)mode - 2, N * C, IH, IW, out_h,
+                            out_w, align_corners, scale_h, scale_w, ws.mutable_data_ptr(), wb, stream);
+  } else if (mode == 2) {
+    st = tvmi_upsample_bilinear2d(in_c.const_data_ptr(), out.mutable_data_ptr(), dt, N * C, IH, IW, out_h, out_w,
+                                  align_corners, scale_h, scale_w, stream);
+  } else {
+    st = tvmi_upsample_bicubic2d(in_c.const_data_ptr(), out.mutable_data_ptr(), dt, N * C, IH, IW, out_h, out_w,
+                                 align_corners, scale_h, scale_w, stream);
+  }
+  check_status(st, "interpolate2d");
+  return out;
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -187,14 +506,30 @@ TORCH_LIBRARY(tvmi, m) {
   m.def("abi_version", &tvmi_abi_version);
   // batched NMS without the per-class python loop of torchvision/ops/boxes.py:113-126
   m.def("nms_segmented(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold) -> Tensor");
+  // aten::upsample_* arithmetic on our kernels (mode 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic;
+  // scale_* <= 0 means "not given")
+  m.def(
+      "interpolate2d(Tensor input, int out_h, int out_w, int mode, bool align_corners, bool antialias, float scale_h, float scale_w) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
   m.impl("nms", &nms);
   m.impl("roi_align", &roi_align_forward);
   m.impl("_roi_align_backward", &roi_align_backward);
+  m.impl("roi_pool", &roi_pool_forward);
+  m.impl("_roi_pool_backward", &roi_pool_backward);
+  m.impl("ps_roi_align", &ps_roi_align_forward);
+  m.impl("_ps_roi_align_backward", &ps_roi_align_backward);
+  m.impl("ps_roi_pool", &ps_roi_pool_forward);
+  m.impl("_ps_roi_pool_backward", &ps_roi_pool_backward);
+  m.impl("deform_conv2d", &deform_conv2d_forward);
+  m.impl("_deform_conv2d_backward", &deform_conv2d_backward);
+  m.impl("box_iou_rotated", &box_iou_rotated);
 }
 
-TORCH_LIBRARY_IMPL(tvmi, CUDA, m) { m.impl("nms_segmented", &nms_segmented); }
+TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
+  m.impl("nms_segmented", &nms_segmented);
+  m.impl("interpolate2d", &interpolate2d);
+}
 
 }  // namespace tvmi_shim
