@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+metric   : boxes/sec RoIAlign+NMS (1000 proposals per image, 256-channel FPN maps)   [BASELINE.json]
+workload : BASELINE config 2 — a batch of 4 padded 800x1344 images per GPU, 4 FPN levels x 256 channels
+           (strides 4/8/16/32, fp32), 1000 proposals per image.  One "step" = one pass of the hot path
+           over that batch: MultiScaleRoIAlign 7x7 (sampling_ratio 2) of the 4000 proposals, then per-image
+           NMS (batched_nms over the image index, IoU 0.5), then — when N > 1 — the one fixed-shape RCCL
+           all-gather of the padded top-100 detections of every image.
+inputs   : synthetic (seeded), resident in HBM before the timed region.
+scaling  : weak — every rank owns its own batch of images (the path shards over images; no data-path
+           collective besides the detection all-gather).  value = boxes processed by ALL ranks / time.
+
+Besides the contract line it reports
+  roofline     : dominant kernel (multi-scale RoIAlign forward): algorithmic bytes per launch
+                 (= all feature maps + output + rois) / its mean launch time measured
+                 with events on the launch stream, against the 8 TB/s HBM peak; `traffic` = HBM bytes
+                 per launch from a separate rocprofv3 --pmc pass (profiles/roofline_traffic.json) or null.
+  cpu_baseline : the reference's own CPU kernels (oracle/_ref, kind "reference") — or the C port when
+                 that library is absent — timed on this host on the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+IMG_H, IMG_W, CHANNELS, BATCH, PROPOSALS = 800, 1344, 256, 4, 1000
+STRIDES = (4, 8, 16, 32)
+POOL, SAMPLING, NMS_THR, MAX_DETS = 7, 2, 0.5, 100
+
+
+def make_inputs(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = {}
+    for i, s in enumerate(STRIDES):
+        feats[str(i)] = torch.randn(BATCH, CHANNELS, IMG_H // s, IMG_W // s, generator=g).to(device)
+    boxes, scores = [], []
+    for _ in range(BATCH):
+        # proposal-like boxes: sqrt(area) log-uniform in [16, 640] px (all four FPN levels receive
+        # proposals) and aspect ratio log-uniform in [1/3, 3] (RPN anchors use 1:2..2:1)
+        xy = torch.rand(PROPOSALS, 2, generator=g) * torch.tensor([IMG_W - 64.0, IMG_H - 64.0])
+        side = torch.exp(torch.rand(PROPOSALS, generator=g) * (math.log(640.0) - math.log(16.0)) + math.log(16.0))
+        aspect = torch.exp((torch.rand(PROPOSALS, generator=g) * 2 - 1) * math.log(3.0))
+        wh = torch.stack([side * aspect.sqrt(), side / aspect.sqrt()], 1)
+        x2y2 = torch.minimum(xy + wh, torch.tensor([float(IMG_W), float(IMG_H)]))
+        boxes.append(torch.cat([xy, x2y2], 1).to(device))
+        scores.append(torch.rand(PROPOSALS, generator=g).to(device))
+    return feats, boxes, scores
+
+
+def algorithmic_bytes(feats, n_boxes):
+    inp = sum(f.numel() * f.element_size() for f in feats.values())
+    out = n_boxes * CHANNELS * POOL * POOL * 4
+    return inp + out + n_boxes * 5 * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    import vision_amd  # fails loudly if the HIP extension is missing
+    from vision_amd import sharding
+
+    feats, boxes, scores = make_inputs(device, seed=1000 + rank)
+    pool = vision_amd.MultiScaleRoIAlign([str(i) for i in range(len(STRIDES))], POOL, SAMPLING)
+    image_shapes = [(IMG_H, IMG_W)] * BATCH
+    all_boxes = torch.cat(boxes)
+    all_scores = torch.cat(scores)
+    img_idx = torch.cat([torch.full((PROPOSALS,), i, device=device, dtype=torch.int64) for i in range(BATCH)])
+
+    def step():
+        with torch.no_grad():
+            pooled = pool(feats, boxes, image_shapes)                               # [4000, 256, 7, 7]
+            keep = vision_amd.batched_nms(all_boxes, all_scores, img_idx, NMS_THR)  # per-image NMS
+            # padded top-MAX_DETS detections per image, fixed shape, ONE launch
+            dets, counts = sharding.pack_kept_detections(all_boxes, all_scores, img_idx, keep, BATCH, MAX_DETS)
+            gd, gc = sharding.all_gather_detections(dets, counts)
+        return pooled, keep, gd, gc
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    boxes_per_step = BATCH * PROPOSALS * world
+    value = boxes_per_step / (ms_per_step / 1e3)
+
+    # ---- roofline of the dominant kernel, measured live with events on the launch stream
+    from vision_amd.poolers import _convert_to_roi_format
+
+    rois5 = _convert_to_roi_format(boxes)
+    flist = [feats[str(i)] for i in range(len(STRIDES))]
+    scales = [1.0 / s for s in STRIDES]
+
+    def roi_op():  # exactly what pool() launches, without its python-side roi formatting
+        return torch.ops.tvmi.multiscale_roi_align(flist, rois5, scales, POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
+
+    with torch.no_grad():
+        for _ in range(5):
+            roi_op()
+        torch.cuda.synchronize()
+        n_k = 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_k):
+            roi_op()
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / n_k
+        # NMS alone, for the breakdown in `config`
+        e0.record()
+        for _ in range(n_k):
+            vision_amd.batched_nms(all_boxes, all_scores, img_idx, NMS_THR)
+        e1.record()
+        torch.cuda.synchronize()
+        nms_ms = e0.elapsed_time(e1) / n_k
+    alg_bytes = algorithmic_bytes(feats, BATCH * PROPOSALS)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("roi_align_fwd_ms_dma", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "boxes/sec RoIAlign+NMS (1000 prop, 256ch FPN)",
+        "value": round(value, 1),
+        "unit": "boxes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 2: per GPU 4x(800x1344) images, FPN P2-P5 x256ch fp32, 1000 proposals/image; "
+                        "step = MultiScaleRoIAlign 7x7 sr2 (1 launch) + per-image NMS@0.5 + all-gather of padded top-100 dets",
+            "boxes_per_step_per_gpu": BATCH * PROPOSALS,
+            "roi_align_ms": round(k_ms, 4),
+            "nms_ms": round(nms_ms, 4),
+            "kept_boxes": int(out[1].numel()),
+            "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
+        },
+        "roofline": {
+            "kernel": "roi_align_fwd_ms_dma<7,7,2>",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "launch_ms": round(k_ms, 4),
+            "traffic": traffic,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(feats, boxes, scores)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(feats, boxes, scores):
+    """The reference's CPU path on the SAME workload, on this host (checker only — never the product)."""
+    from oracle import oracle as O
+
+    cpu_feats = {k: v.cpu() for k, v in feats.items()}
+    cpu_boxes = [b.cpu() for b in boxes]
+    cpu_scores = [s.cpu() for s in scores]
+    kind = "reference" if O.load_reference() else "port"
+    import vision_amd
+    from vision_amd.poolers import LevelMapper, _convert_to_roi_format
+
+    rois = _convert_to_roi_format(cpu_boxes)
+    levels = LevelMapper(2, 5)(cpu_boxes)
+    scales = [1.0 / s for s in STRIDES]
+    torch.set_num_threads(1)
+
+    def run_once():
+        t0 = time.perf_counter()
+        for lvl in range(len(STRIDES)):
+            sel = torch.nonzero(levels == lvl)[:, 0]
+            if kind == "reference":
+                torch.ops.torchvision.roi_align(cpu_feats[str(lvl)], rois[sel], scales[lvl], POOL, POOL, SAMPLING, False)
+            else:
+                O.roi_align(cpu_feats[str(lvl)].numpy(), rois[sel].numpy(), scales[lvl], POOL, POOL, SAMPLING, False)
+        for b, s in zip(cpu_boxes, cpu_scores):
+            if kind == "reference":
+                torch.ops.torchvision.nms(b, s, NMS_THR)
+            else:
+                O.nms(b.numpy(), s.numpy(), NMS_THR)
+        return time.perf_counter() - t0
+
+    times = [run_once()]  # first run doubles as warm-up and is kept if the budget is tight
+    budget = 20.0
+    while sum(times) < budget and len(times) < 9:
+        times.append(run_once())
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": round(BATCH * PROPOSALS / med, 1),
+        "unit": "boxes/s",
+        "cores": 1,
+        "kind": kind,
+        "sample": f"full step workload (4 images x 1000 proposals, 4 FPN levels, RoIAlign 7x7 + per-image NMS), "
+                  f"median of {len(times)} runs, {sum(times):.1f} s of CPU work, single-threaded reference kernels; "
+                  f"host has {os.cpu_count()} logical CPUs",
+        "seconds_per_step": round(med, 4),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,9 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
  * torchvision/csrc/ops/cpu/roi_align_kernel.cpp:18-115,183-289 and
  * cpu/roi_align_common.h:32-124.
  *   input  [N,C,H,W]  output [K,C,PH,PW] (fully overwritten, no pre-zero needed)
+ *   workspace (optional, may be NULL): 2*K*4 bytes of device scratch (RoI processing order +
+ *   per-RoI "declined by the LDS-DMA kernel" flags).  Without it the fp32 fast path that needs
+ *   the flags is not used; results do not depend on it.
  * backward: grad [K,C,PH,PW] read with the given element strides; grad_input
  * [N,C,H,W] must be zero-filled by the caller (the launcher accumulates atomically).
  * F16/BF16 accumulate in fp32.
@@ -71,12 +74,29 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
 int tvmi_roi_align_forward(const void* input, const void* rois, void* output, tvmi_dtype dt,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                            int64_t pooled_h, int64_t pooled_w, double spatial_scale,
-                           int64_t sampling_ratio, int aligned, void* stream);
+                           int64_t sampling_ratio, int aligned, void* workspace, size_t workspace_bytes,
+                           void* stream);
 int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input, tvmi_dtype dt,
                             int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                             int64_t pooled_h, int64_t pooled_w, double spatial_scale,
                             int64_t sampling_ratio, int aligned, int64_t n_stride,
                             int64_t c_stride, int64_t h_stride, int64_t w_stride, void* stream);
+
+/* Multi-scale RoIAlign (FPN): replaces the per-level python loop of
+ * torchvision/ops/poolers.py:147-227 (_multiscale_roi_align: LevelMapper -> torch.where ->
+ * roi_align -> index_put per level) with ONE launch.  `inputs[l]` is level l's [N,C,H_l,W_l]
+ * feature map (same N, C, dtype), `rois` [K,5] are in IMAGE coordinates; the level of a RoI
+ * is floor(canonical_level + log2(sqrt(area)/canonical_scale) + eps) clamped to
+ * [k_min, k_max], minus k_min (poolers.py:73-84).  output [K,C,PH,PW], fully overwritten.
+ * F32 / F16 / BF16.
+ */
+int tvmi_multiscale_roi_align_forward(const void* const* inputs, const int64_t* heights,
+                                      const int64_t* widths, const double* spatial_scales,
+                                      int64_t n_levels, const void* rois, void* output, tvmi_dtype dt,
+                                      int64_t N, int64_t C, int64_t K, int64_t pooled_h, int64_t pooled_w,
+                                      int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
+                                      double canonical_scale, double canonical_level, double eps,
+                                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ----------------------------------------------- RoIPool / PSRoIAlign / PSRoIPool ------
  * Replaces: cuda/roi_pool_kernel.cu:15-125,127-260, cuda/ps_roi_align_kernel.cu,
@@ -142,6 +162,18 @@ int tvmi_deformable_col2im_coord(const void* columns, const void* input, const v
                                  int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t stride_h,
                                  int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w,
                                  int64_t offset_groups, int use_mask, void* stream);
+
+/* ---------------------------------------------------- detection post-processing --------
+ * One launch from the score-ordered keep list of a (batched) NMS to the fixed-shape payload
+ * that is all-gathered across GPUs: dets [num_images, max_dets, 6] fp32 = (x1,y1,x2,y2,score,
+ * label) zero padded, counts [num_images] int32.  Replaces the index / split / top-k glue of
+ * torchvision/models/detection/roi_heads.py:720-735 and the pickled all_gather_object of
+ * references/detection/utils.py:70-83.  boxes [N,4] fp32, scores [N] fp32, labels [N] int64 or
+ * NULL, image_idx [N] int64, keep [num_keep] int64 (descending score).  num_images <= 256.
+ */
+int tvmi_pack_detections(const float* boxes, const float* scores, const int64_t* labels,
+                         const int64_t* image_idx, const int64_t* keep, int64_t num_keep, int64_t num_images,
+                         int64_t max_dets, float* dets, int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------- box_iou_rotated ------------
  * Replaces: cuda/box_iou_rotated_kernel.cu:41-188; semantics of box_iou_rotated_utils.h:67-383

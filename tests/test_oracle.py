@@ -1,0 +1,141 @@
+"""Pins the oracle: the plain-C restatement (oracle/tvmi_oracle.c) must reproduce
+(a) the committed golden vectors generated from the reference's own CPU kernels,
+(b) the reference itself (oracle/_ref) on fresh seeded inputs when it is available, and
+(c) the known-answer vectors the reference's tests hold for this path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from helpers import adversarial_nms_inputs, gen, golden, python_greedy_nms, rois_for
+
+
+def test_nms_golden_bit_exact():
+    g = golden("nms")
+    for i in range(int(g["count"])):
+        keep = O.nms(g[f"boxes{i}"], g[f"scores{i}"], float(g[f"thr{i}"]))
+        assert np.array_equal(keep, g[f"keep{i}"]), f"case {i}"
+
+
+def test_roi_ops_golden():
+    g = golden("roi_ops")
+    x, rois = g["x"], g["rois"]
+    C = x.shape[1]
+    for scale in (1.0, 0.5):
+        for sr in (-1, 2):
+            for aligned in (False, True):
+                key = f"s{scale}_sr{sr}_a{int(aligned)}"
+                y = O.roi_align(x, rois, scale, 5, 5, sr, aligned)
+                np.testing.assert_array_equal(y, g["roi_align_" + key])
+                gr = np.linspace(-1, 1, y.size, dtype=np.float32).reshape(y.shape)
+                gin = O.roi_align_backward(gr, rois, scale, 5, 5, 2, C, 10, 10, sr, aligned)
+                np.testing.assert_allclose(gin, g["roi_align_bwd_" + key], rtol=0, atol=1e-6)
+            y, m = O.ps_roi_align(x, rois[:-1], scale, 5, 5, sr)
+            np.testing.assert_array_equal(y, g[f"ps_roi_align_s{scale}_sr{sr}"])
+            np.testing.assert_array_equal(m, g[f"ps_roi_align_map_s{scale}_sr{sr}"])
+        y, a = O.roi_pool(x, rois, scale, 5, 5)
+        np.testing.assert_array_equal(y, g[f"roi_pool_s{scale}"])
+        np.testing.assert_array_equal(a, g[f"roi_pool_argmax_s{scale}"])
+        y, m = O.ps_roi_pool(x, rois, scale, 5, 5)
+        np.testing.assert_array_equal(y, g[f"ps_roi_pool_s{scale}"])
+        np.testing.assert_array_equal(m, g[f"ps_roi_pool_map_s{scale}"])
+
+
+def test_deform_conv2d_golden():
+    g = golden("deform_conv2d")
+    args = dict(stride=(2, 1), pad=(1, 0), dil=(2, 1), groups=2, offset_groups=3)
+    out = O.deform_conv2d(g["x"], g["weight"], g["offset"], g["mask"], g["bias"], use_mask=True, **args)
+    np.testing.assert_allclose(out, g["out_mask"], rtol=0, atol=1e-5)
+    out = O.deform_conv2d(g["x"], g["weight"], g["offset"], None, g["bias"], use_mask=False, **args)
+    np.testing.assert_allclose(out, g["out_nomask"], rtol=0, atol=1e-5)
+
+
+def test_box_iou_rotated_golden():
+    g = golden("box_iou_rotated")
+    np.testing.assert_array_equal(O.box_iou_rotated(g["b1"], g["b2"]), g["iou"])
+    np.testing.assert_array_equal(O.box_iou_rotated(g["b1"].astype(np.float64), g["b2"].astype(np.float64)), g["iou64"])
+
+
+def test_box_iou_rotated_reference_known_answers():
+    # analytic matrix of the reference's TestRotatedBoxIou.test_iou (test/test_ops.py:1848-1875)
+    boxes = np.array([[0, 0, 10, 10, 45], [0, 0, 10, 10, 135], [0, 0, 10, 10, -45], [0, 0, 10, 10, -135],
+                      [100, 100, 10, 10, 30], [50, 50, 20, 10, 45], [50, 50, 20, 10, 135], [50, 50, 20, 10, -135]],
+                     dtype=np.float32)
+    t = 1 / 3
+    expected = np.array([[1, 1, 1, 1, 0, 0, 0, 0]] * 4 + [[0, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 1, t, 1],
+                                                            [0, 0, 0, 0, 0, t, 1, t], [0, 0, 0, 0, 0, 1, t, 1]], dtype=np.float32)
+    for dt in (np.float32, np.float64):
+        np.testing.assert_allclose(O.box_iou_rotated(boxes.astype(dt), boxes.astype(dt)), expected, atol=1e-4, rtol=1e-4)
+
+
+def test_resize_golden_pins_torch_cpu():
+    g = golden("resize")
+    img = g["img"]
+    for key in g.files:
+        if key in ("img", "torch_version"):
+            continue
+        mode, size, flag = key.rsplit("_", 2)
+        oh, ow = (int(v) for v in size.split("x"))
+        out = O.interpolate(img, (oh, ow), mode, align_corners=flag == "ac1", antialias=flag == "aa1")
+        np.testing.assert_allclose(out, g[key], rtol=0, atol=1e-5, err_msg=key)
+
+
+def test_nms_matches_independent_greedy_loop():
+    # same construction as the reference's test_nms_ref (test/test_ops.py:916-925)
+    for thr in (0.2, 0.5, 0.8):
+        for seed in range(3):
+            boxes, scores = adversarial_nms_inputs(300, thr, gen(seed))
+            keep = O.nms(boxes.numpy(), scores.numpy(), thr)
+            assert np.array_equal(keep, python_greedy_nms(boxes, scores, thr).numpy())
+
+
+def test_nms_segmented_equals_per_class_loop():
+    g = gen(4)
+    boxes = torch.rand(500, 4, generator=g) * 50
+    boxes[:, 2:] += boxes[:, :2]
+    scores = torch.rand(500, generator=g)
+    idxs = torch.randint(0, 5, (500,), generator=g)
+    keep = O.nms(boxes.numpy(), scores.numpy(), 0.4, idxs.numpy())
+    mask = np.zeros(500, dtype=bool)
+    for c in range(5):
+        sel = np.nonzero(idxs.numpy() == c)[0]
+        mask[sel[O.nms(boxes.numpy()[sel], scores.numpy()[sel], 0.4)]] = True
+    expect = np.nonzero(mask)[0]
+    expect = expect[np.argsort(-scores.numpy()[expect], kind="stable")]
+    assert np.array_equal(keep, expect)
+
+
+# ---------------------------------------------------------------- against the reference itself
+def test_oracle_vs_reference_fresh_inputs(need_ref, tv):
+    g = gen(21)
+    for dt in (torch.float32, torch.float64):
+        x = torch.randn(2, 18, 13, 11, generator=g).to(dt)
+        rois = rois_for(2, 25, 22, 26, 2, 20, g, dt)
+        rois[0, 1:] = torch.tensor([-5.0, -4.0, 40.0, 35.0], dtype=dt)
+        for scale, sr, al in ((0.5, 2, False), (0.5, 0, True), (1.0, 3, True)):
+            ref = tv.roi_align(x, rois, scale, 3, 3, sr, al).numpy()
+            np.testing.assert_array_equal(O.roi_align(x.numpy(), rois.numpy(), scale, 3, 3, sr, al), ref)
+            gr = torch.randn(ref.shape, generator=g).to(dt)
+            refb = tv._roi_align_backward(gr, rois, scale, 3, 3, 2, 18, 13, 11, sr, al).numpy()
+            np.testing.assert_allclose(O.roi_align_backward(gr.numpy(), rois.numpy(), scale, 3, 3, 2, 18, 13, 11, sr, al),
+                                       refb, rtol=0, atol=1e-6)
+        y, a = tv.roi_pool(x, rois, 0.5, 3, 3)
+        yo, ao = O.roi_pool(x.numpy(), rois.numpy(), 0.5, 3, 3)
+        np.testing.assert_array_equal(yo, y.numpy())
+        np.testing.assert_array_equal(ao, a.numpy())
+        y, m = tv.ps_roi_align(x, rois, 0.5, 3, 3, 2)
+        yo, mo = O.ps_roi_align(x.numpy(), rois.numpy(), 0.5, 3, 3, 2)
+        np.testing.assert_array_equal(yo, y.numpy())
+        np.testing.assert_array_equal(mo, m.numpy())
+        gr = torch.randn(y.shape, generator=g).to(dt)
+        np.testing.assert_allclose(O.ps_roi_align_backward(gr.numpy(), rois.numpy(), mo, 0.5, 3, 3, 2, 2, 18, 13, 11),
+                                   tv._ps_roi_align_backward(gr, rois, m, 0.5, 3, 3, 2, 2, 18, 13, 11).numpy(), atol=1e-6)
+        y, m = tv.ps_roi_pool(x, rois, 0.5, 3, 3)
+        yo, mo = O.ps_roi_pool(x.numpy(), rois.numpy(), 0.5, 3, 3)
+        np.testing.assert_array_equal(yo, y.numpy())
+        np.testing.assert_array_equal(mo, m.numpy())
+        np.testing.assert_allclose(O.ps_roi_pool_backward(gr.numpy(), rois.numpy(), mo, 0.5, 3, 3, 2, 18, 13, 11),
+                                   tv._ps_roi_pool_backward(gr, rois, m, 0.5, 3, 3, 2, 18, 13, 11).numpy(), atol=1e-6)
+        boxes, scores = adversarial_nms_inputs(700, 0.5, g, dup=True)
+        boxes, scores = boxes.to(dt), scores.to(dt)
+        assert np.array_equal(O.nms(boxes.numpy(), scores.numpy(), 0.5), tv.nms(boxes, scores, 0.5).numpy())

@@ -1,0 +1,27 @@
+"""Runs one hot-path kernel a few times (for rocprofv3 --pmc / --kernel-trace passes)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, vision_amd, bench
+which = sys.argv[1] if len(sys.argv) > 1 else "roi7"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+feats, boxes, scores = bench.make_inputs(dev, 1000)
+shapes = [(800, 1344)] * 4
+with torch.no_grad():
+    if which in ("roi7", "roi14"):
+        pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7 if which == "roi7" else 14, 2)
+        for _ in range(reps):
+            pool(feats, boxes, shapes)
+    elif which == "nms":
+        b, s = torch.cat(boxes), torch.cat(scores)
+        idx = torch.cat([torch.full((1000,), i, device=dev, dtype=torch.int64) for i in range(4)])
+        for _ in range(reps):
+            vision_amd.batched_nms(b, s, idx, 0.5)
+    elif which == "dcn":
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(2, 256, 100, 136, generator=g).to(dev); w = (torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(dev)
+        off = torch.randn(2, 18, 100, 136, generator=g).to(dev)
+        for _ in range(reps):
+            vision_amd.deform_conv2d(x, off, w, padding=1)
+torch.cuda.synchronize()

@@ -116,7 +116,24 @@ def _fake_box_iou_rotated(boxes1, boxes2):
     return boxes1.new_empty((boxes1.size(0), boxes2.size(0)), dtype=torch.float32)
 
 
+def _fake_multiscale(features, rois, scales, pooled_height, pooled_width, sampling_ratio, aligned, k_min, k_max,
+                     canonical_scale, canonical_level, eps):
+    return features[0].new_empty((rois.size(0), features[0].size(1), pooled_height, pooled_width))
+
+
+def _fake_interpolate2d(input, out_h, out_w, mode, align_corners, antialias, scale_h, scale_w):
+    return input.new_empty((input.size(0), input.size(1), out_h, out_w))
+
+
+def _fake_pack_detections(boxes, scores, labels, image_idx, keep, num_images, max_dets):
+    return (boxes.new_empty((num_images, max_dets, 6), dtype=torch.float32),
+            boxes.new_empty((num_images,), dtype=torch.int32))
+
+
 _FAKES = {
+    "tvmi::pack_detections": _fake_pack_detections,
+    "tvmi::multiscale_roi_align": _fake_multiscale,
+    "tvmi::interpolate2d": _fake_interpolate2d,
     "torchvision::nms": _fake_nms,
     "tvmi::nms_segmented": _fake_nms_segmented,
     "torchvision::roi_align": _fake_roi_align,

@@ -10,19 +10,24 @@
 //     cuda/nms_kernel.cu:45 — that is NOT what we reproduce);
 //   * 0/0 = NaN compares false, so degenerate boxes neither suppress nor get suppressed.
 //
-// Structure (differs from cuda/nms_kernel.cu:56-148):
-//   K1 nms_mask_kernel : one wave per (64-row block) x (8 x 64-column blocks).  Lane = column
-//      box (registers); the 64 row boxes sit in LDS and are broadcast.  For every row the
-//      64-lane predicate is turned into the 64-bit suppression word by the compare itself
-//      (__ballot, an SGPR pair) and parked in lane `row`; after 8 column blocks each lane
-//      owns one full 64-byte line of the row-major mask and stores it with 4 dwordx4.
-//      Boxes are gathered through `order` in-kernel (no index_select pass), areas are
-//      recomputed from the box (same value the reference caches).
-//   K2 nms_sweep_kernel: ONE 1024-thread workgroup walks the 64-box blocks in order.  Wave 0
-//      resolves the diagonal 64x64 tile with a register-only scalar loop (v_readlane), the
-//      whole workgroup then ORs the kept rows into the LDS-resident `removed` bit-vector with
-//      coalesced row reads, and wave 0 appends the kept original indices (in score order)
-//      and finally the count — no N-step single-thread loop, no masked_select pass.
+// Structure (differs from cuda/nms_kernel.cu:56-148, whose second kernel is one block doing
+// N serial steps with a barrier each):
+//   K1 nms_mask_tiles  : one wave per upper-triangular 64x64 tile.  Lane = column box (in
+//      registers), the 64 row boxes sit in LDS and are broadcast; for every row the 64-lane
+//      predicate becomes the 64-bit suppression word through the compare itself (__ballot =
+//      an SGPR pair) and is parked in lane `row`.  The mask is stored TILE-major: tile
+//      (rb, cb) is 64 consecutive words, so both this store and every later read of a tile
+//      is one coalesced 512-byte access.  Boxes are gathered through `order` in-kernel.
+//   The greedy sweep is blocked in super-blocks of 16 x 64 boxes and formulated as a PULL:
+//   K2 nms_colreduce   : (super-blocks > 0) removed[cb] |= OR over rows kept in EARLIER
+//      super-blocks of tile(rb, cb)[row] — thousands of independent waves, each a masked
+//      512-byte load + a DPP OR-reduction + one atomic.
+//   K3 nms_resolve     : one 16-wave workgroup per super-block.  Wave c owns column block c:
+//      it prefetches its diagonal tile and the <=15 tiles above it into registers (no memory
+//      access inside the serial chain), folds in the keep bits of the blocks before it as
+//      they are published through LDS, then resolves its own 64 boxes with a scalar loop over
+//      the not-yet-removed bits (s_ff1 + v_readlane).  Kept original indices are written in
+//      score order and the running count stays on the device — no masked_select pass.
 #include <algorithm>
 #include <type_traits>
 
@@ -31,9 +36,10 @@
 namespace tvmi {
 namespace {
 
-constexpr int kColGroup = 8;  // column blocks per wave task (8 x 8 B = one 64-B mask line)
-constexpr int kMaskWaves = 4; // waves per workgroup in K1
-constexpr int kSweepThreads = 1024;
+constexpr int kMaskWaves = 4;    // waves (= tiles of one row block) per workgroup in K1
+constexpr int kSuper = 16;       // 64-box blocks per super-block
+constexpr int kReduceRows = 8;   // row blocks folded per wave in K2
+typedef unsigned long long u64;
 
 template <typename T>
 struct Box {
@@ -58,182 +64,217 @@ __device__ __forceinline__ Box<T> load_box(const T* dets, int64_t i) {
   return b;
 }
 
-// mask layout: row-major [n][cb_pad] u64, cb_pad = col_blocks rounded up to kColGroup.
+// ---- wave-wide OR of a 32-bit value: DPP inside each 16-lane row, v_readlane across rows
+__device__ __forceinline__ unsigned int wave_or32(unsigned int v) {
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+  return (unsigned int)__builtin_amdgcn_readlane((int)v, 0) | (unsigned int)__builtin_amdgcn_readlane((int)v, 16) |
+         (unsigned int)__builtin_amdgcn_readlane((int)v, 32) | (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ u64 wave_or64(u64 v) {
+  return ((u64)wave_or32((unsigned int)(v >> 32)) << 32) | (u64)wave_or32((unsigned int)v);
+}
+__device__ __forceinline__ u64 uniform64(u64 v) {  // value is wave-uniform: move it to SGPRs
+  return ((u64)(unsigned int)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (u64)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+  return ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
+         (u64)(unsigned int)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// mask layout: tile (rb, cb) = 64 words at mask + (rb*CB + cb)*64; word r = row rb*64+r.
 template <typename T>
-__global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_kernel(
-    const T* __restrict__ dets, const int64_t* __restrict__ order, const int64_t* __restrict__ seg,
-    int n, int col_blocks, int cb_pad, double thr, unsigned long long* __restrict__ mask) {
-  __shared__ T s_row[kMaskWaves][64][5];       // x1,y1,x2,y2,area of the wave's row block
-  __shared__ long long s_seg[kMaskWaves][64];
+__global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
+    const T* __restrict__ dets, const int64_t* __restrict__ order, const int64_t* __restrict__ seg, int n, int CB,
+    double thr, u64* __restrict__ mask) {
+  __shared__ T s_row[64][5];  // x1,y1,x2,y2,area of the row block
+  __shared__ long long s_seg[64];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int row_blk = blockIdx.y;
-  const int col_grp = blockIdx.x * kMaskWaves + wave;
-  const int cb0 = col_grp * kColGroup;
-  if (cb0 >= cb_pad) return;
-  const int row0 = row_blk * 64;
-  const int my_row = row0 + lane;
-  unsigned long long words[kColGroup];
-#pragma unroll
-  for (int q = 0; q < kColGroup; ++q) words[q] = 0ull;
-
-  // Column groups entirely left of the diagonal hold no (j > i) pair
-  // (the sweep never reads them, so they are not even written)
-  const bool active = (cb0 + kColGroup - 1 >= row_blk) && (cb0 < col_blocks);
-  if (!active) return;
-  {
-    // stage the 64 row boxes (wave-private LDS region; no workgroup barrier needed)
-    {
-      T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-      long long sg = 0;
-      if (my_row < n) {
-        const int64_t oi = order[my_row];
-        const Box<T> b = load_box<T>(dets, oi);
-        x1 = b.x1;
-        y1 = b.y1;
-        x2 = b.x2;
-        y2 = b.y2;
-        if (seg) sg = seg[oi];
-      }
-      s_row[wave][lane][0] = x1;
-      s_row[wave][lane][1] = y1;
-      s_row[wave][lane][2] = x2;
-      s_row[wave][lane][3] = y2;
-      s_row[wave][lane][4] = (x2 - x1) * (y2 - y1);
-      s_seg[wave][lane] = sg;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rb = blockIdx.y;
+  const int cb = blockIdx.x * kMaskWaves + wave;
+  if ((int)(blockIdx.x * kMaskWaves + kMaskWaves - 1) < rb) return;  // whole workgroup left of the diagonal
+  const int row0 = rb * 64;
+  if (threadIdx.x < 64) {
+    const int r = row0 + lane;
+    T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    long long sg = 0;
+    if (r < n) {
+      const int64_t oi = order[r];
+      const Box<T> b = load_box<T>(dets, oi);
+      x1 = b.x1;
+      y1 = b.y1;
+      x2 = b.x2;
+      y2 = b.y2;
+      if (seg) sg = seg[oi];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int rows_here = min(64, n - row0);
-#pragma unroll
-    for (int q = 0; q < kColGroup; ++q) {
-      const int cb = cb0 + q;
-      if (cb < row_blk || cb >= col_blocks) continue;  // wave-uniform
-      const int j = cb * 64 + lane;
-      T jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0;
-      long long jseg = 0;
-      const bool jvalid = j < n;
-      if (jvalid) {
-        const int64_t oj = order[j];
-        const Box<T> b = load_box<T>(dets, oj);
-        jx1 = b.x1;
-        jy1 = b.y1;
-        jx2 = b.x2;
-        jy2 = b.y2;
-        if (seg) jseg = seg[oj];
-      }
-      const T jarea = (jx2 - jx1) * (jy2 - jy1);
-      const bool diag = cb == row_blk;
-      unsigned long long mine = 0ull;
-      for (int i = 0; i < rows_here; ++i) {
-        const T ix1 = s_row[wave][i][0], iy1 = s_row[wave][i][1];
-        const T ix2 = s_row[wave][i][2], iy2 = s_row[wave][i][3];
-        const T iarea = s_row[wave][i][4];
-        const T xx1 = ix1 > jx1 ? ix1 : jx1;  // std::max(ix1, x1[j])
-        const T yy1 = iy1 > jy1 ? iy1 : jy1;
-        const T xx2 = jx2 < ix2 ? jx2 : ix2;  // std::min(ix2, x2[j])
-        const T yy2 = jy2 < iy2 ? jy2 : iy2;
-        const T dw = xx2 - xx1, dh = yy2 - yy1;
-        const T w = (T)0 < dw ? dw : (T)0;    // std::max(0, xx2-xx1)
-        const T h = (T)0 < dh ? dh : (T)0;
-        const T inter = w * h;
-        const T ovr = inter / (iarea + jarea - inter);
-        bool p = ((double)ovr > thr) && jvalid;
-        if (diag) p = p && (lane > i);
-        if (seg) p = p && (jseg == s_seg[wave][i]);
-        const unsigned long long word = __ballot(p);
-        if (lane == i) mine = word;
-      }
-      words[q] = mine;
-    }
+    s_row[lane][0] = x1;
+    s_row[lane][1] = y1;
+    s_row[lane][2] = x2;
+    s_row[lane][3] = y2;
+    s_row[lane][4] = (x2 - x1) * (y2 - y1);
+    s_seg[lane] = sg;
   }
-  if (my_row < n) {
-    unsigned long long* dst = mask + (size_t)my_row * cb_pad + cb0;
-    ulonglong2* d2 = reinterpret_cast<ulonglong2*>(dst);
-#pragma unroll
-    for (int q = 0; q < kColGroup / 2; ++q) d2[q] = make_ulonglong2(words[2 * q], words[2 * q + 1]);
+  __syncthreads();
+  if (cb < rb || cb >= CB) return;
+  const int j = cb * 64 + lane;
+  T jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0;
+  long long jseg = 0;
+  const bool jvalid = j < n;
+  if (jvalid) {
+    const int64_t oj = order[j];
+    const Box<T> b = load_box<T>(dets, oj);
+    jx1 = b.x1;
+    jy1 = b.y1;
+    jx2 = b.x2;
+    jy2 = b.y2;
+    if (seg) jseg = seg[oj];
   }
+  const T jarea = (jx2 - jx1) * (jy2 - jy1);
+  const bool diag = cb == rb;
+  const int rows_here = min(64, n - row0);
+  u64 mine = 0ull;
+  for (int i = 0; i < rows_here; ++i) {
+    const T ix1 = s_row[i][0], iy1 = s_row[i][1], ix2 = s_row[i][2], iy2 = s_row[i][3];
+    const T iarea = s_row[i][4];
+    const T xx1 = ix1 > jx1 ? ix1 : jx1;  // std::max(ix1, x1[j])
+    const T yy1 = iy1 > jy1 ? iy1 : jy1;
+    const T xx2 = jx2 < ix2 ? jx2 : ix2;  // std::min(ix2, x2[j])
+    const T yy2 = jy2 < iy2 ? jy2 : iy2;
+    const T dw = xx2 - xx1, dh = yy2 - yy1;
+    const T w = (T)0 < dw ? dw : (T)0;    // std::max(0, xx2-xx1)
+    const T h = (T)0 < dh ? dh : (T)0;
+    const T inter = w * h;
+    const T ovr = inter / (iarea + jarea - inter);
+    bool p = ((double)ovr > thr) && jvalid;
+    if (diag) p = p && (lane > i);
+    if (seg) p = p && (jseg == s_seg[i]);
+    const u64 word = __ballot(p);
+    if (lane == i) mine = word;
+  }
+  mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
 }
 
-__global__ __launch_bounds__(kSweepThreads) void nms_sweep_kernel(
-    const unsigned long long* __restrict__ mask, const int64_t* __restrict__ order, int n,
-    int col_blocks, int cb_pad, int64_t* __restrict__ keep_out, int64_t* __restrict__ num_keep) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_removed[];  // [col_blocks + 2]
-  unsigned long long* s_keepbits = s_removed + col_blocks;                        // [1]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  for (int c = tid; c < col_blocks; c += kSweepThreads) s_removed[c] = 0ull;
-  __syncthreads();
-  int64_t count = 0;  // meaningful in wave 0 only
-  for (int b = 0; b < col_blocks; ++b) {
-    const int row0 = b * 64;
-    if (tid < 64) {
-      const int row = row0 + lane;
-      unsigned long long diag = 0ull;
-      if (row < n) diag = mask[(size_t)row * cb_pad + b];
-      const unsigned long long rem_v = s_removed[b];
-      // wave-uniform: keep the running word in SGPRs so the 64-step resolve is scalar code
-      unsigned long long rem =
-          ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(rem_v >> 32)) << 32) |
-          (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)rem_v);
-      const int rows_here = min(64, n - row0);
-      if (rows_here < 64) rem |= ~0ull << rows_here;  // rows past n are "removed"
-      unsigned long long keep = 0ull;
-      const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+// K2: fold the rows kept in super-blocks before `b0` into removed[cb] for cb in [b0, b1).
+__global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mask, const u64* __restrict__ keepbits,
+                                                     u64* __restrict__ removed, int CB, int b0, int b1) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cb = b0 + blockIdx.x;
+  if (cb >= b1) return;
+  const int rb_begin = (blockIdx.y * 4 + wave) * kReduceRows;
+  u64 acc = 0ull;
 #pragma unroll
-      for (int kbit = 0; kbit < 64; ++kbit) {
-        const unsigned long long rk =
-            ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, kbit) << 32) |
-            (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, kbit);
-        if (!((rem >> kbit) & 1ull)) {  // wave-uniform
-          keep |= 1ull << kbit;
-          rem |= rk;
-        }
-      }
-      if (lane == 0) *s_keepbits = keep;
-      // append kept original indices in order
-      const bool kept = (keep >> lane) & 1ull;
-      if (kept) {
-        const unsigned long long below = keep & ((1ull << lane) - 1ull);
-        keep_out[count + __popcll(below)] = order[row0 + lane];
-      }
-      count += __popcll(keep);
+  for (int q = 0; q < kReduceRows; ++q) {
+    const int rb = rb_begin + q;
+    if (rb < b0) {
+      const u64 w = mask[((size_t)rb * CB + cb) * 64 + lane];
+      const u64 kb = keepbits[rb];
+      if ((kb >> lane) & 1ull) acc |= w;
     }
-    __syncthreads();
-    const unsigned long long keep = *s_keepbits;
-    // OR the kept rows of this block into removed[] for all later column blocks.
-    for (int c = b + 1 + tid; c < col_blocks; c += kSweepThreads) {
-      unsigned long long acc = 0ull;
-      unsigned long long kb = keep;
-      while (kb) {
-        const int kbit = __ffsll((long long)kb) - 1;
-        kb &= kb - 1ull;
-        acc |= mask[(size_t)(row0 + kbit) * cb_pad + c];
-      }
-      if (acc) s_removed[c] |= acc;
-    }
-    __syncthreads();
   }
-  if (tid == 0) *num_keep = count;
+  const u64 red = wave_or64(acc);
+  if (lane == 0 && red) atomicOr(&removed[cb], red);
+}
+
+// K3: resolve the (up to) kSuper blocks [b0, b1) of one super-block.
+__global__ __launch_bounds__(kSuper * kWave) void nms_resolve(const u64* __restrict__ mask,
+                                                              const int64_t* __restrict__ order,
+                                                              const u64* __restrict__ removed,
+                                                              u64* __restrict__ keepbits, int n, int CB, int b0, int b1,
+                                                              int64_t* __restrict__ keep_out,
+                                                              int64_t* __restrict__ num_keep) {
+  __shared__ u64 s_keep[kSuper];
+  const int lane = threadIdx.x & 63;
+  // wave-uniform by construction; readfirstlane tells the compiler, so the whole resolve chain
+  // (candidate word, ctz, readlane index) is scalar code instead of an exec-masked VALU loop
+  const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's block in the super-block
+  const int cb = b0 + c_loc;
+  const bool have = cb < b1;
+  // prefetch: diagonal tile word of this lane's row + the tiles above it inside the super-block
+  u64 diag = 0ull, above[kSuper - 1];
+  u64 rem = 0ull;
+  if (have) {
+    diag = mask[((size_t)cb * CB + cb) * 64 + lane];
+    rem = removed[cb];
+  }
+#pragma unroll
+  for (int q = 0; q < kSuper - 1; ++q) {
+    above[q] = 0ull;
+    if (have && q < c_loc) above[q] = mask[((size_t)(b0 + q) * CB + cb) * 64 + lane];
+  }
+  rem = uniform64(rem);
+  const int rows_here = have ? min(64, n - cb * 64) : 0;
+  const u64 valid = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+  u64 my_keep = 0ull;
+#pragma unroll
+  for (int step = 0; step < kSuper; ++step) {
+    if (step == c_loc && have) {
+      // every earlier block of the super-block is folded in: resolve my 64 boxes
+      u64 cand = uniform64(~rem & valid);
+      u64 keep = 0ull;
+      while (cand) {  // wave-uniform scalar loop over the surviving candidates
+        const int k = __builtin_ctzll(cand);
+        const u64 bit = 1ull << k;
+        keep |= bit;
+        cand &= ~(readlane64(diag, k) | bit);
+      }
+      my_keep = keep;
+      if (lane == 0) {
+        s_keep[c_loc] = keep;
+        keepbits[cb] = keep;
+      }
+    }
+    __syncthreads();
+    if (step < kSuper - 1 && have && step < c_loc) {
+      const u64 kb = s_keep[step];
+      const u64 contrib = ((kb >> lane) & 1ull) ? above[step] : 0ull;
+      rem |= wave_or64(contrib);
+    }
+  }
+  // append the kept original indices in score order
+  if (have) {
+    int64_t base = *num_keep;
+    for (int q = 0; q < c_loc; ++q) base += __popcll(s_keep[q]);
+    if ((my_keep >> lane) & 1ull) {
+      const u64 below = my_keep & ((1ull << lane) - 1ull);
+      keep_out[base + __popcll(below)] = order[(int64_t)cb * 64 + lane];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t total = *num_keep;
+    for (int q = 0; q < b1 - b0; ++q) total += __popcll(s_keep[q]);
+    *num_keep = total;
+  }
 }
 
 template <typename T>
-int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr,
-           void* workspace, int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
-  const int col_blocks = (int)ceil_div(n, 64);
-  const int cb_pad = (int)(ceil_div(col_blocks, kColGroup) * kColGroup);
-  unsigned long long* mask = static_cast<unsigned long long*>(workspace);
-  const int col_groups = cb_pad / kColGroup;
-  const dim3 grid((unsigned)ceil_div(col_groups, kMaskWaves), (unsigned)col_blocks);
-  nms_mask_kernel<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(
-      static_cast<const T*>(dets), order, seg, (int)n, col_blocks, cb_pad, thr, mask);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return set_error((int)e, "tvmi_nms: mask kernel launch");
-  const size_t lds = (size_t)(col_blocks + 2) * sizeof(unsigned long long);
-  nms_sweep_kernel<<<dim3(1), dim3(kSweepThreads), lds, stream>>>(mask, order, (int)n, col_blocks,
-                                                                  cb_pad, keep_out, num_keep);
-  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms: sweep kernel launch");
+int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr, void* workspace,
+           int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
+  const int CB = (int)ceil_div(n, 64);
+  u64* mask = static_cast<u64*>(workspace);
+  u64* removed = mask + (size_t)CB * CB * 64;
+  u64* keepbits = removed + CB;
+  hipError_t e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
+  if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
+  const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
+  nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), order, seg, (int)n, CB,
+                                                                   thr, mask);
+  for (int b0 = 0; b0 < CB; b0 += kSuper) {
+    const int b1 = std::min(CB, b0 + kSuper);
+    if (b0 > 0) {
+      const dim3 rgrid((unsigned)(b1 - b0), (unsigned)ceil_div(b0, 4 * kReduceRows));
+      nms_colreduce<<<rgrid, dim3(256), 0, stream>>>(mask, keepbits, removed, CB, b0, b1);
+    }
+    nms_resolve<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, removed, keepbits, (int)n, CB, b0, b1, keep_out,
+                                                              num_keep);
+  }
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
 }
 
 }  // namespace
@@ -241,9 +282,8 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
 
 extern "C" size_t tvmi_nms_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
-  const int64_t col_blocks = tvmi::ceil_div(n, 64);
-  const int64_t cb_pad = tvmi::ceil_div(col_blocks, tvmi::kColGroup) * tvmi::kColGroup;
-  return (size_t)n * (size_t)cb_pad * sizeof(unsigned long long);
+  const size_t CB = (size_t)tvmi::ceil_div(n, 64);
+  return (CB * CB * 64 + 2 * CB) * sizeof(unsigned long long);
 }
 
 extern "C" int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,

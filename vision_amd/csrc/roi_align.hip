@@ -20,6 +20,10 @@
 // Backward mirrors this: gradients of a channel group are accumulated into the LDS window
 // with ds_add_f32 and flushed with ONE global atomic per touched pixel instead of 4 per
 // sample.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "tvmi_common.h"
 
 namespace tvmi {
@@ -29,6 +33,7 @@ constexpr int kThreads = 256;
 constexpr int kMaxTab = 128;      // max PH*gh (and PW*gw) samples per axis kept in LDS
 constexpr int kWinFloats = 8192;  // LDS window capacity in floats (32 KiB)
 constexpr int kChunk = 32;        // channels per workgroup
+constexpr int kMaxLevels = 8;     // FPN levels served by one multi-scale launch
 
 template <typename A>
 struct RoiGeom {
@@ -229,18 +234,17 @@ __device__ __forceinline__ int build_tables(TileShared& s, const RoiGeom<float>&
   return mode;
 }
 
+// One workgroup = one (RoI k, channel chunk starting at c0) of one feature map.
 template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_tile(
-    const T* __restrict__ input, const T* __restrict__ rois, T* __restrict__ output, int C, int H,
-    int W, int PH_, int PW_, float spatial_scale, int sr_, int aligned, int nchunks) {
-  __shared__ TileShared s;
+__device__ __forceinline__ void roi_align_fwd_block(TileShared& s, const T* __restrict__ input,
+                                                    const T* __restrict__ rois, T* __restrict__ output,
+                                                    int C, int H, int W, int PH_, int PW_,
+                                                    float spatial_scale, int sr_, int aligned, int k, int c0) {
   const int PH = PHT > 0 ? PHT : PH_;
   const int PW = PWT > 0 ? PWT : PW_;
   const int sr = SRT > 0 ? SRT : sr_;
   const int PHW = PH * PW;
   const int tid = threadIdx.x;
-  const int k = blockIdx.x / nchunks;
-  const int c0 = (blockIdx.x - k * nchunks) * kChunk;
   const int cc = min(kChunk, C - c0);
 
   RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PH, PW, sr, aligned != 0);
@@ -339,6 +343,816 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_tile(
     }
     __syncthreads();
   }
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_tile(
+    const T* __restrict__ input, const T* __restrict__ rois, T* __restrict__ output, int C, int H,
+    int W, int PH_, int PW_, float spatial_scale, int sr_, int aligned, int nchunks) {
+  __shared__ TileShared s;
+  const int k = blockIdx.x / nchunks;
+  const int c0 = (blockIdx.x - k * nchunks) * kChunk;
+  roi_align_fwd_block<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
+                                        aligned, k, c0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-scale forward: the FPN level of every RoI is chosen IN the kernel
+// (torchvision/ops/poolers.py:47-84, LevelMapper: floor(k0 + log2(sqrt(area)/s0) + eps) clamped
+// to [k_min, k_max]) and all levels are served by ONE launch that writes straight into the
+// [K,C,PH,PW] result — no torch.where / index / index_put round trips per level
+// (poolers.py:199-222).
+struct MsLevels {
+  const void* ptr[kMaxLevels];
+  int H[kMaxLevels];
+  int W[kMaxLevels];
+  float scale[kMaxLevels];
+  int n_levels;
+  int k_min, k_max;
+  float s0, lvl0, eps;
+};
+
+template <typename T>
+__device__ __forceinline__ int fpn_level(const T* roi, const MsLevels& lv) {
+  const float x1 = ld(roi + 1), y1 = ld(roi + 2), x2 = ld(roi + 3), y2 = ld(roi + 4);
+  const float s = sqrtf((x2 - x1) * (y2 - y1));
+  float t = floorf(lv.lvl0 + log2f(s / lv.s0) + lv.eps);
+  t = fminf(fmaxf(t, (float)lv.k_min), (float)lv.k_max);  // NaN area -> k_min like torch.clamp? (clamp keeps NaN)
+  int l = (t == t) ? (int)t - lv.k_min : 0;
+  return min(max(l, 0), lv.n_levels - 1);
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_tile(MsLevels lv, const T* __restrict__ rois,
+                                                                 T* __restrict__ output, int C, int PH_,
+                                                                 int PW_, int sr_, int aligned, int nchunks) {
+  __shared__ TileShared s;
+  const int k = blockIdx.x / nchunks;
+  const int c0 = (blockIdx.x - k * nchunks) * kChunk;
+  const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
+  roi_align_fwd_block<T, PHT, PWT, SRT>(s, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                        PH_, PW_, lv.scale[l], sr_, aligned, k, c0);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Wave-autonomous forward ("v3"): every wave owns one (RoI, channel chunk) unit end to end —
+// its own axis tables, its own LDS window, no workgroup barrier anywhere, so the 16 resident
+// waves of a CU drift apart and hide each other's memory latency.  The window is staged with a
+// 2-D lane mapping (lane = (row-in-group, column), column count padded to a power of two) so
+// that no integer division sits on the staging path, and out-of-tensor pad cells read the
+// CLAMPED element — exactly what the reference multiplies its zero weight with.
+constexpr int kWaveWin = 2048;   // floats of LDS window per wave (8 KiB)
+constexpr int kWaveTab = 64;     // samples per axis held in the per-wave tables
+
+struct WaveShared {
+  float4 ytab[kWaveTab];  // {bits(lo), l, h, -}: one 16-byte LDS read per sample row
+  float4 xtab[kWaveTab];
+  float win[kWaveWin];
+};
+
+__device__ int g_roi_force_mode = 0;  // debug knob (tvmi_debug_set): 0 auto, 1 never stage through LDS
+
+// Stages CH channel windows (rows y0.., cols x0.., clamped into the tensor) with RG row-groups
+// each: RG*CH independent loads are in flight per lane before the first LDS write.  Lanes
+// beyond the window edge re-read the edge element (same address, same value), so there is no
+// predication and no integer division anywhere on this path; the channel base pointer is
+// wave-uniform (SGPR) and the per-lane offsets are 32-bit.
+template <typename T, int RG, int CH>
+__device__ __forceinline__ void stage_window(float* __restrict__ win, const T* __restrict__ in_cg, int64_t plane_sz,
+                                             int gc, int nrg, int wsz, const int (&goff)[RG], const int (&loff)[RG]) {
+  for (int ch0 = 0; ch0 < gc; ch0 += CH) {
+    float v[CH][RG];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = min(ch0 + c, gc - 1);  // tail: duplicate the last channel (idempotent)
+      const T* chp = in_cg + (int64_t)ch * plane_sz;
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+        if (rg < nrg) v[c][rg] = ld(chp + goff[rg]);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = min(ch0 + c, gc - 1);
+      float* wch = win + ch * wsz;
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+        if (rg < nrg) wch[loff[rg]] = v[c][rg];
+    }
+  }
+}
+
+template <typename T, int RG, int CH>
+__device__ __forceinline__ void stage_window_setup(float* __restrict__ win, const T* __restrict__ in_cg,
+                                                   int64_t plane_sz, int gc, int nrg, int wsz, int rpi, int rsub,
+                                                   int colc, int gxc, int y0, int wh, int wstride, int H, int W) {
+  int goff[RG], loff[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    const int r = min(rg * rpi + rsub, wh - 1);
+    goff[rg] = min(y0 + r, H - 1) * W + gxc;
+    loff[rg] = r * wstride + colc;
+  }
+  stage_window<T, RG, CH>(win, in_cg, plane_sz, gc, nrg, wsz, goff, loff);
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* __restrict__ input,
+                                                        const T* __restrict__ rois, T* __restrict__ output,
+                                                        int C, int H, int W, int PH_, int PW_, float spatial_scale,
+                                                        int sr_, int aligned, int k, int c0, int chunk, int force_mode) {
+  const int PH = PHT > 0 ? PHT : PH_;
+  const int PW = PWT > 0 ? PWT : PW_;
+  const int sr = SRT > 0 ? SRT : sr_;
+  const int PHW = PH * PW;
+  const int lane = threadIdx.x & 63;
+  const int cc = min(chunk, C - c0);
+  RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PH, PW, sr, aligned != 0);
+  if (SRT > 0) {
+    g.gh = SRT;
+    g.gw = SRT;
+  }
+  T* out = output + ((int64_t)k * C + c0) * PHW;
+  const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
+  const int64_t plane_sz = (int64_t)H * W;
+  const int gh = g.gh, gw = g.gw;
+  const int ny = PH * gh, nx = PW * gw;
+  if (gh <= 0 || gw <= 0) {
+    for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
+    return;
+  }
+  if (ny > kWaveTab || nx > kWaveTab) {  // tables do not fit: arithmetic on the fly
+    for (int o = lane; o < cc * PHW; o += 64) {
+      const int c = o / PHW, bin = o - c * PHW;
+      const int ph = bin / PW, pw = bin - ph * PW;
+      st(out + o, roi_align_point<T, float>(in0 + c * plane_sz, H, W, g, ph, pw));
+    }
+    return;
+  }
+  // ---- axis tables (one lane per sample) and the window they span
+  int y0, y1, x0, x1;
+  {
+    int lo = 0, hi = 0;
+    float l = 0.f, h = 0.f;
+    bool v = false;
+    if (lane < ny) v = axis_sample<float>(H, g.start_h, g.bin_h, gh, lane / gh, lane % gh, lo, hi, l, h);
+    const unsigned long long bal = __ballot(v);
+    if (bal == 0ull) {
+      for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
+      return;
+    }
+    {  // sample coordinates are monotonic in the lane index (either direction: malformed RoIs with
+       // aligned=True have negative bins), so the extremes sit at the first / last valid lane
+      const int fl = __builtin_ctzll(bal), ll = 63 - __builtin_clzll(bal);
+      y0 = min(__builtin_amdgcn_readlane(lo, fl), __builtin_amdgcn_readlane(lo, ll));
+      y1 = max(__builtin_amdgcn_readlane(hi, fl), __builtin_amdgcn_readlane(hi, ll));
+    }
+    if (lane < ny) s.ytab[lane] = make_float4(__int_as_float(v ? lo : y0), l, h, 0.f);
+  }
+  {
+    int lo = 0, hi = 0;
+    float l = 0.f, h = 0.f;
+    bool v = false;
+    if (lane < nx) v = axis_sample<float>(W, g.start_w, g.bin_w, gw, lane / gw, lane % gw, lo, hi, l, h);
+    const unsigned long long bal = __ballot(v);
+    if (bal == 0ull) {
+      for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
+      return;
+    }
+    {
+      const int fl = __builtin_ctzll(bal), ll = 63 - __builtin_clzll(bal);
+      x0 = min(__builtin_amdgcn_readlane(lo, fl), __builtin_amdgcn_readlane(lo, ll));
+      x1 = max(__builtin_amdgcn_readlane(hi, fl), __builtin_amdgcn_readlane(hi, ll));
+    }
+    if (lane < nx) s.xtab[lane] = make_float4(__int_as_float(v ? lo : x0), l, h, 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // divide like the reference; a power-of-two count (the usual 2x2 grid) is an exact multiply
+  const float count = g.count;
+  const int icount = gh * gw;
+  const bool pow2 = icount > 0 && (icount & (icount - 1)) == 0;
+  const float inv_count = 1.f / count;
+  const int wh = y1 - y0 + 2, ww = x1 - x0 + 2;  // +1 pad row/col: only ever met by a zero weight
+  int wpad = 1;
+  while (wpad < ww) wpad <<= 1;
+  const int wstride = ww | 1;
+  const int wsz = wh * wstride;
+  const int rpi = wpad <= 64 ? 64 / wpad : 1;  // window rows staged per wave-instruction
+  const int nrg = (wh + rpi - 1) / rpi;
+  int G = (ww <= 64 && nrg <= 16 && force_mode != 1) ? kWaveWin / wsz : 0;
+  if (G > cc) G = cc;
+
+  if (G < 1) {
+    // window too large (or staging disabled): table-driven gathers straight from global memory
+    for (int o = lane; o < cc * PHW; o += 64) {
+      const int c = o / PHW, bin = o - c * PHW;
+      const int ph = bin / PW, pw = bin - ph * PW;
+      const T* plane = in0 + c * plane_sz;
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float4 ye = s.ytab[ph * gh + iy];
+        const int ylo = __float_as_int(ye.x);
+        const float ly = ye.y, hy = ye.z;
+        const T* r0 = plane + (int64_t)ylo * W;
+        const T* r1 = plane + (int64_t)min(ylo + 1, H - 1) * W;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float4 xe = s.xtab[pw * gw + ix];
+          const int xlo = __float_as_int(xe.x), xhi = min(xlo + 1, W - 1);
+          const float lx = xe.y, hx = xe.z;
+          acc += (hy * hx) * ld(r0 + xlo) + (hy * lx) * ld(r0 + xhi) + (ly * hx) * ld(r1 + xlo) + (ly * lx) * ld(r1 + xhi);
+        }
+      }
+      st(out + o, pow2 ? acc * inv_count : acc / count);
+    }
+    return;
+  }
+
+  const int rsub = lane / wpad, col = lane - rsub * wpad;
+  const int colc = min(col, ww - 1);
+  const int gxc = min(x0 + colc, W - 1);
+  const int wbias = y0 * wstride + x0;  // tables hold absolute coordinates
+  for (int cg = 0; cg < cc; cg += G) {
+    const int gc = min(G, cc - cg);
+    const T* in_cg = in0 + (int64_t)cg * plane_sz;
+    if (force_mode == 2) {
+    } else if (nrg <= 4)
+      stage_window_setup<T, 4, 4>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    else if (nrg <= 8)
+      stage_window_setup<T, 8, 2>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    else
+      stage_window_setup<T, 16, 1>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nout = force_mode == 3 ? 0 : gc * PHW;
+    for (int o = lane; o < nout; o += 64) {
+      const int ch = o / PHW, bin = o - ch * PHW;
+      const int ph = bin / PW, pw = bin - ph * PW;
+      const float* wbase = s.win + (ch * wsz - wbias);
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float4 ye = s.ytab[ph * gh + iy];
+        const float* row = wbase + __float_as_int(ye.x) * wstride;
+        const float ly = ye.y, hy = ye.z;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float4 xe = s.xtab[pw * gw + ix];
+          const float* p = row + __float_as_int(xe.x);
+          const float lx = xe.y, hx = xe.z;
+          acc += (hy * hx) * p[0] + (hy * lx) * p[1] + (ly * hx) * p[wstride] + (ly * lx) * p[wstride + 1];
+        }
+      }
+      st(out + cg * PHW + o, pow2 ? acc * inv_count : acc / count);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fast wave unit for the compile-time shapes (7x7 / 14x14, sampling_ratio 2): lane = output
+// bin.  Each lane keeps the 4 samples of its bin(s) in REGISTERS for the whole unit — one LDS
+// offset and the separable bilinear factors (ly,hy / lx,hx) per sample — so the per-channel
+// inner loop is nothing but 2 ds_read2_b32 + 6 multiply-adds per sample and one coalesced
+// store of the PH*PW outputs of that channel.  The bilinear form hy*(hx*v1+lx*v2) +
+// ly*(hx*v3+lx*v4) is evaluated with explicit fused multiply-adds; it differs from the
+// reference's (hy*hx)*v1+... association by rounding only (<1e-6 relative).
+template <typename T, int PHT, int PWT, int SRT>
+__device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* __restrict__ input,
+                                                        const T* __restrict__ rois, T* __restrict__ output,
+                                                        int C, int H, int W, float spatial_scale, int aligned,
+                                                        int k, int c0, int chunk, int force_mode) {
+  constexpr int PHW = PHT * PWT;
+  constexpr int NB = (PHW + 63) / 64;  // bins per lane
+  constexpr int NS = SRT * SRT;        // samples per bin
+  constexpr int ny = PHT * SRT, nx = PWT * SRT;
+  static_assert(ny <= 64 && nx <= 64, "axis samples must fit one wave");
+  const int lane = threadIdx.x & 63;
+  const int cc = min(chunk, C - c0);
+  RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
+  T* out = output + ((int64_t)k * C + c0) * PHW;
+  const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
+  const int64_t plane_sz = (int64_t)H * W;
+
+  // ---- window bounds: one lane per axis sample, first/last valid sample via ballot
+  int y0, y1, x0, x1;
+  {
+    int lo = 0, hi = 0;
+    float l, h;
+    bool v = false;
+    if (lane < ny) v = axis_sample<float>(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, hi, l, h);
+    const unsigned long long by = __ballot(v);
+    int lo2 = 0, hi2 = 0;
+    bool v2 = false;
+    if (lane < nx) v2 = axis_sample<float>(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo2, hi2, l, h);
+    const unsigned long long bx = __ballot(v2);
+    if (by == 0ull || bx == 0ull) {  // every sample of one axis is outside: all outputs are 0
+      for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
+      return;
+    }
+    {  // monotonic in the lane index, either direction (negative bins of malformed RoIs)
+      const int fy_ = __builtin_ctzll(by), ly_ = 63 - __builtin_clzll(by);
+      const int fx_ = __builtin_ctzll(bx), lx_ = 63 - __builtin_clzll(bx);
+      y0 = min(__builtin_amdgcn_readlane(lo, fy_), __builtin_amdgcn_readlane(lo, ly_));
+      y1 = max(__builtin_amdgcn_readlane(hi, fy_), __builtin_amdgcn_readlane(hi, ly_));
+      x0 = min(__builtin_amdgcn_readlane(lo2, fx_), __builtin_amdgcn_readlane(lo2, lx_));
+      x1 = max(__builtin_amdgcn_readlane(hi2, fx_), __builtin_amdgcn_readlane(hi2, lx_));
+    }
+  }
+  const int wh = y1 - y0 + 2, ww = x1 - x0 + 2;  // +1 pad row/col: only ever met by a zero weight
+  int wpad = 1;
+  while (wpad < ww) wpad <<= 1;
+  const int wstride = ww | 1;
+  const int wsz = wh * wstride;
+  const int rpi = wpad <= 64 ? 64 / wpad : 1;
+  const int nrg = (wh + rpi - 1) / rpi;
+  int G = (ww <= 64 && nrg <= 16 && force_mode != 1) ? kWaveWin / wsz : 0;
+  if (G > cc) G = cc;
+
+  // ---- per-lane sample set-up (registers)
+  int off[NB][NS];
+  float fy[NB][SRT][2], fx[NB][SRT][2];  // {l, h} per axis sample
+  int gy[NB][SRT], gxx[NB][SRT];         // absolute low indices (global-gather fallback)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int bin = min(lane + 64 * b, PHW - 1);
+    const int ph = bin / PWT, pw = bin - ph * PWT;
+    int ylo[SRT], xlo[SRT];
+#pragma unroll
+    for (int i = 0; i < SRT; ++i) {
+      int hi;
+      float l, h;
+      const bool vy = axis_sample<float>(H, g.start_h, g.bin_h, SRT, ph, i, ylo[i], hi, l, h);
+      fy[b][i][0] = l;
+      fy[b][i][1] = h;
+      if (!vy) ylo[i] = y0;
+      gy[b][i] = ylo[i];
+      const bool vx = axis_sample<float>(W, g.start_w, g.bin_w, SRT, pw, i, xlo[i], hi, l, h);
+      fx[b][i][0] = l;
+      fx[b][i][1] = h;
+      if (!vx) xlo[i] = x0;
+      gxx[b][i] = xlo[i];
+    }
+#pragma unroll
+    for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < SRT; ++ix) off[b][iy * SRT + ix] = (ylo[iy] - y0) * wstride + (xlo[ix] - x0);
+  }
+  const float inv_count = 1.f / (float)NS;  // SRT*SRT is a power of two here or handled below
+  constexpr bool kPow2 = (NS & (NS - 1)) == 0;
+
+  if (G < 1) {
+    // window too large for LDS: same register set-up, taps straight from global memory
+    for (int c = 0; c < cc; ++c) {
+      const T* plane = in0 + (int64_t)c * plane_sz;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int iy = 0; iy < SRT; ++iy) {
+          const T* r0 = plane + (int64_t)gy[b][iy] * W;
+          const T* r1 = plane + (int64_t)min(gy[b][iy] + 1, H - 1) * W;
+#pragma unroll
+          for (int ix = 0; ix < SRT; ++ix) {
+            const int xl = gxx[b][ix], xh = min(xl + 1, W - 1);
+            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(r0 + xh), fx[b][ix][1] * ld(r0 + xl));
+            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(r1 + xh), fx[b][ix][1] * ld(r1 + xl));
+            acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+            acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+          }
+        }
+        const int bin = lane + 64 * b;
+        if (bin < PHW) st(out + c * PHW + bin, kPow2 ? acc * inv_count : acc / (float)NS);
+      }
+    }
+    return;
+  }
+
+  const int rsub = lane / wpad, col = lane - rsub * wpad;
+  const int colc = min(col, ww - 1);
+  const int gxc = min(x0 + colc, W - 1);
+  for (int cg = 0; cg < cc; cg += G) {
+    const int gc = min(G, cc - cg);
+    const T* in_cg = in0 + (int64_t)cg * plane_sz;
+    if (nrg <= 2)
+      stage_window_setup<T, 2, 8>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    else if (nrg <= 4)
+      stage_window_setup<T, 4, 4>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    else if (nrg <= 8)
+      stage_window_setup<T, 8, 2>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    else
+      stage_window_setup<T, 16, 1>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int ch = 0; ch < gc; ++ch) {
+      const float* wbase = s.win + ch * wsz;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int iy = 0; iy < SRT; ++iy) {
+#pragma unroll
+          for (int ix = 0; ix < SRT; ++ix) {
+            const float* p = wbase + off[b][iy * SRT + ix];
+            const float t0 = __builtin_fmaf(fx[b][ix][0], p[1], fx[b][ix][1] * p[0]);
+            const float t1 = __builtin_fmaf(fx[b][ix][0], p[wstride + 1], fx[b][ix][1] * p[wstride]);
+            acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+            acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+          }
+        }
+        const int bin = lane + 64 * b;
+        if (bin < PHW) st(out + (cg + ch) * PHW + bin, kPow2 ? acc * inv_count : acc / (float)NS);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-DMA wave unit (fp32, compile-time shapes): the window rows go HBM/L2 -> LDS directly
+// (global_load_lds_dword: per-lane global address, LDS slot = wave base + lane*4), 16 DMA
+// instructions per pass, DOUBLE-BUFFERED — the DMAs of pass p+1 are in flight while pass p is
+// gathered from LDS, and a counted `s_waitcnt vmcnt(16)` (never 0 inside the loop) retires
+// exactly the previous pass.  No staging VGPRs, no ds_write, no workgroup barrier; the window
+// image is [channel][row][wpad] with wpad = 64 / rows-per-instruction, so a lane's slot is a
+// pure function of its lane id, and lanes past the window edge fetch the clamped edge element
+// (the very element the reference multiplies its zero weight with).
+constexpr int kDmaPerPass = 4;                   // DMA instructions (x 1 KiB) per pass and buffer
+constexpr int kDmaBlk = 260;                     // LDS floats per DMA instruction block (256 + 4 skew, 16-B aligned)
+constexpr int kDmaBuf = kDmaPerPass * kDmaBlk;   // floats per buffer
+
+struct DmaShared {
+  __attribute__((aligned(16))) float buf[2 * kDmaBuf];
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Window image in LDS, built by 16-byte LDS-DMA pieces (global_load_lds_dwordx4: every lane
+// moves 4 consecutive floats of a window row; 4-byte source alignment is enough on gfx950).
+// One DMA instruction = 64 lanes = `rpi` rows of `lpr` (odd) quads; its 256-float block starts
+// every 260 floats.  slot(r, c) = (r / rpi) * 260 + (r % rpi) * 4*lpr + c.
+// The window is [y0, y0+wh) x [x0, x0+4*nq): no pad row/column is needed because a sample that
+// sits on the last row/column (where the reference uses x_high = x_low with weight 0) is
+// re-expressed on the pair (dim-2, dim-1) with factors (0, 1) — the same value, never an
+// out-of-row read; the window is shifted left when it would run past the row end.
+struct DmaWindow {
+  int state, y0, x0, wh, nq, lpr, rpi, nrg;
+};
+
+// lo/l/h of one axis sample in the "shifted" form described above (dim >= 2)
+__device__ __forceinline__ bool axis_sample_shifted(int dim, float start, float bin, int grid, int p, int i, int& lo,
+                                                    float& l, float& h) {
+  int hi;
+  const bool v = axis_sample<float>(dim, start, bin, grid, p, i, lo, hi, l, h);
+  if (!v) {
+    lo = 0;
+    l = h = 0.f;
+    return false;
+  }
+  if (lo > dim - 2) {  // lo == dim-1: value is in[dim-1]
+    lo = dim - 2;
+    l = 1.f;
+    h = 0.f;
+  }
+  return true;
+}
+
+template <int PHT, int PWT, int SRT>
+__device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, int W) {
+  constexpr int ny = PHT * SRT, nx = PWT * SRT;
+  const int lane = threadIdx.x & 63;
+  DmaWindow w;
+  w.state = 2;
+  w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = 0;
+  if (H < 2 || W < 4) return w;
+  int lo = 0, lo2 = 0;
+  float l, h;
+  bool v = false, v2 = false;
+  if (lane < ny) v = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, l, h);
+  if (lane < nx) v2 = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo2, l, h);
+  const unsigned long long by = __ballot(v), bx = __ballot(v2);
+  if (by == 0ull || bx == 0ull) {  // every sample of one axis is outside the map: all outputs are zero
+    w.state = 0;
+    return w;
+  }
+  // sample coordinates are monotonic in the lane index, in either direction (malformed RoIs with
+  // aligned=True have negative bins): the extremes sit at the first / last valid lane
+  const int ya = __builtin_amdgcn_readlane(lo, __builtin_ctzll(by)), yb = __builtin_amdgcn_readlane(lo, 63 - __builtin_clzll(by));
+  const int xa = __builtin_amdgcn_readlane(lo2, __builtin_ctzll(bx)), xb = __builtin_amdgcn_readlane(lo2, 63 - __builtin_clzll(bx));
+  w.y0 = min(ya, yb);
+  const int y1 = max(ya, yb) + 1;
+  const int x0 = min(xa, xb);
+  const int x1 = max(xa, xb) + 1;
+  w.wh = y1 - w.y0 + 1;
+  w.nq = (x1 - x0 + 4) >> 2;            // quads covering [x0, x1]
+  w.x0 = min(x0, W - 4 * w.nq);         // keep every quad inside the row
+  if (w.x0 < 0) return w;               // map narrower than the window image
+  w.lpr = w.nq | 1;
+  if (w.lpr > 64) return w;
+  w.rpi = 64 / w.lpr;
+  w.nrg = (w.wh + w.rpi - 1) / w.rpi;
+  // 1 = DMA path (<= 8 DMA instructions per channel), 2 = register-staged / global-gather path
+  w.state = w.nrg <= 2 * kDmaPerPass ? 1 : 2;
+  return w;
+}
+
+template <int NRG>
+__device__ __forceinline__ void dma_issue_pass(const float* __restrict__ in_pass, int64_t plane_sz, int gc,
+                                               const int (&goff)[NRG], float* __restrict__ dst) {
+  constexpr int G = NRG <= kDmaPerPass ? kDmaPerPass / NRG : 1;
+#pragma unroll
+  for (int c = 0; c < G; ++c) {
+    const float* chp = in_pass + (int64_t)min(c, gc - 1) * plane_sz;  // tail: re-fetch the last channel
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(chp + goff[rg]), (lds_ptr_t)(dst + (c * NRG + rg) * kDmaBlk), 16, 0, 0);
+    }
+  }
+}
+
+template <int PHT, int PWT, int SRT, int NRG>
+__device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const float* __restrict__ in0, float* __restrict__ out,
+                                                     int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
+                                                     const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
+                                                     const float (&fy)[(PHT * PWT + 63) / 64][SRT][2],
+                                                     const float (&fx)[(PHT * PWT + 63) / 64][SRT][2]) {
+  constexpr int PHW = PHT * PWT;
+  constexpr int NB = (PHW + 63) / 64;
+  constexpr int NS = SRT * SRT;
+  constexpr bool kDouble = NRG <= kDmaPerPass;  // 8 row groups use both buffers as one
+  constexpr int G = kDouble ? kDmaPerPass / NRG : 1;
+  constexpr bool kPow2 = (NS & (NS - 1)) == 0;
+  const float inv_count = 1.f / (float)NS;
+  const int lane = threadIdx.x & 63;
+  const int rsub = min(lane / dw.lpr, dw.rpi - 1);
+  const int q = min(lane - (lane / dw.lpr) * dw.lpr, dw.nq - 1);
+  const int gx = dw.x0 + 4 * q;
+  int goff[NRG];
+#pragma unroll
+  for (int rg = 0; rg < NRG; ++rg) goff[rg] = min(dw.y0 + min(rg * dw.rpi + rsub, dw.wh - 1), H - 1) * W + gx;
+  const int npass = (cc + G - 1) / G;
+  if (kDouble) dma_issue_pass<NRG>(in0, plane_sz, min(G, cc), goff, s.buf);
+  for (int p = 0; p < npass; ++p) {
+    const int cg = p * G;
+    const int gc = min(G, cc - cg);
+    const float* cur;
+    if (kDouble) {
+      if (p + 1 < npass) {
+        dma_issue_pass<NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
+                            s.buf + ((p + 1) & 1) * kDmaBuf);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything older than those 4 DMAs has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      cur = s.buf + (p & 1) * kDmaBuf;
+    } else {
+      dma_issue_pass<NRG>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, s.buf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      cur = s.buf;
+    }
+    for (int ch = 0; ch < gc; ++ch) {
+      const float* wbase = cur + ch * (NRG * kDmaBlk);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int iy = 0; iy < SRT; ++iy) {
+#pragma unroll
+          for (int ix = 0; ix < SRT; ++ix) {
+            const float* q0 = wbase + off[b][iy * SRT + ix][0];
+            const float* q1 = wbase + off[b][iy * SRT + ix][1];
+            const float t0 = __builtin_fmaf(fx[b][ix][0], q0[1], fx[b][ix][1] * q0[0]);
+            const float t1 = __builtin_fmaf(fx[b][ix][0], q1[1], fx[b][ix][1] * q1[0]);
+            acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+            acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+          }
+        }
+        const int bin = lane + 64 * b;
+        if (bin < PHW) __builtin_nontemporal_store(kPow2 ? acc * inv_count : acc / (float)NS, out + (cg + ch) * PHW + bin);
+      }
+    }
+    // the ds_reads above are complete (their results were consumed) before the next DMAs may
+    // overwrite this buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int PHT, int PWT, int SRT>
+__device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const float* __restrict__ input,
+                                                       const float* __restrict__ rois, float* __restrict__ output,
+                                                       int C, int H, int W, float spatial_scale, int aligned, int k,
+                                                       int c0, int chunk, int* __restrict__ declined) {
+  constexpr int PHW = PHT * PWT;
+  constexpr int NB = (PHW + 63) / 64;
+  constexpr int NS = SRT * SRT;
+  const int lane = threadIdx.x & 63;
+  const int cc = min(chunk, C - c0);
+  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
+  float* out = output + ((int64_t)k * C + c0) * PHW;
+  const float* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
+  const int64_t plane_sz = (int64_t)H * W;
+  const DmaWindow dw = dma_window<PHT, PWT, SRT>(g, H, W);
+  if (c0 == 0 && lane == 0) declined[k] = dw.state == 2;  // tells the fallback launch what is left
+  if (dw.state == 2) return;
+  if (dw.state == 0) {
+    for (int o = lane; o < cc * PHW; o += 64) out[o] = 0.f;
+    return;
+  }
+  // ---- per-lane sample set-up (registers): LDS slots of the two tap rows + separable factors
+  int off[NB][NS][2];
+  float fy[NB][SRT][2], fx[NB][SRT][2];
+  const int rstride = 4 * dw.lpr;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int bin = min(lane + 64 * b, PHW - 1);
+    const int ph = bin / PWT, pw = bin - ph * PWT;
+    int rlo[SRT][2], xlo[SRT];
+#pragma unroll
+    for (int i = 0; i < SRT; ++i) {
+      int lo;
+      float l, h;
+      const bool vy = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, ph, i, lo, l, h);
+      fy[b][i][0] = l;
+      fy[b][i][1] = h;
+      const int r = vy ? lo - dw.y0 : 0;
+      rlo[i][0] = (r / dw.rpi) * kDmaBlk + (r % dw.rpi) * rstride;
+      rlo[i][1] = ((r + 1) / dw.rpi) * kDmaBlk + ((r + 1) % dw.rpi) * rstride;
+      const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
+      fx[b][i][0] = l;
+      fx[b][i][1] = h;
+      xlo[i] = vx ? lo - dw.x0 : 0;
+    }
+#pragma unroll
+    for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < SRT; ++ix) {
+        off[b][iy * SRT + ix][0] = rlo[iy][0] + xlo[ix];
+        off[b][iy * SRT + ix][1] = rlo[iy][1] + xlo[ix];
+      }
+  }
+  if (dw.nrg <= 1)
+    roi_align_dma_passes<PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+  else if (dw.nrg <= 2)
+    roi_align_dma_passes<PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+  else if (dw.nrg <= 4)
+    roi_align_dma_passes<PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+  else
+    roi_align_dma_passes<PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* __restrict__ input,
+                                                        const T* __restrict__ rois, T* __restrict__ output, int C,
+                                                        int H, int W, int PH_, int PW_, float spatial_scale, int sr_,
+                                                        int aligned, int k, int c0, int chunk, int force_mode,
+                                                        const int* __restrict__ declined) {
+  if constexpr (PHT > 0 && PWT > 0 && SRT > 0) {
+    if constexpr (std::is_same<T, float>::value) {
+      // this launch only mops up what the DMA launch declined
+      if (declined && declined[k] == 0) return;
+    }
+    roi_align_fwd_wave_fast<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, spatial_scale, aligned, k, c0, chunk,
+                                              force_mode);
+  }
+  else
+    roi_align_fwd_wave_unit<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_, aligned,
+                                              k, c0, chunk, force_mode);
+}
+
+// XCD-aware work placement.  Workgroup b is observed to run on XCD b % 8 (a speed assumption
+// only — nothing depends on it for correctness).  Each XCD gets a CONTIGUOUS range of RoIs and
+// walks it channel-chunk by channel-chunk, so at any moment an XCD's private 4 MiB L2 is asked
+// for one thin channel slice of the feature maps (which fits) by ALL of its RoIs, and the
+// overlap between neighbouring RoI windows turns into L2 hits instead of HBM re-reads.
+__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const int* __restrict__ order, int& k,
+                                          int& chunk_idx) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
+  const int xcd = blockIdx.x & 7;
+  const int64_t j = blockIdx.x >> 3;
+  const int64_t kbase = K >> 3, krem = K & 7;
+  const int64_t Kx = kbase + (xcd < krem ? 1 : 0);
+  const int64_t kstart = xcd * kbase + (xcd < krem ? xcd : krem);
+  const int64_t local = j * (kThreads / 64) + wave;
+  if (local >= Kx * nchunks) return false;
+  chunk_idx = (int)(local / Kx);
+  k = (int)(kstart + (local - (int64_t)chunk_idx * Kx));
+  if (order) k = order[k];
+  return true;
+}
+
+// Locality order of the RoIs: a stable-enough counting sort by (image, 32-pixel band of the box
+// centre).  Cutting the sorted list into 8 contiguous ranges (one per XCD, see wave_unit) gives
+// every XCD a horizontal band of one image, i.e. a slice of every feature map that fits its L2.
+constexpr int kOrderBins = 4096;
+template <typename T>
+__global__ __launch_bounds__(1024) void roi_locality_order(const T* __restrict__ rois, int K, int* __restrict__ order) {
+  __shared__ int hist[kOrderBins];
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
+  __syncthreads();
+  auto bin_of = [&](int k) {
+    const T* r = rois + (int64_t)k * 5;
+    int b = (int)ld(r);
+    const float cy = 0.5f * ((float)ld(r + 2) + (float)ld(r + 4));
+    int band = (cy == cy) ? (int)fminf(fmaxf(cy * (1.f / 32.f), 0.f), 63.f) : 0;
+    b = min(max(b, 0), 63);
+    return b * 64 + band;
+  };
+  for (int k = tid; k < K; k += 1024) atomicAdd(&hist[bin_of(k)], 1);
+  __syncthreads();
+  // exclusive scan of 4096 bins: 4 per thread + block scan
+  int loc[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    loc[q] = sum;
+    sum += hist[tid * 4 + q];
+  }
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int base = part[tid] - sum;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hist[tid * 4 + q] = base + loc[q];
+  __syncthreads();
+  for (int k = tid; k < K; k += 1024) order[atomicAdd(&hist[bin_of(k)], 1)] = k;
+}
+
+inline unsigned wave_unit_grid(int64_t K, int nchunks) {
+  const int64_t per_xcd = ceil_div(ceil_div(K, 8) * nchunks, kThreads / 64);
+  return (unsigned)(8 * per_xcd);
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restrict__ input, const T* __restrict__ rois,
+                                                               T* __restrict__ output, int C, int H, int W, int PH_,
+                                                               int PW_, float spatial_scale, int sr_, int aligned,
+                                                               int nchunks, int chunk, int64_t nunits,
+                                                               const int* __restrict__ declined,
+                                                               const int* __restrict__ order) {
+  __shared__ WaveShared s[kThreads / 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
+  int k, ci;
+  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  const int c0 = ci * chunk;
+  roi_align_wave_dispatch<T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
+                                            aligned, k, c0, chunk, g_roi_force_mode, declined);
+}
+
+template <int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const float* __restrict__ input,
+                                                              const float* __restrict__ rois, float* __restrict__ output,
+                                                              int C, int H, int W, float spatial_scale, int aligned,
+                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
+                                                              const int* __restrict__ order) {
+  __shared__ DmaShared s[kThreads / 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
+  int k, ci;
+  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  roi_align_fwd_wave_dma<PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
+                                        chunk, declined);
+}
+
+template <int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const float* __restrict__ rois,
+                                                                 float* __restrict__ output, int C, int aligned,
+                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
+                                                                 const int* __restrict__ order) {
+  __shared__ DmaShared s[kThreads / 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
+  int k, ci;
+  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+  roi_align_fwd_wave_dma<PHT, PWT, SRT>(s[wave], static_cast<const float*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                        lv.scale[l], aligned, k, ci * chunk, chunk, declined);
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, const T* __restrict__ rois,
+                                                                  T* __restrict__ output, int C, int PH_, int PW_,
+                                                                  int sr_, int aligned, int nchunks, int chunk,
+                                                                  int64_t nunits, const int* __restrict__ declined,
+                                                                  const int* __restrict__ order) {
+  __shared__ WaveShared s[kThreads / 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
+  int k, ci;
+  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  const int c0 = ci * chunk;
+  const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
+  roi_align_wave_dispatch<T, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
+                                            lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, c0, chunk,
+                                            g_roi_force_mode, declined);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -479,10 +1293,32 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_tile(
   }
 }
 
+// debug / tuning knobs (tvmi_debug_set): [0] kernel variant 0 = block-tiled, 1 = wave-autonomous;
+// [1] channels per unit for the wave variant; [2] force mode (device side)
+int g_cfg_variant = 1;
+int g_cfg_chunk = 32;
+int g_cfg_dma = 1;
+int g_cfg_order = 0;
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static void load_env_cfg() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  g_cfg_variant = env_int("TVMI_ROI_VARIANT", g_cfg_variant);
+  g_cfg_chunk = env_int("TVMI_ROI_CHUNK", g_cfg_chunk);
+  g_cfg_dma = env_int("TVMI_ROI_DMA", g_cfg_dma);
+  g_cfg_order = env_int("TVMI_ROI_ORDER", g_cfg_order);
+}
+
 template <typename T>
 int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               hipStream_t stream) {
+               int* order, int* declined, hipStream_t stream) {
+  load_env_cfg();
   const T* in = static_cast<const T*>(input);
   const T* r = static_cast<const T*>(rois);
   T* out = static_cast<T*>(output);
@@ -492,13 +1328,42 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
     roi_align_fwd_generic<T><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(
         in, r, out, total, (int)C, (int)H, (int)W, (int)PH, (int)PW, scale, (int)sr, aligned);
   } else {
-    const int nchunks = (int)ceil_div(C, kChunk);
-    const dim3 grid((unsigned)(K * nchunks)), block(kThreads);
     const float fs = (float)scale;
-#define TVMI_FWD(PHT, PWT, SRT)                                                                  \
-  roi_align_fwd_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H,   \
-                                                                   (int)W, (int)PH, (int)PW, fs, \
-                                                                   (int)sr, aligned, nchunks)
+    const bool wavev = g_cfg_variant == 1;
+    if (order && wavev && g_cfg_order) {
+      roi_locality_order<T><<<dim3(1), dim3(1024), 0, stream>>>(r, (int)K, order);
+    } else {
+      order = nullptr;
+    }
+    const int chunk = wavev ? g_cfg_chunk : kChunk;
+    const int nchunks = (int)ceil_div(C, chunk);
+    const int64_t nunits = K * nchunks;
+    const dim3 grid(wavev ? wave_unit_grid(K, nchunks) : (unsigned)nunits), block(kThreads);
+    // fallback launch (what the DMA launch declined): coarser units, it is almost always empty
+    const int fb_chunk = 64, fb_nchunks = (int)ceil_div(C, fb_chunk);
+    const int64_t fb_nunits = K * fb_nchunks;
+    const dim3 fb_grid(wave_unit_grid(K, fb_nchunks));
+#define TVMI_FWD(PHT, PWT, SRT)                                                                              \
+  if (wavev) {                                                                                               \
+    bool dma = false;                                                                                        \
+    if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                              \
+      if (g_cfg_dma && declined) {                                                                           \
+        roi_align_fwd_dma<PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, \
+                                                                     aligned, nchunks, chunk, nunits, declined, order); \
+        dma = true;                                                                                          \
+      }                                                                                                      \
+    }                                                                                                        \
+    if (dma)                                                                                                 \
+      roi_align_fwd_wave<T, PHT, PWT, SRT><<<fb_grid, block, 0, stream>>>(                                   \
+          in, r, out, (int)C, (int)H, (int)W, (int)PH, (int)PW, fs, (int)sr, aligned, fb_nchunks, fb_chunk,  \
+          fb_nunits, declined, order);                                                                       \
+    else                                                                                                     \
+      roi_align_fwd_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W,   \
+                                                                       (int)PH, (int)PW, fs, (int)sr, aligned, \
+                                                                       nchunks, chunk, nunits, nullptr, order); \
+  } else                                                                                                     \
+    roi_align_fwd_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W,     \
+                                                                     (int)PH, (int)PW, fs, (int)sr, aligned, nchunks)
     if (PH == 7 && PW == 7 && sr == 2) {
       TVMI_FWD(7, 7, 2);
     } else if (PH == 14 && PW == 14 && sr == 2) {
@@ -545,6 +1410,55 @@ int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, 
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_backward");
 }
 
+template <typename T>
+int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
+                  int64_t PW, int64_t sr, int aligned, int* order, int* declined, hipStream_t stream) {
+  load_env_cfg();
+  const T* r = static_cast<const T*>(rois);
+  T* out = static_cast<T*>(output);
+  const bool wavev = g_cfg_variant == 1;
+  if (order && wavev && g_cfg_order) {
+    roi_locality_order<T><<<dim3(1), dim3(1024), 0, stream>>>(r, (int)K, order);
+  } else {
+    order = nullptr;
+  }
+  const int chunk = wavev ? g_cfg_chunk : kChunk;
+  const int nchunks = (int)ceil_div(C, chunk);
+  const int64_t nunits = K * nchunks;
+  const dim3 grid(wavev ? wave_unit_grid(K, nchunks) : (unsigned)nunits), block(kThreads);
+  const int fb_chunk = 64, fb_nchunks = (int)ceil_div(C, fb_chunk);
+  const int64_t fb_nunits = K * fb_nchunks;
+  const dim3 fb_grid(wave_unit_grid(K, fb_nchunks));
+#define TVMI_MS(PHT, PWT, SRT)                                                                                  \
+  if (wavev) {                                                                                                  \
+    bool dma = false;                                                                                           \
+    if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                                 \
+      if (g_cfg_dma && declined) {                                                                              \
+        roi_align_fwd_ms_dma<PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks,   \
+                                                                        chunk, nunits, declined, order);        \
+        dma = true;                                                                                             \
+      }                                                                                                         \
+    }                                                                                                           \
+    if (dma)                                                                                                    \
+      roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<fb_grid, block, 0, stream>>>(                                   \
+          lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, aligned, fb_nchunks, fb_chunk, fb_nunits, declined, order); \
+    else                                                                                                        \
+      roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(                                      \
+          lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, aligned, nchunks, chunk, nunits, nullptr, order);      \
+  } else                                                                                                        \
+    roi_align_fwd_ms_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW,   \
+                                                                        (int)sr, aligned, nchunks)
+  if (PH == 7 && PW == 7 && sr == 2) {
+    TVMI_MS(7, 7, 2);
+  } else if (PH == 14 && PW == 14 && sr == 2) {
+    TVMI_MS(14, 14, 2);
+  } else {
+    TVMI_MS(0, 0, 0);
+  }
+#undef TVMI_MS
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward");
+}
+
 }  // namespace
 }  // namespace tvmi
 
@@ -552,8 +1466,10 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
                                       tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W,
                                       int64_t K, int64_t pooled_h, int64_t pooled_w,
                                       double spatial_scale, int64_t sampling_ratio, int aligned,
-                                      void* stream) {
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
+  int* order = (workspace && workspace_bytes >= 2 * (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
+  int* declined = order ? order + K : nullptr;
   TVMI_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0, "roi_align: negative size");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(input && rois && output, "roi_align: null pointer");
@@ -563,7 +1479,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
   TVMI_DISPATCH_FLOAT(dt, "roi_align_forward",
                       return tvmi::launch_fwd<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h,
                                                         pooled_w, spatial_scale, sampling_ratio,
-                                                        aligned, s));
+                                                        aligned, order, declined, s));
   return 0;
 }
 
@@ -584,5 +1500,62 @@ extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void*
                                                         pooled_h, pooled_w, spatial_scale,
                                                         sampling_ratio, aligned, n_stride, c_stride,
                                                         h_stride, w_stride, s));
+  return 0;
+}
+
+extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, const int64_t* heights,
+                                                 const int64_t* widths, const double* spatial_scales,
+                                                 int64_t n_levels, const void* rois, void* output, tvmi_dtype dt,
+                                                 int64_t N, int64_t C, int64_t K, int64_t pooled_h,
+                                                 int64_t pooled_w, int64_t sampling_ratio, int aligned,
+                                                 int64_t k_min, int64_t k_max, double canonical_scale,
+                                                 double canonical_level, double eps, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "multiscale_roi_align: pooled size must be positive");
+  TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "multiscale_roi_align: 1..8 levels supported");
+  if (K * C * pooled_h * pooled_w == 0) return 0;
+  TVMI_CHECK_ARG(inputs && heights && widths && spatial_scales && rois && output, "multiscale_roi_align: null pointer");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16,
+                 "multiscale_roi_align: float32 / float16 / bfloat16 only");
+  TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align: size exceeds 32-bit launch limits");
+  tvmi::MsLevels lv;
+  for (int i = 0; i < tvmi::kMaxLevels; ++i) {
+    const int j = i < n_levels ? i : 0;
+    TVMI_CHECK_ARG(inputs[j] != nullptr && heights[j] * widths[j] < (1ll << 31), "multiscale_roi_align: bad level");
+    lv.ptr[i] = inputs[j];
+    lv.H[i] = (int)heights[j];
+    lv.W[i] = (int)widths[j];
+    lv.scale[i] = (float)spatial_scales[j];
+  }
+  lv.n_levels = (int)n_levels;
+  lv.k_min = (int)k_min;
+  lv.k_max = (int)k_max;
+  lv.s0 = (float)canonical_scale;
+  lv.lvl0 = (float)canonical_level;
+  lv.eps = (float)eps;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* order = (workspace && workspace_bytes >= 2 * (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
+  int* declined = order ? order + K : nullptr;
+  switch (dt) {
+    case TVMI_F32:
+      return tvmi::launch_ms_fwd<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, order, declined, s);
+    case TVMI_F16:
+      return tvmi::launch_ms_fwd<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, order, declined, s);
+    default:
+      return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned,
+                                                 order, declined, s);
+  }
+}
+
+// Tuning/debug knob, NOT part of the supported ABI (not declared in include/tvmi.h).
+extern "C" int tvmi_debug_set(int key, int value) {
+  if (key == 0) tvmi::g_cfg_variant = value;
+  if (key == 1 && value > 0) tvmi::g_cfg_chunk = value;
+  if (key == 3) tvmi::g_cfg_dma = value;
+  if (key == 4) tvmi::g_cfg_order = value;
+  if (key == 2) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(tvmi::g_roi_force_mode), &value, sizeof(int));
+    return (int)e;
+  }
   return 0;
 }

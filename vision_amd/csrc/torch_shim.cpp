@@ -18,6 +18,7 @@
 #include <torch/library.h>
 
 #include <tuple>
+#include <vector>
 
 #include "../../include/tvmi.h"
 
@@ -114,10 +115,11 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
   at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, input.options());
   if (output.numel() == 0) return output;
   at::Tensor input_ = input.contiguous(), rois_ = rois.contiguous();
+  at::Tensor ws = at::empty({2 * K}, input.options().dtype(at::kInt));  // order + declined-flag scratch
   check_status(tvmi_roi_align_forward(input_.const_data_ptr(), rois_.const_data_ptr(), output.mutable_data_ptr(),
                                       dtype_of(input, "roi_align"), input.size(0), C, H, W, K, pooled_height,
                                       pooled_width, spatial_scale, sampling_ratio, aligned ? 1 : 0,
-                                      current_stream(input)),
+                                      ws.mutable_data_ptr(), 2 * (size_t)K * sizeof(int32_t), current_stream(input)),
                "roi_align");
   return output;
 }
@@ -464,6 +466,72 @@ at::Tensor interpolate2d(const at::Tensor& input, int64_t out_h, int64_t out_w, 
   return out;
 }
 
+// ---- multi-scale RoIAlign in one launch (torchvision/ops/poolers.py:147-227)
+at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois, at::ArrayRef<double> scales,
+                                int64_t pooled_height, int64_t pooled_width, int64_t sampling_ratio, bool aligned,
+                                int64_t k_min, int64_t k_max, double canonical_scale, double canonical_level,
+                                double eps) {
+  TORCH_CHECK(features.size() >= 1 && features.size() <= 8, "multiscale_roi_align: 1..8 feature levels supported");
+  TORCH_CHECK(features.size() == scales.size(), "multiscale_roi_align: one scale per feature level");
+  TORCH_CHECK(rois.is_cuda() && rois.dim() == 2 && rois.size(1) == 5, "rois must be a CUDA tensor of shape [K, 5]");
+  const at::Tensor& f0 = features[0];
+  TORCH_CHECK(f0.is_cuda() && f0.dim() == 4, "features must be 4d CUDA tensors");
+  c10::DeviceGuard guard(f0.device());
+  std::vector<at::Tensor> keep;
+  std::vector<const void*> ptrs;
+  std::vector<int64_t> hs, ws;
+  for (const at::Tensor& f : features) {
+    TORCH_CHECK(f.is_cuda() && f.dim() == 4 && f.size(0) == f0.size(0) && f.size(1) == f0.size(1) &&
+                    f.scalar_type() == f0.scalar_type() && f.device() == f0.device(),
+                "multiscale_roi_align: feature levels must share device, dtype, batch and channel sizes");
+    keep.push_back(f.contiguous());
+    ptrs.push_back(keep.back().const_data_ptr());
+    hs.push_back(f.size(2));
+    ws.push_back(f.size(3));
+  }
+  at::Tensor rois_ = rois.to(f0.scalar_type()).contiguous();
+  const int64_t K = rois.size(0), C = f0.size(1);
+  at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, f0.options());
+  if (output.numel() == 0) return output;
+  at::Tensor order_ws = at::empty({2 * K}, f0.options().dtype(at::kInt));  // order + declined-flag scratch
+  check_status(tvmi_multiscale_roi_align_forward(ptrs.data(), hs.data(), ws.data(), scales.data(),
+                                                 (int64_t)features.size(), rois_.const_data_ptr(),
+                                                 output.mutable_data_ptr(), dtype_of(f0, "multiscale_roi_align"),
+                                                 f0.size(0), C, K, pooled_height, pooled_width, sampling_ratio,
+                                                 aligned ? 1 : 0, k_min, k_max, canonical_scale, canonical_level, eps,
+                                                 order_ws.mutable_data_ptr(), 2 * (size_t)K * sizeof(int32_t),
+                                                 current_stream(f0)),
+               "multiscale_roi_align");
+  return output;
+}
+
+// ---- detection payload packing (one launch; see include/tvmi.h)
+std::tuple<at::Tensor, at::Tensor> pack_detections(const at::Tensor& boxes, const at::Tensor& scores,
+                                                   const c10::optional<at::Tensor>& labels, const at::Tensor& image_idx,
+                                                   const at::Tensor& keep, int64_t num_images, int64_t max_dets) {
+  TORCH_CHECK(boxes.is_cuda() && scores.is_cuda() && image_idx.is_cuda() && keep.is_cuda(), "pack_detections: CUDA tensors expected");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && scores.dim() == 1 && scores.size(0) == boxes.size(0) &&
+                  image_idx.dim() == 1 && image_idx.size(0) == boxes.size(0) && keep.dim() == 1,
+              "pack_detections: boxes [N,4], scores [N], image_idx [N], keep [M] expected");
+  c10::DeviceGuard guard(boxes.device());
+  at::Tensor b = boxes.to(at::kFloat).contiguous(), s = scores.to(at::kFloat).contiguous();
+  at::Tensor ii = image_idx.to(at::kLong).contiguous(), k = keep.to(at::kLong).contiguous();
+  at::Tensor lab;
+  const int64_t* lab_ptr = nullptr;
+  if (labels.has_value() && labels->defined()) {
+    lab = labels->to(at::kLong).contiguous();
+    lab_ptr = lab.const_data_ptr<int64_t>();
+  }
+  at::Tensor dets = at::empty({num_images, max_dets, 6}, b.options());
+  at::Tensor counts = at::empty({num_images}, b.options().dtype(at::kInt));
+  check_status(tvmi_pack_detections(b.const_data_ptr<float>(), s.const_data_ptr<float>(), lab_ptr,
+                                    ii.const_data_ptr<int64_t>(), k.const_data_ptr<int64_t>(), k.size(0), num_images,
+                                    max_dets, dets.mutable_data_ptr<float>(), counts.mutable_data_ptr<int32_t>(),
+                                    current_stream(boxes)),
+               "pack_detections");
+  return std::make_tuple(dets, counts);
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -509,6 +577,10 @@ TORCH_LIBRARY(tvmi, m) {
   // aten::upsample_* arithmetic on our kernels (mode 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic;
   // scale_* <= 0 means "not given")
   m.def(
+      "pack_detections(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, int num_images, int max_dets) -> (Tensor, Tensor)");
+  m.def(
+      "multiscale_roi_align(Tensor[] features, Tensor rois, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor");
+  m.def(
       "interpolate2d(Tensor input, int out_h, int out_w, int mode, bool align_corners, bool antialias, float scale_h, float scale_w) -> Tensor");
 }
 
@@ -530,6 +602,8 @@ TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
 TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("nms_segmented", &nms_segmented);
   m.impl("interpolate2d", &interpolate2d);
+  m.impl("multiscale_roi_align", &multiscale_roi_align);
+  m.impl("pack_detections", &pack_detections);
 }
 
 }  // namespace tvmi_shim

@@ -60,8 +60,17 @@ def _multiscale_roi_align(x_filtered: List[Tensor], boxes: List[Tensor], output_
     if len(x_filtered) == 1:
         return roi_align(x_filtered[0], rois, output_size=output_size, spatial_scale=scales[0],
                          sampling_ratio=sampling_ratio)
-    levels = mapper(boxes)
     first = x_filtered[0]
+    if first.is_cuda and first.dtype in (torch.float32, torch.float16, torch.bfloat16) and not (
+        torch.is_grad_enabled() and any(f.requires_grad for f in x_filtered)
+    ):
+        # one launch for all levels: level assignment happens in the kernel, results land
+        # directly in the [K, C, PH, PW] output (no torch.where / index_put per level)
+        return torch.ops.tvmi.multiscale_roi_align(
+            list(x_filtered), rois.to(first.dtype), [float(s) for s in scales], int(output_size[0]),
+            int(output_size[1]), int(sampling_ratio), False, int(mapper.k_min), int(mapper.k_max), float(mapper.s0),
+            float(mapper.lvl0), float(mapper.eps))
+    levels = mapper(boxes)
     result = torch.zeros((len(rois), first.shape[1]) + tuple(output_size), dtype=first.dtype, device=first.device)
     for level, (feature, scale) in enumerate(zip(x_filtered, scales)):
         idx = torch.where(levels == level)[0]
