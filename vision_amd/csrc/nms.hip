@@ -214,14 +214,17 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve(const u64* __restr
   for (int step = 0; step < kSuper; ++step) {
     if (step == c_loc && have) {
       // every earlier block of the super-block is folded in: resolve my 64 boxes
-      u64 cand = uniform64(~rem & valid);
-      u64 keep = 0ull;
-      while (cand) {  // wave-uniform scalar loop over the surviving candidates
-        const int k = __builtin_ctzll(cand);
-        const u64 bit = 1ull << k;
-        keep |= bit;
-        cand &= ~(readlane64(diag, k) | bit);
+      // Only boxes whose diagonal row is non-empty can change the outcome, and a box's removed
+      // bit is final once every lower-indexed non-empty row has been handled — so the serial
+      // (wave-uniform, scalar) loop visits just the surviving non-empty rows, in order.
+      u64 r = uniform64(rem);
+      u64 active = uniform64(__ballot(diag != 0ull)) & ~r & valid;
+      while (active) {
+        const int k = __builtin_ctzll(active);
+        r |= readlane64(diag, k);          // box k is kept: apply its row
+        active &= ~(r | (1ull << k));      // drop k and everything it (or earlier rows) removed
       }
+      const u64 keep = ~r & valid;
       my_keep = keep;
       if (lane == 0) {
         s_keep[c_loc] = keep;
@@ -252,6 +255,83 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve(const u64* __restr
   }
 }
 
+// K3': the whole sweep of a small problem (CB <= kSmallCB column blocks, i.e. N <= 4096) in ONE
+// workgroup and ONE launch: the super-blocks are walked in order, the column reduction over
+// earlier super-blocks is done by the wave that owns the column (its lanes accumulate the masked
+// tile words, one DPP reduction at the end) with the keep bits held in LDS, then the same
+// register-resident resolve chain as nms_resolve.  Removes 2 memsets + 2 launches per
+// super-block from the latency-bound case (RPN / box-head sizes).
+constexpr int kSmallCB = 64;
+__global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __restrict__ mask,
+                                                                  const int64_t* __restrict__ order, int n, int CB,
+                                                                  int64_t* __restrict__ keep_out,
+                                                                  int64_t* __restrict__ num_keep) {
+  __shared__ u64 s_keepbits[kSmallCB];
+  __shared__ int s_base[kSmallCB + 1];
+  const int lane = threadIdx.x & 63;
+  const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int b0 = 0; b0 < CB; b0 += kSuper) {
+    const int b1 = min(CB, b0 + kSuper);
+    const int cb = b0 + c_loc;
+    const bool have = cb < b1;
+    u64 diag = 0ull, above[kSuper - 1];
+    if (have) diag = mask[((size_t)cb * CB + cb) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < kSuper - 1; ++q) {
+      above[q] = 0ull;
+      if (have && q < c_loc) above[q] = mask[((size_t)(b0 + q) * CB + cb) * 64 + lane];
+    }
+    // pull from every earlier super-block (their keep bits are final and in LDS)
+    u64 acc = 0ull;
+    if (have) {
+      for (int rb = 0; rb < b0; ++rb) {
+        const u64 w = mask[((size_t)rb * CB + cb) * 64 + lane];
+        if ((s_keepbits[rb] >> lane) & 1ull) acc |= w;
+      }
+    }
+    u64 rem = b0 > 0 ? wave_or64(acc) : 0ull;
+    const int rows_here = have ? min(64, n - cb * 64) : 0;
+    const u64 valid = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+#pragma unroll
+    for (int step = 0; step < kSuper; ++step) {
+      if (step == c_loc && have) {
+        u64 r = uniform64(rem);
+        u64 active = uniform64(__ballot(diag != 0ull)) & ~r & valid;
+        while (active) {
+          const int k = __builtin_ctzll(active);
+          r |= readlane64(diag, k);
+          active &= ~(r | (1ull << k));
+        }
+        if (lane == 0) s_keepbits[cb] = ~r & valid;
+      }
+      __syncthreads();
+      if (step < kSuper - 1 && have && step < c_loc) {
+        const u64 kb = s_keepbits[b0 + step];
+        const u64 contrib = ((kb >> lane) & 1ull) ? above[step] : 0ull;
+        rem |= wave_or64(contrib);
+      }
+    }
+  }
+  // exclusive prefix of the per-block keep counts, then every wave appends its blocks' indices
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < CB; ++b) {
+      s_base[b] = run;
+      run += __popcll(s_keepbits[b]);
+    }
+    s_base[CB] = run;
+    *num_keep = run;
+  }
+  __syncthreads();
+  for (int b = c_loc; b < CB; b += kSuper) {
+    const u64 kb = s_keepbits[b];
+    if ((kb >> lane) & 1ull) {
+      const u64 below = kb & ((1ull << lane) - 1ull);
+      keep_out[s_base[b] + __popcll(below)] = order[(int64_t)b * 64 + lane];
+    }
+  }
+}
+
 template <typename T>
 int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr, void* workspace,
            int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
@@ -259,12 +339,16 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   u64* mask = static_cast<u64*>(workspace);
   u64* removed = mask + (size_t)CB * CB * 64;
   u64* keepbits = removed + CB;
-  hipError_t e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
-  if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
   const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
   nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), order, seg, (int)n, CB,
                                                                    thr, mask);
+  if (CB <= kSmallCB) {  // latency-bound sizes: the whole sweep is one launch
+    nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, (int)n, CB, keep_out, num_keep);
+    TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
+  }
+  hipError_t e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
+  if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
   for (int b0 = 0; b0 < CB; b0 += kSuper) {
     const int b1 = std::min(CB, b0 + kSuper);
     if (b0 > 0) {
