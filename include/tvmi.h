@@ -69,7 +69,7 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
  *   the flags is not used; results do not depend on it.
  * backward: grad [K,C,PH,PW] read with the given element strides; grad_input
  * [N,C,H,W] must be zero-filled by the caller (the launcher accumulates atomically).
- * F16/BF16 accumulate in fp32.
+ * F16/BF16 accumulate in fp32.  backward workspace (optional): K*4 bytes (declined flags).
  */
 int tvmi_roi_align_forward(const void* input, const void* rois, void* output, tvmi_dtype dt,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
@@ -80,7 +80,8 @@ int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input
                             int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                             int64_t pooled_h, int64_t pooled_w, double spatial_scale,
                             int64_t sampling_ratio, int aligned, int64_t n_stride,
-                            int64_t c_stride, int64_t h_stride, int64_t w_stride, void* stream);
+                            int64_t c_stride, int64_t h_stride, int64_t w_stride, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* Multi-scale RoIAlign (FPN): replaces the per-level python loop of
  * torchvision/ops/poolers.py:147-227 (_multiscale_roi_align: LevelMapper -> torch.where ->
