@@ -421,3 +421,31 @@ def test_pack_detections_matches_host_reference():
     assert torch.equal(d.cpu(), d_ref)
     d0, c0 = sharding.pack_kept_detections(boxes.to(DEV), scores.to(DEV), img.to(DEV), keep[:0].to(DEV), B, D)
     assert d0.abs().sum().item() == 0 and c0.sum().item() == 0
+
+
+@pytest.mark.parametrize("H,W", [(1, 9), (2, 3), (3, 5), (25, 42), (13, 43), (50, 84), (7, 4), (64, 64)])
+def test_roi_align_dma_path_edge_geometries(tv, H, W):
+    """7x7/14x14 sampling_ratio-2 fast paths (LDS-DMA window, shifted edge samples) on awkward map sizes:
+    maps narrower than a quad, widths not divisible by 4, RoIs hugging every border, windows of every size class."""
+    g = gen(30 + H + W)
+    N, C = 2, 40
+    x = torch.randn(N, C, H, W, generator=g)
+    k = 64
+    x1 = torch.rand(k, generator=g) * W * 1.2 - 0.1 * W
+    y1 = torch.rand(k, generator=g) * H * 1.2 - 0.1 * H
+    bw = torch.rand(k, generator=g) ** 2 * W * 1.1
+    bh = torch.rand(k, generator=g) ** 2 * H * 1.1
+    rois = torch.stack([torch.randint(0, N, (k,), generator=g).float(), x1, y1, x1 + bw, y1 + bh], 1)
+    rois[0, 1:] = torch.tensor([0.0, 0.0, float(W), float(H)])
+    rois[1, 1:] = torch.tensor([W - 1.0, H - 1.0, float(W), float(H)])
+    rois[2, 1:] = torch.tensor([W - 0.5, 0.0, W + 3.0, float(H)])
+    rois[3, 1:] = torch.tensor([-2.0, -2.0, 0.4, 0.4])
+    for P in (7, 14):
+        for aligned in (False, True):
+            y = tv.roi_align(x.to(DEV), rois.to(DEV), 1.0, P, P, 2, aligned)
+            ref = O.roi_align(x.numpy(), rois.numpy(), 1.0, P, P, 2, aligned)
+            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=TOL)
+            gr = torch.randn(ref.shape, generator=g)
+            gi = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), 1.0, P, P, N, C, H, W, 2, aligned)
+            refb = O.roi_align_backward(gr.numpy(), rois.numpy(), 1.0, P, P, N, C, H, W, 2, aligned)
+            np.testing.assert_allclose(gi.cpu().numpy(), refb, rtol=1e-4, atol=TOL * max(1.0, float(np.abs(refb).max())))
