@@ -449,3 +449,26 @@ def test_roi_align_dma_path_edge_geometries(tv, H, W):
             gi = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), 1.0, P, P, N, C, H, W, 2, aligned)
             refb = O.roi_align_backward(gr.numpy(), rois.numpy(), 1.0, P, P, N, C, H, W, 2, aligned)
             np.testing.assert_allclose(gi.cpu().numpy(), refb, rtol=1e-4, atol=TOL * max(1.0, float(np.abs(refb).max())))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 5e-3)])
+@pytest.mark.parametrize("P", [7, 14])
+def test_roi_align_16bit_dma_path(tv, dtype, tol, P):
+    """fp16 / bf16 through the LDS-DMA fast path (8 elements per 16-byte piece); bar = the reference's own
+    half / bf16 tolerances (test/test_ops.py:133-140) against the fp32 result on the rounded inputs."""
+    g = gen(40 + P)
+    N, C, H, W = 2, 48, 50, 84
+    x = torch.rand(N, C, H, W, generator=g).to(dtype)
+    rois = rois_for(N, 120, W * 16, H * 16, 16, 500, g).to(dtype)
+    y = tv.roi_align(x.to(DEV), rois.to(DEV), 1 / 16, P, P, 2, False)
+    assert y.dtype == dtype
+    ref = O.roi_align(x.float().numpy(), rois.float().numpy(), 1 / 16, P, P, 2, False)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=tol, atol=tol)
+    feats = {str(i): torch.rand(N, 32, 800 // s, 1344 // s, generator=g).to(dtype) for i, s in enumerate((4, 8, 16, 32))}
+    boxes = [random_boxes(100, 1344, 800, 8, 600, g) for _ in range(N)]
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], P, 2)
+    with torch.no_grad():
+        out = pool({k: v.to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * N)
+    assert out.dtype == dtype
+    ref32 = pool({k: v.float().to(DEV) for k, v in feats.items()}, [b.to(dtype).float().to(DEV) for b in boxes], [(800, 1344)] * N)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref32.cpu().numpy(), rtol=tol, atol=tol)

@@ -823,14 +823,15 @@ __device__ __forceinline__ bool axis_sample_shifted(int dim, float start, float 
   return true;
 }
 
-template <int PHT, int PWT, int SRT>
+// EPP = elements per 16-byte DMA piece (4 for fp32, 8 for fp16/bf16); nq then counts pieces.
+template <int PHT, int PWT, int SRT, int EPP = 4>
 __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, int W) {
   constexpr int ny = PHT * SRT, nx = PWT * SRT;
   const int lane = threadIdx.x & 63;
   DmaWindow w;
   w.state = 2;
   w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = 0;
-  if (H < 2 || W < 4) return w;
+  if (H < 2 || W < EPP) return w;
   int lo = 0, lo2 = 0;
   float l, h;
   bool v = false, v2 = false;
@@ -850,12 +851,11 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   const int x0 = min(xa, xb);
   const int x1 = max(xa, xb) + 1;
   w.wh = y1 - w.y0 + 1;
-  // 16-byte ALIGNED quads whenever the row pitch allows it (W % 4 == 0; tensor bases are 256-byte
-  // aligned): a misaligned dwordx4 piece is split into dwords by the texture addresser (measured
-  // ~78 TA cycles per 1-KiB DMA instruction against 16 for aligned ones).
-  const int xal = (W & 3) == 0 ? (x0 & ~3) : x0;
-  w.nq = (x1 - xal + 4) >> 2;           // quads covering [xal, x1]
-  w.x0 = min(xal, W - 4 * w.nq);        // keep every quad inside the row (no-op in the aligned case)
+  // pieces start on 16-byte boundaries whenever the row pitch allows it (measured: no effect on
+  // the texture-addresser cost either way; kept because it never costs more than one extra piece)
+  const int xal = (W % EPP) == 0 ? x0 - (x0 % EPP) : x0;
+  w.nq = (x1 - xal + EPP) / EPP;        // pieces covering [xal, x1]
+  w.x0 = min(xal, W - EPP * w.nq);      // keep every piece inside the row (no-op in the aligned case)
   if (w.x0 < 0) return w;               // map narrower than the window image
   w.lpr = w.nq | 1;
   if (w.lpr > 64) return w;
@@ -866,22 +866,24 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   return w;
 }
 
-template <int NRG>
-__device__ __forceinline__ void dma_issue_pass(const float* __restrict__ in_pass, int64_t plane_sz, int gc,
-                                               const int (&goff)[NRG], float* __restrict__ dst) {
+constexpr int kDmaBlkBytes = kDmaBlk * 4;  // 1040
+
+template <typename T, int NRG>
+__device__ __forceinline__ void dma_issue_pass(const T* __restrict__ in_pass, int64_t plane_sz, int gc,
+                                               const int (&goff)[NRG], char* __restrict__ dst) {
   constexpr int G = NRG <= kDmaPerPass ? kDmaPerPass / NRG : 1;
 #pragma unroll
   for (int c = 0; c < G; ++c) {
-    const float* chp = in_pass + (int64_t)min(c, gc - 1) * plane_sz;  // tail: re-fetch the last channel
+    const T* chp = in_pass + (int64_t)min(c, gc - 1) * plane_sz;  // tail: re-fetch the last channel
 #pragma unroll
     for (int rg = 0; rg < NRG; ++rg) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(chp + goff[rg]), (lds_ptr_t)(dst + (c * NRG + rg) * kDmaBlk), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(chp + goff[rg]), (lds_ptr_t)(dst + (c * NRG + rg) * kDmaBlkBytes), 16, 0, 0);
     }
   }
 }
 
-template <int PHT, int PWT, int SRT, int NRG>
-__device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const float* __restrict__ in0, float* __restrict__ out,
+template <typename T, int PHT, int PWT, int SRT, int NRG>
+__device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __restrict__ in0, T* __restrict__ out,
                                                      int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
                                                      const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
                                                      const float (&fy)[(PHT * PWT + 63) / 64][SRT][2],
@@ -889,39 +891,42 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const float* 
   constexpr int PHW = PHT * PWT;
   constexpr int NB = (PHW + 63) / 64;
   constexpr int NS = SRT * SRT;
-  constexpr bool kDouble = NRG <= kDmaPerPass;  // 8 row groups use both buffers as one
+  constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int BLK = kDmaBlkBytes / (int)sizeof(T);  // elements per DMA block incl. skew
+  constexpr bool kDouble = NRG <= kDmaPerPass;        // 8 row groups use both buffers as one
   constexpr int G = kDouble ? kDmaPerPass / NRG : 1;
   constexpr bool kPow2 = (NS & (NS - 1)) == 0;
   const float inv_count = 1.f / (float)NS;
   const int lane = threadIdx.x & 63;
   const int rsub = min(lane / dw.lpr, dw.rpi - 1);
   const int q = min(lane - (lane / dw.lpr) * dw.lpr, dw.nq - 1);
-  const int gx = dw.x0 + 4 * q;
+  const int gx = dw.x0 + EPP * q;
+  char* const bytes = reinterpret_cast<char*>(s.buf);
   int goff[NRG];
 #pragma unroll
   for (int rg = 0; rg < NRG; ++rg) goff[rg] = min(dw.y0 + min(rg * dw.rpi + rsub, dw.wh - 1), H - 1) * W + gx;
   const int npass = (cc + G - 1) / G;
-  if (kDouble) dma_issue_pass<NRG>(in0, plane_sz, min(G, cc), goff, s.buf);
+  if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
   for (int p = 0; p < npass; ++p) {
     const int cg = p * G;
     const int gc = min(G, cc - cg);
-    const float* cur;
+    const T* cur;
     if (kDouble) {
       if (p + 1 < npass) {
-        dma_issue_pass<NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
-                            s.buf + ((p + 1) & 1) * kDmaBuf);
+        dma_issue_pass<T, NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
+                               bytes + ((p + 1) & 1) * (kDmaBuf * 4));
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything older than those 4 DMAs has landed
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      cur = s.buf + (p & 1) * kDmaBuf;
+      cur = reinterpret_cast<const T*>(bytes + (p & 1) * (kDmaBuf * 4));
     } else {
-      dma_issue_pass<NRG>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, s.buf);
+      dma_issue_pass<T, NRG>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, bytes);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      cur = s.buf;
+      cur = reinterpret_cast<const T*>(bytes);
     }
     for (int ch = 0; ch < gc; ++ch) {
-      const float* wbase = cur + ch * (NRG * kDmaBlk);
+      const T* wbase = cur + ch * (NRG * BLK);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         float acc = 0.f;
@@ -929,16 +934,22 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const float* 
         for (int iy = 0; iy < SRT; ++iy) {
 #pragma unroll
           for (int ix = 0; ix < SRT; ++ix) {
-            const float* q0 = wbase + off[b][iy * SRT + ix][0];
-            const float* q1 = wbase + off[b][iy * SRT + ix][1];
-            const float t0 = __builtin_fmaf(fx[b][ix][0], q0[1], fx[b][ix][1] * q0[0]);
-            const float t1 = __builtin_fmaf(fx[b][ix][0], q1[1], fx[b][ix][1] * q1[0]);
+            const T* q0 = wbase + off[b][iy * SRT + ix][0];
+            const T* q1 = wbase + off[b][iy * SRT + ix][1];
+            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), fx[b][ix][1] * ld(q0));
+            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), fx[b][ix][1] * ld(q1));
             acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
             acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
           }
         }
         const int bin = lane + 64 * b;
-        if (bin < PHW) __builtin_nontemporal_store(kPow2 ? acc * inv_count : acc / (float)NS, out + (cg + ch) * PHW + bin);
+        if (bin < PHW) {
+          const float r = kPow2 ? acc * inv_count : acc / (float)NS;
+          if constexpr (std::is_same<T, float>::value)
+            __builtin_nontemporal_store(r, out + (cg + ch) * PHW + bin);
+          else
+            st(out + (cg + ch) * PHW + bin, r);
+        }
       }
     }
     // the ds_reads above are complete (their results were consumed) before the next DMAs may
@@ -947,31 +958,33 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const float* 
   }
 }
 
-template <int PHT, int PWT, int SRT>
-__device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const float* __restrict__ input,
-                                                       const float* __restrict__ rois, float* __restrict__ output,
+template <typename T, int PHT, int PWT, int SRT>
+__device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __restrict__ input,
+                                                       const T* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
                                                        int c0, int chunk, int* __restrict__ declined) {
   constexpr int PHW = PHT * PWT;
   constexpr int NB = (PHW + 63) / 64;
   constexpr int NS = SRT * SRT;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int BLK = kDmaBlkBytes / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
   const int cc = min(chunk, C - c0);
-  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
-  float* out = output + ((int64_t)k * C + c0) * PHW;
-  const float* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
+  const RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
+  T* out = output + ((int64_t)k * C + c0) * PHW;
+  const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
   const int64_t plane_sz = (int64_t)H * W;
-  const DmaWindow dw = dma_window<PHT, PWT, SRT>(g, H, W);
+  const DmaWindow dw = dma_window<PHT, PWT, SRT, EPP>(g, H, W);
   if (c0 == 0 && lane == 0) declined[k] = dw.state == 2;  // tells the fallback launch what is left
   if (dw.state == 2) return;
   if (dw.state == 0) {
-    for (int o = lane; o < cc * PHW; o += 64) out[o] = 0.f;
+    for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
     return;
   }
   // ---- per-lane sample set-up (registers): LDS slots of the two tap rows + separable factors
   int off[NB][NS][2];
   float fy[NB][SRT][2], fx[NB][SRT][2];
-  const int rstride = 4 * dw.lpr;
+  const int rstride = EPP * dw.lpr;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int bin = min(lane + 64 * b, PHW - 1);
@@ -985,8 +998,8 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const float
       fy[b][i][0] = l;
       fy[b][i][1] = h;
       const int r = vy ? lo - dw.y0 : 0;
-      rlo[i][0] = (r / dw.rpi) * kDmaBlk + (r % dw.rpi) * rstride;
-      rlo[i][1] = ((r + 1) / dw.rpi) * kDmaBlk + ((r + 1) % dw.rpi) * rstride;
+      rlo[i][0] = (r / dw.rpi) * BLK + (r % dw.rpi) * rstride;
+      rlo[i][1] = ((r + 1) / dw.rpi) * BLK + ((r + 1) % dw.rpi) * rstride;
       const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
       fx[b][i][0] = l;
       fx[b][i][1] = h;
@@ -1001,13 +1014,13 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const float
       }
   }
   if (dw.nrg <= 1)
-    roi_align_dma_passes<PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
   else if (dw.nrg <= 2)
-    roi_align_dma_passes<PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
   else if (dw.nrg <= 4)
-    roi_align_dma_passes<PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
   else
-    roi_align_dma_passes<PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -1017,10 +1030,8 @@ __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* 
                                                         int aligned, int k, int c0, int chunk, int force_mode,
                                                         const int* __restrict__ declined) {
   if constexpr (PHT > 0 && PWT > 0 && SRT > 0) {
-    if constexpr (std::is_same<T, float>::value) {
-      // this launch only mops up what the DMA launch declined
-      if (declined && declined[k] == 0) return;
-    }
+    // when the DMA launch ran first, this launch only mops up what it declined
+    if (declined && declined[k] == 0) return;
     roi_align_fwd_wave_fast<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, spatial_scale, aligned, k, c0, chunk,
                                               force_mode);
   }
@@ -1114,9 +1125,9 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restri
                                             aligned, k, c0, chunk, g_roi_force_mode, declined);
 }
 
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const float* __restrict__ input,
-                                                              const float* __restrict__ rois, float* __restrict__ output,
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restrict__ input,
+                                                              const T* __restrict__ rois, T* __restrict__ output,
                                                               int C, int H, int W, float spatial_scale, int aligned,
                                                               int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
                                                               const int* __restrict__ order) {
@@ -1124,21 +1135,21 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const float* __res
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
-  roi_align_fwd_wave_dma<PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
+  roi_align_fwd_wave_dma<T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
                                         chunk, declined);
 }
 
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const float* __restrict__ rois,
-                                                                 float* __restrict__ output, int C, int aligned,
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const T* __restrict__ rois,
+                                                                 T* __restrict__ output, int C, int aligned,
                                                                  int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
                                                                  const int* __restrict__ order) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
-  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  roi_align_fwd_wave_dma<PHT, PWT, SRT>(s[wave], static_cast<const float*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+  const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
+  roi_align_fwd_wave_dma<T, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
                                         lv.scale[l], aligned, k, ci * chunk, chunk, declined);
 }
 
@@ -1501,9 +1512,9 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
 #define TVMI_FWD(PHT, PWT, SRT)                                                                              \
   if (wavev) {                                                                                               \
     bool dma = false;                                                                                        \
-    if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                              \
+    if constexpr ((PHT) > 0) {                                                                               \
       if (g_cfg_dma && declined) {                                                                           \
-        roi_align_fwd_dma<PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, \
+        roi_align_fwd_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, \
                                                                      aligned, nchunks, chunk, nunits, declined, order); \
         dma = true;                                                                                          \
       }                                                                                                      \
@@ -1599,9 +1610,9 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
 #define TVMI_MS(PHT, PWT, SRT)                                                                                  \
   if (wavev) {                                                                                                  \
     bool dma = false;                                                                                           \
-    if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                                 \
+    if constexpr ((PHT) > 0) {                                                                                  \
       if (g_cfg_dma && declined) {                                                                              \
-        roi_align_fwd_ms_dma<PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks,   \
+        roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks,   \
                                                                         chunk, nunits, declined, order);        \
         dma = true;                                                                                             \
       }                                                                                                         \
