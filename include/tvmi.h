@@ -69,13 +69,16 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
  *   the flags is not used; results do not depend on it.
  * backward: grad [K,C,PH,PW] read with the given element strides; grad_input
  * [N,C,H,W] must be zero-filled by the caller (the launcher accumulates atomically).
- * F16/BF16 accumulate in fp32.  backward workspace (optional): K*4 bytes (declined flags).
+ * F16/BF16 accumulate in fp32.  backward workspace (optional, tvmi_roi_align_backward_workspace_bytes):
+ * per-tile RoI lists of the tile-stationary (atomic-free) fp32 backward; without it the per-RoI
+ * atomic kernel is used.
  */
 int tvmi_roi_align_forward(const void* input, const void* rois, void* output, tvmi_dtype dt,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                            int64_t pooled_h, int64_t pooled_w, double spatial_scale,
                            int64_t sampling_ratio, int aligned, void* workspace, size_t workspace_bytes,
                            void* stream);
+size_t tvmi_roi_align_backward_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t K);
 int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input, tvmi_dtype dt,
                             int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                             int64_t pooled_h, int64_t pooled_w, double spatial_scale,

@@ -138,13 +138,14 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
   if (grad.numel() == 0) return grad_input;
   at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
   at::Tensor rois_ = rois.contiguous();
-  at::Tensor ws = at::empty({rois.size(0)}, grad.options().dtype(at::kInt));
+  const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, height, width, rois.size(0));
+  at::Tensor ws = at::empty({(int64_t)ws_bytes}, grad.options().dtype(at::kByte));
   check_status(tvmi_roi_align_backward(grad.const_data_ptr(), rois_.const_data_ptr(), grad_input.mutable_data_ptr(),
                                        dtype_of(grad, "_roi_align_backward"), batch_size, channels, height,
                                        width, rois.size(0), pooled_height, pooled_width, spatial_scale,
                                        sampling_ratio, aligned ? 1 : 0, grad.stride(0), grad.stride(1),
-                                       grad.stride(2), grad.stride(3), ws.mutable_data_ptr(),
-                                       (size_t)rois.size(0) * sizeof(int32_t), current_stream(grad)),
+                                       grad.stride(2), grad.stride(3), ws.mutable_data_ptr(), ws_bytes,
+                                       current_stream(grad)),
                "_roi_align_backward");
   return grad_input;
 }
