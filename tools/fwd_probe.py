@@ -1,0 +1,40 @@
+"""RoIAlign forward timing under footprint variations (is the kernel memory-latency or issue bound?)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, vision_amd, bench
+from vision_amd.poolers import _convert_to_roi_format
+dev = torch.device("cuda:0")
+def tm(fn, n=30, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+feats, boxes, scores = bench.make_inputs(dev, 1000)
+scales = [1 / s for s in bench.STRIDES]
+fl = [feats[str(i)] for i in range(4)]
+def run(bx, tag, P=7):
+    rois = _convert_to_roi_format(bx)
+    t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fl, rois, scales, P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6))
+    print(f"{tag:40s} P={P}: {t:.4f} ms")
+for P in (7, 14):
+    run(boxes, "baseline", P)
+    # same sizes, centres squeezed into 10 % of the image, all on image 0 -> L2-resident footprint
+    sq = []
+    for b in boxes:
+        c = (b[:, :2] + b[:, 2:]) / 2; wh = b[:, 2:] - b[:, :2]
+        c = c * 0.1 + 300
+        sq.append(torch.cat([c - wh / 2, c + wh / 2], 1).clamp(min=0))
+    allb = torch.cat(sq)
+    z = torch.zeros(0, 4, device=dev)
+    run([allb, z, z, z], "squeezed centres, image 0 (L2 resident)", P)
+    one = boxes[0][:1].repeat(4000, 1)
+    run([one, z, z, z], "one RoI x4000 (L1 resident)", P)
+    # sorted by level+position (locality)
+    key = []
+    for b in boxes:
+        key.append(b)
+    run([b[torch.argsort((b[:, 1] // 64) * 100 + b[:, 0] // 64)] for b in boxes], "sorted by 64px cell", P)

@@ -1046,14 +1046,14 @@ __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* 
 // for one thin channel slice of the feature maps (which fits) by ALL of its RoIs, and the
 // overlap between neighbouring RoI windows turns into L2 hits instead of HBM re-reads.
 __device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const int* __restrict__ order, int& k,
-                                          int& chunk_idx) {
+                                          int& chunk_idx, int wpb = kThreads / 64) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   const int xcd = blockIdx.x & 7;
   const int64_t j = blockIdx.x >> 3;
   const int64_t kbase = K >> 3, krem = K & 7;
   const int64_t Kx = kbase + (xcd < krem ? 1 : 0);
   const int64_t kstart = xcd * kbase + (xcd < krem ? xcd : krem);
-  const int64_t local = j * (kThreads / 64) + wave;
+  const int64_t local = j * wpb + wave;
   if (local >= Kx * nchunks) return false;
   chunk_idx = (int)(local / Kx);
   k = (int)(kstart + (local - (int64_t)chunk_idx * Kx));
@@ -1104,8 +1104,8 @@ __global__ __launch_bounds__(1024) void roi_locality_order(const T* __restrict__
   for (int k = tid; k < K; k += 1024) order[atomicAdd(&hist[bin_of(k)], 1)] = k;
 }
 
-inline unsigned wave_unit_grid(int64_t K, int nchunks) {
-  const int64_t per_xcd = ceil_div(ceil_div(K, 8) * nchunks, kThreads / 64);
+inline unsigned wave_unit_grid(int64_t K, int nchunks, int wpb = kThreads / 64) {
+  const int64_t per_xcd = ceil_div(ceil_div(K, 8) * nchunks, wpb);
   return (unsigned)(8 * per_xcd);
 }
 
@@ -1139,15 +1139,15 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restric
                                         chunk, declined);
 }
 
-template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const T* __restrict__ rois,
+template <typename T, int PHT, int PWT, int SRT, int WPB = kThreads / 64>
+__global__ __launch_bounds__(64 * WPB) void roi_align_fwd_ms_dma(MsLevels lv, const T* __restrict__ rois,
                                                                  T* __restrict__ output, int C, int aligned,
                                                                  int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
                                                                  const int* __restrict__ order) {
-  __shared__ DmaShared s[kThreads / 64];
+  __shared__ DmaShared s[WPB];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci, WPB)) return;
   const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
   roi_align_fwd_wave_dma<T, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
                                         lv.scale[l], aligned, k, ci * chunk, chunk, declined);
@@ -1316,6 +1316,7 @@ int g_cfg_chunk = 32;
 int g_cfg_dma = 1;
 int g_cfg_order = 0;
 int g_cfg_bwd_dense = 1;
+int g_cfg_dma_wpb = 4;
 int g_cfg_bwd_tiles = 0;
 int g_cfg_bwd_wave = 0;  // wave-autonomous backward: measured slower than the block-tiled one (7.1 vs 4.5 ms
                          // on config 2, both bound by global float atomics) — kept behind TVMI_ROI_BWD_WAVE=1
@@ -1335,6 +1336,7 @@ static void load_env_cfg() {
   g_cfg_bwd_wave = env_int("TVMI_ROI_BWD_WAVE", g_cfg_bwd_wave);
   g_cfg_bwd_tiles = env_int("TVMI_ROI_BWD_TILES", g_cfg_bwd_tiles);
   g_cfg_bwd_dense = env_int("TVMI_ROI_BWD_DENSE", g_cfg_bwd_dense);
+  g_cfg_dma_wpb = env_int("TVMI_ROI_DMA_WPB", g_cfg_dma_wpb);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1693,7 +1695,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __r
                                                                 float* __restrict__ grad_input, int C, int H, int W,
                                                                 float spatial_scale, int aligned, int nchunks, int chunk,
                                                                 int64_t nunits, int64_t ns, int64_t cs, int64_t hs,
-                                                                int64_t ws, int* __restrict__ declined) {
+                                                                int64_t ws, int* __restrict__ declined, int dbg) {
   using DS = DenseShared<PHT, PWT, SRT>;
   __shared__ DS sh[kThreads / 64];
   constexpr int ny = PHT * SRT, nx = PWT * SRT;
@@ -1799,13 +1801,21 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __r
     }
     // 3. window rows: one global atomic per pixel, contiguous along the row
     const bool write_ok = col_ok && slot < gc;
+    float dbgacc = 0.f;
     float* plane = gi0 + (int64_t)(cg + myslot) * plane_sz + (int64_t)y0 * W + x0 + col;
     for (int r = 0; r < wh; ++r) {
       float v = 0.f;
 #pragma unroll
       for (int ph = 0; ph < PHT; ++ph) v = __builtin_fmaf(s.ayd[r][ph], t[ph], v);
-      if (write_ok && v != 0.f) unsafeAtomicAdd(plane + (int64_t)r * W, v);
+      if (dbg == 0) {
+        if (write_ok && v != 0.f) unsafeAtomicAdd(plane + (int64_t)r * W, v);
+      } else if (dbg == 2) {
+        if (write_ok && v != 0.f) plane[(int64_t)r * W] = v;
+      } else {
+        dbgacc += v;
+      }
     }
+    if (dbg == 3 && dbgacc == 12345.f) plane[0] = dbgacc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1900,7 +1910,7 @@ int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, 
     if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                            \
       if (g_cfg_bwd_dense && declined && H * W * C < (1ll << 31)) {                                        \
         roi_align_bwd_dense<PHT, PWT, SRT><<<dim3(wave_unit_grid(K, wnchunks)), block, 0, stream>>>(       \
-            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined); \
+            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined, g_cfg_bwd_dense - 1); \
         dflags = declined;                                                                                 \
       } else if (g_cfg_bwd_tiles && bws && H * W * C < (1ll << 31)) {                                      \
         BwdTiling tl;                                                                                      \
@@ -1969,8 +1979,15 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
     bool dma = false;                                                                                           \
     if constexpr ((PHT) > 0) {                                                                                  \
       if (g_cfg_dma && declined) {                                                                              \
-        roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks,   \
-                                                                        chunk, nunits, declined, order);        \
+        if (g_cfg_dma_wpb == 1)                                                                                 \
+          roi_align_fwd_ms_dma<T, PHT, PWT, SRT, 1><<<dim3(wave_unit_grid(K, nchunks, 1)), dim3(64), 0, stream>>>( \
+              lv, r, out, (int)C, aligned, nchunks, chunk, nunits, declined, order);                            \
+        else if (g_cfg_dma_wpb == 2)                                                                            \
+          roi_align_fwd_ms_dma<T, PHT, PWT, SRT, 2><<<dim3(wave_unit_grid(K, nchunks, 2)), dim3(128), 0, stream>>>( \
+              lv, r, out, (int)C, aligned, nchunks, chunk, nunits, declined, order);                            \
+        else                                                                                                    \
+          roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
+                                                                          chunk, nunits, declined, order);      \
         dma = true;                                                                                             \
       }                                                                                                         \
     }                                                                                                           \

@@ -134,6 +134,14 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
   TORCH_CHECK(grad.scalar_type() == rois.scalar_type(),
               "roi_align_backward_kernel: grad and rois must have the same type");
   c10::DeviceGuard guard(grad.device());
+  if (grad.numel() != 0 && (grad.scalar_type() == at::kHalf || grad.scalar_type() == at::kBFloat16)) {
+    // 16-bit gradients: accumulate in fp32 (native float atomics, the dense kernel) and round once at the end.
+    // The reference accumulates with 16-bit atomics (cuda/roi_align_kernel.cu:317-330); this is both faster on
+    // gfx950 (no CAS loops) and closer to the exact sum.
+    return roi_align_backward(grad.to(at::kFloat), rois.to(at::kFloat), spatial_scale, pooled_height, pooled_width,
+                              batch_size, channels, height, width, sampling_ratio, aligned)
+        .to(grad.scalar_type());
+  }
   at::Tensor grad_input = at::zeros({batch_size, channels, height, width}, grad.options());
   if (grad.numel() == 0) return grad_input;
   at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
