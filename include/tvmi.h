@@ -179,6 +179,32 @@ int tvmi_pack_detections(const float* boxes, const float* scores, const int64_t*
                          const int64_t* image_idx, const int64_t* keep, int64_t num_keep, int64_t num_images,
                          int64_t max_dets, float* dets, int32_t* counts, void* stream);
 
+/* Candidate generation for the detector's two post-processing stages, batched over images
+ * (one launch each; the segmented NMS that follows is tvmi_nms with segment ids, the top-k
+ * packing is tvmi_pack_detections):
+ *  tvmi_detection_candidates — RoIHeads.postprocess_detections, models/detection/roi_heads.py:
+ *    680-722: softmax over C classes, BoxCoder.decode_single per class (_utils.py:183-224,
+ *    weights are divisors), clip_boxes_to_image (ops/boxes.py:171-199), background dropped,
+ *    valid = score > score_thresh && w >= min_size && h >= min_size (ops/boxes.py:148-168).
+ *    class_logits [R,C], box_regression [R,4C], proposals [R,4], row_image [R] int32,
+ *    image_hw [B,2] = (height,width) -> cand_boxes [R,C-1,4], cand_scores [R,C-1],
+ *    cand_valid [R,C-1] uint8 (class c at column c-1).
+ *  tvmi_rpn_candidates — RegionProposalNetwork.filter_proposals, models/detection/rpn.py:
+ *    266-286 for the per-level top-k survivors `top_idx` [B,T] (indices into the A anchors):
+ *    gather, sigmoid, clip, valid = w,h >= min_size && prob >= score_thresh, level id from
+ *    level_offsets [L] (first anchor of each level).  boxes_in [B,A,4] are the decoded
+ *    proposals, or — when `deltas` [B,A,4] is not NULL — the anchors, decoded here with
+ *    weights (1,1,1,1) for the survivors only (rpn.py:364-366 decodes every anchor).
+ */
+int tvmi_detection_candidates(const float* class_logits, const float* box_regression, const float* proposals,
+                              const int32_t* row_image, const float* image_hw, int64_t R, int64_t C, int64_t B,
+                              float wx, float wy, float ww, float wh, float bbox_xform_clip, float score_thresh,
+                              float min_size, float* cand_boxes, float* cand_scores, uint8_t* cand_valid, void* stream);
+int tvmi_rpn_candidates(const float* objectness, const float* boxes_in, const float* deltas, const int64_t* top_idx,
+                        const int64_t* level_offsets, const float* image_hw, int64_t B, int64_t A, int64_t T, int64_t L,
+                        float bbox_xform_clip, float score_thresh, float min_size, float* out_boxes, float* out_scores,
+                        int64_t* out_levels, uint8_t* out_valid, void* stream);
+
 /* ---------------------------------------------------------- box_iou_rotated ------------
  * Replaces: cuda/box_iou_rotated_kernel.cu:41-188; semantics of box_iou_rotated_utils.h:67-383
  * and cpu/box_iou_rotated_kernel.cpp:29-115.  boxes [N,5]/[M,5] = (cx,cy,w,h,angle_deg),
@@ -210,6 +236,15 @@ size_t tvmi_upsample_aa2d_workspace_bytes(int mode, int64_t IH, int64_t IW, int6
 int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt, int mode, int64_t NC, int64_t IH,
                        int64_t IW, int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------- mask paste --------
+ * Batched replacement of paste_masks_in_image (models/detection/roi_heads.py:486-500, with
+ * expand_masks :404-413, expand_boxes :378-395 and paste_mask_in_image :416-437 folded in):
+ * masks [N,M,M] (dt), boxes [N,4] float32 xyxy in image pixels, output [N,im_h,im_w] (dt),
+ * every element written.  The reference loops over detections in Python; this is one launch.
+ */
+int tvmi_paste_masks(const void* masks, const float* boxes, void* output, tvmi_dtype dt, int64_t N, int64_t M,
+                     int64_t im_h, int64_t im_w, int64_t padding, void* stream);
 
 #ifdef __cplusplus
 }

@@ -207,3 +207,114 @@ def interpolate(x, size, mode, align_corners=False, antialias=False, scale=(-1.0
         lib().oracle_interpolate2d(_p(x), _p(out), N * C, IH, IW, OH, OW, _MODES[mode], int(bool(align_corners)),
                                    ctypes.c_double(scale[0]), ctypes.c_double(scale[1]))
     return out
+
+
+def paste_masks_in_image(masks, boxes, img_shape, padding=1):
+    """models/detection/roi_heads.py:486-500 restated per detection: expand_masks (:404-413, zero
+    pad), expand_boxes (:378-395, float32 arithmetic op by op), int64 truncation, bilinear
+    resize of the padded mask to the integer box size (paste_mask_in_image :416-437, via the C
+    oracle's aten::upsample_bilinear2d restatement) and the clipped slice-assign."""
+    masks = _c(masks, np.float32)
+    boxes = _c(boxes, np.float32)
+    im_h, im_w = int(img_shape[0]), int(img_shape[1])
+    N, _, M, _ = masks.shape
+    scale = np.float32(float(M + 2 * padding) / M)
+    out = np.zeros((N, 1, im_h, im_w), dtype=np.float32)
+    half = np.float32(0.5)
+    for n in range(N):
+        b = boxes[n]
+        w_half = (b[2] - b[0]) * half * scale
+        h_half = (b[3] - b[1]) * half * scale
+        x_c = (b[2] + b[0]) * half
+        y_c = (b[3] + b[1]) * half
+        e = [int(np.trunc(v)) for v in (x_c - w_half, y_c - h_half, x_c + w_half, y_c + h_half)]
+        w = max(e[2] - e[0] + 1, 1)
+        h = max(e[3] - e[1] + 1, 1)
+        padded = np.pad(masks[n, 0], padding)[None, None]
+        m = interpolate(padded, (h, w), "bilinear")[0, 0]
+        x_0, x_1 = max(e[0], 0), min(e[2] + 1, im_w)
+        y_0, y_1 = max(e[1], 0), min(e[3] + 1, im_h)
+        if x_1 > x_0 and y_1 > y_0:
+            out[n, 0, y_0:y_1, x_0:x_1] = m[y_0 - e[1]:y_1 - e[1], x_0 - e[0]:x_1 - e[0]]
+    return out
+
+
+# ---- detector post-processing (python-level reference code restated in numpy float32)
+_BBOX_XFORM_CLIP = float(np.log(1000.0 / 16))  # models/detection/_utils.py:141
+
+
+def decode_boxes(rel_codes, boxes, weights):
+    """BoxCoder.decode_single, models/detection/_utils.py:183-224 (float32, op by op)."""
+    f = np.float32
+    rel_codes, boxes = _c(rel_codes, f), _c(boxes, f)
+    widths, heights = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    ctr_x, ctr_y = boxes[:, 0] + f(0.5) * widths, boxes[:, 1] + f(0.5) * heights
+    wx, wy, ww, wh = (f(w) for w in weights)
+    dx, dy = rel_codes[:, 0::4] / wx, rel_codes[:, 1::4] / wy
+    dw = np.minimum(rel_codes[:, 2::4] / ww, f(_BBOX_XFORM_CLIP))
+    dh = np.minimum(rel_codes[:, 3::4] / wh, f(_BBOX_XFORM_CLIP))
+    pcx, pcy = dx * widths[:, None] + ctr_x[:, None], dy * heights[:, None] + ctr_y[:, None]
+    pw, ph = np.exp(dw) * widths[:, None], np.exp(dh) * heights[:, None]
+    hw, hh = f(0.5) * pw, f(0.5) * ph
+    return np.stack([pcx - hw, pcy - hh, pcx + hw, pcy + hh], axis=2)  # [R, C, 4]
+
+
+def _clip(boxes, shape):
+    """clip_boxes_to_image, ops/boxes.py:171-199."""
+    h, w = shape
+    out = boxes.copy()
+    out[..., 0::2] = np.clip(boxes[..., 0::2], 0, np.float32(w))
+    out[..., 1::2] = np.clip(boxes[..., 1::2], 0, np.float32(h))
+    return out
+
+
+def postprocess_detections(class_logits, box_regression, proposals, image_shapes, weights=(10.0, 10.0, 5.0, 5.0),
+                           score_thresh=0.05, nms_thresh=0.5, detections_per_img=100):
+    """RoIHeads.postprocess_detections, models/detection/roi_heads.py:680-737."""
+    f = np.float32
+    logits = _c(class_logits, f)
+    C = logits.shape[1]
+    pred = decode_boxes(box_regression, np.concatenate(proposals), weights)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    scores = e / e.sum(1, keepdims=True)
+    out, start = [], 0
+    for p, shape in zip(proposals, image_shapes):
+        n = len(p)
+        b = _clip(pred[start:start + n], shape)[:, 1:].reshape(-1, 4)
+        s = scores[start:start + n, 1:].reshape(-1)
+        lab = np.tile(np.arange(1, C), n)
+        start += n
+        sel = np.nonzero(s > f(score_thresh))[0]
+        b, s, lab = b[sel], s[sel], lab[sel]
+        sel = np.nonzero(((b[:, 2] - b[:, 0]) >= f(1e-2)) & ((b[:, 3] - b[:, 1]) >= f(1e-2)))[0]
+        b, s, lab = b[sel], s[sel], lab[sel]
+        keep = nms(b, s, nms_thresh, idxs=lab)[:detections_per_img]
+        out.append((b[keep], s[keep], lab[keep]))
+    return out
+
+
+def filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level, pre_nms_top_n, post_nms_top_n,
+                     nms_thresh=0.7, score_thresh=0.0, min_size=1e-3):
+    """RegionProposalNetwork.filter_proposals, models/detection/rpn.py:231-286."""
+    f = np.float32
+    proposals, objectness = _c(proposals, f), _c(objectness, f)
+    B = proposals.shape[0]
+    objectness = objectness.reshape(B, -1)
+    out = []
+    for i in range(B):
+        idx, lvl, off = [], [], 0
+        for l, n in enumerate(num_anchors_per_level):
+            k = min(pre_nms_top_n, n)
+            idx.append(stable_descending_order(objectness[i, off:off + n])[:k] + off)
+            lvl.append(np.full(k, l))
+            off += n
+        idx, lvl = np.concatenate(idx), np.concatenate(lvl)
+        b = _clip(proposals[i, idx], image_shapes[i])
+        s = (f(1) / (f(1) + np.exp(-objectness[i, idx]))).astype(f)
+        sel = np.nonzero(((b[:, 2] - b[:, 0]) >= f(min_size)) & ((b[:, 3] - b[:, 1]) >= f(min_size)))[0]
+        b, s, lvl = b[sel], s[sel], lvl[sel]
+        sel = np.nonzero(s >= f(score_thresh))[0]
+        b, s, lvl = b[sel], s[sel], lvl[sel]
+        keep = nms(b, s, nms_thresh, idxs=lvl)[:post_nms_top_n]
+        out.append((b[keep], s[keep]))
+    return out

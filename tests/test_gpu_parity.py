@@ -472,3 +472,84 @@ def test_roi_align_16bit_dma_path(tv, dtype, tol, P):
     assert out.dtype == dtype
     ref32 = pool({k: v.float().to(DEV) for k, v in feats.items()}, [b.to(dtype).float().to(DEV) for b in boxes], [(800, 1344)] * N)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref32.cpu().numpy(), rtol=tol, atol=tol)
+
+
+# ------------------------------------------------------------------ mask paste
+def test_paste_masks_golden_and_oracle():
+    """One-launch paste_masks_in_image vs the reference python's own output (tests/golden/detection.npz) and,
+    on a full-size canvas, vs the oracle restatement.  The pasted rectangle (integer box arithmetic) must be
+    identical; values within 1e-5 (fp32 bilinear, association of the 4-tap sum differs from aten's CPU kernel)."""
+    G = golden("detection")
+    boxes, shape = torch.from_numpy(G["paste_boxes"]), tuple(int(v) for v in G["paste_shape"])
+    for M, pad in ((28, 1), (14, 2), (7, 0)):
+        want = G[f"paste_out_M{M}_p{pad}"]
+        got = vision_amd.paste_masks_in_image(torch.from_numpy(G[f"paste_masks_M{M}_p{pad}"]).to(DEV), boxes.to(DEV), shape, padding=pad)
+        got = got.cpu().numpy()
+        assert got.shape == want.shape
+        assert np.array_equal(got != 0, want != 0)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+    g = gen(77)
+    im_h, im_w, n = 800, 1333, 24
+    b = random_boxes(n, im_w, im_h, 2, 700, g)
+    b[0] = torch.tensor([-5.0, -3.0, 40.0, 30.0])          # sticks out on the top-left
+    b[1] = torch.tensor([1300.0, 780.0, 1340.0, 805.0])    # sticks out on the bottom-right
+    m = torch.rand(n, 1, 28, 28, generator=g)
+    got = vision_amd.paste_masks_in_image(m.to(DEV), b.to(DEV), (im_h, im_w)).cpu().numpy()
+    ref = O.paste_masks_in_image(m.numpy(), b.numpy(), (im_h, im_w))
+    assert np.array_equal(got != 0, ref != 0)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
+    # 16-bit masks keep their dtype; empty input keeps the reference's empty shape
+    h = vision_amd.paste_masks_in_image(m.half().to(DEV), b.to(DEV), (im_h, im_w))
+    assert h.dtype == torch.float16
+    np.testing.assert_allclose(h.float().cpu().numpy(), O.paste_masks_in_image(m.half().float().numpy(), b.numpy(), (im_h, im_w)), rtol=0, atol=2e-3)
+    assert vision_amd.paste_masks_in_image(m[:0].to(DEV), b[:0].to(DEV), (im_h, im_w)).shape == (0, 1, im_h, im_w)
+
+
+# ------------------------------------------------------------------ fused post-processing (SURVEY.md §8f-1)
+def test_postprocess_detections_golden_and_oracle():
+    """Batched postprocess_detections (candidate kernel + segmented NMS + packing) vs the reference python's own
+    output: identical labels / order, scores within 1e-6, boxes within 1e-4 px (device expf vs torch's CPU exp)."""
+    G = golden("detection")
+    shapes = [tuple(int(v) for v in s) for s in G["det_shapes"]]
+    props = [torch.from_numpy(G[f"det_props{i}"]).to(DEV) for i in range(len(shapes))]
+    kw = dict(score_thresh=0.05, nms_thresh=0.5, detections_per_img=20)
+    boxes, scores, labels = vision_amd.postprocess_detections(torch.from_numpy(G["det_logits"]).to(DEV),
+                                                              torch.from_numpy(G["det_reg"]).to(DEV), props, shapes, **kw)
+    for i in range(len(shapes)):
+        assert np.array_equal(labels[i].cpu().numpy(), G[f"det_labels{i}"])
+        np.testing.assert_allclose(scores[i].cpu().numpy(), G[f"det_scores{i}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(boxes[i].cpu().numpy(), G[f"det_boxes{i}"], rtol=0, atol=1e-4)
+    # model-sized batch against the oracle restatement: 4 images x 1000 proposals x 91 classes
+    g = gen(91)
+    shapes = [(800, 1333), (800, 1200), (750, 1333), (640, 960)]
+    props = [random_boxes(1000, w, h, 8, 500, g) for h, w in shapes]
+    logits = torch.randn(4000, 91, generator=g) * 3
+    reg = torch.randn(4000, 364, generator=g) * 0.5
+    dets, counts = vision_amd.postprocess_detections(logits.to(DEV), reg.to(DEV), [p.to(DEV) for p in props], shapes, padded=True)
+    ref = O.postprocess_detections(logits.numpy(), reg.numpy(), [p.numpy() for p in props], shapes)
+    for i, (b, s, lab) in enumerate(ref):
+        n = int(counts[i])
+        assert n == len(lab)
+        d = dets[i, :n].cpu().numpy()
+        assert np.array_equal(d[:, 5].astype(np.int64), lab)
+        np.testing.assert_allclose(d[:, 4], s, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(d[:, :4], b, rtol=0, atol=2e-3)
+        assert not dets[i, n:].any()
+
+
+def test_filter_proposals_golden_and_fused_decode():
+    G = golden("detection")
+    shapes = [tuple(int(v) for v in s) for s in G["det_shapes"]]
+    levels = [int(v) for v in G["rpn_levels"]]
+    kw = dict(pre_nms_top_n=60, post_nms_top_n=40, nms_thresh=0.7, score_thresh=0.1)
+    obj = torch.from_numpy(G["rpn_objectness"]).to(DEV)
+    for fused in (False, True):
+        if fused:  # anchors + deltas, decoded inside the kernel for the survivors only
+            b, s = vision_amd.filter_proposals(torch.from_numpy(G["rpn_anchors"]).to(DEV), obj, shapes, levels,
+                                               pred_bbox_deltas=torch.from_numpy(G["rpn_deltas"]).to(DEV), **kw)
+        else:
+            b, s = vision_amd.filter_proposals(torch.from_numpy(G["rpn_proposals"]).to(DEV), obj, shapes, levels, **kw)
+        for i in range(2):
+            assert b[i].shape == G[f"rpn_boxes{i}"].shape
+            np.testing.assert_allclose(s[i].cpu().numpy(), G[f"rpn_scores{i}"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(b[i].cpu().numpy(), G[f"rpn_boxes{i}"], rtol=0, atol=1e-4)

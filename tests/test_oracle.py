@@ -139,3 +139,50 @@ def test_oracle_vs_reference_fresh_inputs(need_ref, tv):
         boxes, scores = adversarial_nms_inputs(700, 0.5, g, dup=True)
         boxes, scores = boxes.to(dt), scores.to(dt)
         assert np.array_equal(O.nms(boxes.numpy(), scores.numpy(), 0.5), tv.nms(boxes, scores, 0.5).numpy())
+
+
+def test_paste_masks_golden():
+    """oracle restatement of paste_masks_in_image vs the reference python's output (tests/golden/detection.npz,
+    oracle/gen_golden_detection.py).  Pasted rectangles must coincide exactly (integer box arithmetic); values
+    within 1e-5 (bilinear association differs between aten's CPU kernel and the restatement)."""
+    G = golden("detection")
+    boxes, shape = G["paste_boxes"], tuple(int(v) for v in G["paste_shape"])
+    for M, pad in ((28, 1), (14, 2), (7, 0)):
+        want = G[f"paste_out_M{M}_p{pad}"]
+        got = O.paste_masks_in_image(G[f"paste_masks_M{M}_p{pad}"], boxes, shape, padding=pad)
+        assert got.shape == want.shape
+        assert np.array_equal(got != 0, want != 0)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+
+
+def _det_golden():
+    G = golden("detection")
+    shapes = [tuple(int(v) for v in s) for s in G["det_shapes"]]
+    props = [G[f"det_props{i}"] for i in range(len(shapes))]
+    return G, shapes, props
+
+
+def test_postprocess_detections_golden():
+    """numpy restatement of RoIHeads.postprocess_detections vs the reference python's own output: same labels in the
+    same order, boxes / scores within 1e-4 / 1e-6 (libm exp vs torch's vectorised exp)."""
+    G, shapes, props = _det_golden()
+    out = O.postprocess_detections(G["det_logits"], G["det_reg"], props, shapes, score_thresh=0.05, nms_thresh=0.5,
+                                   detections_per_img=20)
+    for i, (b, s, lab) in enumerate(out):
+        assert np.array_equal(lab, G[f"det_labels{i}"])
+        np.testing.assert_allclose(s, G[f"det_scores{i}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(b, G[f"det_boxes{i}"], rtol=0, atol=1e-4)
+
+
+def test_filter_proposals_golden():
+    G = golden("detection")
+    shapes = [tuple(int(v) for v in s) for s in G["det_shapes"]]
+    out = O.filter_proposals(G["rpn_proposals"], G["rpn_objectness"], shapes, [int(v) for v in G["rpn_levels"]], 60, 40,
+                             nms_thresh=0.7, score_thresh=0.1)
+    for i, (b, s) in enumerate(out):
+        assert b.shape == G[f"rpn_boxes{i}"].shape
+        np.testing.assert_allclose(s, G[f"rpn_scores{i}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(b, G[f"rpn_boxes{i}"], rtol=0, atol=1e-4)
+    # decode restatement vs the reference's decoded proposals
+    dec = O.decode_boxes(G["rpn_deltas"].reshape(-1, 4), G["rpn_anchors"].reshape(-1, 4), (1.0, 1.0, 1.0, 1.0))[:, 0]
+    np.testing.assert_allclose(dec, G["rpn_proposals"].reshape(-1, 4), rtol=0, atol=1e-4)

@@ -47,4 +47,6 @@ from .roi_ops import (  # noqa: E402,F401
 from .deform_conv import DeformConv2d, deform_conv2d  # noqa: E402,F401
 from .poolers import LevelMapper, MultiScaleRoIAlign  # noqa: E402,F401
 from .resize import interpolate, resize  # noqa: E402,F401
+from .masks import expand_boxes, expand_masks, paste_masks_in_image  # noqa: E402,F401
+from .detection_post import filter_proposals, postprocess_detections  # noqa: E402,F401
 from . import sharding  # noqa: E402,F401

@@ -130,7 +130,27 @@ def _fake_pack_detections(boxes, scores, labels, image_idx, keep, num_images, ma
             boxes.new_empty((num_images,), dtype=torch.int32))
 
 
+def _fake_paste_masks(masks, boxes, im_h, im_w, padding):
+    return masks.new_empty((masks.shape[0], 1, im_h, im_w))
+
+
+def _fake_detection_candidates(class_logits, box_regression, proposals, row_image, image_hw, weights, clip, score_thresh, min_size):
+    R, C = class_logits.shape
+    f = class_logits.new_empty
+    return f((R, C - 1, 4), dtype=torch.float32), f((R, C - 1), dtype=torch.float32), f((R, C - 1), dtype=torch.uint8)
+
+
+def _fake_rpn_candidates(objectness, boxes, deltas, top_idx, level_offsets, image_hw, clip, score_thresh, min_size):
+    B, T = top_idx.shape
+    f = objectness.new_empty
+    return (f((B, T, 4), dtype=torch.float32), f((B, T), dtype=torch.float32), f((B, T), dtype=torch.int64),
+            f((B, T), dtype=torch.uint8))
+
+
 _FAKES = {
+    "tvmi::paste_masks": _fake_paste_masks,
+    "tvmi::detection_candidates": _fake_detection_candidates,
+    "tvmi::rpn_candidates": _fake_rpn_candidates,
     "tvmi::pack_detections": _fake_pack_detections,
     "tvmi::multiscale_roi_align": _fake_multiscale,
     "tvmi::interpolate2d": _fake_interpolate2d,

@@ -79,6 +79,107 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
   for (int i = tid; i < num_images; i += kPackThreads) counts[i] = min(s_cnt[i], max_dets);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Candidate generation for the two post-processing stages of a two-stage detector, batched
+// over the images of a step.  Both replace a chain of ~15 elementwise /
+// indexing torch kernels PER IMAGE in the reference with one launch per batch; what follows
+// them (class- / level-segmented NMS, top-k packing) are tvmi_nms with segment ids and
+// tvmi_pack_detections.  Arithmetic follows the reference op by op in fp32 (this TU is built
+// with -ffp-contract=off): BoxCoder.decode_single (models/detection/_utils.py:183-224),
+// clip_boxes_to_image (ops/boxes.py:171-199), remove_small_boxes (ops/boxes.py:148-168).
+
+// decode_single for one (box, code) pair; weights are divisors exactly like the reference
+__device__ __forceinline__ float4 decode_box(const float4 box, const float4 code, float wx, float wy, float ww, float wh,
+                                             float clip) {
+  const float width = box.z - box.x, height = box.w - box.y;
+  const float ctr_x = box.x + 0.5f * width, ctr_y = box.y + 0.5f * height;
+  const float dx = code.x / wx, dy = code.y / wy;
+  const float dw = fminf(code.z / ww, clip), dh = fminf(code.w / wh, clip);
+  const float pcx = dx * width + ctr_x, pcy = dy * height + ctr_y;
+  const float pw = expf(dw) * width, ph = expf(dh) * height;
+  const float hw = 0.5f * pw, hh = 0.5f * ph;
+  return make_float4(pcx - hw, pcy - hh, pcx + hw, pcy + hh);
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// roi_heads.py:680-737 up to (not including) batched_nms: softmax over classes, per-class
+// decode, clip, drop background / low score / small boxes.  One wave per RoI row.
+__global__ __launch_bounds__(256) void det_candidates_kernel(const float* __restrict__ logits, const float* __restrict__ reg,
+                                                             const float* __restrict__ props,
+                                                             const int32_t* __restrict__ row_image,
+                                                             const float* __restrict__ image_hw, int R, int C, int B,
+                                                             float wx, float wy, float ww, float wh, float clip,
+                                                             float score_thresh, float min_size,
+                                                             float* __restrict__ cand_boxes, float* __restrict__ cand_scores,
+                                                             uint8_t* __restrict__ cand_valid) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (r >= R) return;
+  const float* lg = logits + (int64_t)r * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lg[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += expf(lg[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float4 box = *reinterpret_cast<const float4*>(props + (int64_t)r * 4);
+  int img = row_image[r];
+  img = min(max(img, 0), B - 1);
+  const float im_h = image_hw[2 * img], im_w = image_hw[2 * img + 1];
+  for (int c = 1 + lane; c < C; c += 64) {
+    const float score = expf(lg[c] - mx) / sum;
+    const float4 code = *reinterpret_cast<const float4*>(reg + ((int64_t)r * C + c) * 4);
+    float4 b = decode_box(box, code, wx, wy, ww, wh, clip);
+    b.x = clampf(b.x, 0.f, im_w);
+    b.z = clampf(b.z, 0.f, im_w);
+    b.y = clampf(b.y, 0.f, im_h);
+    b.w = clampf(b.w, 0.f, im_h);
+    const bool ok = score > score_thresh && (b.z - b.x) >= min_size && (b.w - b.y) >= min_size;
+    const int64_t o = (int64_t)r * (C - 1) + (c - 1);
+    *reinterpret_cast<float4*>(cand_boxes + o * 4) = b;
+    cand_scores[o] = score;
+    cand_valid[o] = ok ? 1 : 0;
+  }
+}
+
+// rpn.py:242-286 up to (not including) batched_nms, for the per-level top-k survivors:
+// gather, (optionally decode anchors + deltas: rpn.py:364-366 does it for EVERY anchor before
+// the top-k, here only the survivors are decoded — same values, elementwise), sigmoid, clip,
+// small-box and score filter, level id.  One lane per (image, survivor).
+__global__ __launch_bounds__(256) void rpn_candidates_kernel(const float* __restrict__ objectness,
+                                                             const float* __restrict__ boxes_in,
+                                                             const float* __restrict__ deltas,
+                                                             const int64_t* __restrict__ top_idx,
+                                                             const int64_t* __restrict__ level_offsets,
+                                                             const float* __restrict__ image_hw, int B, int64_t A, int T,
+                                                             int L, float clip, float score_thresh, float min_size,
+                                                             float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                             int64_t* __restrict__ out_levels, uint8_t* __restrict__ out_valid) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * T) return;
+  const int b = (int)(i / T);
+  int64_t a = top_idx[i];
+  a = min(max(a, (int64_t)0), A - 1);
+  float4 box = *reinterpret_cast<const float4*>(boxes_in + ((int64_t)b * A + a) * 4);
+  if (deltas) box = decode_box(box, *reinterpret_cast<const float4*>(deltas + ((int64_t)b * A + a) * 4), 1.f, 1.f, 1.f, 1.f, clip);
+  const float im_h = image_hw[2 * b], im_w = image_hw[2 * b + 1];
+  box.x = clampf(box.x, 0.f, im_w);
+  box.z = clampf(box.z, 0.f, im_w);
+  box.y = clampf(box.y, 0.f, im_h);
+  box.w = clampf(box.w, 0.f, im_h);
+  const float prob = 1.f / (1.f + expf(-objectness[(int64_t)b * A + a]));
+  int lvl = 0;
+  for (int l = 1; l < L; ++l) lvl += a >= level_offsets[l] ? 1 : 0;
+  *reinterpret_cast<float4*>(out_boxes + i * 4) = box;
+  out_scores[i] = prob;
+  out_levels[i] = lvl;
+  out_valid[i] = ((box.z - box.x) >= min_size && (box.w - box.y) >= min_size && prob >= score_thresh) ? 1 : 0;
+}
+
 }  // namespace
 }  // namespace tvmi
 
@@ -93,4 +194,37 @@ extern "C" int tvmi_pack_detections(const float* boxes, const float* scores, con
   tvmi::pack_detections_kernel<<<dim3(1), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
       boxes, scores, labels, image_idx, keep, num_keep, (int)num_images, (int)max_dets, dets, counts);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections");
+}
+
+extern "C" int tvmi_detection_candidates(const float* class_logits, const float* box_regression, const float* proposals,
+                                         const int32_t* row_image, const float* image_hw, int64_t R, int64_t C,
+                                         int64_t B, float wx, float wy, float ww, float wh, float bbox_xform_clip,
+                                         float score_thresh, float min_size, float* cand_boxes, float* cand_scores,
+                                         uint8_t* cand_valid, void* stream) {
+  TVMI_CHECK_ARG(R >= 0 && C >= 1 && B >= 1, "detection_candidates: bad sizes");
+  if (R == 0 || C == 1) return 0;
+  TVMI_CHECK_ARG(class_logits && box_regression && proposals && row_image && image_hw && cand_boxes && cand_scores && cand_valid,
+                 "detection_candidates: null pointer");
+  TVMI_CHECK_ARG(R * C < (1ll << 31), "detection_candidates: size too large");
+  tvmi::det_candidates_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      class_logits, box_regression, proposals, row_image, image_hw, (int)R, (int)C, (int)B, wx, wy, ww, wh, bbox_xform_clip,
+      score_thresh, min_size, cand_boxes, cand_scores, cand_valid);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_detection_candidates");
+}
+
+extern "C" int tvmi_rpn_candidates(const float* objectness, const float* boxes_in, const float* deltas,
+                                   const int64_t* top_idx, const int64_t* level_offsets, const float* image_hw, int64_t B,
+                                   int64_t A, int64_t T, int64_t L, float bbox_xform_clip, float score_thresh,
+                                   float min_size, float* out_boxes, float* out_scores, int64_t* out_levels,
+                                   uint8_t* out_valid, void* stream) {
+  TVMI_CHECK_ARG(B >= 0 && A >= 0 && T >= 0 && L >= 1, "rpn_candidates: bad sizes");
+  if (B * T == 0) return 0;
+  TVMI_CHECK_ARG(A > 0 && objectness && boxes_in && top_idx && level_offsets && image_hw && out_boxes && out_scores &&
+                     out_levels && out_valid,
+                 "rpn_candidates: null pointer");
+  TVMI_CHECK_ARG(B * T < (1ll << 31) && B <= (1 << 20), "rpn_candidates: size too large");
+  tvmi::rpn_candidates_kernel<<<dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      objectness, boxes_in, deltas, top_idx, level_offsets, image_hw, (int)B, A, (int)T, (int)L, bbox_xform_clip,
+      score_thresh, min_size, out_boxes, out_scores, out_levels, out_valid);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_rpn_candidates");
 }

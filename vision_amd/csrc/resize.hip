@@ -224,6 +224,80 @@ inline int taps_for(int mode, float scale) {
   return (int)ceilf(support) * 2 + 1;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Batched paste_masks_in_image (models/detection/roi_heads.py:378-437,486-500): for every
+// detection n, zero-pad the M x M mask by `padding`, expand the box by (M+2p)/M, truncate to
+// integers, bilinearly resize the padded mask to the integer box size (align_corners=False)
+// and paste it into an im_h x im_w canvas.  The reference does this with a Python loop of
+// F.interpolate + zeros + slice-assign + stack (its eval loop carries a FIXME about exactly
+// that); here ONE output-stationary launch writes every canvas pixel once: a pixel outside its
+// detection's clipped box is 0, a pixel inside evaluates its 4 taps straight from the
+// (L2-resident) M x M mask.  The kernel is a pure HBM write stream (N*im_h*im_w elements).
+// Box arithmetic follows expand_boxes op by op in float (this TU is built with
+// -ffp-contract=off) so the integer box — and therefore the paste rectangle — is bit-exact.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void paste_masks_kernel(const T* __restrict__ masks, const float* __restrict__ boxes,
+                                                               T* __restrict__ out, int M, int im_h, int im_w, int pad,
+                                                               float scale) {
+  const int n = blockIdx.y;
+  const int64_t plane = (int64_t)im_h * im_w;
+  const float* b = boxes + (int64_t)n * 4;
+  const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+  float w_half = (b2 - b0) * 0.5f, h_half = (b3 - b1) * 0.5f;
+  const float x_c = (b2 + b0) * 0.5f, y_c = (b3 + b1) * 0.5f;
+  w_half *= scale;
+  h_half *= scale;
+  const long long e0 = (long long)(x_c - w_half), e2 = (long long)(x_c + w_half);
+  const long long e1 = (long long)(y_c - h_half), e3 = (long long)(y_c + h_half);
+  const long long w = max(e2 - e0 + 1, 1ll), h = max(e3 - e1 + 1, 1ll);
+  const long long x_0 = max(e0, 0ll), x_1 = min(e2 + 1, (long long)im_w);
+  const long long y_0 = max(e1, 0ll), y_1 = min(e3 + 1, (long long)im_h);
+  const bool sane = h < (1ll << 30) && w < (1ll << 30);
+  const int IN = M + 2 * pad;
+  const float sh = (float)IN / (float)h, sw = (float)IN / (float)w;
+  const T* m = masks + (int64_t)n * M * M;
+  T* o = out + (int64_t)n * plane;
+  auto pixel = [&](int y, int x) -> float {
+    if (!(y >= y_0 && y < y_1 && x >= x_0 && x < x_1 && sane)) return 0.f;
+    const Lin ly = linear_index(sh, (int)(y - e1), IN, (int)h, false);
+    const Lin lx = linear_index(sw, (int)(x - e0), IN, (int)w, false);
+    auto tap = [&](int iy, int ix) -> float {
+      iy -= pad;
+      ix -= pad;
+      return (iy < 0 || iy >= M || ix < 0 || ix >= M) ? 0.f : ld(m + iy * M + ix);
+    };
+    return ly.l0 * (lx.l0 * tap(ly.i0, lx.i0) + lx.l1 * tap(ly.i0, lx.i1)) +
+           ly.l1 * (lx.l0 * tap(ly.i1, lx.i0) + lx.l1 * tap(ly.i1, lx.i1));
+  };
+  // VEC consecutive canvas elements per lane = one 16-byte store (the canvas is a pure write stream)
+  const int64_t nvec = plane / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t e = i * VEC;
+    int y = (int)(e / im_w), x = (int)(e - (int64_t)y * im_w);
+    struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; } pk;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      T t;
+      st(&t, pixel(y, x));
+      pk.v[j] = t;
+      if (++x == im_w) {
+        x = 0;
+        ++y;
+      }
+    }
+    if constexpr (sizeof(T) * VEC == 16) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 u;
+      __builtin_memcpy(&u, &pk, 16);
+      __builtin_nontemporal_store(u, reinterpret_cast<u32x4*>(o + e));
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[e + j] = pk.v[j];
+    }
+  }
+}
+
 struct Launch {
   dim3 grid;
   int nc_per_block;
@@ -314,4 +388,30 @@ extern "C" int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt
                           (const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)NC, (int)IH, (int)IW, (int)OH,
                           (int)OW, yt, xt, L.nc_per_block));
   TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_aa2d");
+}
+
+extern "C" int tvmi_paste_masks(const void* masks, const float* boxes, void* output, tvmi_dtype dt, int64_t N,
+                                int64_t M, int64_t im_h, int64_t im_w, int64_t padding, void* stream) {
+  if (N * im_h * im_w == 0) return 0;
+  TVMI_CHECK_ARG(masks && boxes && output, "paste_masks: null pointer");
+  TVMI_CHECK_ARG(M > 0 && padding >= 0 && M + 2 * padding < 32768, "paste_masks: mask size out of range");
+  TVMI_CHECK_ARG(N <= 65535 && im_h * im_w < (1ll << 31), "paste_masks: size too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float scale = (float)((double)(M + 2 * padding) / (double)M);
+  // 16-byte packs when every canvas starts 16-byte aligned, else scalar stores
+#define TVMI_PASTE(VEC)                                                                                        \
+  paste_masks_kernel<scalar_t, VEC><<<dim3((unsigned)std::min<int64_t>(ceil_div(im_h * im_w / (VEC), kThreads),  \
+                                                                      std::max<int64_t>(1, 32768 / N)),        \
+                                           (unsigned)N),                                                       \
+                                      dim3(kThreads), 0, s>>>((const scalar_t*)masks, boxes, (scalar_t*)output, (int)M, \
+                                                              (int)im_h, (int)im_w, (int)padding, scale)
+  TVMI_DISPATCH_FLOAT(dt, "paste_masks", {
+    constexpr int V = 16 / (int)sizeof(scalar_t);
+    if ((im_h * im_w) % V == 0 && reinterpret_cast<uintptr_t>(output) % 16 == 0)
+      TVMI_PASTE(V);
+    else
+      TVMI_PASTE(1);
+  });
+#undef TVMI_PASTE
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_paste_masks");
 }

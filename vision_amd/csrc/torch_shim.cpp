@@ -543,6 +543,95 @@ std::tuple<at::Tensor, at::Tensor> pack_detections(const at::Tensor& boxes, cons
   return std::make_tuple(dets, counts);
 }
 
+// ---- batched paste_masks_in_image (roi_heads.py:486-500) in one launch
+at::Tensor paste_masks(const at::Tensor& masks, const at::Tensor& boxes, int64_t im_h, int64_t im_w, int64_t padding) {
+  TORCH_CHECK(masks.is_cuda() && boxes.is_cuda(), "paste_masks: CUDA tensors expected");
+  TORCH_CHECK(masks.dim() == 4 && masks.size(1) == 1 && masks.size(2) == masks.size(3),
+              "paste_masks: masks must have shape [N, 1, M, M]");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && boxes.size(0) == masks.size(0),
+              "paste_masks: boxes must have shape [N, 4]");
+  TORCH_CHECK(im_h >= 0 && im_w >= 0 && padding >= 0, "paste_masks: negative size");
+  c10::DeviceGuard guard(masks.device());
+  const int64_t N = masks.size(0), M = masks.size(2);
+  at::Tensor out = at::empty({N, 1, im_h, im_w}, masks.options());
+  if (out.numel() == 0) return out;
+  at::Tensor m = masks.contiguous(), b = boxes.to(at::kFloat).contiguous();
+  check_status(tvmi_paste_masks(m.const_data_ptr(), b.const_data_ptr<float>(), out.mutable_data_ptr(),
+                                dtype_of(masks, "paste_masks"), N, M, im_h, im_w, padding, current_stream(masks)),
+               "paste_masks");
+  return out;
+}
+
+// ---- candidate generation for the two post-processing stages (postprocess.hip)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> detection_candidates(const at::Tensor& class_logits,
+                                                                    const at::Tensor& box_regression,
+                                                                    const at::Tensor& proposals, const at::Tensor& row_image,
+                                                                    const at::Tensor& image_hw, at::ArrayRef<double> weights,
+                                                                    double bbox_xform_clip, double score_thresh,
+                                                                    double min_size) {
+  TORCH_CHECK(class_logits.is_cuda() && box_regression.is_cuda() && proposals.is_cuda() && row_image.is_cuda() &&
+                  image_hw.is_cuda(),
+              "detection_candidates: CUDA tensors expected");
+  TORCH_CHECK(class_logits.dim() == 2, "detection_candidates: class_logits must be [R, C]");
+  const int64_t R = class_logits.size(0), C = class_logits.size(1);
+  TORCH_CHECK(box_regression.dim() == 2 && box_regression.size(0) == R && box_regression.size(1) == 4 * C,
+              "detection_candidates: box_regression must be [R, 4*C]");
+  TORCH_CHECK(proposals.dim() == 2 && proposals.size(0) == R && proposals.size(1) == 4 && row_image.numel() == R,
+              "detection_candidates: proposals [R,4] and row_image [R] expected");
+  TORCH_CHECK(image_hw.dim() == 2 && image_hw.size(1) == 2 && image_hw.size(0) >= 1, "detection_candidates: image_hw must be [B, 2]");
+  TORCH_CHECK(weights.size() == 4, "detection_candidates: 4 box coder weights expected");
+  c10::DeviceGuard guard(class_logits.device());
+  at::Tensor lg = class_logits.to(at::kFloat).contiguous(), rg = box_regression.to(at::kFloat).contiguous();
+  at::Tensor pr = proposals.to(at::kFloat).contiguous(), ri = row_image.to(at::kInt).contiguous();
+  at::Tensor hw = image_hw.to(at::kFloat).contiguous();
+  const int64_t Cm = C > 0 ? C - 1 : 0;
+  at::Tensor cb = at::empty({R, Cm, 4}, lg.options()), cs = at::empty({R, Cm}, lg.options());
+  at::Tensor cv = at::empty({R, Cm}, lg.options().dtype(at::kByte));
+  check_status(tvmi_detection_candidates(lg.const_data_ptr<float>(), rg.const_data_ptr<float>(), pr.const_data_ptr<float>(),
+                                         ri.const_data_ptr<int32_t>(), hw.const_data_ptr<float>(), R, C, hw.size(0),
+                                         (float)weights[0], (float)weights[1], (float)weights[2], (float)weights[3],
+                                         (float)bbox_xform_clip, (float)score_thresh, (float)min_size,
+                                         cb.mutable_data_ptr<float>(), cs.mutable_data_ptr<float>(),
+                                         cv.mutable_data_ptr<uint8_t>(), current_stream(class_logits)),
+               "detection_candidates");
+  return std::make_tuple(cb, cs, cv);
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> rpn_candidates(
+    const at::Tensor& objectness, const at::Tensor& boxes, const c10::optional<at::Tensor>& deltas, const at::Tensor& top_idx,
+    const at::Tensor& level_offsets, const at::Tensor& image_hw, double bbox_xform_clip, double score_thresh,
+    double min_size) {
+  TORCH_CHECK(objectness.is_cuda() && boxes.is_cuda() && top_idx.is_cuda() && level_offsets.is_cuda() && image_hw.is_cuda(),
+              "rpn_candidates: CUDA tensors expected");
+  TORCH_CHECK(objectness.dim() == 2 && boxes.dim() == 3 && boxes.size(0) == objectness.size(0) &&
+                  boxes.size(1) == objectness.size(1) && boxes.size(2) == 4,
+              "rpn_candidates: objectness [B,A] and boxes [B,A,4] expected");
+  const int64_t B = objectness.size(0), A = objectness.size(1);
+  TORCH_CHECK(top_idx.dim() == 2 && top_idx.size(0) == B, "rpn_candidates: top_idx must be [B, T]");
+  TORCH_CHECK(image_hw.dim() == 2 && image_hw.size(0) == B && image_hw.size(1) == 2, "rpn_candidates: image_hw must be [B, 2]");
+  TORCH_CHECK(level_offsets.dim() == 1 && level_offsets.numel() >= 1, "rpn_candidates: level_offsets must be [L]");
+  c10::DeviceGuard guard(objectness.device());
+  const int64_t T = top_idx.size(1);
+  at::Tensor ob = objectness.to(at::kFloat).contiguous(), bx = boxes.to(at::kFloat).contiguous();
+  at::Tensor ti = top_idx.to(at::kLong).contiguous(), lo = level_offsets.to(at::kLong).contiguous();
+  at::Tensor hw = image_hw.to(at::kFloat).contiguous(), dl;
+  const float* dptr = nullptr;
+  if (deltas.has_value() && deltas->defined()) {
+    TORCH_CHECK(deltas->sizes() == boxes.sizes(), "rpn_candidates: deltas must match boxes");
+    dl = deltas->to(at::kFloat).contiguous();
+    dptr = dl.const_data_ptr<float>();
+  }
+  at::Tensor ob_ = at::empty({B, T, 4}, ob.options()), os = at::empty({B, T}, ob.options());
+  at::Tensor ol = at::empty({B, T}, ob.options().dtype(at::kLong)), ov = at::empty({B, T}, ob.options().dtype(at::kByte));
+  check_status(tvmi_rpn_candidates(ob.const_data_ptr<float>(), bx.const_data_ptr<float>(), dptr, ti.const_data_ptr<int64_t>(),
+                                   lo.const_data_ptr<int64_t>(), hw.const_data_ptr<float>(), B, A, T, lo.numel(),
+                                   (float)bbox_xform_clip, (float)score_thresh, (float)min_size,
+                                   ob_.mutable_data_ptr<float>(), os.mutable_data_ptr<float>(), ol.mutable_data_ptr<int64_t>(),
+                                   ov.mutable_data_ptr<uint8_t>(), current_stream(objectness)),
+               "rpn_candidates");
+  return std::make_tuple(ob_, os, ol, ov);
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -591,6 +680,13 @@ TORCH_LIBRARY(tvmi, m) {
       "pack_detections(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, int num_images, int max_dets) -> (Tensor, Tensor)");
   m.def(
       "multiscale_roi_align(Tensor[] features, Tensor rois, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor");
+  // roi_heads.py:680-722 / rpn.py:266-286 up to the NMS, batched over images (one launch each)
+  m.def(
+      "detection_candidates(Tensor class_logits, Tensor box_regression, Tensor proposals, Tensor row_image, Tensor image_hw, float[] weights, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor)");
+  m.def(
+      "rpn_candidates(Tensor objectness, Tensor boxes, Tensor? deltas, Tensor top_idx, Tensor level_offsets, Tensor image_hw, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor, Tensor)");
+  // python loop of roi_heads.py:486-500 (pad + expand + resize + paste per detection) as one launch
+  m.def("paste_masks(Tensor masks, Tensor boxes, int im_h, int im_w, int padding) -> Tensor");
   m.def(
       "interpolate2d(Tensor input, int out_h, int out_w, int mode, bool align_corners, bool antialias, float scale_h, float scale_w) -> Tensor");
 }
@@ -615,6 +711,9 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("interpolate2d", &interpolate2d);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
   m.impl("pack_detections", &pack_detections);
+  m.impl("paste_masks", &paste_masks);
+  m.impl("detection_candidates", &detection_candidates);
+  m.impl("rpn_candidates", &rpn_candidates);
 }
 
 }  // namespace tvmi_shim
