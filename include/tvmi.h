@@ -58,6 +58,22 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
              double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
              int64_t* keep_out, int64_t* num_keep_out, void* stream);
 
+/* Segment-major form of the same operation for batched_nms (ops/boxes.py:57-126): the caller
+ * additionally provides the STABLE partition of the score order by segment id —
+ *   perm     [n] int64: perm[p] = rank in `order` of the box at segment-major position p
+ *   seg_keys [n] int64: segment id at position p, ascending (i.e. the values / indices of a
+ *                       stable ascending sort of seg[order[.]])
+ * Only tiles whose two 64-box blocks share a segment are evaluated and every segment is swept
+ * by its own workgroup; keep_out is still in global score order, identical to tvmi_nms with
+ * `seg`.  A segment may span at most 128 64-box blocks (8,192 boxes; beyond that one workgroup
+ * per segment is the wrong shape); otherwise num_keep_out is set to -1 and keep_out is
+ * unspecified — callers fall back to tvmi_nms, whose sweep is parallel over column blocks.
+ */
+size_t tvmi_nms_segmented_workspace_bytes(int64_t n);
+int tvmi_nms_segmented(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm, int64_t n,
+                       double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+                       int64_t* num_keep_out, void* stream);
+
 /* ------------------------------------------------------------- RoIAlign ----------
  * Replaces: torchvision/csrc/ops/cuda/roi_align_kernel.cu:68-143,334-394 (forward),
  * :204-332,396-466 (backward); arithmetic follows

@@ -94,6 +94,30 @@ def test_batched_nms_native_segmented_path():
     assert torch.equal(a, b)
 
 
+def test_batched_nms_segment_major_layouts():
+    """Segment-major path (n > 4096): ragged segments — singletons, segments that start and end inside one 64-box
+    block, segments spanning many blocks, duplicate scores (stable tie order), sparse / negative / huge ids — and a
+    segment above the 8,192-box limit, which must fall back to the global-order pipeline with the same answer."""
+    g = gen(61)
+    n = 12000
+    boxes = random_boxes(n, 600, 600, 4, 120, g)
+    scores = (torch.rand(n, generator=g) * 64).floor() / 64          # many exact ties
+    sizes = [1, 1, 2, 63, 64, 65, 1, 700, 3, 1500, 5000]
+    idxs = torch.cat([torch.full((m,), i, dtype=torch.int64) for i, m in enumerate(sizes)])
+    idxs = torch.cat([idxs, torch.randint(100, 140, (n - len(idxs),), generator=g)])
+    remap = torch.arange(200) * 7919 - 300_000                         # sparse ids, some negative
+    remap[3] = 2 ** 40
+    idxs = remap[idxs][torch.randperm(n, generator=g)]
+    keep = torch.ops.tvmi.nms_segmented(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), 0.4).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.4, idxs.numpy()))
+    big = torch.where(torch.arange(n) < 9000, torch.zeros(n, dtype=torch.int64), idxs)  # one 9000-box segment
+    keep = torch.ops.tvmi.nms_segmented(boxes.to(DEV), scores.to(DEV), big.to(DEV), 0.4).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.4, big.numpy()))
+    # float64 boxes through the same path
+    keep = torch.ops.tvmi.nms_segmented(boxes.double().to(DEV), scores.double().to(DEV), idxs.to(DEV), 0.4).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.double().numpy(), scores.double().numpy(), 0.4, idxs.numpy()))
+
+
 def test_nms_100k_properties(tv):
     # BASELINE config 3 size; oracle too slow here -> size-independent properties
     g = gen(7)

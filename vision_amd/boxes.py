@@ -21,14 +21,19 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
 def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
     """NMS that never suppresses across categories (ops/boxes.py:57-91).
 
-    Same strategy switch as the reference: up to 100k box elements on the GPU (4k on CPU)
-    the boxes are shifted per category and a single nms() is run ("coordinate trick",
-    :93-109); above that the reference loops over categories in python (:113-126).  On CUDA
-    tensors that loop is replaced by ONE segmented launch (`tvmi::nms_segmented`, identical
-    result: IoU is evaluated on the unshifted boxes and category-mismatched pairs never
-    suppress), so there is no torch.unique / torch.where host round trip per category.
-    """
-    if boxes.numel() > (4000 if boxes.device.type == "cpu" else 100_000):
+    The reference switches between shifting the boxes per category and running one nms()
+    ("coordinate trick", :93-109) and a python loop over categories (:113-126).  On device
+    tensors both are replaced by ONE segment-major launch chain (`tvmi::nms_segmented`): IoU is
+    evaluated on the unshifted boxes (the loop's arithmetic, exactly), category-mismatched pairs
+    are never even tested, every category is swept by its own workgroup, and there is no
+    torch.unique / torch.where host round trip per category.  CPU tensors (tests only) follow the
+    reference's switch."""
+    if boxes.is_cuda:
+        assert_has_ops()
+        if boxes.numel() == 0:
+            return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+        return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold)
+    if boxes.numel() > 4000:
         return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)
     return _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold)
 

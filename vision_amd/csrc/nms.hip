@@ -361,6 +361,309 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Segment-major batched NMS.  With segment ids (classes / levels / images) the suppression
+// matrix is block diagonal once the boxes are laid out segment by segment (score order kept
+// inside a segment): only tiles whose two 64-box blocks share a segment are evaluated, and
+// every segment is swept by its own workgroup, concurrently — instead of N x N pair tests
+// and ONE serial sweep over all N boxes in global score order.  The caller provides the
+// stable partition of the score order by segment (`perm`, `keys`: a second stable sort);
+// the result is emitted in global score order, identical to the unsegmented formulation.
+//   position p (segment-major)  --perm-->  g (rank in global score order)  --order-->  box
+// Blocks are NOT padded per segment: a 64-box block may hold the tail of one segment and the
+// heads of others; cross-segment mask bits are zero, so a workgroup sweeping the block range
+// of "its" segments may resolve foreign rows of its first block incorrectly — it never writes
+// them (each keep bit is published by exactly one workgroup, with an atomicOr).
+constexpr int kSegMaxBlocks = 128;  // blocks one sweep workgroup handles (8,192 boxes per segment); its pull over
+                                   // earlier super-blocks is O(blocks^2) tile reads by ONE workgroup, so larger
+                                   // segments are sent back to the global-order pipeline (colreduce + resolve)
+
+__device__ __forceinline__ int upper_bound_key(const int64_t* __restrict__ keys, int n, int64_t v) {
+  int lo = 0, hi = n;  // first p with keys[p] > v
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void nms_seg_layout(const int64_t* __restrict__ order, const int64_t* __restrict__ perm,
+                                                      int n, int64_t* __restrict__ oidx, int* __restrict__ invperm) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int64_t g = perm[p];
+  oidx[p] = order[g];
+  invperm[g] = p;
+}
+
+// one workgroup per row block; its waves walk the column blocks that share a segment with it
+template <typename T>
+__global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T* __restrict__ dets,
+                                                                         const int64_t* __restrict__ oidx,
+                                                                         const int64_t* __restrict__ keys, int n, int CB,
+                                                                         double thr, u64* __restrict__ mask) {
+  __shared__ T s_row[64][5];
+  __shared__ long long s_key[64];
+  __shared__ int s_cbmax;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int rb = blockIdx.x;
+  const int row0 = rb * 64;
+  if (threadIdx.x < 64) {
+    const int r = row0 + lane;
+    T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    long long k = 0;
+    if (r < n) {
+      const Box<T> b = load_box<T>(dets, oidx[r]);
+      x1 = b.x1;
+      y1 = b.y1;
+      x2 = b.x2;
+      y2 = b.y2;
+      k = keys[r];
+    }
+    s_row[lane][0] = x1;
+    s_row[lane][1] = y1;
+    s_row[lane][2] = x2;
+    s_row[lane][3] = y2;
+    s_row[lane][4] = (x2 - x1) * (y2 - y1);
+    s_key[lane] = k;
+    if (lane == 0) {
+      // column blocks that share a segment with this row block end with the segment of its last row; a
+      // segment beyond the sweep limit is going to be redone by the global-order pipeline: skip its tiles
+      const int64_t klast = keys[min(n - 1, row0 + 63)];
+      const int cbm = (upper_bound_key(keys, n, klast) - 1) >> 6;
+      const int first_blk = upper_bound_key(keys, n, klast - 1) >> 6;  // ids are integers: first p with key >= klast
+      s_cbmax = (cbm - first_blk + 1 > kSegMaxBlocks) ? rb - 1 : cbm;
+    }
+  }
+  __syncthreads();
+  const int cbmax = s_cbmax;
+  const int rows_here = min(64, n - row0);
+  for (int cb = rb + wave; cb <= cbmax; cb += kMaskWaves) {
+    const int j = cb * 64 + lane;
+    T jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0;
+    long long jkey = 0;
+    const bool jvalid = j < n;
+    if (jvalid) {
+      const Box<T> b = load_box<T>(dets, oidx[j]);
+      jx1 = b.x1;
+      jy1 = b.y1;
+      jx2 = b.x2;
+      jy2 = b.y2;
+      jkey = keys[j];
+    }
+    const T jarea = (jx2 - jx1) * (jy2 - jy1);
+    const bool diag = cb == rb;
+    u64 mine = 0ull;
+    for (int i = 0; i < rows_here; ++i) {
+      const T ix1 = s_row[i][0], iy1 = s_row[i][1], ix2 = s_row[i][2], iy2 = s_row[i][3];
+      const T iarea = s_row[i][4];
+      const T xx1 = ix1 > jx1 ? ix1 : jx1;
+      const T yy1 = iy1 > jy1 ? iy1 : jy1;
+      const T xx2 = jx2 < ix2 ? jx2 : ix2;
+      const T yy2 = jy2 < iy2 ? jy2 : iy2;
+      const T dw = xx2 - xx1, dh = yy2 - yy1;
+      const T w = (T)0 < dw ? dw : (T)0;
+      const T h = (T)0 < dh ? dh : (T)0;
+      const T inter = w * h;
+      const T ovr = inter / (iarea + jarea - inter);
+      bool pr = ((double)ovr > thr) && jvalid && (jkey == s_key[i]);
+      if (diag) pr = pr && (lane > i);
+      const u64 word = __ballot(pr);
+      if (lane == i) mine = word;
+    }
+    mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
+  }
+}
+
+// one workgroup per 64-box block in which at least one segment starts: it sweeps the blocks
+// from its own to the end of the last segment that starts in it
+__global__ __launch_bounds__(kSuper * kWave) void nms_sweep_seg(const u64* __restrict__ mask,
+                                                                const int64_t* __restrict__ keys, int n, int CB,
+                                                                u64* __restrict__ keepbits, int* __restrict__ err) {
+  __shared__ u64 s_keepbits[kSegMaxBlocks];
+  __shared__ int s_info[3];  // first start position, end position, number of blocks
+  const int lane = threadIdx.x & 63;
+  const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int B0 = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const int p = B0 * 64 + lane;
+    const bool start = p < n && (p == 0 || keys[p] != keys[p - 1]);
+    const u64 starts = __ballot(start);
+    if (lane == 0) {
+      if (starts == 0ull) {
+        s_info[2] = 0;
+      } else {
+        const int end = upper_bound_key(keys, n, keys[min(n - 1, B0 * 64 + 63)]);
+        s_info[0] = B0 * 64 + __builtin_ctzll(starts);
+        s_info[1] = end;
+        s_info[2] = ((end - 1) >> 6) + 1 - B0;
+      }
+    }
+  }
+  __syncthreads();
+  const int nb = s_info[2];
+  if (nb == 0) return;
+  if (nb > kSegMaxBlocks) {
+    if (threadIdx.x == 0) *err = 1;
+    return;
+  }
+  const int first = s_info[0], end = s_info[1];
+  for (int b0 = 0; b0 < nb; b0 += kSuper) {
+    const int b1 = min(nb, b0 + kSuper);
+    const int lb = b0 + c_loc;  // local block of this wave
+    const int cb = B0 + lb;
+    const bool have = lb < b1;
+    u64 diag = 0ull, above[kSuper - 1];
+    if (have) diag = mask[((size_t)cb * CB + cb) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < kSuper - 1; ++q) {
+      above[q] = 0ull;
+      if (have && q < c_loc) above[q] = mask[((size_t)(B0 + b0 + q) * CB + cb) * 64 + lane];
+    }
+    u64 acc = 0ull;
+    if (have) {
+      for (int rl = 0; rl < b0; ++rl) {
+        const u64 w = mask[((size_t)(B0 + rl) * CB + cb) * 64 + lane];
+        if ((s_keepbits[rl] >> lane) & 1ull) acc |= w;
+      }
+    }
+    u64 rem = b0 > 0 ? wave_or64(acc) : 0ull;
+    const int rows_here = have ? min(64, n - cb * 64) : 0;
+    const u64 valid = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+#pragma unroll
+    for (int step = 0; step < kSuper; ++step) {
+      if (step == c_loc && have) {
+        u64 r = uniform64(rem);
+        u64 active = uniform64(__ballot(diag != 0ull)) & ~r & valid;
+        while (active) {
+          const int k = __builtin_ctzll(active);
+          r |= readlane64(diag, k);
+          active &= ~(r | (1ull << k));
+        }
+        if (lane == 0) s_keepbits[lb] = ~r & valid;
+      }
+      __syncthreads();
+      if (step < kSuper - 1 && have && step < c_loc) {
+        const u64 kb = s_keepbits[b0 + step];
+        const u64 contrib = ((kb >> lane) & 1ull) ? above[step] : 0ull;
+        rem |= wave_or64(contrib);
+      }
+    }
+  }
+  // publish the keep bits of the rows this workgroup owns: positions [first, end)
+  for (int lb = threadIdx.x; lb < nb; lb += kSuper * kWave) {
+    const int p0 = (B0 + lb) * 64;
+    u64 own = ~0ull;
+    if (first > p0) own &= ~((1ull << (first - p0)) - 1ull);         // first - p0 < 64: only in the first block
+    if (end < p0 + 64) own &= (1ull << (end - p0)) - 1ull;           // end - p0 >= 1
+    const u64 bits = s_keepbits[lb] & own;
+    if (bits) atomicOr(&keepbits[B0 + lb], bits);
+  }
+}
+
+// emission in GLOBAL score order: g -> position -> keep bit, two-pass compaction
+__device__ __forceinline__ bool seg_kept(const u64* __restrict__ keepbits, const int* __restrict__ invperm, int g, int n) {
+  if (g >= n) return false;
+  const int p = invperm[g];
+  return (keepbits[p >> 6] >> (p & 63)) & 1ull;
+}
+
+__global__ __launch_bounds__(1024) void nms_seg_count(const u64* __restrict__ keepbits, const int* __restrict__ invperm, int n,
+                                                      int* __restrict__ counts) {
+  __shared__ int s_w[16];
+  const int g = blockIdx.x * 1024 + threadIdx.x;
+  const u64 bal = __ballot(seg_kept(keepbits, invperm, g, n));
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += s_w[w];
+    counts[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void nms_seg_emit(const u64* __restrict__ keepbits, const int* __restrict__ invperm,
+                                                     const int64_t* __restrict__ order, const int* __restrict__ counts, int n,
+                                                     const int* __restrict__ err, int64_t* __restrict__ keep_out,
+                                                     int64_t* __restrict__ num_keep) {
+  __shared__ int s_w[16];
+  __shared__ int s_part[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // exclusive prefix of the chunk counts before this chunk
+  int part = 0;
+  for (int c = threadIdx.x; c < (int)blockIdx.x; c += 1024) part += counts[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) s_part[wave] = part;
+  const int g = blockIdx.x * 1024 + threadIdx.x;
+  const bool kept = seg_kept(keepbits, invperm, g, n);
+  const u64 bal = __ballot(kept);
+  if (lane == 0) s_w[wave] = __popcll(bal);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < 16; ++w) base += s_part[w];
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += s_w[w];
+  if (kept) keep_out[base + before + __popcll(bal & ((1ull << lane) - 1ull))] = order[g];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    int tot = base;
+    for (int w = 0; w < 16; ++w) tot += s_w[w];
+    *num_keep = *err ? -1 : tot;
+  }
+}
+
+struct SegWorkspace {
+  u64* mask;
+  u64* keepbits;
+  int64_t* oidx;
+  int* invperm;
+  int* counts;
+  int* err;
+};
+inline size_t seg_workspace_layout(int64_t n, char* base, SegWorkspace* w) {
+  const size_t CB = (size_t)ceil_div(n, 64), NC = (size_t)ceil_div(n, 1024);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = base ? base + off : nullptr;
+    off += (bytes + 255) & ~(size_t)255;
+    return ptr;
+  };
+  char* m = take(CB * CB * 64 * sizeof(u64));
+  char* kb = take((CB + 1) * sizeof(u64));  // keep bits + (err, pad) right behind them: one memset
+  char* oi = take((size_t)n * sizeof(int64_t));
+  char* ip = take((size_t)n * sizeof(int));
+  char* ct = take(NC * sizeof(int));
+  if (w) {
+    w->mask = reinterpret_cast<u64*>(m);
+    w->keepbits = reinterpret_cast<u64*>(kb);
+    w->err = reinterpret_cast<int*>(kb + CB * sizeof(u64));
+    w->oidx = reinterpret_cast<int64_t*>(oi);
+    w->invperm = reinterpret_cast<int*>(ip);
+    w->counts = reinterpret_cast<int*>(ct);
+  }
+  return off;
+}
+
+template <typename T>
+int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, const int64_t* perm, int64_t n, double thr,
+               void* workspace, int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
+  const int CB = (int)ceil_div(n, 64), NC = (int)ceil_div(n, 1024);
+  SegWorkspace w;
+  seg_workspace_layout(n, static_cast<char*>(workspace), &w);
+  hipError_t e = hipMemsetAsync(w.keepbits, 0, sizeof(u64) * ((size_t)CB + 1), stream);
+  if (e != hipSuccess) return set_error((int)e, "tvmi_nms_segmented: memset");
+  nms_seg_layout<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream>>>(order, perm, (int)n, w.oidx, w.invperm);
+  nms_mask_tiles_seg<T><<<dim3((unsigned)CB), dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), w.oidx, keys,
+                                                                                  (int)n, CB, thr, w.mask);
+  nms_sweep_seg<<<dim3((unsigned)CB), dim3(kSuper * kWave), 0, stream>>>(w.mask, keys, (int)n, CB, w.keepbits, w.err);
+  nms_seg_count<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, (int)n, w.counts);
+  nms_seg_emit<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, order, w.counts, (int)n, w.err, keep_out,
+                                                            num_keep);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_segmented");
+}
+
 }  // namespace
 }  // namespace tvmi
 
@@ -388,4 +691,28 @@ extern "C" int tvmi_nms(const void* dets, const int64_t* order, const int64_t* s
   if (dt == TVMI_F32)
     return tvmi::launch<float>(dets, order, seg, n, iou_threshold, workspace, keep_out, num_keep_out, s);
   return tvmi::launch<double>(dets, order, seg, n, iou_threshold, workspace, keep_out, num_keep_out, s);
+}
+
+extern "C" size_t tvmi_nms_segmented_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return tvmi::seg_workspace_layout(n, nullptr, nullptr);
+}
+
+extern "C" int tvmi_nms_segmented(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
+                                  int64_t n, double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
+                                  int64_t* keep_out, int64_t* num_keep_out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_CHECK_ARG(n >= 0, "nms_segmented: negative box count");
+  TVMI_CHECK_ARG(num_keep_out != nullptr, "nms_segmented: num_keep_out is null");
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(num_keep_out, 0, sizeof(int64_t), s);
+    return e == hipSuccess ? 0 : tvmi::set_error((int)e, "tvmi_nms_segmented: memset");
+  }
+  TVMI_CHECK_ARG(dets && order && seg_keys && perm && keep_out && workspace, "nms_segmented: null pointer");
+  TVMI_CHECK_ARG(n <= 1200000, "nms_segmented: more than 1.2M boxes is not supported by the bitmask path");
+  TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_segmented_workspace_bytes(n), "nms_segmented: workspace too small");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms_segmented: dets must be float32 or float64");
+  if (dt == TVMI_F32)
+    return tvmi::launch_seg<float>(dets, order, seg_keys, perm, n, iou_threshold, workspace, keep_out, num_keep_out, s);
+  return tvmi::launch_seg<double>(dets, order, seg_keys, perm, n, iou_threshold, workspace, keep_out, num_keep_out, s);
 }

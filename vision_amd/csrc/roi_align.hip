@@ -1317,6 +1317,7 @@ int g_cfg_dma = 1;
 int g_cfg_order = 0;
 int g_cfg_bwd_dense = 1;
 int g_cfg_dma_wpb = 4;
+int g_cfg_dma_extra_lds = 0;  // analysis knob: unused dynamic LDS per workgroup (lowers occupancy)
 int g_cfg_bwd_tiles = 0;
 int g_cfg_bwd_wave = 0;  // wave-autonomous backward: measured slower than the block-tiled one (7.1 vs 4.5 ms
                          // on config 2, both bound by global float atomics) — kept behind TVMI_ROI_BWD_WAVE=1
@@ -1337,6 +1338,7 @@ static void load_env_cfg() {
   g_cfg_bwd_tiles = env_int("TVMI_ROI_BWD_TILES", g_cfg_bwd_tiles);
   g_cfg_bwd_dense = env_int("TVMI_ROI_BWD_DENSE", g_cfg_bwd_dense);
   g_cfg_dma_wpb = env_int("TVMI_ROI_DMA_WPB", g_cfg_dma_wpb);
+  g_cfg_dma_extra_lds = env_int("TVMI_ROI_DMA_EXTRA_LDS", g_cfg_dma_extra_lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1986,7 +1988,7 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
           roi_align_fwd_ms_dma<T, PHT, PWT, SRT, 2><<<dim3(wave_unit_grid(K, nchunks, 2)), dim3(128), 0, stream>>>( \
               lv, r, out, (int)C, aligned, nchunks, chunk, nunits, declined, order);                            \
         else                                                                                                    \
-          roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
+          roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, g_cfg_dma_extra_lds, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
                                                                           chunk, nunits, declined, order);      \
         dma = true;                                                                                             \
       }                                                                                                         \

@@ -13,6 +13,7 @@
 // torchvision.ops wrapper bind to this library unchanged.
 // Define TVMI_NO_SCHEMA_DEFS when another library in the process already owns the m.def()s.
 #include <ATen/ATen.h>
+#include <cstdlib>
 #include <c10/core/DeviceGuard.h>
 #include <torch/csrc/inductor/aoti_torch/c/shim.h>
 #include <torch/library.h>
@@ -80,10 +81,30 @@ at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores,
     seg_c = seg->to(at::kLong).contiguous();
     seg_ptr = seg_c.const_data_ptr<int64_t>();
   }
-  const size_t ws_bytes = tvmi_nms_workspace_bytes(n);
-  at::Tensor workspace = at::empty({(int64_t)ws_bytes}, dets.options().dtype(at::kByte));
   at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
   at::Tensor num = at::empty({1}, dets.options().dtype(at::kLong));
+  static const bool seg_major = []() {
+    const char* e = std::getenv("TVMI_NMS_SEGMAJOR");
+    return !(e && e[0] == '0');
+  }();
+  if (seg_ptr && seg_major && n > 4096) {  // up to 4096 boxes the single-launch global sweep is as fast
+    // segment-major path: stable partition of the score order by segment (a second sort), block-diagonal
+    // masks, one sweep workgroup per segment
+    auto parted = at::sort(seg_c.index_select(0, order), /*stable=*/true, /*dim=*/0, /*descending=*/false);
+    at::Tensor keys = std::get<0>(parted), perm = std::get<1>(parted);
+    const size_t sb = tvmi_nms_segmented_workspace_bytes(n);
+    at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
+    check_status(tvmi_nms_segmented(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), keys.const_data_ptr<int64_t>(),
+                                    perm.const_data_ptr<int64_t>(), n, iou_threshold, dtype_of(boxes, "nms"),
+                                    sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(),
+                                    num.mutable_data_ptr<int64_t>(), current_stream(dets)),
+                 "nms_segmented");
+    const int64_t nk = num.item<int64_t>();  // the one host sync (data-dependent size)
+    if (nk >= 0) return keep.narrow(0, 0, nk);
+    // a segment above 8,192 boxes: fall through to the global-order pipeline
+  }
+  const size_t ws_bytes = tvmi_nms_workspace_bytes(n);
+  at::Tensor workspace = at::empty({(int64_t)ws_bytes}, dets.options().dtype(at::kByte));
   check_status(tvmi_nms(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), seg_ptr, n, iou_threshold,
                         dtype_of(boxes, "nms"), workspace.mutable_data_ptr(), ws_bytes,
                         keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(),
