@@ -7,8 +7,9 @@ metric   : boxes/sec RoIAlign+NMS (1000 proposals per image, 256-channel FPN map
 workload : BASELINE config 2 — a batch of 4 padded 800x1344 images per GPU, 4 FPN levels x 256 channels
            (strides 4/8/16/32, fp32), 1000 proposals per image.  One "step" = one pass of the hot path
            over that batch: MultiScaleRoIAlign 7x7 (sampling_ratio 2) of the 4000 proposals, then per-image
-           NMS (batched_nms over the image index, IoU 0.5), then — when N > 1 — the one fixed-shape RCCL
-           all-gather of the padded top-100 detections of every image.
+           NMS (batched_nms over the image index, IoU 0.5), packing of the padded top-100 detections of every
+           image (fixed shape) and — when N > 1 — their one RCCL all-gather.  The per-rank part has no host
+           synchronisation, so the launches queue back to back (--graph replays them from a captured hipGraph).
 inputs   : synthetic (seeded), resident in HBM before the timed region.
 scaling  : weak — every rank owns its own batch of images (the path shards over images; no data-path
            collective besides the detection all-gather).  value = boxes processed by ALL ranks / time.
@@ -71,6 +72,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the per-rank chain from a captured hipGraph (measured: no gain "
+                    "over eager sync-free launches on this stack, so off by default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,14 +97,42 @@ def main():
     all_scores = torch.cat(scores)
     img_idx = torch.cat([torch.full((PROPOSALS,), i, device=device, dtype=torch.int64) for i in range(BATCH)])
 
+    def device_step():
+        # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable)
+        pooled = pool(feats, boxes, image_shapes)                                          # [4000, 256, 7, 7], 1 launch
+        keep, num = vision_amd.boxes.batched_nms_padded(all_boxes, all_scores, img_idx, NMS_THR, BATCH)  # per-image NMS, 1 launch
+        # padded top-MAX_DETS detections per image, fixed shape, ONE launch, keep length read on the device
+        dets, counts = sharding.pack_kept_detections(all_boxes, all_scores, img_idx, keep, BATCH, MAX_DETS, num_keep=num)
+        return pooled, num, dets, counts
+
+    graph, static_out = None, None
+    if args.graph:
+        # launch-bound chain (~12 short kernels behind the RoIAlign launch): capture it once, replay per step
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    device_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                static_out = device_step()
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            graph, static_out = None, None
+            torch.cuda.synchronize()
+
     def step():
         with torch.no_grad():
-            pooled = pool(feats, boxes, image_shapes)                               # [4000, 256, 7, 7]
-            keep = vision_amd.batched_nms(all_boxes, all_scores, img_idx, NMS_THR)  # per-image NMS
-            # padded top-MAX_DETS detections per image, fixed shape, ONE launch
-            dets, counts = sharding.pack_kept_detections(all_boxes, all_scores, img_idx, keep, BATCH, MAX_DETS)
-            gd, gc = sharding.all_gather_detections(dets, counts)
-        return pooled, keep, gd, gc
+            if graph is not None:
+                graph.replay()
+                pooled, num, dets, counts = static_out
+            else:
+                pooled, num, dets, counts = device_step()
+            gd, gc = sharding.all_gather_detections(dets, counts)   # the one collective (no-op at world 1)
+        return pooled, num, gd, gc
 
     def sync():
         if world > 1:
@@ -149,7 +180,7 @@ def main():
         # NMS alone, for the breakdown in `config`
         e0.record()
         for _ in range(n_k):
-            vision_amd.batched_nms(all_boxes, all_scores, img_idx, NMS_THR)
+            vision_amd.boxes.batched_nms_padded(all_boxes, all_scores, img_idx, NMS_THR, BATCH)
         e1.record()
         torch.cuda.synchronize()
         nms_ms = e0.elapsed_time(e1) / n_k
@@ -182,7 +213,8 @@ def main():
             "boxes_per_step_per_gpu": BATCH * PROPOSALS,
             "roi_align_ms": round(k_ms, 4),
             "nms_ms": round(nms_ms, 4),
-            "kept_boxes": int(out[1].numel()),
+            "kept_boxes": int(out[1].item()),
+            "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
         },
         "roofline": {

@@ -74,6 +74,17 @@ int tvmi_nms_segmented(const void* dets, const int64_t* order, const int64_t* se
                        double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes, int64_t* keep_out,
                        int64_t* num_keep_out, void* stream);
 
+/* Detector-step sizes in two launches and without the second sort: n <= 4096 boxes, segment ids
+ * in [0, num_segments), num_segments <= 1024, every segment <= 1024 boxes (per-image / per-level
+ * / per-class lists of one batch).  Same inputs and result as tvmi_nms with `seg`; per-segment
+ * tiles instead of an N x N mask, one sweep chain per segment, all segments concurrently.
+ * Inputs outside those limits give num_keep_out = -1 (fall back to tvmi_nms).
+ */
+size_t tvmi_nms_small_segments_workspace_bytes(int64_t n, int64_t num_segments);
+int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
+                            int64_t num_segments, double iou_threshold, tvmi_dtype dt, void* workspace,
+                            size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream);
+
 /* ------------------------------------------------------------- RoIAlign ----------
  * Replaces: torchvision/csrc/ops/cuda/roi_align_kernel.cu:68-143,334-394 (forward),
  * :204-332,396-466 (backward); arithmetic follows
@@ -194,6 +205,13 @@ int tvmi_deformable_col2im_coord(const void* columns, const void* input, const v
 int tvmi_pack_detections(const float* boxes, const float* scores, const int64_t* labels,
                          const int64_t* image_idx, const int64_t* keep, int64_t num_keep, int64_t num_images,
                          int64_t max_dets, float* dets, int32_t* counts, void* stream);
+/* Same, with the length of `keep` read on the device (num_keep_dev [1] int64, e.g. tvmi_nms's
+ * num_keep_out on the same stream; clamped to [0, keep_capacity]): NMS -> packed payload with
+ * no host synchronisation in between, so the chain can be captured in a hipGraph. */
+int tvmi_pack_detections_devcount(const float* boxes, const float* scores, const int64_t* labels,
+                                  const int64_t* image_idx, const int64_t* keep, int64_t keep_capacity,
+                                  const int64_t* num_keep_dev, int64_t num_images, int64_t max_dets, float* dets,
+                                  int32_t* counts, void* stream);
 
 /* Candidate generation for the detector's two post-processing stages, batched over images
  * (one launch each; the segmented NMS that follows is tvmi_nms with segment ids, the top-k

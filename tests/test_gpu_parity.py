@@ -118,6 +118,32 @@ def test_batched_nms_segment_major_layouts():
     assert np.array_equal(keep, O.nms(boxes.double().numpy(), scores.double().numpy(), 0.4, idxs.numpy()))
 
 
+def test_batched_nms_single_launch_small_path():
+    """n <= 4096 with a promised id range: the small path (per-segment tiles, concurrent sweeps, last-workgroup compaction)
+    must equal the oracle bit for bit — ragged segments, empty ids, ties, fp64 — and inputs that break its limits
+    (a segment above 1024 boxes, an id outside the promised range) must still give the right answer (fallback)."""
+    g = gen(63)
+    for n, S, thr in ((4000, 4, 0.5), (4096, 91, 0.3), (777, 1024, 0.7), (65, 3, 0.5), (1, 1, 0.5)):
+        boxes = random_boxes(n, 500, 400, 4, 150, g)
+        scores = (torch.rand(n, generator=g) * 128).floor() / 128
+        idxs = torch.randint(0, S, (n,), generator=g)
+        idxs[idxs == 1] = 0                                              # id 1 stays empty
+        keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), thr, num_segments=S).cpu().numpy()
+        assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), thr, idxs.numpy())), (n, S)
+    keep = vision_amd.batched_nms(boxes.double().to(DEV), scores.double().to(DEV), idxs.to(DEV), 0.5, num_segments=1).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.double().numpy(), scores.double().numpy(), 0.5, idxs.numpy()))
+    n = 3000
+    boxes = random_boxes(n, 500, 400, 4, 150, g)
+    scores = torch.rand(n, generator=g)
+    big = torch.where(torch.arange(n) < 1500, torch.zeros(n, dtype=torch.int64), torch.randint(1, 5, (n,), generator=g))
+    keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), big.to(DEV), 0.5, num_segments=5).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.5, big.numpy()))            # 1500-box segment
+    keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), (big + 7).to(DEV), 0.5, num_segments=5).cpu().numpy()
+    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.5, big.numpy()))            # ids outside [0, 5)
+    _, num = vision_amd.boxes.batched_nms_padded(boxes.to(DEV), scores.to(DEV), big.to(DEV), 0.5, num_segments=5)
+    assert int(num) == -1                                                                           # sync-free form reports it
+
+
 def test_nms_100k_properties(tv):
     # BASELINE config 3 size; oracle too slow here -> size-independent properties
     g = gen(7)
@@ -577,3 +603,43 @@ def test_filter_proposals_golden_and_fused_decode():
             assert b[i].shape == G[f"rpn_boxes{i}"].shape
             np.testing.assert_allclose(s[i].cpu().numpy(), G[f"rpn_scores{i}"], rtol=0, atol=1e-6)
             np.testing.assert_allclose(b[i].cpu().numpy(), G[f"rpn_boxes{i}"], rtol=0, atol=1e-4)
+
+
+def test_sync_free_nms_pack_chain_and_graph_replay():
+    """batched_nms_padded + pack_kept_detections(num_keep=...) == the synchronising pair, eagerly and when the
+    chain is captured in a hipGraph and replayed on fresh input values."""
+    from vision_amd import sharding
+    g = gen(71)
+    n, B = 2700, 3   # ~900 boxes per image: inside the 1024-per-segment limit of the small path
+    boxes = random_boxes(n, 800, 600, 4, 200, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    img = torch.randint(0, B, (n,), generator=g).to(DEV)
+    keep = vision_amd.batched_nms(boxes, scores, img, 0.5)
+    want_d, want_c = sharding.pack_kept_detections(boxes, scores, img, keep, B, 50)
+    kp, num = vision_amd.boxes.batched_nms_padded(boxes, scores, img, 0.5, B)
+    assert int(num) == keep.numel() and torch.equal(kp[: keep.numel()], keep)
+    got_d, got_c = sharding.pack_kept_detections(boxes, scores, img, kp, B, 50, num_keep=num)
+    assert torch.equal(got_d, want_d) and torch.equal(got_c, want_c)
+    # graph capture / replay with the inputs overwritten in place
+    sb, ss = boxes.clone(), scores.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            k2, n2 = vision_amd.boxes.batched_nms_padded(sb, ss, img, 0.5, B)
+            sharding.pack_kept_detections(sb, ss, img, k2, B, 50, num_keep=n2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        k2, n2 = vision_amd.boxes.batched_nms_padded(sb, ss, img, 0.5, B)
+        d2, c2 = sharding.pack_kept_detections(sb, ss, img, k2, B, 50, num_keep=n2)
+    nb = random_boxes(n, 800, 600, 4, 200, g).to(DEV)
+    ns = torch.rand(n, generator=g).to(DEV)
+    sb.copy_(nb)
+    ss.copy_(ns)
+    graph.replay()
+    torch.cuda.synchronize()
+    keep = vision_amd.batched_nms(nb, ns, img, 0.5)
+    want_d, want_c = sharding.pack_kept_detections(nb, ns, img, keep, B, 50)
+    assert int(n2) == keep.numel() and torch.equal(d2, want_d) and torch.equal(c2, want_c)

@@ -40,7 +40,7 @@ def _fake_nms(dets, scores, iou_threshold):
     return dets.new_empty(n, dtype=torch.long)
 
 
-def _fake_nms_segmented(dets, scores, idxs, iou_threshold):
+def _fake_nms_segmented(dets, scores, idxs, iou_threshold, num_segments=-1):
     return _fake_nms(dets, scores, iou_threshold)
 
 
@@ -147,7 +147,17 @@ def _fake_rpn_candidates(objectness, boxes, deltas, top_idx, level_offsets, imag
             f((B, T), dtype=torch.uint8))
 
 
+def _fake_nms_padded(dets, scores, idxs, iou_threshold, num_segments=-1):
+    return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
+
+
+def _fake_pack_devcount(boxes, scores, labels, image_idx, keep, num_keep, num_images, max_dets):
+    return boxes.new_empty((num_images, max_dets, 6), dtype=torch.float32), boxes.new_empty((num_images,), dtype=torch.int32)
+
+
 _FAKES = {
+    "tvmi::nms_segmented_padded": _fake_nms_padded,
+    "tvmi::pack_detections_devcount": _fake_pack_devcount,
     "tvmi::paste_masks": _fake_paste_masks,
     "tvmi::detection_candidates": _fake_detection_candidates,
     "tvmi::rpn_candidates": _fake_rpn_candidates,

@@ -18,7 +18,7 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
     return torch.ops.torchvision.nms(boxes, scores, iou_threshold)
 
 
-def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
+def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float, num_segments: int = -1) -> Tensor:
     """NMS that never suppresses across categories (ops/boxes.py:57-91).
 
     The reference switches between shifting the boxes per category and running one nms()
@@ -26,16 +26,28 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
     tensors both are replaced by ONE segment-major launch chain (`tvmi::nms_segmented`): IoU is
     evaluated on the unshifted boxes (the loop's arithmetic, exactly), category-mismatched pairs
     are never even tested, every category is swept by its own workgroup, and there is no
-    torch.unique / torch.where host round trip per category.  CPU tensors (tests only) follow the
-    reference's switch."""
+    torch.unique / torch.where host round trip per category.  `num_segments` (extension, optional): a
+    promise that 0 <= idxs < num_segments, which lets N <= 4096 run as a single launch.  CPU tensors
+    (tests only) follow the reference's switch."""
     if boxes.is_cuda:
         assert_has_ops()
         if boxes.numel() == 0:
             return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-        return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold)
+        return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold, int(num_segments))
     if boxes.numel() > 4000:
         return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)
     return _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold)
+
+
+def batched_nms_padded(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float,
+                       num_segments: int = -1) -> Tuple[Tensor, Tensor]:
+    """batched_nms without the host synchronisation on the result size (device tensors only): returns
+    (`keep` [N] int64 whose first `num[0]` entries are the reference's result, `num` [1] int64 on the device;
+    -1 if the input broke the promised limits).  Feed both to
+    `vision_amd.sharding.pack_kept_detections(..., num_keep=num)`.
+    `num_segments` > 0 promises 0 <= idxs < num_segments; for N <= 4096 the whole batched NMS is then one launch."""
+    assert_has_ops()
+    return torch.ops.tvmi.nms_segmented_padded(boxes, scores, idxs, iou_threshold, int(num_segments))
 
 
 def _batched_nms_coordinate_trick(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:

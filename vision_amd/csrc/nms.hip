@@ -614,6 +614,222 @@ __global__ __launch_bounds__(1024) void nms_seg_emit(const u64* __restrict__ kee
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Small batched NMS (n <= 4096 boxes, ids in [0, S), every segment <= 1024 boxes: the RPN /
+// box-head / per-image sizes of a detector step) in TWO launches and no second sort:
+//  A. nms_small_seg_tiles: workgroup (s, y) collects segment s from the score-ordered list
+//     (stable; every workgroup of the segment repeats this cheap scan), and each of its waves
+//     builds one upper-triangular 64x64 suppression tile of the segment -> tiles[s][t][64]
+//     (136 tiles per segment at most, spread over 9 workgroups: the pair tests use the chip,
+//     not one CU per segment); workgroup (s, 0) also stores the segment's global ranks.
+//  B. nms_small_seg_sweep: workgroup s sweeps its segment (one super-block: no pull phase),
+//     publishes one flag per box, and the LAST workgroup to finish (device-scope fence +
+//     ticket) compacts the flags in global score order into keep_out / num_keep.
+// Versus mask kernel + global sweep: no N x N mask, S resolve chains run concurrently.
+constexpr int kSmallSegBoxes = 1024;
+constexpr int kSmallSegBlocks = kSmallSegBoxes / 64;                          // 16 = kSuper
+constexpr int kSmallSegTiles = kSmallSegBlocks * (kSmallSegBlocks + 1) / 2;  // 136
+
+struct SmallSegWorkspace {
+  int* sync_words;       // [0] finished workgroups, [1] error flag
+  int* gcnt;             // [S] boxes per segment
+  int* glist;            // [S][1024] global rank of the i-th box of the segment
+  unsigned char* flags;  // [n] keep flag per global rank
+  u64* tiles;            // [S][136][64]
+};
+inline size_t small_seg_workspace_layout(int64_t n, int64_t S, char* base, SmallSegWorkspace* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* ptr = base ? base + off : nullptr;
+    off += (bytes + 255) & ~(size_t)255;
+    return ptr;
+  };
+  char* sw = take(2 * sizeof(int));
+  char* gc = take((size_t)S * sizeof(int));
+  char* gl = take((size_t)S * kSmallSegBoxes * sizeof(int));
+  char* fl = take((size_t)n);
+  char* tl = take((size_t)S * kSmallSegTiles * 64 * sizeof(u64));
+  if (w) {
+    w->sync_words = reinterpret_cast<int*>(sw);
+    w->gcnt = reinterpret_cast<int*>(gc);
+    w->glist = reinterpret_cast<int*>(gl);
+    w->flags = reinterpret_cast<unsigned char*>(fl);
+    w->tiles = reinterpret_cast<u64*>(tl);
+  }
+  return off;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict__ dets, const int64_t* __restrict__ order,
+                                                            const int64_t* __restrict__ seg, int n, int S, double thr,
+                                                            SmallSegWorkspace ws) {
+  __shared__ T s_box[kSmallSegBoxes][5];
+  __shared__ int s_wcnt[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int me = blockIdx.x;
+  const bool scribe = blockIdx.y == 0;  // the workgroup of this segment that records the list
+  int* glist = ws.glist + (size_t)me * kSmallSegBoxes;
+  // ---- collect my segment, in score order
+  int cnt = 0;
+  bool bad = false;
+  for (int base = 0; base < n; base += 1024) {
+    const int g = base + tid;
+    bool mine = false;
+    int64_t oi = 0;
+    if (g < n) {
+      oi = order[g];
+      const int64_t sg = seg[oi];
+      mine = sg == me;
+      bad |= sg < 0 || sg >= S;
+    }
+    const u64 bal = __ballot(mine);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_wcnt[w];
+      before += w < wave ? c : 0;
+      total += c;
+    }
+    const int pos = cnt + before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (mine && pos < kSmallSegBoxes) {
+      const Box<T> b = load_box<T>(dets, oi);
+      s_box[pos][0] = b.x1;
+      s_box[pos][1] = b.y1;
+      s_box[pos][2] = b.x2;
+      s_box[pos][3] = b.y2;
+      s_box[pos][4] = (b.x2 - b.x1) * (b.y2 - b.y1);
+      if (scribe) glist[pos] = g;
+    }
+    cnt += total;
+    __syncthreads();
+  }
+  if (scribe) {
+    // over-long segment or an id outside [0, S): the caller redoes the input on the general path
+    const bool any_bad = me == 0 ? __syncthreads_or(bad) : false;
+    if (tid == 0) {
+      if (cnt > kSmallSegBoxes || any_bad) ws.sync_words[1] = 1;
+      ws.gcnt[me] = min(cnt, kSmallSegBoxes);
+    }
+  }
+  cnt = min(cnt, kSmallSegBoxes);
+  const int nb = (cnt + 63) >> 6;
+  const int t = blockIdx.y * 16 + wave;
+  if (t >= nb * (nb + 1) / 2) return;
+  int rb = 0, rem = t;
+  while (rem >= nb - rb) {
+    rem -= nb - rb;
+    ++rb;
+  }
+  const int cb = rb + rem;
+  const int j = cb * 64 + lane;
+  const bool jvalid = j < cnt;
+  const int jj = jvalid ? j : 0;
+  const T jx1 = s_box[jj][0], jy1 = s_box[jj][1], jx2 = s_box[jj][2], jy2 = s_box[jj][3], jarea = s_box[jj][4];
+  const bool diag = cb == rb;
+  const int rows_here = min(64, cnt - rb * 64);
+  u64 mine = 0ull;
+  for (int i = 0; i < rows_here; ++i) {
+    const int r = rb * 64 + i;
+    const T ix1 = s_box[r][0], iy1 = s_box[r][1], ix2 = s_box[r][2], iy2 = s_box[r][3], iarea = s_box[r][4];
+    const T xx1 = ix1 > jx1 ? ix1 : jx1;
+    const T yy1 = iy1 > jy1 ? iy1 : jy1;
+    const T xx2 = jx2 < ix2 ? jx2 : ix2;
+    const T yy2 = jy2 < iy2 ? jy2 : iy2;
+    const T dw = xx2 - xx1, dh = yy2 - yy1;
+    const T w = (T)0 < dw ? dw : (T)0;
+    const T h = (T)0 < dh ? dh : (T)0;
+    const T inter = w * h;
+    const T ovr = inter / (iarea + jarea - inter);
+    bool pr = ((double)ovr > thr) && jvalid;
+    if (diag) pr = pr && (lane > i);
+    const u64 word = __ballot(pr);
+    if (lane == i) mine = word;
+  }
+  ws.tiles[((size_t)me * kSmallSegTiles + t) * 64 + lane] = mine;
+}
+
+__global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int64_t* __restrict__ order, int n,
+                                                                      SmallSegWorkspace ws, int64_t* __restrict__ keep_out,
+                                                                      int64_t* __restrict__ num_keep) {
+  static_assert(kSmallSegBlocks == kSuper, "one super-block per segment");
+  __shared__ u64 s_keepbits[kSmallSegBlocks];
+  __shared__ int s_wcnt[16];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int me = blockIdx.x;
+  const int cnt = ws.gcnt[me];
+  const int nb = (cnt + 63) >> 6;
+  const u64* tiles = ws.tiles + (size_t)me * kSmallSegTiles * 64;
+  {
+    auto tile_index = [nb](int rb, int cb) { return rb * nb - (rb * (rb - 1)) / 2 + (cb - rb); };
+    const int c_loc = wave;
+    const bool have = c_loc < nb;
+    u64 diag = 0ull, above[kSuper - 1];
+    if (have) diag = tiles[tile_index(c_loc, c_loc) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < kSuper - 1; ++q) {
+      above[q] = 0ull;
+      if (have && q < c_loc) above[q] = tiles[tile_index(q, c_loc) * 64 + lane];
+    }
+    u64 rem = 0ull;
+    const int rows_here = have ? min(64, cnt - c_loc * 64) : 0;
+    const u64 valid = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+#pragma unroll
+    for (int step = 0; step < kSuper; ++step) {
+      if (step == c_loc && have) {
+        u64 r = uniform64(rem);
+        u64 active = uniform64(__ballot(diag != 0ull)) & ~r & valid;
+        while (active) {
+          const int k = __builtin_ctzll(active);
+          r |= readlane64(diag, k);
+          active &= ~(r | (1ull << k));
+        }
+        if (lane == 0) s_keepbits[c_loc] = ~r & valid;
+      }
+      __syncthreads();
+      if (step < kSuper - 1 && have && step < c_loc) {
+        const u64 kb = s_keepbits[step];
+        const u64 contrib = ((kb >> lane) & 1ull) ? above[step] : 0ull;
+        rem |= wave_or64(contrib);
+      }
+    }
+  }
+  // one flag per box of my segment, at its global rank
+  const int* glist = ws.glist + (size_t)me * kSmallSegBoxes;
+  for (int i = tid; i < cnt; i += kSuper * kWave)
+    ws.flags[glist[i]] = (unsigned char)((s_keepbits[i >> 6] >> (i & 63)) & 1ull);
+  // last workgroup out compacts the flags in global score order
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_flag = atomicAdd(&ws.sync_words[0], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_flag) return;
+  __threadfence();
+  const volatile unsigned char* vflags = ws.flags;
+  int run = 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int g = base + tid;
+    const bool kept = g < n && vflags[g] != 0;
+    const u64 bal = __ballot(kept);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_wcnt[w];
+      before += w < wave ? c : 0;
+      total += c;
+    }
+    if (kept) keep_out[run + before + __popcll(bal & ((1ull << lane) - 1ull))] = order[g];
+    run += total;
+    __syncthreads();
+  }
+  if (tid == 0) *num_keep = *(volatile int*)&ws.sync_words[1] ? -1 : run;
+}
+
 struct SegWorkspace {
   u64* mask;
   u64* keepbits;
@@ -715,4 +931,42 @@ extern "C" int tvmi_nms_segmented(const void* dets, const int64_t* order, const 
   if (dt == TVMI_F32)
     return tvmi::launch_seg<float>(dets, order, seg_keys, perm, n, iou_threshold, workspace, keep_out, num_keep_out, s);
   return tvmi::launch_seg<double>(dets, order, seg_keys, perm, n, iou_threshold, workspace, keep_out, num_keep_out, s);
+}
+
+extern "C" size_t tvmi_nms_small_segments_workspace_bytes(int64_t n, int64_t num_segments) {
+  if (n <= 0 || num_segments <= 0) return 0;
+  return tvmi::small_seg_workspace_layout(n, num_segments, nullptr, nullptr);
+}
+
+extern "C" int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
+                                       int64_t num_segments, double iou_threshold, tvmi_dtype dt, void* workspace,
+                                       size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_CHECK_ARG(n >= 0 && num_keep_out != nullptr, "nms_small_segments: bad arguments");
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(num_keep_out, 0, sizeof(int64_t), s);
+    return e == hipSuccess ? 0 : tvmi::set_error((int)e, "tvmi_nms_small_segments: memset");
+  }
+  TVMI_CHECK_ARG(dets && order && seg && keep_out && workspace, "nms_small_segments: null pointer");
+  TVMI_CHECK_ARG(n <= 4096 && num_segments >= 1 && num_segments <= 1024,
+                 "nms_small_segments: needs n <= 4096 and 1 <= num_segments <= 1024");
+  TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_small_segments_workspace_bytes(n, num_segments),
+                 "nms_small_segments: workspace too small");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms_small_segments: dets must be float32 or float64");
+  tvmi::SmallSegWorkspace w;
+  tvmi::small_seg_workspace_layout(n, num_segments, static_cast<char*>(workspace), &w);
+  hipError_t e = hipMemsetAsync(w.sync_words, 0, 2 * sizeof(int), s);
+  if (e != hipSuccess) return tvmi::set_error((int)e, "tvmi_nms_small_segments: memset");
+  // a segment of m boxes has ceil(m/64)*(ceil(m/64)+1)/2 tiles; m <= min(n, 1024)
+  const int nbmax = (int)std::min<int64_t>(tvmi::kSmallSegBlocks, tvmi::ceil_div(n, 64));
+  const dim3 grid((unsigned)num_segments, (unsigned)tvmi::ceil_div(nbmax * (nbmax + 1) / 2, 16));
+  if (dt == TVMI_F32)
+    tvmi::nms_small_seg_tiles<float><<<grid, dim3(1024), 0, s>>>(static_cast<const float*>(dets), order, seg, (int)n,
+                                                                 (int)num_segments, iou_threshold, w);
+  else
+    tvmi::nms_small_seg_tiles<double><<<grid, dim3(1024), 0, s>>>(static_cast<const double*>(dets), order, seg, (int)n,
+                                                                  (int)num_segments, iou_threshold, w);
+  tvmi::nms_small_seg_sweep<<<dim3((unsigned)num_segments), dim3(tvmi::kSuper * tvmi::kWave), 0, s>>>(order, (int)n, w, keep_out,
+                                                                                                    num_keep_out);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_small_segments");
 }

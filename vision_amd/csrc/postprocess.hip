@@ -17,8 +17,11 @@ constexpr int kPackMaxImages = 256;
 
 __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ labels,
-    const int64_t* __restrict__ image_idx, const int64_t* __restrict__ keep, int64_t num_keep, int num_images,
-    int max_dets, float* __restrict__ dets, int32_t* __restrict__ counts) {
+    const int64_t* __restrict__ image_idx, const int64_t* __restrict__ keep, int64_t num_keep,
+    const int64_t* __restrict__ num_keep_dev, int num_images, int max_dets, float* __restrict__ dets,
+    int32_t* __restrict__ counts) {
+  // the keep list may come straight from an NMS launch on the same stream: its length then lives on the device
+  if (num_keep_dev) num_keep = min(max(*num_keep_dev, (int64_t)0), num_keep);
   __shared__ int s_cnt[kPackMaxImages];                 // kept so far per image
   __shared__ int s_wave[kPackWaves][kPackMaxImages];    // this chunk: kept per (wave, image)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,8 +195,22 @@ extern "C" int tvmi_pack_detections(const float* boxes, const float* scores, con
   TVMI_CHECK_ARG(dets && counts && (num_keep == 0 || (boxes && scores && image_idx && keep)),
                  "pack_detections: null pointer");
   tvmi::pack_detections_kernel<<<dim3(1), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
-      boxes, scores, labels, image_idx, keep, num_keep, (int)num_images, (int)max_dets, dets, counts);
+      boxes, scores, labels, image_idx, keep, num_keep, nullptr, (int)num_images, (int)max_dets, dets, counts);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections");
+}
+
+extern "C" int tvmi_pack_detections_devcount(const float* boxes, const float* scores, const int64_t* labels,
+                                             const int64_t* image_idx, const int64_t* keep, int64_t keep_capacity,
+                                             const int64_t* num_keep_dev, int64_t num_images, int64_t max_dets,
+                                             float* dets, int32_t* counts, void* stream) {
+  TVMI_CHECK_ARG(num_images >= 0 && max_dets >= 0 && keep_capacity >= 0, "pack_detections: negative size");
+  if (num_images == 0) return 0;
+  TVMI_CHECK_ARG(num_images <= tvmi::kPackMaxImages, "pack_detections: at most 256 images per call");
+  TVMI_CHECK_ARG(dets && counts && num_keep_dev && (keep_capacity == 0 || (boxes && scores && image_idx && keep)),
+                 "pack_detections: null pointer");
+  tvmi::pack_detections_kernel<<<dim3(1), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
+      boxes, scores, labels, image_idx, keep, keep_capacity, num_keep_dev, (int)num_images, (int)max_dets, dets, counts);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections_devcount");
 }
 
 extern "C" int tvmi_detection_candidates(const float* class_logits, const float* box_regression, const float* proposals,

@@ -53,8 +53,12 @@ void check_status(int status, const char* op) {
 }
 
 // ---- nms: cuda/nms_kernel.cu:166-258 (checks and messages), cpu/nms_kernel.cpp (semantics)
-at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores,
-                         const c10::optional<at::Tensor>& seg, double iou_threshold) {
+// Returns (keep [n] with a valid prefix, num [1] int64 on the device).  `allow_sync`: the segment-major path needs
+// one look at `num` to detect an over-long segment; without it (graph-capturable form) n > 4096 still takes that path
+// and reports -1 in `num` for such inputs.
+std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Tensor& scores,
+                                            const c10::optional<at::Tensor>& seg, double iou_threshold, int64_t num_segments,
+                                            bool allow_sync) {
   TORCH_CHECK(dets.is_cuda(), "dets must be a CUDA tensor");
   TORCH_CHECK(scores.is_cuda(), "scores must be a CUDA tensor");
   TORCH_CHECK(dets.dim() == 2, "boxes should be a 2d tensor, got ", dets.dim(), "D");
@@ -65,7 +69,8 @@ at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores,
               dets.size(0), " and ", scores.size(0));
   c10::DeviceGuard guard(dets.device());
   const int64_t n = dets.size(0);
-  if (dets.numel() == 0) return at::empty({0}, dets.options().dtype(at::kLong));
+  if (dets.numel() == 0)
+    return std::make_tuple(at::empty({0}, dets.options().dtype(at::kLong)), at::zeros({1}, dets.options().dtype(at::kLong)));
 
   // Half/BFloat16 boxes are evaluated in fp32, as cuda/nms_kernel.cu:32-53 does for Half.
   at::Tensor boxes = dets;
@@ -87,6 +92,18 @@ at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores,
     const char* e = std::getenv("TVMI_NMS_SEGMAJOR");
     return !(e && e[0] == '0');
   }();
+  if (seg_ptr && seg_major && n <= 4096 && num_segments >= 1 && num_segments <= 1024) {
+    // detector-step sizes with a known id range: per-segment tiles + concurrent per-segment sweeps, no second sort
+    const size_t sb = tvmi_nms_small_segments_workspace_bytes(n, num_segments);
+    at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
+    check_status(tvmi_nms_small_segments(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), seg_ptr, n, num_segments,
+                                         iou_threshold, dtype_of(boxes, "nms"), sws.mutable_data_ptr(), sb,
+                                         keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(),
+                                         current_stream(dets)),
+                 "nms_small_segments");
+    if (!allow_sync || num.item<int64_t>() >= 0) return std::make_tuple(keep, num);
+    // a segment above 1024 boxes or an id outside [0, num_segments): general path below
+  }
   if (seg_ptr && seg_major && n > 4096) {  // up to 4096 boxes the single-launch global sweep is as fast
     // segment-major path: stable partition of the score order by segment (a second sort), block-diagonal
     // masks, one sweep workgroup per segment
@@ -99,8 +116,7 @@ at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores,
                                     sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(),
                                     num.mutable_data_ptr<int64_t>(), current_stream(dets)),
                  "nms_segmented");
-    const int64_t nk = num.item<int64_t>();  // the one host sync (data-dependent size)
-    if (nk >= 0) return keep.narrow(0, 0, nk);
+    if (!allow_sync || num.item<int64_t>() >= 0) return std::make_tuple(keep, num);
     // a segment above 8,192 boxes: fall through to the global-order pipeline
   }
   const size_t ws_bytes = tvmi_nms_workspace_bytes(n);
@@ -110,12 +126,27 @@ at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores,
                         keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(),
                         current_stream(dets)),
                "nms");
-  const int64_t num_keep = num.item<int64_t>();  // the one host sync (data-dependent size)
-  return keep.narrow(0, 0, num_keep);
+  return std::make_tuple(keep, num);
 }
 
+at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores, const c10::optional<at::Tensor>& seg,
+                         double iou_threshold, int64_t num_segments) {
+  auto r = nms_impl(dets, scores, seg, iou_threshold, num_segments, /*allow_sync=*/true);
+  if (std::get<0>(r).numel() == 0) return std::get<0>(r);
+  const int64_t num_keep = std::get<1>(r).item<int64_t>();  // the one host sync (data-dependent size)
+  return std::get<0>(r).narrow(0, 0, num_keep);
+}
+
+// no host synchronisation: (keep [n] whose first num[0] entries are valid, num [1] int64 on the device)
+std::tuple<at::Tensor, at::Tensor> nms_segmented_padded(const at::Tensor& dets, const at::Tensor& scores,
+                                                        const c10::optional<at::Tensor>& seg, double iou_threshold,
+                                                        int64_t num_segments) {
+  return nms_impl(dets, scores, seg, iou_threshold, num_segments, /*allow_sync=*/false);
+}
+
+
 at::Tensor nms(const at::Tensor& dets, const at::Tensor& scores, double iou_threshold) {
-  return nms_segmented(dets, scores, c10::nullopt, iou_threshold);
+  return nms_segmented(dets, scores, c10::nullopt, iou_threshold, -1);
 }
 
 // ---- roi_align: cuda/roi_align_kernel.cu:334-466
@@ -653,6 +684,36 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> rpn_candidates(
   return std::make_tuple(ob_, os, ol, ov);
 }
 
+std::tuple<at::Tensor, at::Tensor> pack_detections_devcount(const at::Tensor& boxes, const at::Tensor& scores,
+                                                            const c10::optional<at::Tensor>& labels,
+                                                            const at::Tensor& image_idx, const at::Tensor& keep,
+                                                            const at::Tensor& num_keep, int64_t num_images, int64_t max_dets) {
+  TORCH_CHECK(boxes.is_cuda() && scores.is_cuda() && image_idx.is_cuda() && keep.is_cuda() && num_keep.is_cuda(),
+              "pack_detections: CUDA tensors expected");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && scores.dim() == 1 && scores.size(0) == boxes.size(0) &&
+                  image_idx.dim() == 1 && image_idx.size(0) == boxes.size(0) && keep.dim() == 1 && num_keep.numel() == 1 &&
+                  num_keep.scalar_type() == at::kLong,
+              "pack_detections: boxes [N,4], scores [N], image_idx [N], keep [M], num_keep [1] int64 expected");
+  c10::DeviceGuard guard(boxes.device());
+  at::Tensor b = boxes.to(at::kFloat).contiguous(), s = scores.to(at::kFloat).contiguous();
+  at::Tensor ii = image_idx.to(at::kLong).contiguous(), k = keep.to(at::kLong).contiguous();
+  at::Tensor lab;
+  const int64_t* lab_ptr = nullptr;
+  if (labels.has_value() && labels->defined()) {
+    lab = labels->to(at::kLong).contiguous();
+    lab_ptr = lab.const_data_ptr<int64_t>();
+  }
+  at::Tensor dets = at::empty({num_images, max_dets, 6}, b.options());
+  at::Tensor counts = at::empty({num_images}, b.options().dtype(at::kInt));
+  check_status(tvmi_pack_detections_devcount(b.const_data_ptr<float>(), s.const_data_ptr<float>(), lab_ptr,
+                                             ii.const_data_ptr<int64_t>(), k.const_data_ptr<int64_t>(), k.size(0),
+                                             num_keep.const_data_ptr<int64_t>(), num_images, max_dets,
+                                             dets.mutable_data_ptr<float>(), counts.mutable_data_ptr<int32_t>(),
+                                             current_stream(boxes)),
+               "pack_detections");
+  return std::make_tuple(dets, counts);
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -693,8 +754,13 @@ TORCH_LIBRARY_FRAGMENT(torchvision, m) {
 // loops in the reference); they live in their own namespace.
 TORCH_LIBRARY(tvmi, m) {
   m.def("abi_version", &tvmi_abi_version);
-  // batched NMS without the per-class python loop of torchvision/ops/boxes.py:113-126
-  m.def("nms_segmented(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold) -> Tensor");
+  // batched NMS without the per-class python loop of torchvision/ops/boxes.py:113-126; num_segments > 0 promises
+  // ids in [0, num_segments) and unlocks the single-launch path for n <= 4096
+  m.def("nms_segmented(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold, int num_segments=-1) -> Tensor");
+  // the same without the host sync on the result size: (keep [n] with a valid prefix, num [1] on the device)
+  m.def("nms_segmented_padded(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold, int num_segments=-1) -> (Tensor, Tensor)");
+  m.def(
+      "pack_detections_devcount(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, Tensor num_keep, int num_images, int max_dets) -> (Tensor, Tensor)");
   // aten::upsample_* arithmetic on our kernels (mode 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic;
   // scale_* <= 0 means "not given")
   m.def(
@@ -729,6 +795,8 @@ TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
 
 TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("nms_segmented", &nms_segmented);
+  m.impl("nms_segmented_padded", &nms_segmented_padded);
+  m.impl("pack_detections_devcount", &pack_detections_devcount);
   m.impl("interpolate2d", &interpolate2d);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
   m.impl("pack_detections", &pack_detections);

@@ -70,7 +70,7 @@ def filter_proposals(proposals: Tensor, objectness: Tensor, image_shapes: Sequen
     sel = valid.reshape(-1).nonzero()[:, 0]
     img = sel // T
     b, s = boxes.reshape(-1, 4)[sel], scores.reshape(-1)[sel]
-    keep = torch.ops.tvmi.nms_segmented(b, s, img * L + levels.reshape(-1)[sel], float(nms_thresh))
+    keep = torch.ops.tvmi.nms_segmented(b, s, img * L + levels.reshape(-1)[sel], float(nms_thresh), B * L)
     dets, counts = torch.ops.tvmi.pack_detections(b, s, None, img, keep, B, int(post_nms_top_n))
     return (dets, counts) if padded else _split(dets, counts, False)
 
@@ -95,6 +95,6 @@ def postprocess_detections(class_logits: Tensor, box_regression: Tensor, proposa
     labels = sel - r * (C - 1) + 1
     img = row_image[r].to(torch.int64)
     b, s = cb.reshape(-1, 4)[sel], cs.reshape(-1)[sel]
-    keep = torch.ops.tvmi.nms_segmented(b, s, img * C + labels, float(nms_thresh))
+    keep = torch.ops.tvmi.nms_segmented(b, s, img * C + labels, float(nms_thresh), B * C)
     dets, counts = torch.ops.tvmi.pack_detections(b, s, labels, img, keep, B, int(detections_per_img))
     return (dets, counts) if padded else _split(dets, counts, True)

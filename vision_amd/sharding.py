@@ -47,10 +47,15 @@ def pack_detections(boxes: Sequence[Tensor], scores: Sequence[Tensor], labels: S
 
 
 def pack_kept_detections(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep: Tensor, num_images: int,
-                          max_dets: int, labels: Tensor = None) -> Tuple[Tensor, Tensor]:
+                          max_dets: int, labels: Tensor = None, num_keep: Tensor = None) -> Tuple[Tensor, Tensor]:
     """Batched form used on the hot path: `keep` is the score-ordered output of a batched NMS over
     all images of this rank; returns the same (`dets`, `counts`) payload as pack_detections.  On CUDA
-    tensors this is ONE launch (`tvmi::pack_detections`)."""
+    tensors this is ONE launch (`tvmi::pack_detections`).  With `num_keep` (a [1] int64 device tensor,
+    from `tvmi::nms_segmented_padded`) only the first num_keep[0] entries of `keep` are read and no host
+    synchronisation happens between the NMS and the packing — the chain is hipGraph-capturable."""
+    if num_keep is not None:
+        return torch.ops.tvmi.pack_detections_devcount(boxes, scores, labels, image_idx, keep, num_keep,
+                                                       int(num_images), int(max_dets))
     if boxes.is_cuda and num_images <= 256:
         return torch.ops.tvmi.pack_detections(boxes, scores, labels, image_idx, keep, int(num_images), int(max_dets))
     ki = image_idx[keep]
