@@ -128,6 +128,19 @@ int tvmi_multiscale_roi_align_forward(const void* const* inputs, const int64_t* 
                                       int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
                                       double canonical_scale, double canonical_level, double eps,
                                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same operation on channels_last feature maps (element (n,c,y,x) at ((n*H+y)*W+x)*C+c;
+ * SURVEY.md §8f-2): lane = channel, taps are coalesced loads off a scalar base, no LDS window.
+ * Output is still the reference's NCHW-contiguous [K,C,PH,PW].  float32, 7x7 bins,
+ * sampling_ratio 2, every level H,W >= 2; a single level with k_min == k_max is plain
+ * roi_align.  The reference instead copies every map to NCHW first
+ * (cuda/roi_align_kernel.cu:365 `input.contiguous()`).
+ */
+int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs, const int64_t* heights, const int64_t* widths,
+                                           const double* spatial_scales, int64_t n_levels, const void* rois,
+                                           void* output, tvmi_dtype dt, int64_t N, int64_t C, int64_t K,
+                                           int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio, int aligned,
+                                           int64_t k_min, int64_t k_max, double canonical_scale,
+                                           double canonical_level, double eps, void* stream);
 
 /* ----------------------------------------------- RoIPool / PSRoIAlign / PSRoIPool ------
  * Replaces: cuda/roi_pool_kernel.cu:15-125,127-260, cuda/ps_roi_align_kernel.cu,

@@ -643,3 +643,34 @@ def test_sync_free_nms_pack_chain_and_graph_replay():
     keep = vision_amd.batched_nms(nb, ns, img, 0.5)
     want_d, want_c = sharding.pack_kept_detections(nb, ns, img, keep, B, 50)
     assert int(n2) == keep.numel() and torch.equal(d2, want_d) and torch.equal(c2, want_c)
+
+
+def test_roi_align_channels_last_native_kernel(tv):
+    """channels_last (NHWC) feature maps take the lane=channel kernel; result must equal the NCHW path's (same
+    arithmetic) and the oracle, for single-level roi_align (incl. aligned / edge RoIs / C not a multiple of 64) and the
+    multi-scale op; output stays NCHW-contiguous like the reference's."""
+    g = gen(83)
+    for C, aligned in ((96, False), (256, True), (70, False)):
+        N, H, W = 2, 46, 61
+        x = torch.rand(N, C, H, W, generator=g)
+        rois = rois_for(N, 150, W * 8, H * 8, 8, 300, g)
+        rois[0, 1:] = torch.tensor([0.0, 0.0, W * 8.0, H * 8.0])
+        rois[1, 1:] = torch.tensor([W * 8 - 4.0, H * 8 - 4.0, W * 8 + 30.0, H * 8 + 20.0])
+        rois[2, 1:] = torch.tensor([-50.0, -40.0, -20.0, -10.0])   # entirely outside: zeros
+        xl = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        assert not xl.is_contiguous()
+        y = tv.roi_align(xl, rois.to(DEV), 1 / 8, 7, 7, 2, aligned)
+        assert y.is_contiguous() and y.shape == (150, C, 7, 7)
+        ref = O.roi_align(x.numpy(), rois.numpy(), 1 / 8, 7, 7, 2, aligned)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=TOL)
+        y2 = tv.roi_align(x.to(DEV), rois.to(DEV), 1 / 8, 7, 7, 2, aligned)
+        np.testing.assert_allclose(y.cpu().numpy(), y2.cpu().numpy(), rtol=0, atol=1e-6)
+    feats = {str(i): torch.rand(2, 64, 800 // s, 1344 // s, generator=g) for i, s in enumerate((4, 8, 16, 32))}
+    boxes = [random_boxes(200, 1344, 800, 8, 700, g) for _ in range(2)]
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    with torch.no_grad():
+        a = pool({k: v.to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * 2)
+        b = pool({k: v.to(DEV).contiguous(memory_format=torch.channels_last) for k, v in feats.items()},
+                 [b.to(DEV) for b in boxes], [(800, 1344)] * 2)
+    assert b.is_contiguous()
+    np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-6)

@@ -1957,6 +1957,126 @@ int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, 
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_backward");
 }
 
+
+// ---------------------------------------------------------------------------------------
+// channels_last (NHWC) forward.  With the channel as the fastest dimension a
+// bilinear tap is 64*CPL CONTIGUOUS floats for the lanes of a wave and its address and weight
+// are wave-uniform: lane = channel, the tap is one coalesced load off a scalar base, the
+// weight is an SGPR operand of the FMA, and there is no LDS window, no per-channel loop and no
+// bank conflict anywhere on the read side.  A wave owns (RoI, 64 channels), walks the bin rows
+// with PW accumulators per lane and parks each finished row in a [channel][bin] LDS block; that
+// block is contiguous in the NCHW output, so it leaves as one linear store stream.  Arithmetic per output is identical to the NCHW kernels (same separable
+// factors, same FMA order).  The reference has no such path: cuda/roi_align_kernel.cu:365
+// calls input.contiguous(), i.e. pays a full NHWC->NCHW copy of every feature map first.
+template <int PHT, int PWT, int SRT>
+struct NhwcShared {
+  float t[64 * (PHT * PWT)];  // [channel][bin], pitch PH*PW (odd for 7x7: conflict-free both ways)
+};
+
+template <int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const float* __restrict__ rois,
+                                                               float* __restrict__ output, int C, int aligned,
+                                                               int ngroups, int64_t nunits) {
+  constexpr int PHW = PHT * PWT;
+  constexpr int NS = SRT * SRT;
+  __shared__ NhwcShared<PHT, PWT, SRT> sh[kThreads / 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  int k, gi;
+  if (!wave_unit(nunits / ngroups, ngroups, nullptr, k, gi)) return;
+  const int c0 = gi * 64;
+  // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
+  const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
+  const int H = lv.H[l], W = lv.W[l];
+  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
+  const int batch = __builtin_amdgcn_readfirstlane(g.batch);
+  // ---- per-RoI sample tables, one sample per lane: element offset of the low tap + the two factors
+  int yoff = 0, xoff = 0;
+  float yl = 0.f, yh = 0.f, xl = 0.f, xh = 0.f;
+  if (lane < PHT * SRT) {
+    int lo;
+    axis_sample_shifted(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, yl, yh);
+    yoff = lo * W * C;
+  }
+  if (lane < PWT * SRT) {
+    int lo;
+    axis_sample_shifted(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo, xl, xh);
+    xoff = lo * C;
+  }
+  const int rowC = W * C;
+  // byte offset of this lane's channel (lanes past the channel count re-read the last channel): the only
+  // per-lane part of a tap address, everything else is scalar
+  const unsigned cl4 = 4u * (unsigned)min(c0 + lane, C - 1);
+  const float* nbase = static_cast<const float*>(lv.ptr[l]) + (int64_t)batch * H * W * C;
+  constexpr bool kPow2 = (NS & (NS - 1)) == 0;
+  const float inv_count = 1.f / (float)NS;
+  float* tl = sh[wave].t;
+  // x-sample parameters are the same for every bin row: SGPRs for the whole unit
+  int sx0[PWT * SRT];
+  float shx[PWT * SRT], slx[PWT * SRT];
+#pragma unroll
+  for (int j = 0; j < PWT * SRT; ++j) {
+    sx0[j] = __builtin_amdgcn_readlane(xoff, j);
+    shx[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xh), j));
+    slx[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl), j));
+  }
+  for (int ph = 0; ph < PHT; ++ph) {
+    float acc[PWT];
+#pragma unroll
+    for (int pw = 0; pw < PWT; ++pw) acc[pw] = 0.f;
+#pragma unroll
+    for (int iy = 0; iy < SRT; ++iy) {
+      const int sy = ph * SRT + iy;
+      const int r0 = __builtin_amdgcn_readlane(yoff, sy);
+      const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yh), sy));
+      const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yl), sy));
+      const float* row0 = nbase + r0;
+      const float* row1 = row0 + rowC;
+#pragma unroll
+      for (int j = 0; j < PWT * SRT; ++j) {
+        const char* p0 = reinterpret_cast<const char*>(row0 + sx0[j]);
+        const char* p1 = reinterpret_cast<const char*>(row1 + sx0[j]);
+        const char* q0 = reinterpret_cast<const char*>(row0 + sx0[j] + C);
+        const char* q1 = reinterpret_cast<const char*>(row1 + sx0[j] + C);
+        const float v00 = *reinterpret_cast<const float*>(p0 + cl4), v01 = *reinterpret_cast<const float*>(q0 + cl4);
+        const float v10 = *reinterpret_cast<const float*>(p1 + cl4), v11 = *reinterpret_cast<const float*>(q1 + cl4);
+        const float t0 = __builtin_fmaf(slx[j], v01, shx[j] * v00);
+        const float t1 = __builtin_fmaf(slx[j], v11, shx[j] * v10);
+        float& a = acc[j / SRT];
+        a = __builtin_fmaf(hy, t0, a);
+        a = __builtin_fmaf(ly, t1, a);
+      }
+    }
+#pragma unroll
+    for (int pw = 0; pw < PWT; ++pw) tl[lane * PHW + ph * PWT + pw] = kPow2 ? acc[pw] * inv_count : acc[pw] / (float)NS;
+  }
+  // ---- the [channel][bin] block is contiguous in the NCHW output: one linear store stream
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* outk = output + ((int64_t)k * C + c0) * PHW;
+  const int nvalid = min(64, C - c0) * PHW;
+#pragma unroll 7
+  for (int it = 0; it < PHW; ++it) {
+    const int idx = it * 64 + lane;
+    if (idx < nvalid) __builtin_nontemporal_store(tl[idx], outk + idx);
+  }
+}
+
+int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH, int64_t PW,
+                       int64_t sr, int aligned, hipStream_t stream) {
+  load_env_cfg();
+  const int ngroups = (int)ceil_div(C, 64);
+  const int64_t nunits = K * ngroups;
+  const dim3 grid(wave_unit_grid(K, ngroups)), block(kThreads);
+  if (!(PH == 7 && PW == 7 && sr == 2))
+    return set_error((int)hipErrorInvalidValue,
+                     "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
+  roi_align_fwd_nhwc<7, 7, 2><<<grid, block, 0, stream>>>(lv, static_cast<const float*>(rois), static_cast<float*>(output),
+                                                          (int)C, aligned, ngroups, nunits);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward_nhwc");
+}
+
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
                   int64_t PW, int64_t sr, int aligned, int* order, int* declined, hipStream_t stream) {
@@ -2107,6 +2227,40 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
       return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned,
                                                  order, declined, s);
   }
+}
+
+extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs, const int64_t* heights,
+                                                      const int64_t* widths, const double* spatial_scales,
+                                                      int64_t n_levels, const void* rois, void* output, tvmi_dtype dt,
+                                                      int64_t N, int64_t C, int64_t K, int64_t pooled_h, int64_t pooled_w,
+                                                      int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
+                                                      double canonical_scale, double canonical_level, double eps,
+                                                      void* stream) {
+  TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "roi_align (channels_last): 1..8 levels supported");
+  if (K * C * pooled_h * pooled_w == 0) return 0;
+  TVMI_CHECK_ARG(inputs && heights && widths && spatial_scales && rois && output, "roi_align (channels_last): null pointer");
+  TVMI_CHECK_ARG(dt == TVMI_F32, "roi_align (channels_last): float32 only");
+  TVMI_CHECK_ARG(pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2,
+                 "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
+  TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 64) < (1ll << 31), "roi_align (channels_last): size exceeds 32-bit launch limits");
+  tvmi::MsLevels lv;
+  for (int i = 0; i < tvmi::kMaxLevels; ++i) {
+    const int j = i < n_levels ? i : 0;
+    TVMI_CHECK_ARG(inputs[j] != nullptr && heights[j] >= 2 && widths[j] >= 2 && heights[j] * widths[j] * C < (1ll << 31),
+                   "roi_align (channels_last): every level needs H, W >= 2 and H*W*C < 2^31");
+    lv.ptr[i] = inputs[j];
+    lv.H[i] = (int)heights[j];
+    lv.W[i] = (int)widths[j];
+    lv.scale[i] = (float)spatial_scales[j];
+  }
+  lv.n_levels = (int)n_levels;
+  lv.k_min = (int)k_min;
+  lv.k_max = (int)k_max;
+  lv.s0 = (float)canonical_scale;
+  lv.lvl0 = (float)canonical_level;
+  lv.eps = (float)eps;
+  return tvmi::launch_ms_fwd_nhwc(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned,
+                                  static_cast<hipStream_t>(stream));
 }
 
 // Tuning/debug knob, NOT part of the supported ABI (not declared in include/tvmi.h).
