@@ -184,6 +184,17 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         nms_ms = e0.elapsed_time(e1) / n_k
+        # the same op on channels_last maps (native NHWC kernel) — reported, never part of `value`
+        flist_cl = [f.contiguous(memory_format=torch.channels_last) for f in flist]
+        for _ in range(3):
+            torch.ops.tvmi.multiscale_roi_align(flist_cl, rois5, scales, POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
+        e0.record()
+        for _ in range(n_k):
+            torch.ops.tvmi.multiscale_roi_align(flist_cl, rois5, scales, POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
+        e1.record()
+        torch.cuda.synchronize()
+        cl_ms = e0.elapsed_time(e1) / n_k
+        del flist_cl
     alg_bytes = algorithmic_bytes(feats, BATCH * PROPOSALS)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
@@ -213,6 +224,7 @@ def main():
             "boxes_per_step_per_gpu": BATCH * PROPOSALS,
             "roi_align_ms": round(k_ms, 4),
             "nms_ms": round(nms_ms, 4),
+            "roi_align_channels_last_ms": round(cl_ms, 4),
             "kept_boxes": int(out[1].item()),
             "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",

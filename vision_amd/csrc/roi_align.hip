@@ -412,6 +412,7 @@ struct WaveShared {
 };
 
 __device__ int g_roi_force_mode = 0;  // debug knob (tvmi_debug_set): 0 auto, 1 never stage through LDS
+__device__ int g_cfg_dma_sparse = 1;  // stage only the sampled rows of tall windows (TVMI_ROI_DMA_SPARSE=0: whole window)
 
 // Stages CH channel windows (rows y0.., cols x0.., clamped into the tensor) with RG row-groups
 // each: RG*CH independent loads are in flight per lane before the first LDS write.  Lanes
@@ -803,6 +804,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // out-of-row read; the window is shifted left when it would run past the row end.
 struct DmaWindow {
   int state, y0, x0, wh, nq, lpr, rpi, nrg;
+  int sparse;  // 1: the LDS image holds only the SAMPLED rows — slot 2s / 2s+1 = low / high tap row of y-sample s
 };
 
 // lo/l/h of one axis sample in the "shifted" form described above (dim >= 2)
@@ -830,7 +832,7 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   const int lane = threadIdx.x & 63;
   DmaWindow w;
   w.state = 2;
-  w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = 0;
+  w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = w.sparse = 0;
   if (H < 2 || W < EPP) return w;
   int lo = 0, lo2 = 0;
   float l, h;
@@ -860,6 +862,13 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   w.lpr = w.nq | 1;
   if (w.lpr > 64) return w;
   w.rpi = 64 / w.lpr;
+  // A window taller than 2 rows per y-sample contains rows no sample touches (bins > 2 px): stage only the
+  // sampled rows.  The kernel is bound by the bytes that cross L2 -> L1, and this drops ~1/3 of them on the
+  // FPN workload (and pulls RoIs that were too tall for 8 DMA blocks per channel back onto this path).
+  if (g_cfg_dma_sparse && w.wh > 2 * ny) {
+    w.sparse = 1;
+    w.wh = 2 * ny;
+  }
   w.nrg = (w.wh + w.rpi - 1) / w.rpi;
   // 1 = DMA path (<= 8 DMA instructions per channel), 2 = register-staged / global-gather path
   w.state = w.nrg <= 2 * kDmaPerPass ? 1 : 2;
@@ -885,6 +894,7 @@ __device__ __forceinline__ void dma_issue_pass(const T* __restrict__ in_pass, in
 template <typename T, int PHT, int PWT, int SRT, int NRG>
 __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __restrict__ in0, T* __restrict__ out,
                                                      int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
+                                                     const RoiGeom<float>& g,
                                                      const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
                                                      const float (&fy)[(PHT * PWT + 63) / 64][SRT][2],
                                                      const float (&fx)[(PHT * PWT + 63) / 64][SRT][2]) {
@@ -904,7 +914,17 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   char* const bytes = reinterpret_cast<char*>(s.buf);
   int goff[NRG];
 #pragma unroll
-  for (int rg = 0; rg < NRG; ++rg) goff[rg] = min(dw.y0 + min(rg * dw.rpi + rsub, dw.wh - 1), H - 1) * W + gx;
+  for (int rg = 0; rg < NRG; ++rg) {
+    const int t = min(rg * dw.rpi + rsub, dw.wh - 1);  // row slot of this lane in row group rg
+    int y = dw.y0 + t;
+    if (dw.sparse) {
+      int lo;
+      float l, h;
+      axis_sample_shifted(H, g.start_h, g.bin_h, SRT, (t >> 1) / SRT, (t >> 1) % SRT, lo, l, h);
+      y = lo + (t & 1);
+    }
+    goff[rg] = min(y, H - 1) * W + gx;
+  }
   const int npass = (cc + G - 1) / G;
   if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
   for (int p = 0; p < npass; ++p) {
@@ -997,7 +1017,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
       const bool vy = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, ph, i, lo, l, h);
       fy[b][i][0] = l;
       fy[b][i][1] = h;
-      const int r = vy ? lo - dw.y0 : 0;
+      const int r = dw.sparse ? 2 * (ph * SRT + i) : (vy ? lo - dw.y0 : 0);
       rlo[i][0] = (r / dw.rpi) * BLK + (r % dw.rpi) * rstride;
       rlo[i][1] = ((r + 1) / dw.rpi) * BLK + ((r + 1) % dw.rpi) * rstride;
       const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
@@ -1014,13 +1034,13 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
       }
   }
   if (dw.nrg <= 1)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 2)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 4)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else
-    roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -1338,6 +1358,10 @@ static void load_env_cfg() {
   g_cfg_bwd_tiles = env_int("TVMI_ROI_BWD_TILES", g_cfg_bwd_tiles);
   g_cfg_bwd_dense = env_int("TVMI_ROI_BWD_DENSE", g_cfg_bwd_dense);
   g_cfg_dma_wpb = env_int("TVMI_ROI_DMA_WPB", g_cfg_dma_wpb);
+  {
+    const int v = env_int("TVMI_ROI_DMA_SPARSE", -1);
+    if (v >= 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cfg_dma_sparse), &v, sizeof(int));
+  }
   g_cfg_dma_extra_lds = env_int("TVMI_ROI_DMA_EXTRA_LDS", g_cfg_dma_extra_lds);
 }
 
