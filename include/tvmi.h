@@ -226,6 +226,12 @@ int tvmi_pack_detections_devcount(const float* boxes, const float* scores, const
                                   const int64_t* num_keep_dev, int64_t num_images, int64_t max_dets, float* dets,
                                   int32_t* counts, void* stream);
 
+/* convert_boxes_to_roi_format (torchvision/ops/_utils.py:18-25) in one launch: per-image box
+ * lists [n_i,4] (dtype dt, contiguous) -> rois [sum n_i, 5] = (image index, x1, y1, x2, y2).
+ * num_images <= 64. */
+int tvmi_boxes_to_rois(const void* const* boxes, const int64_t* counts, int64_t num_images, void* rois,
+                       tvmi_dtype dt, void* stream);
+
 /* Candidate generation for the detector's two post-processing stages, batched over images
  * (one launch each; the segmented NMS that follows is tvmi_nms with segment ids, the top-k
  * packing is tvmi_pack_detections):

@@ -674,3 +674,12 @@ def test_roi_align_channels_last_native_kernel(tv):
                  [b.to(DEV) for b in boxes], [(800, 1344)] * 2)
     assert b.is_contiguous()
     np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_boxes_to_rois_one_launch():
+    g = gen(5)
+    for dt in (torch.float32, torch.float16, torch.float64):
+        lists = [random_boxes(n, 300, 200, 2, 100, g).to(dt) for n in (5, 0, 17, 1)]
+        want = torch.cat([torch.cat([torch.full_like(b[:, :1], i) for i, b in enumerate(lists)]), torch.cat(lists)], 1)
+        got = vision_amd.roi_ops.convert_boxes_to_roi_format([b.to(DEV) for b in lists])
+        assert got.dtype == dt and torch.equal(got.cpu(), want)

@@ -183,6 +183,30 @@ __global__ __launch_bounds__(256) void rpn_candidates_kernel(const float* __rest
   out_valid[i] = ((box.z - box.x) >= min_size && (box.w - box.y) >= min_size && prob >= score_thresh) ? 1 : 0;
 }
 
+// convert_boxes_to_roi_format (ops/_utils.py:18-25: cat(boxes), a full_like id column per image, two more
+// cats = 7 tiny launches for a batch of 4) as one launch: rois[k] = (image index, x1, y1, x2, y2).
+constexpr int kRoiFmtMaxImages = 64;
+struct BoxLists {
+  const void* ptr[kRoiFmtMaxImages];
+  int end[kRoiFmtMaxImages];  // exclusive prefix end of every image's boxes in the concatenation
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void boxes_to_rois_kernel(BoxLists bl, T* __restrict__ rois, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  int img = 0;
+  for (int i = 0; i < bl.n - 1; ++i) img += k >= bl.end[i] ? 1 : 0;
+  const int first = img > 0 ? bl.end[img - 1] : 0;
+  const T* b = static_cast<const T*>(bl.ptr[img]) + (int64_t)(k - first) * 4;
+  T* r = rois + (int64_t)k * 5;
+  st(r, (float)img);
+  r[1] = b[0];
+  r[2] = b[1];
+  r[3] = b[2];
+  r[4] = b[3];
+}
+
 }  // namespace
 }  // namespace tvmi
 
@@ -244,4 +268,29 @@ extern "C" int tvmi_rpn_candidates(const float* objectness, const float* boxes_i
       objectness, boxes_in, deltas, top_idx, level_offsets, image_hw, (int)B, A, (int)T, (int)L, bbox_xform_clip,
       score_thresh, min_size, out_boxes, out_scores, out_levels, out_valid);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_rpn_candidates");
+}
+
+extern "C" int tvmi_boxes_to_rois(const void* const* boxes, const int64_t* counts, int64_t num_images, void* rois,
+                                  tvmi_dtype dt, void* stream) {
+  TVMI_CHECK_ARG(num_images >= 0 && num_images <= tvmi::kRoiFmtMaxImages, "boxes_to_rois: at most 64 images per call");
+  if (num_images == 0) return 0;
+  TVMI_CHECK_ARG(boxes && counts && rois, "boxes_to_rois: null pointer");
+  tvmi::BoxLists bl;
+  int64_t run = 0;
+  for (int i = 0; i < tvmi::kRoiFmtMaxImages; ++i) {
+    if (i < num_images) {
+      TVMI_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || boxes[i]), "boxes_to_rois: bad box list");
+      run += counts[i];
+    }
+    bl.ptr[i] = i < num_images ? boxes[i] : nullptr;
+    TVMI_CHECK_ARG(run < (1ll << 31), "boxes_to_rois: too many boxes");
+    bl.end[i] = (int)run;
+  }
+  bl.n = (int)num_images;
+  if (run == 0) return 0;
+  const dim3 grid((unsigned)((run + 255) / 256));
+  TVMI_DISPATCH_FLOAT(dt, "boxes_to_rois",
+                      tvmi::boxes_to_rois_kernel<scalar_t><<<grid, dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+                          bl, static_cast<scalar_t*>(rois), (int)run));
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_boxes_to_rois");
 }

@@ -754,6 +754,32 @@ std::tuple<at::Tensor, at::Tensor> pack_detections_devcount(const at::Tensor& bo
   return std::make_tuple(dets, counts);
 }
 
+// ---- convert_boxes_to_roi_format (ops/_utils.py:18-25) in one launch
+at::Tensor boxes_to_rois(at::TensorList boxes) {
+  TORCH_CHECK(boxes.size() >= 1 && boxes.size() <= 64, "boxes_to_rois: 1..64 box lists supported");
+  const at::Tensor& b0 = boxes[0];
+  TORCH_CHECK(b0.is_cuda(), "boxes_to_rois: CUDA tensors expected");
+  c10::DeviceGuard guard(b0.device());
+  std::vector<at::Tensor> keep;
+  std::vector<const void*> ptrs;
+  std::vector<int64_t> counts;
+  int64_t total = 0;
+  for (const at::Tensor& b : boxes) {
+    TORCH_CHECK(b.is_cuda() && b.dim() == 2 && b.size(1) == 4 && b.scalar_type() == b0.scalar_type() && b.device() == b0.device(),
+                "boxes_to_rois: every entry must be a [n, 4] tensor of the same dtype and device");
+    keep.push_back(b.contiguous());
+    ptrs.push_back(keep.back().const_data_ptr());
+    counts.push_back(b.size(0));
+    total += b.size(0);
+  }
+  at::Tensor rois = at::empty({total, 5}, b0.options());
+  if (total == 0) return rois;
+  check_status(tvmi_boxes_to_rois(ptrs.data(), counts.data(), (int64_t)boxes.size(), rois.mutable_data_ptr(),
+                                  dtype_of(b0, "boxes_to_rois"), current_stream(b0)),
+               "boxes_to_rois");
+  return rois;
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -812,6 +838,8 @@ TORCH_LIBRARY(tvmi, m) {
       "detection_candidates(Tensor class_logits, Tensor box_regression, Tensor proposals, Tensor row_image, Tensor image_hw, float[] weights, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor)");
   m.def(
       "rpn_candidates(Tensor objectness, Tensor boxes, Tensor? deltas, Tensor top_idx, Tensor level_offsets, Tensor image_hw, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor, Tensor)");
+  // ops/_utils.py:18-25 (cat + full_like per image + 2 cats) as one launch
+  m.def("boxes_to_rois(Tensor[] boxes) -> Tensor");
   // python loop of roi_heads.py:486-500 (pad + expand + resize + paste per detection) as one launch
   m.def("paste_masks(Tensor masks, Tensor boxes, int im_h, int im_w, int padding) -> Tensor");
   m.def(
@@ -841,6 +869,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("multiscale_roi_align", &multiscale_roi_align);
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);
+  m.impl("boxes_to_rois", &boxes_to_rois);
   m.impl("detection_candidates", &detection_candidates);
   m.impl("rpn_candidates", &rpn_candidates);
 }

@@ -25,6 +25,11 @@ class LevelMapper:
 
 
 def _convert_to_roi_format(boxes: List[Tensor]) -> Tensor:
+    """ops/_utils.py:18-25.  On device tensors this is ONE launch (`tvmi::boxes_to_rois`) instead of the
+    reference's cat + full_like per image + two more cats."""
+    if len(boxes) and boxes[0].is_cuda and len(boxes) <= 64 and boxes[0].is_floating_point() and \
+            all(b.dtype == boxes[0].dtype and not b.requires_grad for b in boxes):
+        return torch.ops.tvmi.boxes_to_rois(list(boxes))
     cat = torch.cat(boxes, dim=0)
     ids = torch.cat([torch.full_like(b[:, :1], i, dtype=cat.dtype, device=cat.device) for i, b in enumerate(boxes)],
                     dim=0)

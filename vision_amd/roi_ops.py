@@ -30,7 +30,12 @@ def check_roi_boxes_shape(boxes: BoxesArg):
 
 
 def convert_boxes_to_roi_format(boxes: Sequence[Tensor]) -> Tensor:
-    """List of per-image [L,4] boxes -> [K,5] with the image index in column 0."""
+    """List of per-image [L,4] boxes -> [K,5] with the image index in column 0 (ops/_utils.py:18-25).
+    Device tensors: one launch (`tvmi::boxes_to_rois`)."""
+    boxes = list(boxes)
+    if (boxes and boxes[0].is_cuda and len(boxes) <= 64 and boxes[0].is_floating_point()
+            and all(b.dtype == boxes[0].dtype and not b.requires_grad for b in boxes)):
+        return torch.ops.tvmi.boxes_to_rois(boxes)
     ids = [torch.full_like(b[:, :1], i) for i, b in enumerate(boxes)]
     return torch.cat([torch.cat(ids, dim=0), torch.cat(list(boxes), dim=0)], dim=1)
 
