@@ -1338,9 +1338,6 @@ int g_cfg_order = 0;
 int g_cfg_bwd_dense = 1;
 int g_cfg_dma_wpb = 4;
 int g_cfg_dma_extra_lds = 0;  // analysis knob: unused dynamic LDS per workgroup (lowers occupancy)
-int g_cfg_bwd_tiles = 0;
-int g_cfg_bwd_wave = 0;  // wave-autonomous backward: measured slower than the block-tiled one (7.1 vs 4.5 ms
-                         // on config 2, both bound by global float atomics) — kept behind TVMI_ROI_BWD_WAVE=1
 
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -1354,8 +1351,6 @@ static void load_env_cfg() {
   g_cfg_chunk = env_int("TVMI_ROI_CHUNK", g_cfg_chunk);
   g_cfg_dma = env_int("TVMI_ROI_DMA", g_cfg_dma);
   g_cfg_order = env_int("TVMI_ROI_ORDER", g_cfg_order);
-  g_cfg_bwd_wave = env_int("TVMI_ROI_BWD_WAVE", g_cfg_bwd_wave);
-  g_cfg_bwd_tiles = env_int("TVMI_ROI_BWD_TILES", g_cfg_bwd_tiles);
   g_cfg_bwd_dense = env_int("TVMI_ROI_BWD_DENSE", g_cfg_bwd_dense);
   g_cfg_dma_wpb = env_int("TVMI_ROI_DMA_WPB", g_cfg_dma_wpb);
   {
@@ -1446,254 +1441,6 @@ __device__ __forceinline__ void roi_align_bwd_passes(DmaShared& s, const float* 
   }
 }
 
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_wave(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                               float* __restrict__ grad_input, int C, int H, int W,
-                                                               float spatial_scale, int aligned, int nchunks, int chunk,
-                                                               int64_t nunits, int64_t ns, int64_t cs, int64_t hs,
-                                                               int64_t ws, int* __restrict__ declined) {
-  __shared__ DmaShared sh[kThreads / 64];
-  constexpr int PHW = PHT * PWT;
-  constexpr int NB = (PHW + 63) / 64;
-  constexpr int NS = SRT * SRT;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, nullptr, k, ci)) return;
-  const int c0 = ci * chunk;
-  const int cc = min(chunk, C - c0);
-  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
-  const DmaWindow dw = dma_window<PHT, PWT, SRT>(g, H, W);
-  if (c0 == 0 && lane == 0) declined[k] = dw.state == 2;
-  if (dw.state != 1) return;  // 0: every sample outside (no gradient), 2: tile kernel takes it
-  const float* gk = grad + (int64_t)k * ns + (int64_t)c0 * cs;
-  float* gi0 = grad_input + ((int64_t)g.batch * C + c0) * H * W;
-  const int64_t plane_sz = (int64_t)H * W;
-  int off[NB][NS][2], goffs[NB];
-  float fy[NB][SRT][2], fx[NB][SRT][2];
-  const int rstride = 4 * dw.lpr;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int bin = min(lane + 64 * b, PHW - 1);
-    const int ph = bin / PWT, pw = bin - ph * PWT;
-    goffs[b] = (int)(ph * hs + pw * ws);
-    int rlo[SRT][2], xlo[SRT];
-#pragma unroll
-    for (int i = 0; i < SRT; ++i) {
-      int lo;
-      float l, h;
-      const bool vy = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, ph, i, lo, l, h);
-      fy[b][i][0] = l;
-      fy[b][i][1] = h;
-      const int r = vy ? lo - dw.y0 : 0;
-      rlo[i][0] = (r / dw.rpi) * kDmaBlk + (r % dw.rpi) * rstride;
-      rlo[i][1] = ((r + 1) / dw.rpi) * kDmaBlk + ((r + 1) % dw.rpi) * rstride;
-      const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
-      fx[b][i][0] = l;
-      fx[b][i][1] = h;
-      xlo[i] = vx ? lo - dw.x0 : 0;
-    }
-#pragma unroll
-    for (int iy = 0; iy < SRT; ++iy)
-#pragma unroll
-      for (int ix = 0; ix < SRT; ++ix) {
-        off[b][iy * SRT + ix][0] = rlo[iy][0] + xlo[ix];
-        off[b][iy * SRT + ix][1] = rlo[iy][1] + xlo[ix];
-      }
-  }
-  DmaShared& s = sh[wave];
-  if (dw.nrg <= 1)
-    roi_align_bwd_passes<PHT, PWT, SRT, 1>(s, gk, gi0, plane_sz, cc, H, W, dw, cs, goffs, off, fy, fx);
-  else if (dw.nrg <= 2)
-    roi_align_bwd_passes<PHT, PWT, SRT, 2>(s, gk, gi0, plane_sz, cc, H, W, dw, cs, goffs, off, fy, fx);
-  else if (dw.nrg <= 4)
-    roi_align_bwd_passes<PHT, PWT, SRT, 4>(s, gk, gi0, plane_sz, cc, H, W, dw, cs, goffs, off, fy, fx);
-  else
-    roi_align_bwd_passes<PHT, PWT, SRT, 8>(s, gk, gi0, plane_sz, cc, H, W, dw, cs, goffs, off, fy, fx);
-}
-
-// ---------------------------------------------------------------------------------------
-// Tile-stationary backward (fp32, compile-time shapes) — no global atomics.
-// The feature map is cut into 32x32-pixel tiles; a binning pre-pass lists, for every tile, the
-// RoIs whose sample rectangle touches it.  A workgroup then OWNS (tile, 8-channel chunk): it
-// accumulates the contributions of all listed RoIs that fall inside its tile in LDS
-// (ds_add_f32) and writes the tile once with plain coalesced stores.  The per-RoI form
-// (roi_align_bwd_tile above, and the reference's cuda/roi_align_kernel.cu:204-332) pays one
-// global float atomic per touched pixel per RoI — ~413 M of them on config 2, which bound it at
-// 4.5 ms; here the only global writes are the 365 MB of grad_input itself.  RoIs spanning more
-// than kBwdMaxTiles tiles (larger than ~250 px on the map) are left to the atomic kernel, which
-// runs afterwards and adds on top.
-constexpr int kBwdTS = 32;         // tile edge in pixels
-constexpr int kBwdCC = 8;          // channels per workgroup
-constexpr int kBwdPitch = 33;      // LDS row pitch (odd)
-constexpr int kBwdMaxTiles = 64;   // per RoI; beyond this the RoI is declined
-
-struct BwdTiling {
-  int tiles_y, tiles_x, tiles_per_img;
-};
-
-// conservative pixel rectangle of a RoI's taps (superset is fine: extra list entries only cost time)
-template <int PHT, int PWT, int SRT>
-__device__ __forceinline__ bool bwd_roi_rect(const float* roi, float scale, int aligned, int H, int W, int& ty0, int& ty1,
-                                             int& tx0, int& tx1, int& batch) {
-  const RoiGeom<float> g = roi_geom<float, float>(roi, scale, PHT, PWT, SRT, aligned != 0);
-  batch = g.batch;
-  const float ya = g.start_h, yb = g.start_h + g.bin_h * (float)PHT;
-  const float xa = g.start_w, xb = g.start_w + g.bin_w * (float)PWT;
-  const float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb), xmin = fminf(xa, xb), xmax = fmaxf(xa, xb);
-  if (!(ymax >= -1.f && ymin <= (float)H && xmax >= -1.f && xmin <= (float)W)) return false;  // also drops NaN
-  const int y0 = max((int)floorf(ymin) - 1, 0), y1 = min((int)floorf(ymax) + 2, H - 1);
-  const int x0 = max((int)floorf(xmin) - 1, 0), x1 = min((int)floorf(xmax) + 2, W - 1);
-  ty0 = y0 / kBwdTS;
-  ty1 = y1 / kBwdTS;
-  tx0 = x0 / kBwdTS;
-  tx1 = x1 / kBwdTS;
-  return true;
-}
-
-// pass 0: count (fill == 0) or fill (fill == 1) the per-tile RoI lists
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(256) void roi_bwd_bin(const float* __restrict__ rois, int K, float scale, int aligned, int N,
-                                                   int H, int W, BwdTiling tl, int* __restrict__ counts,
-                                                   const int* __restrict__ offsets, int* __restrict__ cursors,
-                                                   int* __restrict__ lists, int* __restrict__ declined, int fill) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  int ty0, ty1, tx0, tx1, b;
-  const bool any = bwd_roi_rect<PHT, PWT, SRT>(rois + (int64_t)k * 5, scale, aligned, H, W, ty0, ty1, tx0, tx1, b);
-  const bool ok_batch = b >= 0 && b < N;
-  const int ntiles = any && ok_batch ? (ty1 - ty0 + 1) * (tx1 - tx0 + 1) : 0;
-  const bool big = ntiles > kBwdMaxTiles;
-  if (!fill) declined[k] = big ? 1 : 0;
-  if (ntiles == 0 || big) return;
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int t = b * tl.tiles_per_img + ty * tl.tiles_x + tx;
-      if (!fill)
-        atomicAdd(&counts[t], 1);
-      else
-        lists[offsets[t] + atomicAdd(&cursors[t], 1)] = k;
-    }
-}
-
-// exclusive scan of the tile counts (single workgroup; T is a few hundred .. a few thousand)
-__global__ __launch_bounds__(1024) void roi_bwd_scan(const int* __restrict__ counts, int* __restrict__ offsets, int T) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int per = (T + 1023) / 1024;
-  int sum = 0;
-  for (int i = 0; i < per; ++i) {
-    const int t = tid * per + i;
-    if (t < T) sum += counts[t];
-  }
-  part[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = part[tid] - sum;
-  for (int i = 0; i < per; ++i) {
-    const int t = tid * per + i;
-    if (t < T) {
-      offsets[t] = run;
-      run += counts[t];
-    }
-  }
-  if (tid == 1023) offsets[T] = part[1023];
-}
-
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(256) void roi_align_bwd_tiles(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                           float* __restrict__ grad_input, int C, int H, int W,
-                                                           float scale, int aligned, BwdTiling tl,
-                                                           const int* __restrict__ offsets, const int* __restrict__ lists,
-                                                           int64_t ns, int64_t cs, int64_t hs, int64_t ws) {
-  constexpr int PHW = PHT * PWT;
-  constexpr int NB = (PHW + 63) / 64;
-  constexpr int NS = SRT * SRT;
-  __shared__ float acc[kBwdCC][kBwdTS][kBwdPitch];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  const int t = blockIdx.x;
-  const int c0 = blockIdx.y * kBwdCC;
-  const int cc = min(kBwdCC, C - c0);
-  const int b = t / tl.tiles_per_img;
-  const int tr = t - b * tl.tiles_per_img;
-  const int ty = tr / tl.tiles_x, tx = tr - ty * tl.tiles_x;
-  const int py0 = ty * kBwdTS, px0 = tx * kBwdTS;
-  for (int i = tid; i < kBwdCC * kBwdTS * kBwdPitch; i += 256) (&acc[0][0][0])[i] = 0.f;
-  __syncthreads();
-  const int beg = offsets[t], end = offsets[t + 1];
-  const float inv_count = 1.f / (float)NS;
-  for (int e = beg + wave; e < end; e += 4) {  // one RoI per wave at a time
-    const int k = lists[e];
-    const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, scale, PHT, PWT, SRT, aligned != 0);
-    const float* gk = grad + (int64_t)k * ns + (int64_t)c0 * cs;
-#pragma unroll
-    for (int bslot = 0; bslot < NB; ++bslot) {
-      const int bin = lane + 64 * bslot;
-      if (bin >= PHW) continue;
-      const int ph = bin / PWT, pw = bin - ph * PWT;
-      // per-sample LDS offsets (tile-relative) and factors; a tap outside the tile gets factor 0
-      int oy[SRT][2], ox[SRT][2];
-      float wy[SRT][2], wx[SRT][2];
-      bool any_y = false, any_x = false;
-#pragma unroll
-      for (int i = 0; i < SRT; ++i) {
-        int lo;
-        float l, h;
-        const bool vy = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, ph, i, lo, l, h);
-        const int r0 = lo - py0, r1 = r0 + 1;
-        const bool in0 = vy && r0 >= 0 && r0 < kBwdTS, in1 = vy && r1 >= 0 && r1 < kBwdTS;
-        oy[i][0] = in0 ? r0 : 0;
-        oy[i][1] = in1 ? r1 : 0;
-        wy[i][0] = in0 ? h : 0.f;
-        wy[i][1] = in1 ? l : 0.f;
-        any_y |= (in0 && h != 0.f) || (in1 && l != 0.f);
-        const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
-        const int q0 = lo - px0, q1 = q0 + 1;
-        const bool jn0 = vx && q0 >= 0 && q0 < kBwdTS, jn1 = vx && q1 >= 0 && q1 < kBwdTS;
-        ox[i][0] = jn0 ? q0 : 0;
-        ox[i][1] = jn1 ? q1 : 0;
-        wx[i][0] = jn0 ? h : 0.f;
-        wx[i][1] = jn1 ? l : 0.f;
-        any_x |= (jn0 && h != 0.f) || (jn1 && l != 0.f);
-      }
-      if (!(any_y && any_x)) continue;  // this bin has no tap inside the tile
-      const int goff = (int)(ph * hs + pw * ws);
-      for (int c = 0; c < cc; ++c) {
-        const float gsc = gk[(int64_t)c * cs + goff] * inv_count;
-#pragma unroll
-        for (int iy = 0; iy < SRT; ++iy) {
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const float gy = gsc * wy[iy][a];
-            if (gy == 0.f) continue;
-            float* row = &acc[c][oy[iy][a]][0];
-#pragma unroll
-            for (int ix = 0; ix < SRT; ++ix) {
-              const float v0 = gy * wx[ix][0], v1 = gy * wx[ix][1];
-              if (v0 != 0.f) atomicAdd(row + ox[ix][0], v0);
-              if (v1 != 0.f) atomicAdd(row + ox[ix][1], v1);
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // the workgroup owns these pixels: plain coalesced stores
-  float* gi = grad_input + ((int64_t)b * C + c0) * H * W;
-  for (int i = tid; i < cc * kBwdTS * kBwdTS; i += 256) {
-    const int c = i / (kBwdTS * kBwdTS), rem = i - c * (kBwdTS * kBwdTS);
-    const int y = rem / kBwdTS, x = rem - y * kBwdTS;
-    if (py0 + y < H && px0 + x < W) gi[((int64_t)c * H + py0 + y) * W + px0 + x] = acc[c][y][x];
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // Dense-separable backward (fp32, compile-time shapes) — no LDS atomics.
 // ds_add_f32 turned out to be the bottleneck of every scatter-style backward on this chip
@@ -1721,7 +1468,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __r
                                                                 float* __restrict__ grad_input, int C, int H, int W,
                                                                 float spatial_scale, int aligned, int nchunks, int chunk,
                                                                 int64_t nunits, int64_t ns, int64_t cs, int64_t hs,
-                                                                int64_t ws, int* __restrict__ declined, int dbg) {
+                                                                int64_t ws, int* __restrict__ declined) {
   using DS = DenseShared<PHT, PWT, SRT>;
   __shared__ DS sh[kThreads / 64];
   constexpr int ny = PHT * SRT, nx = PWT * SRT;
@@ -1827,21 +1574,13 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __r
     }
     // 3. window rows: one global atomic per pixel, contiguous along the row
     const bool write_ok = col_ok && slot < gc;
-    float dbgacc = 0.f;
     float* plane = gi0 + (int64_t)(cg + myslot) * plane_sz + (int64_t)y0 * W + x0 + col;
     for (int r = 0; r < wh; ++r) {
       float v = 0.f;
 #pragma unroll
       for (int ph = 0; ph < PHT; ++ph) v = __builtin_fmaf(s.ayd[r][ph], t[ph], v);
-      if (dbg == 0) {
-        if (write_ok && v != 0.f) unsafeAtomicAdd(plane + (int64_t)r * W, v);
-      } else if (dbg == 2) {
-        if (write_ok && v != 0.f) plane[(int64_t)r * W] = v;
-      } else {
-        dbgacc += v;
-      }
+      if (write_ok && v != 0.f) unsafeAtomicAdd(plane + (int64_t)r * W, v);
     }
-    if (dbg == 3 && dbgacc == 12345.f) plane[0] = dbgacc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1913,7 +1652,7 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
 template <typename T>
 int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int64_t ns, int64_t cs, int64_t hs, int64_t ws, int* declined, int* bws, hipStream_t stream) {
+               int64_t ns, int64_t cs, int64_t hs, int64_t ws, int* declined, hipStream_t stream) {
   load_env_cfg();
   const T* g = static_cast<const T*>(grad);
   const T* r = static_cast<const T*>(rois);
@@ -1936,32 +1675,7 @@ int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, 
     if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                            \
       if (g_cfg_bwd_dense && declined && H * W * C < (1ll << 31)) {                                        \
         roi_align_bwd_dense<PHT, PWT, SRT><<<dim3(wave_unit_grid(K, wnchunks)), block, 0, stream>>>(       \
-            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined, g_cfg_bwd_dense - 1); \
-        dflags = declined;                                                                                 \
-      } else if (g_cfg_bwd_tiles && bws && H * W * C < (1ll << 31)) {                                      \
-        BwdTiling tl;                                                                                      \
-        tl.tiles_y = (int)ceil_div(H, kBwdTS);                                                             \
-        tl.tiles_x = (int)ceil_div(W, kBwdTS);                                                             \
-        tl.tiles_per_img = tl.tiles_y * tl.tiles_x;                                                        \
-        const int T_ = (int)(N * tl.tiles_per_img);                                                        \
-        int* counts = bws + K;                                                                             \
-        int* offsets = counts + (T_ + 1);                                                                  \
-        int* cursors = offsets + (T_ + 1);                                                                 \
-        int* lists = cursors + (T_ + 1);                                                                   \
-        (void)hipMemsetAsync(counts, 0, sizeof(int) * 3 * (size_t)(T_ + 1), stream);                       \
-        const dim3 bgrid((unsigned)ceil_div(K, 256));                                                      \
-        roi_bwd_bin<PHT, PWT, SRT><<<bgrid, dim3(256), 0, stream>>>(r, (int)K, fs, aligned, (int)N, (int)H, (int)W, tl, \
-                                                                    counts, offsets, cursors, lists, bws, 0); \
-        roi_bwd_scan<<<dim3(1), dim3(1024), 0, stream>>>(counts, offsets, T_);                             \
-        roi_bwd_bin<PHT, PWT, SRT><<<bgrid, dim3(256), 0, stream>>>(r, (int)K, fs, aligned, (int)N, (int)H, (int)W, tl, \
-                                                                    counts, offsets, cursors, lists, bws, 1); \
-        roi_align_bwd_tiles<PHT, PWT, SRT><<<dim3((unsigned)T_, (unsigned)ceil_div(C, kBwdCC)), dim3(256), 0, stream>>>( \
-            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, tl, offsets, lists, ns, cs, hs, ws);            \
-        dflags = bws;                                                                                      \
-      } else                                                                                               \
-      if (g_cfg_bwd_wave && declined && H * W * C < (1ll << 31)) {                                         \
-        roi_align_bwd_wave<PHT, PWT, SRT><<<dim3(wave_unit_grid(K, wnchunks)), block, 0, stream>>>(        \
-            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined); \
+            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined);  \
         dflags = declined;                                                                                 \
       }                                                                                                    \
     }                                                                                                      \
@@ -2183,8 +1897,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
 
 extern "C" size_t tvmi_roi_align_backward_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t K) {
   if (N <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
-  const int64_t T = N * tvmi::ceil_div(H, tvmi::kBwdTS) * tvmi::ceil_div(W, tvmi::kBwdTS);
-  return (size_t)(K + 3 * (T + 1) + K * tvmi::kBwdMaxTiles) * sizeof(int);
+  return (size_t)K * sizeof(int);  // one "left to the fallback launch" flag per RoI
 }
 
 extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input,
@@ -2195,7 +1908,6 @@ extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void*
                                        int64_t w_stride, void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
   int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int)) ? static_cast<int*>(workspace) : nullptr;
-  int* bws = (workspace && workspace_bytes >= tvmi_roi_align_backward_workspace_bytes(N, H, W, K)) ? static_cast<int*>(workspace) : nullptr;
   if (K * C * pooled_h * pooled_w == 0 || N * H * W == 0) return 0;
   TVMI_CHECK_ARG(grad && rois && grad_input, "roi_align_backward: null pointer");
   TVMI_CHECK_ARG(H * W < (1ll << 31) && K * tvmi::ceil_div(C, 32) < (1ll << 31),
@@ -2205,7 +1917,7 @@ extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void*
                       return tvmi::launch_bwd<scalar_t>(grad, rois, grad_input, N, C, H, W, K,
                                                         pooled_h, pooled_w, spatial_scale,
                                                         sampling_ratio, aligned, n_stride, c_stride,
-                                                        h_stride, w_stride, declined, bws, s));
+                                                        h_stride, w_stride, declined, s));
   return 0;
 }
 
