@@ -128,6 +128,19 @@ int tvmi_multiscale_roi_align_forward(const void* const* inputs, const int64_t* 
                                       int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
                                       double canonical_scale, double canonical_level, double eps,
                                       void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the multi-scale form in one launch: grad [K,C,PH,PW] (element strides given) is
+ * scattered into the gradient map of each RoI's level, grad_inputs[l] = [N,C,H_l,W_l] (dt,
+ * contiguous, ZERO-initialised by the caller).  Replaces the per-level autograd loop the
+ * reference runs through poolers.py:199-222 + _roi_align_backward.  workspace: K ints.
+ */
+int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void* const* grad_inputs,
+                                       const int64_t* heights, const int64_t* widths, const double* spatial_scales,
+                                       int64_t n_levels, tvmi_dtype dt, int64_t N, int64_t C, int64_t K, int64_t pooled_h,
+                                       int64_t pooled_w, int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
+                                       double canonical_scale, double canonical_level, double eps, int64_t n_stride,
+                                       int64_t c_stride, int64_t h_stride, int64_t w_stride, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+
 /* The same operation on channels_last feature maps (element (n,c,y,x) at ((n*H+y)*W+x)*C+c;
  * SURVEY.md §8f-2): lane = channel, taps are coalesced loads off a scalar base, no LDS window.
  * Output is still the reference's NCHW-contiguous [K,C,PH,PW].  float32, 7x7 bins,

@@ -683,3 +683,31 @@ def test_boxes_to_rois_one_launch():
         want = torch.cat([torch.cat([torch.full_like(b[:, :1], i) for i, b in enumerate(lists)]), torch.cat(lists)], 1)
         got = vision_amd.roi_ops.convert_boxes_to_roi_format([b.to(DEV) for b in lists])
         assert got.dtype == dt and torch.equal(got.cpu(), want)
+
+
+def test_multiscale_roi_align_backward_single_launch():
+    """Autograd through the fused multi-scale op (one backward launch for all levels) == the per-level loop of
+    torchvision/ops/poolers.py:199-222 run through `_roi_align_backward`, and == the oracle level by level."""
+    g = gen(97)
+    N, C = 2, 40
+    shapes = [(800 // s, 1344 // s) for s in (4, 8, 16, 32)]
+    feats = [torch.rand(N, C, h, w, generator=g) for h, w in shapes]
+    boxes = [random_boxes(150, 1344, 800, 8, 700, g) for _ in range(N)]
+    for P in (7, 14, 5):
+        pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], P, 2)
+        fd = [f.to(DEV).requires_grad_(True) for f in feats]
+        out = pool({str(i): f for i, f in enumerate(fd)}, [b.to(DEV) for b in boxes], [(800, 1344)] * N)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout.to(DEV))
+        rois = vision_amd.roi_ops.convert_boxes_to_roi_format(boxes)
+        levels = pool.map_levels(boxes)
+        for l, (h, w) in enumerate(shapes):
+            idx = torch.nonzero(levels == l)[:, 0]
+            ref = O.roi_align_backward(gout[idx].numpy(), rois[idx].numpy(), pool.scales[l], P, P, N, C, h, w, 2, False)
+            np.testing.assert_allclose(fd[l].grad.cpu().numpy(), ref, rtol=1e-4, atol=TOL * max(1.0, float(np.abs(ref).max())))
+    # 16-bit maps: fp32 accumulation inside, dtype preserved outside
+    fd = [f.to(DEV).half().requires_grad_(True) for f in feats]
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = pool({str(i): f for i, f in enumerate(fd)}, [b.to(DEV) for b in boxes], [(800, 1344)] * N)
+    out.float().sum().backward()
+    assert all(f.grad is not None and f.grad.dtype == torch.float16 for f in fd)

@@ -33,6 +33,10 @@ for dt in (torch.float32, torch.bfloat16, torch.float16):
                 tv._roi_align_backward(grads[l], r[sel[l]], scales[l], P, P, f.shape[0], 256, f.shape[2], f.shape[3], 2, False)
         t = tm(bwd, n=10)
         res[f"bwd_{P}x{P}_{str(dt)[6:]}"] = (t, (out_bytes + 2 * in_bytes) / t / 1e6)
+        gall = torch.randn(4000, 256, P, P, device=dev).to(dt)
+        hs = [f.shape[2] for f in fl]; ws = [f.shape[3] for f in fl]
+        t = tm(lambda: torch.ops.tvmi.multiscale_roi_align_backward(gall, r, hs, ws, scales, 4, P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6), n=10)
+        res[f"bwd_fused_{P}x{P}_{str(dt)[6:]}"] = (t, (out_bytes + 2 * in_bytes) / t / 1e6)
 for k, (t, gbs) in res.items(): print(f"config2 {k}: {t:.4f} ms  ({gbs:.0f} GB/s algorithmic)")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(1, 256, 200, 272, generator=g).to(dev)

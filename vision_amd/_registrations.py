@@ -121,6 +121,27 @@ def _fake_multiscale(features, rois, scales, pooled_height, pooled_width, sampli
     return features[0].new_empty((rois.size(0), features[0].size(1), pooled_height, pooled_width))
 
 
+def _fake_multiscale_bwd(grad, rois, heights, widths, scales, batch_size, pooled_height, pooled_width, sampling_ratio,
+                         aligned, k_min, k_max, canonical_scale, canonical_level, eps):
+    return [grad.new_empty((batch_size, grad.size(1), h, w)) for h, w in zip(heights, widths)]
+
+
+def _multiscale_setup(ctx, inputs, output):
+    features, rois = inputs[0], inputs[1]
+    ctx.save_for_backward(rois)
+    ctx.shapes = [tuple(f.shape) for f in features]
+    ctx.params = inputs[2:]
+
+
+def _multiscale_backward(ctx, grad):
+    (rois,) = ctx.saved_tensors
+    scales, ph, pw, sr, aligned, k_min, k_max, s0, lvl0, eps = ctx.params
+    grads = torch.ops.tvmi.multiscale_roi_align_backward(
+        grad, rois, [s[2] for s in ctx.shapes], [s[3] for s in ctx.shapes], scales, ctx.shapes[0][0], ph, pw, sr, aligned,
+        k_min, k_max, s0, lvl0, eps)
+    return (list(grads), None) + (None,) * len(ctx.params)
+
+
 def _fake_interpolate2d(input, out_h, out_w, mode, align_corners, antialias, scale_h, scale_w):
     return input.new_empty((input.size(0), input.size(1), out_h, out_w))
 
@@ -168,6 +189,7 @@ _FAKES = {
     "tvmi::rpn_candidates": _fake_rpn_candidates,
     "tvmi::pack_detections": _fake_pack_detections,
     "tvmi::multiscale_roi_align": _fake_multiscale,
+    "tvmi::multiscale_roi_align_backward": _fake_multiscale_bwd,
     "tvmi::interpolate2d": _fake_interpolate2d,
     "torchvision::nms": _fake_nms,
     "tvmi::nms_segmented": _fake_nms_segmented,
@@ -283,6 +305,8 @@ def register_all():
         setup, backward = _make_roi_autograd(fwd, bwd, nb, tail, aux)
         torch.library.register_autograd(tv + fwd, backward, setup_context=setup)
         torch.library.register_autograd(tv + bwd, _no_double_backward(fwd))
+    torch.library.register_autograd("tvmi::multiscale_roi_align", _multiscale_backward, setup_context=_multiscale_setup)
+    torch.library.register_autograd("tvmi::multiscale_roi_align_backward", _no_double_backward("multiscale_roi_align"))
     torch.library.register_autograd(tv + "deform_conv2d", _deform_backward, setup_context=_deform_setup)
     torch.library.register_autograd(tv + "_deform_conv2d_backward", _no_double_backward("deform_conv2d"))
 

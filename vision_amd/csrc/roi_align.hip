@@ -1232,7 +1232,7 @@ template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_bwd_tile(
     const T* __restrict__ grad, const T* __restrict__ rois, T* __restrict__ grad_input, int C, int H,
     int W, int PH_, int PW_, float spatial_scale, int sr_, int aligned, int nchunks, int64_t ns,
-    int64_t cs, int64_t hs, int64_t ws, const int* __restrict__ declined) {
+    int64_t cs, int64_t hs, int64_t ws, const int* __restrict__ declined, MsLevels lv, int use_ms) {
   __shared__ TileShared s;
   const int PH = PHT > 0 ? PHT : PH_;
   const int PW = PWT > 0 ? PWT : PW_;
@@ -1241,6 +1241,13 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_tile(
   const int tid = threadIdx.x;
   const int k = blockIdx.x / nchunks;
   if (declined && declined[k] == 0) return;  // this RoI was handled by the wave kernel
+  if (use_ms) {  // multi-scale form: the RoI picks its level's gradient map
+    const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
+    grad_input = static_cast<T*>(const_cast<void*>(lv.ptr[l]));
+    H = lv.H[l];
+    W = lv.W[l];
+    spatial_scale = lv.scale[l];
+  }
   const int c0 = (blockIdx.x - k * nchunks) * kChunk;
   const int cc = min(kChunk, C - c0);
 
@@ -1468,7 +1475,8 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __r
                                                                 float* __restrict__ grad_input, int C, int H, int W,
                                                                 float spatial_scale, int aligned, int nchunks, int chunk,
                                                                 int64_t nunits, int64_t ns, int64_t cs, int64_t hs,
-                                                                int64_t ws, int* __restrict__ declined) {
+                                                                int64_t ws, int* __restrict__ declined, MsLevels lv,
+                                                                int use_ms) {
   using DS = DenseShared<PHT, PWT, SRT>;
   __shared__ DS sh[kThreads / 64];
   constexpr int ny = PHT * SRT, nx = PWT * SRT;
@@ -1479,6 +1487,13 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __r
   if (!wave_unit(nunits / nchunks, nchunks, nullptr, k, ci)) return;
   const int c0 = ci * chunk;
   const int cc = min(chunk, C - c0);
+  if (use_ms) {  // multi-scale form: the RoI picks its level's gradient map (poolers.py:73-84)
+    const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+    grad_input = static_cast<float*>(const_cast<void*>(lv.ptr[l]));
+    H = lv.H[l];
+    W = lv.W[l];
+    spatial_scale = lv.scale[l];
+  }
   const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
   // ---- window bounds (shifted samples: lo + 1 is always inside the map)
   int y0 = 0, wh = 0, x0 = 0, ww = 0, state = 2;
@@ -1652,13 +1667,18 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
 template <typename T>
 int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int64_t ns, int64_t cs, int64_t hs, int64_t ws, int* declined, hipStream_t stream) {
+               int64_t ns, int64_t cs, int64_t hs, int64_t ws, int* declined, hipStream_t stream,
+               const MsLevels* ms = nullptr) {
   load_env_cfg();
   const T* g = static_cast<const T*>(grad);
   const T* r = static_cast<const T*>(rois);
   T* gi = static_cast<T*>(grad_input);
   const int64_t total = K * C * PH * PW;
+  MsLevels lv{};
+  const int use_ms = ms != nullptr;
+  if (ms) lv = *ms;
   if constexpr (std::is_same<T, double>::value) {
+    if (ms) return set_error((int)hipErrorInvalidValue, "multiscale_roi_align_backward: float64 is not supported");
     const int64_t blocks = std::min<int64_t>(ceil_div(total, kThreads), 1 << 20);
     roi_align_bwd_generic<T><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(
         g, r, gi, total, (int)C, (int)H, (int)W, (int)PH, (int)PW, scale, (int)sr, aligned, ns, cs,
@@ -1675,13 +1695,13 @@ int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, 
     if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                            \
       if (g_cfg_bwd_dense && declined && H * W * C < (1ll << 31)) {                                        \
         roi_align_bwd_dense<PHT, PWT, SRT><<<dim3(wave_unit_grid(K, wnchunks)), block, 0, stream>>>(       \
-            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined);  \
+            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined, lv, use_ms); \
         dflags = declined;                                                                                 \
       }                                                                                                    \
     }                                                                                                      \
     roi_align_bwd_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(g, r, gi, (int)C, (int)H, (int)W,     \
                                                                      (int)PH, (int)PW, fs, (int)sr, aligned, \
-                                                                     nchunks, ns, cs, hs, ws, dflags);     \
+                                                                     nchunks, ns, cs, hs, ws, dflags, lv, use_ms); \
   }
     if (PH == 7 && PW == 7 && sr == 2) {
       TVMI_BWD(7, 7, 2);
@@ -1962,6 +1982,56 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
     default:
       return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned,
                                                  order, declined, s);
+  }
+}
+
+extern "C" int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void* const* grad_inputs,
+                                                  const int64_t* heights, const int64_t* widths,
+                                                  const double* spatial_scales, int64_t n_levels, tvmi_dtype dt, int64_t N,
+                                                  int64_t C, int64_t K, int64_t pooled_h, int64_t pooled_w,
+                                                  int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
+                                                  double canonical_scale, double canonical_level, double eps,
+                                                  int64_t n_stride, int64_t c_stride, int64_t h_stride, int64_t w_stride,
+                                                  void* workspace, size_t workspace_bytes, void* stream) {
+  TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "multiscale_roi_align_backward: pooled size must be positive");
+  TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "multiscale_roi_align_backward: 1..8 levels supported");
+  if (K * C * pooled_h * pooled_w == 0 || N == 0) return 0;
+  TVMI_CHECK_ARG(grad && rois && grad_inputs && heights && widths && spatial_scales, "multiscale_roi_align_backward: null pointer");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16, "multiscale_roi_align_backward: float32 / float16 / bfloat16 only");
+  TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align_backward: size exceeds 32-bit launch limits");
+  tvmi::MsLevels lv;
+  int64_t hmax = 1, wmax = 1;
+  for (int i = 0; i < tvmi::kMaxLevels; ++i) {
+    const int j = i < n_levels ? i : 0;
+    TVMI_CHECK_ARG(grad_inputs[j] != nullptr && heights[j] > 0 && widths[j] > 0 && heights[j] * widths[j] * C < (1ll << 31),
+                   "multiscale_roi_align_backward: bad level");
+    lv.ptr[i] = grad_inputs[j];
+    lv.H[i] = (int)heights[j];
+    lv.W[i] = (int)widths[j];
+    lv.scale[i] = (float)spatial_scales[j];
+    hmax = std::max(hmax, heights[j]);
+    wmax = std::max(wmax, widths[j]);
+  }
+  lv.n_levels = (int)n_levels;
+  lv.k_min = (int)k_min;
+  lv.k_max = (int)k_max;
+  lv.s0 = (float)canonical_scale;
+  lv.lvl0 = (float)canonical_level;
+  lv.eps = (float)eps;
+  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int)) ? static_cast<int*>(workspace) : nullptr;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // H / W / scale / grad_input of the single-level signature are placeholders: every RoI takes them from its level
+  switch (dt) {
+    case TVMI_F32:
+      return tvmi::launch_bwd<float>(grad, rois, grad_inputs[0], N, C, hmax, wmax, K, pooled_h, pooled_w, spatial_scales[0],
+                                     sampling_ratio, aligned, n_stride, c_stride, h_stride, w_stride, declined, s, &lv);
+    case TVMI_F16:
+      return tvmi::launch_bwd<__half>(grad, rois, grad_inputs[0], N, C, hmax, wmax, K, pooled_h, pooled_w, spatial_scales[0],
+                                      sampling_ratio, aligned, n_stride, c_stride, h_stride, w_stride, declined, s, &lv);
+    default:
+      return tvmi::launch_bwd<__hip_bfloat16>(grad, rois, grad_inputs[0], N, C, hmax, wmax, K, pooled_h, pooled_w,
+                                              spatial_scales[0], sampling_ratio, aligned, n_stride, c_stride, h_stride,
+                                              w_stride, declined, s, &lv);
   }
 }
 

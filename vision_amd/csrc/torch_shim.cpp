@@ -608,6 +608,47 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
   return output;
 }
 
+// backward of the fused multi-scale op: one launch scatters into every level's gradient map
+std::vector<at::Tensor> multiscale_roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, at::IntArrayRef heights,
+                                                      at::IntArrayRef widths, at::ArrayRef<double> scales, int64_t batch_size,
+                                                      int64_t pooled_height, int64_t pooled_width, int64_t sampling_ratio,
+                                                      bool aligned, int64_t k_min, int64_t k_max, double canonical_scale,
+                                                      double canonical_level, double eps) {
+  TORCH_CHECK(grad.is_cuda() && rois.is_cuda() && grad.dim() == 4 && rois.dim() == 2 && rois.size(1) == 5 &&
+                  grad.size(0) == rois.size(0),
+              "multiscale_roi_align_backward: grad [K,C,PH,PW] and rois [K,5] CUDA tensors expected");
+  TORCH_CHECK(heights.size() >= 1 && heights.size() <= 8 && heights.size() == widths.size() && heights.size() == scales.size(),
+              "multiscale_roi_align_backward: 1..8 levels with one height / width / scale each");
+  c10::DeviceGuard guard(grad.device());
+  const bool low = grad.scalar_type() == at::kHalf || grad.scalar_type() == at::kBFloat16;
+  // 16-bit gradients accumulate in fp32 and are rounded once (see roi_align_backward)
+  at::Tensor g = low ? grad.to(at::kFloat) : grad;
+  at::Tensor r = rois.to(g.scalar_type()).contiguous();
+  TORCH_CHECK(g.scalar_type() == at::kFloat, "multiscale_roi_align_backward: float32 / float16 / bfloat16 only");
+  const int64_t K = g.size(0), C = g.size(1);
+  std::vector<at::Tensor> outs;
+  std::vector<void*> ptrs;
+  std::vector<int64_t> hs(heights.begin(), heights.end()), ws(widths.begin(), widths.end());
+  for (size_t i = 0; i < heights.size(); ++i) {
+    outs.push_back(at::zeros({batch_size, C, heights[i], widths[i]}, g.options()));
+    ptrs.push_back(outs.back().mutable_data_ptr());
+  }
+  if (g.numel() != 0 && batch_size != 0) {
+    at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
+    at::Tensor wsp = at::empty({K}, g.options().dtype(at::kInt));
+    check_status(tvmi_multiscale_roi_align_backward(g.const_data_ptr(), r.const_data_ptr(), ptrs.data(), hs.data(), ws.data(),
+                                                    scales.data(), (int64_t)heights.size(), TVMI_F32, batch_size, C, K,
+                                                    pooled_height, pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max,
+                                                    canonical_scale, canonical_level, eps, g.stride(0), g.stride(1),
+                                                    g.stride(2), g.stride(3), wsp.mutable_data_ptr(), (size_t)K * sizeof(int32_t),
+                                                    current_stream(grad)),
+                 "multiscale_roi_align_backward");
+  }
+  if (low)
+    for (auto& o : outs) o = o.to(grad.scalar_type());
+  return outs;
+}
+
 // ---- detection payload packing (one launch; see include/tvmi.h)
 std::tuple<at::Tensor, at::Tensor> pack_detections(const at::Tensor& boxes, const at::Tensor& scores,
                                                    const c10::optional<at::Tensor>& labels, const at::Tensor& image_idx,
@@ -833,6 +874,8 @@ TORCH_LIBRARY(tvmi, m) {
       "pack_detections(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, int num_images, int max_dets) -> (Tensor, Tensor)");
   m.def(
       "multiscale_roi_align(Tensor[] features, Tensor rois, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor");
+  m.def(
+      "multiscale_roi_align_backward(Tensor grad, Tensor rois, int[] heights, int[] widths, float[] scales, int batch_size, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor[]");
   // roi_heads.py:680-722 / rpn.py:266-286 up to the NMS, batched over images (one launch each)
   m.def(
       "detection_candidates(Tensor class_logits, Tensor box_regression, Tensor proposals, Tensor row_image, Tensor image_hw, float[] weights, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor)");
@@ -867,6 +910,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("pack_detections_devcount", &pack_detections_devcount);
   m.impl("interpolate2d", &interpolate2d);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
+  m.impl("multiscale_roi_align_backward", &multiscale_roi_align_backward);
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);
   m.impl("boxes_to_rois", &boxes_to_rois);

@@ -66,11 +66,10 @@ def _multiscale_roi_align(x_filtered: List[Tensor], boxes: List[Tensor], output_
         return roi_align(x_filtered[0], rois, output_size=output_size, spatial_scale=scales[0],
                          sampling_ratio=sampling_ratio)
     first = x_filtered[0]
-    if first.is_cuda and first.dtype in (torch.float32, torch.float16, torch.bfloat16) and not (
-        torch.is_grad_enabled() and any(f.requires_grad for f in x_filtered)
-    ):
+    if first.is_cuda and first.dtype in (torch.float32, torch.float16, torch.bfloat16):
         # one launch for all levels: level assignment happens in the kernel, results land
-        # directly in the [K, C, PH, PW] output (no torch.where / index_put per level)
+        # directly in the [K, C, PH, PW] output (no torch.where / index_put per level); the
+        # registered autograd formula is one launch too (tvmi::multiscale_roi_align_backward)
         return torch.ops.tvmi.multiscale_roi_align(
             list(x_filtered), rois.to(first.dtype), [float(s) for s in scales], int(output_size[0]),
             int(output_size[1]), int(sampling_ratio), False, int(mapper.k_min), int(mapper.k_max), float(mapper.s0),
