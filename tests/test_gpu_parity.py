@@ -711,3 +711,29 @@ def test_multiscale_roi_align_backward_single_launch():
     out = pool({str(i): f for i, f in enumerate(fd)}, [b.to(DEV) for b in boxes], [(800, 1344)] * N)
     out.float().sum().backward()
     assert all(f.grad is not None and f.grad.dtype == torch.float16 for f in fd)
+
+
+def test_box_iou_pairwise_bit_identical_to_reference_tensor_math():
+    """One-launch box_iou / generalized_box_iou vs the reference formulas (ops/boxes.py:314-391, 409-436) evaluated
+    with torch CPU tensor math: identical bits (same operations, same order, no contraction), incl. the reference's
+    known-answer matrix (test/test_ops.py:1652-1658), degenerate boxes (0/0 = NaN) and float16 upcast."""
+    from vision_amd import boxes as VB
+    g = gen(17)
+    b1 = random_boxes(37, 500, 400, 1, 200, g)
+    b2 = random_boxes(1000, 500, 400, 1, 200, g)
+    b2[5] = b1[3]
+    b2[6, 2:] = b2[6, :2]                      # zero-area box
+    for a, b in ((b1, b2), (b1.double(), b2.double()), (b1.half(), b2.half())):
+        inter, union = VB._box_inter_union(a, b)          # CPU tensor math == the reference's
+        want = inter / union
+        got = vision_amd.box_iou(a.to(DEV), b.to(DEV)).cpu()
+        assert got.dtype == want.dtype and torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+        lti = torch.min(a[:, None, :2], b[None, :, :2]); rbi = torch.max(a[:, None, 2:], b[None, :, 2:])
+        whi = VB._upcast(rbi - lti).clamp(min=0); areai = whi[..., 0] * whi[..., 1]
+        wantg = want - (areai - union) / areai
+        gotg = vision_amd.generalized_box_iou(a.to(DEV), b.to(DEV)).cpu()
+        assert torch.equal(torch.nan_to_num(gotg, nan=-7.0), torch.nan_to_num(wantg, nan=-7.0))
+    kat1 = torch.tensor([[0, 0, 100, 100], [0, 0, 50, 50], [200, 200, 300, 300], [0, 0, 25, 25]], dtype=torch.float32)
+    kat2 = torch.tensor([[0, 0, 100, 100], [0, 0, 50, 50], [200, 200, 300, 300]], dtype=torch.float32)
+    expected = torch.tensor([[1.0, 0.25, 0.0], [0.25, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0625, 0.25, 0.0]])
+    assert torch.allclose(vision_amd.box_iou(kat1.to(DEV), kat2.to(DEV)).cpu(), expected, atol=1e-4)

@@ -31,6 +31,7 @@ from .boxes import (  # noqa: E402,F401
     box_area,
     box_iou,
     clip_boxes_to_image,
+    generalized_box_iou,
     nms,
     remove_small_boxes,
 )

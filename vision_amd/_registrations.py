@@ -176,12 +176,18 @@ def _fake_pack_devcount(boxes, scores, labels, image_idx, keep, num_keep, num_im
     return boxes.new_empty((num_images, max_dets, 6), dtype=torch.float32), boxes.new_empty((num_images,), dtype=torch.int32)
 
 
+def _fake_box_iou_pairwise(boxes1, boxes2, generalized):
+    dt = torch.float64 if torch.float64 in (boxes1.dtype, boxes2.dtype) else torch.float32
+    return boxes1.new_empty((boxes1.shape[0], boxes2.shape[0]), dtype=dt)
+
+
 def _fake_boxes_to_rois(boxes):
     return boxes[0].new_empty((sum(b.shape[0] for b in boxes), 5))
 
 
 _FAKES = {
     "tvmi::boxes_to_rois": _fake_boxes_to_rois,
+    "tvmi::box_iou_pairwise": _fake_box_iou_pairwise,
     "tvmi::nms_segmented_padded": _fake_nms_padded,
     "tvmi::pack_detections_devcount": _fake_pack_devcount,
     "tvmi::paste_masks": _fake_paste_masks,

@@ -100,8 +100,29 @@ def box_iou(boxes1: Tensor, boxes2: Tensor, fmt: str = "xyxy") -> Tensor:
         return torch.ops.torchvision.box_iou_rotated(boxes1, boxes2)
     if fmt != "xyxy":
         raise ValueError(f"Unsupported box format {fmt!r}; convert to xyxy or cxcywhr first")
+    if _native_pairwise(boxes1, boxes2):
+        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, False)
     inter, union = _box_inter_union(boxes1, boxes2)
     return inter / union
+
+
+def _native_pairwise(boxes1: Tensor, boxes2: Tensor) -> bool:
+    # one launch on device tensors (the matcher's use, roi_heads.py:595 / rpn.py:167, runs without grad)
+    return (boxes1.is_cuda and boxes2.is_cuda and boxes1.dim() == 2 and boxes2.dim() == 2 and boxes1.is_floating_point()
+            and boxes2.is_floating_point() and not (torch.is_grad_enabled() and (boxes1.requires_grad or boxes2.requires_grad)))
+
+
+def generalized_box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """Pairwise generalized IoU [N, M] of xyxy boxes (ops/boxes.py:409-436)."""
+    if _native_pairwise(boxes1, boxes2):
+        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, True)
+    inter, union = _box_inter_union(boxes1, boxes2)
+    iou = inter / union
+    lti = torch.min(boxes1[..., :, None, :2], boxes2[..., None, :, :2])
+    rbi = torch.max(boxes1[..., :, None, 2:], boxes2[..., None, :, 2:])
+    whi = _upcast(rbi - lti).clamp(min=0)
+    areai = whi[..., 0] * whi[..., 1]
+    return iou - (areai - union) / areai
 
 
 def clip_boxes_to_image(boxes: Tensor, size: Tuple[int, int]) -> Tensor:

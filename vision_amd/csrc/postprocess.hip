@@ -207,6 +207,41 @@ __global__ __launch_bounds__(256) void boxes_to_rois_kernel(BoxLists bl, T* __re
   r[4] = b[3];
 }
 
+// Pairwise axis-aligned IoU / generalized IoU (ops/boxes.py:314-391, 409-436): the reference builds
+// [N,M,2] temporaries with ~10 elementwise launches; here one thread per (i, j), j fastest, same
+// operations in the same order (this TU has no FP contraction), so values are bit-identical to the
+// reference's CPU tensor math.
+// `src16`: the boxes came from float16 (1) / bfloat16 (2) tensors — the reference then forms rb - lt in that type
+// BEFORE upcasting (`_upcast(rb - lt)`), so the difference is rounded to 16 bits here too.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void box_iou_pairwise_kernel(const T* __restrict__ b1, const T* __restrict__ b2,
+                                                               T* __restrict__ out, int N, int M, int src16) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= M) return;
+  const T ax1 = b1[i * 4 + 0], ay1 = b1[i * 4 + 1], ax2 = b1[i * 4 + 2], ay2 = b1[i * 4 + 3];
+  const T bx1 = b2[(int64_t)j * 4 + 0], by1 = b2[(int64_t)j * 4 + 1], bx2 = b2[(int64_t)j * 4 + 2], by2 = b2[(int64_t)j * 4 + 3];
+  const T area1 = (ax2 - ax1) * (ay2 - ay1), area2 = (bx2 - bx1) * (by2 - by1);
+  auto tmax = [](T a, T b) { return (a != a || a > b) ? a : b; };  // torch.max / torch.min propagate NaN
+  auto tmin = [](T a, T b) { return (a != a || a < b) ? a : b; };
+  auto clamp0 = [](T v) { return v < (T)0 ? (T)0 : v; };           // clamp(min=0) keeps NaN
+  auto r16 = [src16](T v) -> T {
+    if (src16 == 1) return (T)__half2float(__float2half_rn((float)v));
+    if (src16 == 2) return (T)__bfloat162float(__float2bfloat16((float)v));
+    return v;
+  };
+  const T w = clamp0(r16(tmin(ax2, bx2) - tmax(ax1, bx1))), h = clamp0(r16(tmin(ay2, by2) - tmax(ay1, by1)));
+  const T inter = w * h;
+  const T uni = area1 + area2 - inter;
+  T r = inter / uni;
+  if (MODE == 1) {
+    const T wi = clamp0(r16(tmax(ax2, bx2) - tmin(ax1, bx1))), hi = clamp0(r16(tmax(ay2, by2) - tmin(ay1, by1)));
+    const T areai = wi * hi;
+    r = r - (areai - uni) / areai;
+  }
+  out[(int64_t)i * M + j] = r;
+}
+
 }  // namespace
 }  // namespace tvmi
 
@@ -293,4 +328,32 @@ extern "C" int tvmi_boxes_to_rois(const void* const* boxes, const int64_t* count
                       tvmi::boxes_to_rois_kernel<scalar_t><<<grid, dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
                           bl, static_cast<scalar_t*>(rois), (int)run));
   TVMI_RETURN_LAUNCH_STATUS("tvmi_boxes_to_rois");
+}
+
+extern "C" int tvmi_box_iou_pairwise(const void* boxes1, const void* boxes2, void* out, tvmi_dtype dt, int64_t N, int64_t M,
+                                     int generalized, int source_16bit, void* stream) {
+  TVMI_CHECK_ARG(N >= 0 && M >= 0, "box_iou_pairwise: negative size");
+  if (N * M == 0) return 0;
+  TVMI_CHECK_ARG(boxes1 && boxes2 && out, "box_iou_pairwise: null pointer");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "box_iou_pairwise: float32 / float64 (upcast 16-bit boxes first)");
+  TVMI_CHECK_ARG(N <= 65535 * 64ll && M < (1ll << 31), "box_iou_pairwise: size too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((M + 255) / 256), (unsigned)std::min<int64_t>(N, 65535));
+  // rows beyond the y-limit of the grid are covered by repeated launches on row slices
+  for (int64_t r0 = 0; r0 < N; r0 += 65535) {
+    const int rows = (int)std::min<int64_t>(65535, N - r0);
+    const dim3 g((unsigned)((M + 255) / 256), (unsigned)rows);
+#define TVMI_IOU(T_, MODE_)                                                                                         \
+  tvmi::box_iou_pairwise_kernel<T_, MODE_><<<g, dim3(256), 0, s>>>(static_cast<const T_*>(boxes1) + r0 * 4,          \
+                                                                   static_cast<const T_*>(boxes2),                   \
+                                                                   static_cast<T_*>(out) + r0 * M, rows, (int)M, source_16bit)
+    if (dt == TVMI_F32) {
+      if (generalized) TVMI_IOU(float, 1); else TVMI_IOU(float, 0);
+    } else {
+      if (generalized) TVMI_IOU(double, 1); else TVMI_IOU(double, 0);
+    }
+#undef TVMI_IOU
+  }
+  (void)grid;
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_box_iou_pairwise");
 }

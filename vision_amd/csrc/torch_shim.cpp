@@ -821,6 +821,25 @@ at::Tensor boxes_to_rois(at::TensorList boxes) {
   return rois;
 }
 
+// ---- pairwise IoU / GIoU in one launch (ops/boxes.py:314-391, 409-436)
+at::Tensor box_iou_pairwise(const at::Tensor& boxes1, const at::Tensor& boxes2, bool generalized) {
+  TORCH_CHECK(boxes1.is_cuda() && boxes2.is_cuda() && boxes1.dim() == 2 && boxes2.dim() == 2 && boxes1.size(1) == 4 &&
+                  boxes2.size(1) == 4,
+              "box_iou_pairwise: boxes1 [N,4] and boxes2 [M,4] CUDA tensors expected");
+  c10::DeviceGuard guard(boxes1.device());
+  // _upcast (ops/_utils.py:72-84) + type promotion of the two inputs
+  auto dt = at::promote_types(boxes1.scalar_type(), boxes2.scalar_type());
+  const int src16 = dt == at::kHalf ? 1 : (dt == at::kBFloat16 ? 2 : 0);
+  if (dt != at::kDouble) dt = at::kFloat;
+  at::Tensor a = boxes1.to(dt).contiguous(), b = boxes2.to(dt).contiguous();
+  at::Tensor out = at::empty({a.size(0), b.size(0)}, a.options());
+  if (out.numel() == 0) return out;
+  check_status(tvmi_box_iou_pairwise(a.const_data_ptr(), b.const_data_ptr(), out.mutable_data_ptr(), dtype_of(a, "box_iou"),
+                                     a.size(0), b.size(0), generalized ? 1 : 0, src16, current_stream(boxes1)),
+               "box_iou_pairwise");
+  return out;
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -881,6 +900,8 @@ TORCH_LIBRARY(tvmi, m) {
       "detection_candidates(Tensor class_logits, Tensor box_regression, Tensor proposals, Tensor row_image, Tensor image_hw, float[] weights, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor)");
   m.def(
       "rpn_candidates(Tensor objectness, Tensor boxes, Tensor? deltas, Tensor top_idx, Tensor level_offsets, Tensor image_hw, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor, Tensor)");
+  // ops/boxes.py:314-391 / 409-436 (box_iou / generalized_box_iou of xyxy boxes) as one launch
+  m.def("box_iou_pairwise(Tensor boxes1, Tensor boxes2, bool generalized) -> Tensor");
   // ops/_utils.py:18-25 (cat + full_like per image + 2 cats) as one launch
   m.def("boxes_to_rois(Tensor[] boxes) -> Tensor");
   // python loop of roi_heads.py:486-500 (pad + expand + resize + paste per detection) as one launch
@@ -914,6 +935,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);
   m.impl("boxes_to_rois", &boxes_to_rois);
+  m.impl("box_iou_pairwise", &box_iou_pairwise);
   m.impl("detection_candidates", &detection_candidates);
   m.impl("rpn_candidates", &rpn_candidates);
 }
