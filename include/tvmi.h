@@ -312,6 +312,17 @@ int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt, int mode,
                        int64_t IW, int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* GeneralizedRCNNTransform.forward for a batch (models/detection/transform.py:119-255) in one
+ * launch: images[i] is [C,H_i,W_i] (dt, contiguous); every output pixel of image i inside
+ * [out_h_i, out_w_i] is the bilinear (align_corners=False) sample of ((x - mean_c) / std_c), the
+ * rest of the [num_images, C, padded_h, padded_w] batch is zero.  The caller applies the
+ * reference's size rules (_resize_image_and_masks :25-72, batch_images :228-246) on the host.
+ */
+int tvmi_normalize_resize_batch(const void* const* images, const int64_t* heights, const int64_t* widths,
+                                const int64_t* out_heights, const int64_t* out_widths, int64_t num_images,
+                                int64_t channels, const float* mean, const float* stdv, void* output, tvmi_dtype dt,
+                                int64_t padded_h, int64_t padded_w, void* stream);
+
 /* ------------------------------------------------------------------- mask paste --------
  * Batched replacement of paste_masks_in_image (models/detection/roi_heads.py:486-500, with
  * expand_masks :404-413, expand_boxes :378-395 and paste_mask_in_image :416-437 folded in):

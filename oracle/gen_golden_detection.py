@@ -105,6 +105,20 @@ def main():
     for i in range(2):
         d[f"rpn_boxes{i}"], d[f"rpn_scores{i}"] = fb[i], fs[i]
         assert 5 < len(fb[i]) <= 40
+
+    # ------------------------------------------------------------ GeneralizedRCNNTransform.forward (eval)
+    from torchvision.models.detection.transform import GeneralizedRCNNTransform
+
+    g = torch.Generator().manual_seed(41)
+    imgs = [torch.rand(3, h, w, generator=g) for h, w in ((47, 83), (120, 64), (33, 33), (90, 211))]
+    for tag, kw in (("a", dict(min_size=96, max_size=160)), ("b", dict(min_size=64, max_size=100)),
+                    ("c", dict(min_size=50, max_size=80, fixed_size=(72, 56)))):
+        tr = GeneralizedRCNNTransform(image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225], **kw).eval()
+        il, _ = tr([im.clone() for im in imgs])
+        d[f"xform_{tag}_out"] = il.tensors
+        d[f"xform_{tag}_sizes"] = np.array(il.image_sizes, dtype=np.int64)
+    for i, im in enumerate(imgs):
+        d[f"xform_img{i}"] = im
     save("detection", **d)
 
 

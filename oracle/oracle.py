@@ -318,3 +318,30 @@ def filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level,
         keep = nms(b, s, nms_thresh, idxs=lvl)[:post_nms_top_n]
         out.append((b[keep], s[keep]))
     return out
+
+
+def transform_images(images, min_size, max_size, mean, std, size_divisible=32, fixed_size=None):
+    """GeneralizedRCNNTransform.forward, eval mode (models/detection/transform.py:119-255): normalize, resize by the
+    reference's scale rule through the C oracle's bilinear restatement, zero-padded batch."""
+    import math
+
+    f = np.float32
+    sizes, resized = [], []
+    for img in images:
+        img = _c(img, f)
+        C, h, w = img.shape
+        norm = (img - np.asarray(mean, f)[:, None, None]) / np.asarray(std, f)[:, None, None]
+        if fixed_size is not None:
+            oh, ow = int(fixed_size[1]), int(fixed_size[0])
+        else:
+            scale = min(float(min_size) / float(min(h, w)), float(max_size) / float(max(h, w)))
+            oh, ow = int(math.floor(float(h) * scale)), int(math.floor(float(w) * scale))
+        resized.append(interpolate(norm[None], (oh, ow), "bilinear")[0])
+        sizes.append((oh, ow))
+    stride = float(size_divisible)
+    hp = int(math.ceil(float(max(s[0] for s in sizes)) / stride) * stride)
+    wp = int(math.ceil(float(max(s[1] for s in sizes)) / stride) * stride)
+    out = np.zeros((len(images), resized[0].shape[0], hp, wp), f)
+    for i, r in enumerate(resized):
+        out[i, :, : r.shape[1], : r.shape[2]] = r
+    return out, sizes

@@ -737,3 +737,24 @@ def test_box_iou_pairwise_bit_identical_to_reference_tensor_math():
     kat2 = torch.tensor([[0, 0, 100, 100], [0, 0, 50, 50], [200, 200, 300, 300]], dtype=torch.float32)
     expected = torch.tensor([[1.0, 0.25, 0.0], [0.25, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0625, 0.25, 0.0]])
     assert torch.allclose(vision_amd.box_iou(kat1.to(DEV), kat2.to(DEV)).cpu(), expected, atol=1e-4)
+
+
+def test_transform_images_one_launch_golden():
+    """Fused normalize + resize + batching vs the reference GeneralizedRCNNTransform's own output (eval mode): same
+    image_sizes and padded shape, values within 2e-5 (fp32 bilinear on normalised taps), padding exactly zero."""
+    G = golden("detection")
+    imgs = [torch.from_numpy(G[f"xform_img{i}"]).to(DEV) for i in range(4)]
+    for tag, kw in (("a", dict(min_size=96, max_size=160)), ("b", dict(min_size=64, max_size=100)),
+                    ("c", dict(min_size=50, max_size=80, fixed_size=(72, 56)))):
+        out, sizes = vision_amd.transform_images(imgs, **kw)
+        want = G[f"xform_{tag}_out"]
+        assert [tuple(s) for s in G[f"xform_{tag}_sizes"]] == sizes and tuple(out.shape) == want.shape
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-5)
+        assert np.array_equal(out.cpu().numpy() == 0, want == 0)
+    # model-sized inputs against the oracle restatement (pinned to torch CPU by tests/test_oracle.py)
+    g = gen(43)
+    big = [torch.rand(3, h, w, generator=g) for h, w in ((1080, 1920), (480, 640))]
+    out, sizes = vision_amd.transform_images([b.to(DEV) for b in big])
+    ref, rsizes = O.transform_images([b.numpy() for b in big], 800, 1333, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    assert sizes == rsizes and tuple(out.shape) == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5)

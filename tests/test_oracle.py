@@ -186,3 +186,15 @@ def test_filter_proposals_golden():
     # decode restatement vs the reference's decoded proposals
     dec = O.decode_boxes(G["rpn_deltas"].reshape(-1, 4), G["rpn_anchors"].reshape(-1, 4), (1.0, 1.0, 1.0, 1.0))[:, 0]
     np.testing.assert_allclose(dec, G["rpn_proposals"].reshape(-1, 4), rtol=0, atol=1e-4)
+
+
+def test_transform_images_golden():
+    """numpy / C restatement of GeneralizedRCNNTransform.forward (eval) vs the reference's own output."""
+    G = golden("detection")
+    imgs = [G[f"xform_img{i}"] for i in range(4)]
+    for tag, kw in (("a", dict(min_size=96, max_size=160)), ("b", dict(min_size=64, max_size=100)),
+                    ("c", dict(min_size=50, max_size=80, fixed_size=(72, 56)))):
+        out, sizes = O.transform_images(imgs, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], **kw)
+        assert [tuple(s) for s in G[f"xform_{tag}_sizes"]] == sizes
+        assert out.shape == G[f"xform_{tag}_out"].shape
+        np.testing.assert_allclose(out, G[f"xform_{tag}_out"], rtol=0, atol=2e-5)

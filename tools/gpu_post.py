@@ -69,3 +69,23 @@ logits = (torch.randn(4000, 91, generator=g) * 3).to(dev); reg = (torch.randn(40
 t1 = tm(lambda: vision_amd.postprocess_detections(logits, reg, props, shapes, padded=True))
 t2 = tm(lambda: ref_postprocess(logits, reg, props, shapes), n=5, warm=1)
 print(f"postprocess_detections 4 x 1000 x 91: fused {t1:.3f} ms | per-image torch chain (with our NMS) {t2:.3f} ms | x{t2 / t1:.1f}")
+
+# ---- fused input transform vs the reference's per-image op chain on the same GPU
+def ref_transform(images, min_size=800, max_size=1333, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    outs = []
+    for im in images:
+        m = torch.as_tensor(mean, dtype=im.dtype, device=im.device); s = torch.as_tensor(std, dtype=im.dtype, device=im.device)
+        x = (im - m[:, None, None]) / s[:, None, None]
+        h, w = x.shape[-2:]
+        sc = min(min_size / min(h, w), max_size / max(h, w))
+        outs.append(F.interpolate(x[None], scale_factor=sc, mode="bilinear", recompute_scale_factor=True, align_corners=False)[0])
+    hp = int(math.ceil(max(o.shape[1] for o in outs) / 32) * 32); wp = int(math.ceil(max(o.shape[2] for o in outs) / 32) * 32)
+    b = outs[0].new_full((len(outs), 3, hp, wp), 0)
+    for i, o in enumerate(outs):
+        b[i, :, : o.shape[1], : o.shape[2]].copy_(o)
+    return b
+imgs = [torch.rand(3, h, w, generator=g).to(dev) for h, w in ((480, 640), (720, 1280), (600, 800), (1080, 1920))]
+a, _ = vision_amd.transform_images(imgs); b = ref_transform(imgs)
+print("transform max |fused - torch chain| =", (a - b).abs().max().item(), tuple(a.shape))
+t1 = tm(lambda: vision_amd.transform_images(imgs)); t2 = tm(lambda: ref_transform(imgs), n=5, warm=1)
+print(f"GeneralizedRCNNTransform 4 images -> {tuple(a.shape)}: fused {t1:.3f} ms | per-image torch chain {t2:.3f} ms | x{t2 / t1:.1f}")

@@ -181,12 +181,17 @@ def _fake_box_iou_pairwise(boxes1, boxes2, generalized):
     return boxes1.new_empty((boxes1.shape[0], boxes2.shape[0]), dtype=dt)
 
 
+def _fake_normalize_resize_batch(images, out_heights, out_widths, mean, std, padded_h, padded_w):
+    return images[0].new_empty((len(images), images[0].shape[0], padded_h, padded_w))
+
+
 def _fake_boxes_to_rois(boxes):
     return boxes[0].new_empty((sum(b.shape[0] for b in boxes), 5))
 
 
 _FAKES = {
     "tvmi::boxes_to_rois": _fake_boxes_to_rois,
+    "tvmi::normalize_resize_batch": _fake_normalize_resize_batch,
     "tvmi::box_iou_pairwise": _fake_box_iou_pairwise,
     "tvmi::nms_segmented_padded": _fake_nms_padded,
     "tvmi::pack_detections_devcount": _fake_pack_devcount,

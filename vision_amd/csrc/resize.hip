@@ -298,6 +298,49 @@ __global__ __launch_bounds__(kThreads) void paste_masks_kernel(const T* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// GeneralizedRCNNTransform.forward for a batch of images (models/detection/transform.py:119-255):
+// per image normalize ((x - mean) / std, :154-165), bilinear resize to the size the reference's
+// scale rule gives (_resize_image_and_masks :25-72, F.interpolate align_corners=False), then
+// zero-padded batching to a common size divisible by 32 (batch_images :228-246).  The reference
+// runs ~6 launches and two host->device copies PER IMAGE; here one output-stationary launch
+// writes the whole [B,3,Hp,Wp] batch once.  Each of the 4 taps is normalised exactly like the
+// reference normalises the source pixel before the interpolation consumes it.
+constexpr int kXformMaxImages = 64;
+struct XformImages {
+  const void* ptr[kXformMaxImages];
+  int H[kXformMaxImages], W[kXformMaxImages];    // source size
+  int OH[kXformMaxImages], OW[kXformMaxImages];  // resized size (<= Hp, Wp)
+  float mean[4], stdv[4];
+  int C;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void normalize_resize_batch_kernel(XformImages im, T* __restrict__ out, int Hp, int Wp) {
+  const int x = blockIdx.x * kThreads + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= Wp) return;
+  const int H = im.H[b], W = im.W[b], OH = im.OH[b], OW = im.OW[b];
+  T* o = out + ((int64_t)b * im.C * Hp + y) * Wp + x;
+  const int64_t oplane = (int64_t)Hp * Wp;
+  if (y >= OH || x >= OW) {
+    for (int c = 0; c < im.C; ++c) st(o + c * oplane, 0.f);
+    return;
+  }
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  const Lin ly = linear_index(sh, y, H, OH, false);
+  const Lin lx = linear_index(sw, x, W, OW, false);
+  const T* src = static_cast<const T*>(im.ptr[b]);
+  const int64_t iplane = (int64_t)H * W;
+  for (int c = 0; c < im.C; ++c) {
+    const T* p = src + c * iplane;
+    const float m = im.mean[c], sd = im.stdv[c];
+    const float v00 = (ld(p + (int64_t)ly.i0 * W + lx.i0) - m) / sd, v01 = (ld(p + (int64_t)ly.i0 * W + lx.i1) - m) / sd;
+    const float v10 = (ld(p + (int64_t)ly.i1 * W + lx.i0) - m) / sd, v11 = (ld(p + (int64_t)ly.i1 * W + lx.i1) - m) / sd;
+    st(o + c * oplane, ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11));
+  }
+}
+
 struct Launch {
   dim3 grid;
   int nc_per_block;
@@ -414,4 +457,38 @@ extern "C" int tvmi_paste_masks(const void* masks, const float* boxes, void* out
   });
 #undef TVMI_PASTE
   TVMI_RETURN_LAUNCH_STATUS("tvmi_paste_masks");
+}
+
+extern "C" int tvmi_normalize_resize_batch(const void* const* images, const int64_t* heights, const int64_t* widths,
+                                           const int64_t* out_heights, const int64_t* out_widths, int64_t num_images,
+                                           int64_t channels, const float* mean, const float* stdv, void* output,
+                                           tvmi_dtype dt, int64_t padded_h, int64_t padded_w, void* stream) {
+  TVMI_CHECK_ARG(num_images >= 0 && num_images <= tvmi::kXformMaxImages, "normalize_resize_batch: at most 64 images per call");
+  if (num_images * channels * padded_h * padded_w == 0) return 0;
+  TVMI_CHECK_ARG(images && heights && widths && out_heights && out_widths && mean && stdv && output,
+                 "normalize_resize_batch: null pointer");
+  TVMI_CHECK_ARG(channels >= 1 && channels <= 4, "normalize_resize_batch: 1..4 channels");
+  TVMI_CHECK_ARG(padded_h <= 65535 && padded_h * padded_w < (1ll << 31), "normalize_resize_batch: size too large");
+  tvmi::XformImages im;
+  for (int i = 0; i < tvmi::kXformMaxImages; ++i) {
+    const int j = i < num_images ? i : 0;
+    TVMI_CHECK_ARG(images[j] && heights[j] > 0 && widths[j] > 0 && heights[j] * widths[j] < (1ll << 31) &&
+                       out_heights[j] > 0 && out_widths[j] > 0 && out_heights[j] <= padded_h && out_widths[j] <= padded_w,
+                   "normalize_resize_batch: bad image geometry");
+    im.ptr[i] = images[j];
+    im.H[i] = (int)heights[j];
+    im.W[i] = (int)widths[j];
+    im.OH[i] = (int)out_heights[j];
+    im.OW[i] = (int)out_widths[j];
+  }
+  for (int c = 0; c < 4; ++c) {
+    im.mean[c] = c < channels ? mean[c] : 0.f;
+    im.stdv[c] = c < channels ? stdv[c] : 1.f;
+  }
+  im.C = (int)channels;
+  const dim3 grid((unsigned)ceil_div(padded_w, kThreads), (unsigned)padded_h, (unsigned)num_images);
+  TVMI_DISPATCH_FLOAT(dt, "normalize_resize_batch",
+                      normalize_resize_batch_kernel<scalar_t><<<grid, dim3(kThreads), 0, static_cast<hipStream_t>(stream)>>>(
+                          im, static_cast<scalar_t*>(output), (int)padded_h, (int)padded_w));
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_normalize_resize_batch");
 }

@@ -840,6 +840,44 @@ at::Tensor box_iou_pairwise(const at::Tensor& boxes1, const at::Tensor& boxes2, 
   return out;
 }
 
+// ---- GeneralizedRCNNTransform.forward for a batch in one launch (resize.hip)
+at::Tensor normalize_resize_batch(at::TensorList images, at::IntArrayRef out_heights, at::IntArrayRef out_widths,
+                                  at::ArrayRef<double> mean, at::ArrayRef<double> stdv, int64_t padded_h, int64_t padded_w) {
+  TORCH_CHECK(images.size() >= 1 && images.size() <= 64, "normalize_resize_batch: 1..64 images supported");
+  TORCH_CHECK(images.size() == out_heights.size() && images.size() == out_widths.size(),
+              "normalize_resize_batch: one output size per image");
+  const at::Tensor& i0 = images[0];
+  TORCH_CHECK(i0.is_cuda() && i0.dim() == 3, "normalize_resize_batch: images must be 3d CUDA tensors [C, H, W]");
+  const int64_t C = i0.size(0);
+  TORCH_CHECK((int64_t)mean.size() == C && (int64_t)stdv.size() == C && C <= 4, "normalize_resize_batch: one mean / std per channel (<= 4)");
+  c10::DeviceGuard guard(i0.device());
+  std::vector<at::Tensor> keep;
+  std::vector<const void*> ptrs;
+  std::vector<int64_t> hs, ws, ohs(out_heights.begin(), out_heights.end()), ows(out_widths.begin(), out_widths.end());
+  for (const at::Tensor& im : images) {
+    TORCH_CHECK(im.is_cuda() && im.dim() == 3 && im.size(0) == C && im.scalar_type() == i0.scalar_type() && im.device() == i0.device(),
+                "normalize_resize_batch: images must share channel count, dtype and device");
+    TORCH_CHECK(im.is_floating_point(), "Expected input images to be of floating type (in range [0, 1]), but found type ",
+                im.scalar_type(), " instead");
+    keep.push_back(im.contiguous());
+    ptrs.push_back(keep.back().const_data_ptr());
+    hs.push_back(im.size(1));
+    ws.push_back(im.size(2));
+  }
+  float m[4] = {0, 0, 0, 0}, sd[4] = {1, 1, 1, 1};
+  for (int64_t c = 0; c < C; ++c) {
+    // torch.as_tensor(image_mean, dtype=image.dtype): the constants are rounded to the image dtype first
+    m[c] = (float)mean[c];
+    sd[c] = (float)stdv[c];
+  }
+  at::Tensor out = at::empty({(int64_t)images.size(), C, padded_h, padded_w}, i0.options());
+  check_status(tvmi_normalize_resize_batch(ptrs.data(), hs.data(), ws.data(), ohs.data(), ows.data(), (int64_t)images.size(), C, m,
+                                           sd, out.mutable_data_ptr(), dtype_of(i0, "normalize_resize_batch"), padded_h,
+                                           padded_w, current_stream(i0)),
+               "normalize_resize_batch");
+  return out;
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -900,6 +938,9 @@ TORCH_LIBRARY(tvmi, m) {
       "detection_candidates(Tensor class_logits, Tensor box_regression, Tensor proposals, Tensor row_image, Tensor image_hw, float[] weights, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor)");
   m.def(
       "rpn_candidates(Tensor objectness, Tensor boxes, Tensor? deltas, Tensor top_idx, Tensor level_offsets, Tensor image_hw, float bbox_xform_clip, float score_thresh, float min_size) -> (Tensor, Tensor, Tensor, Tensor)");
+  // models/detection/transform.py:119-255 (normalize + resize + zero-padded batching) as one launch
+  m.def(
+      "normalize_resize_batch(Tensor[] images, int[] out_heights, int[] out_widths, float[] mean, float[] std, int padded_h, int padded_w) -> Tensor");
   // ops/boxes.py:314-391 / 409-436 (box_iou / generalized_box_iou of xyxy boxes) as one launch
   m.def("box_iou_pairwise(Tensor boxes1, Tensor boxes2, bool generalized) -> Tensor");
   // ops/_utils.py:18-25 (cat + full_like per image + 2 cats) as one launch
@@ -935,6 +976,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);
   m.impl("boxes_to_rois", &boxes_to_rois);
+  m.impl("normalize_resize_batch", &normalize_resize_batch);
   m.impl("box_iou_pairwise", &box_iou_pairwise);
   m.impl("detection_candidates", &detection_candidates);
   m.impl("rpn_candidates", &rpn_candidates);
