@@ -79,6 +79,41 @@ def test_nms_against_reference_cpu_kernel(tv, need_ref):
         assert torch.equal(tv.nms(b.to(DEV), s.to(DEV), 0.7).cpu(), tv.nms(b, s, 0.7))
 
 
+def test_nms_threshold_edge_is_exact_without_the_division(tv):
+    """The mask kernels decide most pairs with two float products and only divide inside a narrow band around the
+    threshold; the outcome must equal the reference's `(double)(inter / union) > thr` for EVERY pair, in particular
+    for IoUs that sit exactly on, one ulp above or one ulp below the threshold (float and double neighbours), for
+    zero / negative unions and for thresholds outside the fast path's range."""
+    g = gen(29)
+    n = 1500
+    # integer-coordinate boxes on a small canvas: thousands of pairs share exactly representable IoUs (1/2, 1/3, 2/3, ...)
+    xy = torch.randint(0, 12, (n, 2), generator=g).float()
+    wh = torch.randint(1, 7, (n, 2), generator=g).float()
+    boxes = torch.cat([xy, xy + wh], 1)
+    boxes[::97, 2:] = boxes[::97, :2]            # zero-area boxes: 0/0
+    boxes[5::131, 2] = boxes[5::131, 0] - 2.0    # inverted boxes: negative area / union
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, 3, (n,), generator=g)
+    thrs = []
+    for q in (0.5, 1.0 / 3.0, 2.0 / 3.0, 0.25, 0.2, 0.6):
+        f = np.float32(q)
+        thrs += [float(q), float(f), float(np.nextafter(f, np.float32(0))), float(np.nextafter(f, np.float32(1))),
+                 float(np.nextafter(np.float64(f), 0.0)), float(np.nextafter(np.float64(f), 1.0))]
+    thrs += [0.0, 1e-40, -0.5, 1.0, 2.0, float("inf")]
+    bd, sd, idd = boxes.to(DEV), scores.to(DEV), idxs.to(DEV)
+    for thr in thrs:
+        want = O.nms(boxes.numpy(), scores.numpy(), thr)
+        assert np.array_equal(tv.nms(bd, sd, thr).cpu().numpy(), want), thr
+        wseg = O.nms(boxes.numpy(), scores.numpy(), thr, idxs.numpy())
+        assert np.array_equal(vision_amd.batched_nms(bd, sd, idd, thr, num_segments=3).cpu().numpy(), wseg), thr
+    big = torch.cat([boxes] * 4) + torch.arange(4 * n)[:, None].float() * 0   # n > 4096: segment-major kernel
+    sbig = torch.rand(4 * n, generator=g)
+    ibig = torch.randint(0, 5, (4 * n,), generator=g)
+    for thr in thrs[:12]:
+        want = O.nms(big.numpy(), sbig.numpy(), thr, ibig.numpy())
+        assert np.array_equal(vision_amd.batched_nms(big.to(DEV), sbig.to(DEV), ibig.to(DEV), thr).cpu().numpy(), want), thr
+
+
 def test_batched_nms_native_segmented_path():
     g = gen(6)
     n = 30000  # numel 120k > 100k -> "vanilla" semantics via tvmi::nms_segmented

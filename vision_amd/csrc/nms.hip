@@ -29,7 +29,9 @@
 //      the not-yet-removed bits (s_ff1 + v_readlane).  Kept original indices are written in
 //      score order and the running count stays on the device — no masked_select pass.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "tvmi_common.h"
 
@@ -85,11 +87,149 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
          (u64)(unsigned int)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// The suppression predicate `(double)(inter / union) > thr` (cpu/nms_kernel.cpp:88) without the IEEE division in
+// the common case.  With u = the smallest float above thr and d = the largest float at or below it, RN(q) > thr
+// <=> RN(q) >= u, which q >= u guarantees, and RN(q) <= d is guaranteed by q <= d.  The host passes
+// t_hi >= u (1 + 2^-20) and t_lo <= d (1 - 2^-20), margins that swallow the rounding of the two float products, so
+//   union > 0 && inter > t_hi * union  => certainly suppressed,   union > 0 && inter < t_lo * union => certainly not,
+// and only lanes inside the 2^-19-wide band (or with a non-positive / NaN union) take the exact division.  The
+// result is bit-identical to evaluating the division everywhere; the mask kernels are VALU-bound and the
+// division + double compare were ~40 % of their instructions.
+struct ThrBand {
+  float lo, hi;
+};
+inline ThrBand thr_band(double thr) {
+  ThrBand b{-INFINITY, INFINITY};  // = "always take the exact path"
+  static const bool force_exact = []() {
+    const char* e = getenv("TVMI_NMS_EXACT");  // analysis knob: evaluate the division for every pair
+    return e && e[0] == '1';
+  }();
+  if (force_exact || !(thr > 1e-30 && thr < 1e30)) return b;
+  float d = (float)thr;
+  if ((double)d > thr) d = nextafterf(d, -INFINITY);  // largest float <= thr
+  const float u = nextafterf(d, INFINITY);            // smallest float > thr
+  b.hi = nextafterf((float)((double)u * (1.0 + 1.0 / 1048576.0)), INFINITY);
+  b.lo = nextafterf((float)((double)d * (1.0 - 1.0 / 1048576.0)), -INFINITY);
+  return b;
+}
+template <typename T>
+__device__ __forceinline__ bool iou_over(T inter, T uni, double thr, ThrBand band) {
+  if constexpr (std::is_same<T, float>::value) {
+    const bool pos = uni > 0.f;
+    const bool sure_t = pos && inter > band.hi * uni;
+    const bool sure_f = pos && inter < band.lo * uni;
+    if (sure_t || sure_f) return sure_t;
+  }
+  return (double)(inter / uni) > thr;
+}
+
+// One 64x64 suppression tile: lane = column box (registers), the row boxes come from LDS (`rows`, 64 rows of 5
+// values: x1,y1,x2,y2,area; `row_keys` = their segment ids or nullptr).  Returns, in lane r, the 64-bit word of row r.
+//
+// exact form: the reference's expression for every pair (also the only form for float64 boxes)
+template <typename T>
+__device__ __forceinline__ u64 suppression_tile_exact(const T* __restrict__ rows, const long long* __restrict__ row_keys,
+                                                      T jx1, T jy1, T jx2, T jy2, T jarea, long long jkey, u64 valid_cols,
+                                                      bool diag, double thr) {
+  const int lane = threadIdx.x & 63;
+  u64 mine = 0ull;
+  for (int i = 0; i < 64; ++i) {
+    const T ix1 = rows[i * 5 + 0], iy1 = rows[i * 5 + 1], ix2 = rows[i * 5 + 2], iy2 = rows[i * 5 + 3];
+    const T iarea = rows[i * 5 + 4];
+    const T xx1 = ix1 > jx1 ? ix1 : jx1;  // std::max(ix1, x1[j])
+    const T yy1 = iy1 > jy1 ? iy1 : jy1;
+    const T xx2 = jx2 < ix2 ? jx2 : ix2;  // std::min(ix2, x2[j])
+    const T yy2 = jy2 < iy2 ? jy2 : iy2;
+    const T dw = xx2 - xx1, dh = yy2 - yy1;
+    const T w = (T)0 < dw ? dw : (T)0;    // std::max(0, xx2 - xx1)
+    const T h = (T)0 < dh ? dh : (T)0;
+    const T inter = w * h;
+    bool p = (double)(inter / (iarea + jarea - inter)) > thr;
+    if (diag) p = p && (lane > i);
+    if (row_keys) p = p && (jkey == row_keys[i]);
+    const u64 word = __ballot(p) & valid_cols;
+    if (lane == i) mine = word;
+  }
+  return mine;
+}
+
+// fast form (float32): the loop is fully unrolled and written for the machine's real bottleneck.  A CU has ONE
+// scalar ALU for its four SIMDs, so a scalar instruction costs as much issue time as a vector one; the per-row work
+// is therefore kept on the vector side: the band test of iou_over() (the union is replaced by NaN when it is not
+// positive, which makes both comparisons false = undecided), raw v_max / v_min (the builtins would canonicalise each
+// LDS operand with an extra instruction; they differ from std::max / std::min only for NaN operands, and a NaN
+// coordinate makes that box's area, the union and the predicate NaN / false either way), the row word parked with
+// v_writelane (lane select through M0).  Per row that leaves three scalar ops (M0, collecting the undecided lanes); a tile
+// with any undecided pair — IoU within 2^-19 of the threshold, or a non-positive union — is simply redone in the
+// exact form, so the result is bit-identical to evaluating the division everywhere.
+template <int I, bool DIAG, bool KEYS>
+__device__ __forceinline__ void suppression_row(const float* __restrict__ rows, const long long* __restrict__ row_keys,
+                                                float jx1, float jy1, float jx2, float jy2, float jarea, long long jkey,
+                                                ThrBand band, int& mine_lo, int& mine_hi, u64& undecided) {
+  const float ix1 = rows[I * 5 + 0], iy1 = rows[I * 5 + 1], ix2 = rows[I * 5 + 2], iy2 = rows[I * 5 + 3];
+  const float iarea = rows[I * 5 + 4];
+  float xx1, yy1, xx2, yy2;
+  asm("v_max_f32 %0, %1, %2" : "=v"(xx1) : "v"(ix1), "v"(jx1));
+  asm("v_max_f32 %0, %1, %2" : "=v"(yy1) : "v"(iy1), "v"(jy1));
+  asm("v_min_f32 %0, %1, %2" : "=v"(xx2) : "v"(ix2), "v"(jx2));
+  asm("v_min_f32 %0, %1, %2" : "=v"(yy2) : "v"(iy2), "v"(jy2));
+  const float dw = xx2 - xx1, dh = yy2 - yy1;
+  const float w = 0.f < dw ? dw : 0.f;
+  const float h = 0.f < dh ? dh : 0.f;
+  const float inter = w * h;
+  float uni = iarea + jarea - inter;
+  uni = uni > 0.f ? uni : __builtin_nanf("");
+  const u64 over = __ballot(inter > band.hi * uni);
+  const u64 under = __ballot(inter < band.lo * uni);
+  undecided |= ~(over | under);
+  u64 word = over;
+  if (DIAG) word &= I < 63 ? (~0ull << ((I + 1) & 63)) : 0ull;  // only columns after the row
+  if (KEYS) word &= __ballot(jkey == row_keys[I]);
+  // gfx9 takes the lane select of v_writelane from an SGPR or M0 (an inline constant assembles but selects the wrong
+  // lane for I >= 32 — measured), and only one SGPR may sit on the constant bus: the row index goes through M0,
+  // which the caller saves and restores around the 64 rows.
+  asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+               : "+v"(mine_lo), "+v"(mine_hi)
+               : "s"((int)(unsigned)word), "n"(I), "s"((int)(unsigned)(word >> 32)));
+}
+
+template <bool DIAG, bool KEYS, int... Is>
+__device__ __forceinline__ void suppression_rows(std::integer_sequence<int, Is...>, const float* __restrict__ rows,
+                                                 const long long* __restrict__ row_keys, float jx1, float jy1, float jx2,
+                                                 float jy2, float jarea, long long jkey, ThrBand band, int& mine_lo,
+                                                 int& mine_hi, u64& undecided) {
+  (suppression_row<Is, DIAG, KEYS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided), ...);
+}
+
+template <typename T>
+__device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, const long long* __restrict__ row_keys,
+                                                T jx1, T jy1, T jx2, T jy2, T jarea, long long jkey, bool jvalid, bool diag,
+                                                double thr, ThrBand band) {
+  const u64 valid_cols = __ballot(jvalid);
+  if constexpr (std::is_same<T, float>::value) {
+    int mine_lo = 0, mine_hi = 0, m0_save;
+    u64 undecided = 0ull;
+    const auto seq = std::make_integer_sequence<int, 64>{};
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0_save));
+    if (row_keys) {
+      if (diag) suppression_rows<true, true>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
+      else suppression_rows<false, true>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
+    } else {
+      if (diag) suppression_rows<true, false>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
+      else suppression_rows<false, false>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
+    }
+    asm volatile("s_mov_b32 m0, %0" : : "s"(m0_save));
+    if ((undecided & valid_cols) == 0ull)
+      return (((u64)(unsigned)mine_hi << 32) | (u64)(unsigned)mine_lo) & valid_cols;
+  }
+  return suppression_tile_exact<T>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, valid_cols, diag, thr);
+}
+
 // mask layout: tile (rb, cb) = 64 words at mask + (rb*CB + cb)*64; word r = row rb*64+r.
 template <typename T>
 __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     const T* __restrict__ dets, const int64_t* __restrict__ order, const int64_t* __restrict__ seg, int n, int CB,
-    double thr, u64* __restrict__ mask) {
+    double thr, ThrBand band, u64* __restrict__ mask) {
   __shared__ T s_row[64][5];  // x1,y1,x2,y2,area of the row block
   __shared__ long long s_seg[64];
   const int lane = threadIdx.x & 63;
@@ -134,27 +274,8 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     if (seg) jseg = seg[oj];
   }
   const T jarea = (jx2 - jx1) * (jy2 - jy1);
-  const bool diag = cb == rb;
-  const int rows_here = min(64, n - row0);
-  u64 mine = 0ull;
-  for (int i = 0; i < rows_here; ++i) {
-    const T ix1 = s_row[i][0], iy1 = s_row[i][1], ix2 = s_row[i][2], iy2 = s_row[i][3];
-    const T iarea = s_row[i][4];
-    const T xx1 = ix1 > jx1 ? ix1 : jx1;  // std::max(ix1, x1[j])
-    const T yy1 = iy1 > jy1 ? iy1 : jy1;
-    const T xx2 = jx2 < ix2 ? jx2 : ix2;  // std::min(ix2, x2[j])
-    const T yy2 = jy2 < iy2 ? jy2 : iy2;
-    const T dw = xx2 - xx1, dh = yy2 - yy1;
-    const T w = (T)0 < dw ? dw : (T)0;    // std::max(0, xx2-xx1)
-    const T h = (T)0 < dh ? dh : (T)0;
-    const T inter = w * h;
-    const T ovr = inter / (iarea + jarea - inter);
-    bool p = ((double)ovr > thr) && jvalid;
-    if (diag) p = p && (lane > i);
-    if (seg) p = p && (jseg == s_seg[i]);
-    const u64 word = __ballot(p);
-    if (lane == i) mine = word;
-  }
+  const u64 mine = suppression_tile<T>(&s_row[0][0], seg ? s_seg : nullptr, jx1, jy1, jx2, jy2, jarea, jseg, jvalid,
+                                       cb == rb, thr, band);
   mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
 }
 
@@ -341,7 +462,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   u64* keepbits = removed + CB;
   const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
   nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), order, seg, (int)n, CB,
-                                                                   thr, mask);
+                                                                   thr, thr_band(thr), mask);
   if (CB <= kSmallCB) {  // latency-bound sizes: the whole sweep is one launch
     nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, (int)n, CB, keep_out, num_keep);
     TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
@@ -402,7 +523,7 @@ template <typename T>
 __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T* __restrict__ dets,
                                                                          const int64_t* __restrict__ oidx,
                                                                          const int64_t* __restrict__ keys, int n, int CB,
-                                                                         double thr, u64* __restrict__ mask) {
+                                                                         double thr, ThrBand band, u64* __restrict__ mask) {
   __shared__ T s_row[64][5];
   __shared__ long long s_key[64];
   __shared__ int s_cbmax;
@@ -439,7 +560,6 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
   }
   __syncthreads();
   const int cbmax = s_cbmax;
-  const int rows_here = min(64, n - row0);
   for (int cb = rb + wave; cb <= cbmax; cb += kMaskWaves) {
     const int j = cb * 64 + lane;
     T jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0;
@@ -454,25 +574,7 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
       jkey = keys[j];
     }
     const T jarea = (jx2 - jx1) * (jy2 - jy1);
-    const bool diag = cb == rb;
-    u64 mine = 0ull;
-    for (int i = 0; i < rows_here; ++i) {
-      const T ix1 = s_row[i][0], iy1 = s_row[i][1], ix2 = s_row[i][2], iy2 = s_row[i][3];
-      const T iarea = s_row[i][4];
-      const T xx1 = ix1 > jx1 ? ix1 : jx1;
-      const T yy1 = iy1 > jy1 ? iy1 : jy1;
-      const T xx2 = jx2 < ix2 ? jx2 : ix2;
-      const T yy2 = jy2 < iy2 ? jy2 : iy2;
-      const T dw = xx2 - xx1, dh = yy2 - yy1;
-      const T w = (T)0 < dw ? dw : (T)0;
-      const T h = (T)0 < dh ? dh : (T)0;
-      const T inter = w * h;
-      const T ovr = inter / (iarea + jarea - inter);
-      bool pr = ((double)ovr > thr) && jvalid && (jkey == s_key[i]);
-      if (diag) pr = pr && (lane > i);
-      const u64 word = __ballot(pr);
-      if (lane == i) mine = word;
-    }
+    const u64 mine = suppression_tile<T>(&s_row[0][0], s_key, jx1, jy1, jx2, jy2, jarea, jkey, jvalid, cb == rb, thr, band);
     mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
   }
 }
@@ -662,7 +764,7 @@ inline size_t small_seg_workspace_layout(int64_t n, int64_t S, char* base, Small
 
 template <typename T>
 __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict__ dets, const int64_t* __restrict__ order,
-                                                            const int64_t* __restrict__ seg, int n, int S, double thr,
+                                                            const int64_t* __restrict__ seg, int n, int S, double thr, ThrBand band,
                                                             SmallSegWorkspace ws) {
   __shared__ T s_box[kSmallSegBoxes][5];
   __shared__ int s_wcnt[16];
@@ -728,26 +830,8 @@ __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict_
   const bool jvalid = j < cnt;
   const int jj = jvalid ? j : 0;
   const T jx1 = s_box[jj][0], jy1 = s_box[jj][1], jx2 = s_box[jj][2], jy2 = s_box[jj][3], jarea = s_box[jj][4];
-  const bool diag = cb == rb;
-  const int rows_here = min(64, cnt - rb * 64);
-  u64 mine = 0ull;
-  for (int i = 0; i < rows_here; ++i) {
-    const int r = rb * 64 + i;
-    const T ix1 = s_box[r][0], iy1 = s_box[r][1], ix2 = s_box[r][2], iy2 = s_box[r][3], iarea = s_box[r][4];
-    const T xx1 = ix1 > jx1 ? ix1 : jx1;
-    const T yy1 = iy1 > jy1 ? iy1 : jy1;
-    const T xx2 = jx2 < ix2 ? jx2 : ix2;
-    const T yy2 = jy2 < iy2 ? jy2 : iy2;
-    const T dw = xx2 - xx1, dh = yy2 - yy1;
-    const T w = (T)0 < dw ? dw : (T)0;
-    const T h = (T)0 < dh ? dh : (T)0;
-    const T inter = w * h;
-    const T ovr = inter / (iarea + jarea - inter);
-    bool pr = ((double)ovr > thr) && jvalid;
-    if (diag) pr = pr && (lane > i);
-    const u64 word = __ballot(pr);
-    if (lane == i) mine = word;
-  }
+  const u64 mine = suppression_tile<T>(&s_box[rb * 64][0], nullptr, jx1, jy1, jx2, jy2, jarea, 0, jvalid, cb == rb, thr,
+                                       band);
   ws.tiles[((size_t)me * kSmallSegTiles + t) * 64 + lane] = mine;
 }
 
@@ -872,7 +956,7 @@ int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, cons
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms_segmented: memset");
   nms_seg_layout<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream>>>(order, perm, (int)n, w.oidx, w.invperm);
   nms_mask_tiles_seg<T><<<dim3((unsigned)CB), dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), w.oidx, keys,
-                                                                                  (int)n, CB, thr, w.mask);
+                                                                                  (int)n, CB, thr, thr_band(thr), w.mask);
   nms_sweep_seg<<<dim3((unsigned)CB), dim3(kSuper * kWave), 0, stream>>>(w.mask, keys, (int)n, CB, w.keepbits, w.err);
   nms_seg_count<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, (int)n, w.counts);
   nms_seg_emit<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, order, w.counts, (int)n, w.err, keep_out,
@@ -962,10 +1046,10 @@ extern "C" int tvmi_nms_small_segments(const void* dets, const int64_t* order, c
   const dim3 grid((unsigned)num_segments, (unsigned)tvmi::ceil_div(nbmax * (nbmax + 1) / 2, 16));
   if (dt == TVMI_F32)
     tvmi::nms_small_seg_tiles<float><<<grid, dim3(1024), 0, s>>>(static_cast<const float*>(dets), order, seg, (int)n,
-                                                                 (int)num_segments, iou_threshold, w);
+                                                                 (int)num_segments, iou_threshold, tvmi::thr_band(iou_threshold), w);
   else
     tvmi::nms_small_seg_tiles<double><<<grid, dim3(1024), 0, s>>>(static_cast<const double*>(dets), order, seg, (int)n,
-                                                                  (int)num_segments, iou_threshold, w);
+                                                                  (int)num_segments, iou_threshold, tvmi::thr_band(iou_threshold), w);
   tvmi::nms_small_seg_sweep<<<dim3((unsigned)num_segments), dim3(tvmi::kSuper * tvmi::kWave), 0, s>>>(order, (int)n, w, keep_out,
                                                                                                     num_keep_out);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_small_segments");
