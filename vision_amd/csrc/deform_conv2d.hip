@@ -22,6 +22,7 @@
 // Backward pieces (im2col, col2im, col2im_coord) are separate kernels combined with plain
 // library GEMMs by the dispatcher glue.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "tvmi_common.h"
@@ -89,6 +90,32 @@ __device__ __forceinline__ void load_tap(Tap<A>& t, const DcnParams& p, const T*
   make_tap<A>(t, p.H, p.W, y, x, mval);
 }
 
+// The 4 corners of a tap are two horizontally adjacent pairs: (o1, o2) and (o3, o4) with o2 - o1 = o4 - o3 in
+// {0, 1}.  The fused kernel is bound by the rate at which the texture addresser retires SCATTERED loads (~1 lane per
+// clock: 62.7 M im2col elements x 4 corners at config 4), so it fetches each pair with ONE 8-byte load.  `sel` says
+// which halves are (v_left, v_right): 0 = (lo, hi) regular; 1 = (lo, lo) and 2 = (hi, hi) when the column was
+// clamped (both taps are the same pixel) — in the last column the pair starts one element earlier so that it never
+// leaves the row.  Needs W >= 2.
+struct PairPlan {
+  int b0, b1, sel;
+};
+struct __attribute__((packed, aligned(4))) F32Pair {
+  float lo, hi;
+};
+__device__ __forceinline__ PairPlan make_pair_plan(const Tap<float>& t, int W) {
+  PairPlan q;
+  q.b0 = t.o1;
+  q.b1 = t.o3;
+  q.sel = 0;
+  if (t.o2 == t.o1) {
+    const bool last_col = (t.o1 % W) == W - 1;
+    q.sel = last_col ? 2 : 1;
+    q.b0 -= last_col ? 1 : 0;
+    q.b1 -= last_col ? 1 : 0;
+  }
+  return q;
+}
+
 template <typename T, typename A>
 __device__ __forceinline__ A sample_tap(const Tap<A>& t, const T* __restrict__ plane) {
   const A v1 = ld(plane + t.o1), v2 = ld(plane + t.o2), v3 = ld(plane + t.o3), v4 = ld(plane + t.o4);
@@ -153,17 +180,24 @@ __global__ void dcn_weight_relayout(const float* __restrict__ w, float* __restri
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WM, int WN>  // waves along M (out channels) and N (pixels); WM*WN == 4
-__global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict__ input,
+// WM x WN waves along M (out channels) and N (pixels), each owning MI x NI MFMA blocks of 32 x 32.
+// More, smaller waves for the same workgroup tile (e.g. 8 waves of 64 x 32 instead of 4 of 64 x 64) double the
+// waves per SIMD on problems that only fill the chip once (config 4: 425 tiles for 256 CUs) — the gathers of the
+// next slab then have another wave's MFMAs to hide behind.
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __restrict__ input,
                                                         const float* __restrict__ wt,
                                                         const float* __restrict__ offset,
                                                         const float* __restrict__ mask,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         DcnParams p, int ICg_pad, int OCg_pad) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int NSUB = 256 / BN;        // channel subsets among the B-tile producers
+  constexpr int NT = 64 * WM * WN;      // threads per workgroup
+  constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+  constexpr int NSUB = NT / BN;         // channel subsets among the B-tile producers
   constexpr int BPT = kBK / NSUB;       // B elements per thread per slab
-  constexpr int APT = kBK * BM / 256;   // A elements per thread per slab (multiple of 4)
+  constexpr int AQ = kBK * BM / 4;               // float4 pieces of the A slab
+  constexpr int AV = (AQ + NT - 1) / NT;         // pieces per thread (the last round may be partial)
+  static_assert(NT % BN == 0 && kBK % NSUB == 0 && BM % 4 == 0, "tile shape does not divide evenly");
   __shared__ __attribute__((aligned(16))) float As[2][kBK][BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK][BN];
 
@@ -188,20 +222,23 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict_
   }
   const float* in_b = input + ((int64_t)pb * p.C + (int64_t)g * p.ICg) * in_plane;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   float bv[BPT][4];   // staged corner values of the next slab
-  float4 av[APT / 4]; // staged weights of the next slab
+  float4 av[AV];      // staged weights of the next slab
   Tap<float> tap_cur;
   tap_cur.o1 = tap_cur.o2 = tap_cur.o3 = tap_cur.o4 = 0;
   tap_cur.w1 = tap_cur.w2 = tap_cur.w3 = tap_cur.w4 = 0.f;
   tap_cur.m = 0.f;
+  PairPlan plan;
+  plan.b0 = plan.b1 = 0;
+  plan.sel = 1;
 
   // Slab iteration space: tap (outer) x offset-group segment x ic0 (inner).
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
@@ -209,7 +246,10 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict_
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
-    if (pix_ok) load_tap<float, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+    if (pix_ok) {
+      load_tap<float, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+      plan = make_pair_plan(tap_cur, p.W);
+    }
   };
   auto issue_loads = [&](int tap, int ic0, int kmax) {
 #pragma unroll
@@ -217,18 +257,20 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict_
       const int kk = csub + e * NSUB;
       if (kk < kmax && pix_ok) {
         const float* pl = in_b + (int64_t)(ic0 + kk) * in_plane;
-        bv[e][0] = pl[tap_cur.o1];
-        bv[e][1] = pl[tap_cur.o2];
-        bv[e][2] = pl[tap_cur.o3];
-        bv[e][3] = pl[tap_cur.o4];
+        const F32Pair r0 = *reinterpret_cast<const F32Pair*>(pl + plan.b0);
+        const F32Pair r1 = *reinterpret_cast<const F32Pair*>(pl + plan.b1);
+        bv[e][0] = r0.lo;  // raw halves; commit() picks (left, right) by plan.sel once the data is needed
+        bv[e][1] = r0.hi;
+        bv[e][2] = r1.lo;
+        bv[e][3] = r1.hi;
       } else {
         bv[e][0] = bv[e][1] = bv[e][2] = bv[e][3] = 0.f;
       }
     }
     const float* wsrc = wt + (((int64_t)g * KK + tap) * ICg_pad + ic0) * OCg_pad + oc0;
 #pragma unroll
-    for (int e = 0; e < APT / 4; ++e) {
-      const int lin = (tid + e * 256) * 4;
+    for (int e = 0; e < AV; ++e) {
+      const int lin = (tid + e * NT) * 4;
       const int kk = lin / BM, m = lin - kk * BM;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (kk < kmax && oc0 + m < OCg_pad) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)kk * OCg_pad + m);
@@ -239,14 +281,15 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < BPT; ++e) {
       const int kk = csub + e * NSUB;
-      Bs[buf][kk][pn] =
-          tap_cur.m * (tap_cur.w1 * bv[e][0] + tap_cur.w2 * bv[e][1] + tap_cur.w3 * bv[e][2] + tap_cur.w4 * bv[e][3]);
+      const float v1 = plan.sel == 2 ? bv[e][1] : bv[e][0], v2 = plan.sel == 1 ? bv[e][0] : bv[e][1];
+      const float v3 = plan.sel == 2 ? bv[e][3] : bv[e][2], v4 = plan.sel == 1 ? bv[e][2] : bv[e][3];
+      Bs[buf][kk][pn] = tap_cur.m * (tap_cur.w1 * v1 + tap_cur.w2 * v2 + tap_cur.w3 * v3 + tap_cur.w4 * v4);
     }
 #pragma unroll
-    for (int e = 0; e < APT / 4; ++e) {
-      const int lin = (tid + e * 256) * 4;
+    for (int e = 0; e < AV; ++e) {
+      const int lin = (tid + e * NT) * 4;
       const int kk = lin / BM, m = lin - kk * BM;
-      *reinterpret_cast<float4*>(&As[buf][kk][m]) = av[e];
+      if (AQ % NT == 0 || kk < kBK) *reinterpret_cast<float4*>(&As[buf][kk][m]) = av[e];
     }
   };
 
@@ -275,15 +318,15 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict_
     const int kq = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int kk = 0; kk < kBK; kk += 2) {
-      float a[2], b[2];
+      float a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = As[buf][kk + kq][wm * 64 + mi * 32 + l31];
+      for (int mi = 0; mi < MI; ++mi) a[mi] = As[buf][kk + kq][(wm * MI + mi) * 32 + l31];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) b[ni] = Bs[buf][kk + kq][wn * 64 + ni * 32 + l31];
+      for (int ni = 0; ni < NI; ++ni) b[ni] = Bs[buf][kk + kq][(wn * NI + ni) * 32 + l31];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
     s_tap = n_tap;
@@ -295,18 +338,18 @@ __global__ __launch_bounds__(256) void dcn_fwd_mfma_f32(const float* __restrict_
   // epilogue: D[row][col], col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (oc)
   const int l31 = lane & 31, kq = lane >> 5;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t pix = pix0 + wn * 64 + ni * 32 + l31;
+  for (int ni = 0; ni < NI; ++ni) {
+    const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
     if (pix >= npix) continue;
     const int ox = (int)(pix % p.ow);
     const int oy = (int)((pix / p.ow) % p.oh);
     const int b = (int)(pix / ((int64_t)p.ow * p.oh));
     float* obase = out + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * p.oh * p.ow + (int64_t)oy * p.ow + ox;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int oc = oc0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
         if (oc < p.OCg) obase[(int64_t)oc * p.oh * p.ow] = acc[mi][ni][r] + bias[g * p.OCg + oc];
       }
     }
@@ -476,7 +519,9 @@ int fill_params(DcnParams& p, int64_t B, int64_t C, int64_t H, int64_t W, int64_
   return 0;
 }
 
-inline bool use_mfma(const DcnParams& p, tvmi_dtype dt) { return dt == TVMI_F32 && p.OCg >= 16 && p.ICg >= 4; }
+inline bool use_mfma(const DcnParams& p, tvmi_dtype dt) {
+  return dt == TVMI_F32 && p.OCg >= 16 && p.ICg >= 4 && p.W >= 2;  // W >= 2: the corner pairs are 8-byte loads
+}
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1 << 20)); }
 
@@ -515,17 +560,25 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     const int64_t wtotal = (int64_t)p.groups * kh * kw * ICg_pad * OCg_pad;
     dcn_weight_relayout<<<grid1d(wtotal), dim3(256), 0, s>>>((const float*)weight, wt, p, ICg_pad, OCg_pad);
     const int64_t npix = (int64_t)B * p.oh * p.ow;
-#define TVMI_DCN(WM, WN)                                                                               \
-  dcn_fwd_mfma_f32<WM, WN>                                                                             \
-      <<<dim3((unsigned)ceil_div(npix, 64 * WN), (unsigned)ceil_div(p.OCg, 64 * WM), (unsigned)p.groups), \
-         dim3(256), 0, s>>>((const float*)input, wt, (const float*)offset, (const float*)mask,            \
-                            (const float*)bias, (float*)output, p, ICg_pad, OCg_pad)
+#define TVMI_DCN(WM, WN, MI, NI)                                                                                  \
+  dcn_fwd_mfma_f32<WM, WN, MI, NI>                                                                                \
+      <<<dim3((unsigned)ceil_div(npix, 32 * NI * WN), (unsigned)ceil_div(p.OCg, 32 * MI * WM), (unsigned)p.groups), \
+         dim3(64 * WM * WN), 0, s>>>((const float*)input, wt, (const float*)offset, (const float*)mask,              \
+                                     (const float*)bias, (float*)output, p, ICg_pad, OCg_pad)
+    // same workgroup tiles as before (256x64 / 128x128 / 64x256); when the tiles fill the chip less than ~3 times,
+    // 8 smaller waves per tile instead of 4 (TVMI_DCN_WAVES=4 / 8 forces either)
+    static const int force_waves = []() {
+      const char* e = getenv("TVMI_DCN_WAVES");
+      return e ? atoi(e) : 0;
+    }();
+    const int64_t ntiles = ceil_div(npix, p.OCg > 128 ? 64 : (p.OCg > 64 ? 128 : 256)) * ceil_div(p.OCg, p.OCg > 128 ? 256 : (p.OCg > 64 ? 128 : 64)) * p.groups;
+    const bool eight = force_waves ? force_waves == 8 : ntiles < 3 * 768;
     if (p.OCg > 128) {
-      TVMI_DCN(4, 1);
+      if (eight) TVMI_DCN(4, 2, 2, 1); else TVMI_DCN(4, 1, 2, 2);
     } else if (p.OCg > 64) {
-      TVMI_DCN(2, 2);
+      if (eight) TVMI_DCN(2, 4, 2, 1); else TVMI_DCN(2, 2, 2, 2);
     } else {
-      TVMI_DCN(1, 4);
+      if (eight) TVMI_DCN(1, 8, 2, 1); else TVMI_DCN(1, 4, 2, 2);
     }
 #undef TVMI_DCN
   } else {
