@@ -22,3 +22,9 @@ for groups, oc in ((1, 256), (1, 128), (1, 64), (256, 256)):
     t = tm(f)
     fl = 2 * 2 * oc * (256 // groups) * 9 * 100 * 136
     print(f"deform_conv2d 2x256x100x136 -> {oc} ch, groups={groups}: {t:.4f} ms  {fl / t / 1e9:.1f} TFLOP/s  (TVMI_DCN_WAVES={os.environ.get('TVMI_DCN_WAVES', 'auto')})")
+# a problem that fills the chip many times over
+x = torch.randn(4, 256, 200, 272, generator=g).to(dev); off = torch.randn(4, 18, 200, 272, generator=g).to(dev)
+w = (torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(dev); b = torch.zeros(256, device=dev)
+t = tm(lambda: torch.ops.torchvision.deform_conv2d(x, w, off, torch.zeros(4, 1, device=dev), b, 1, 1, 1, 1, 1, 1, 1, 1, False), n=5)
+fl = 2 * 4 * 256 * 256 * 9 * 200 * 272
+print(f"deform_conv2d 4x256x200x272 -> 256 ch: {t:.4f} ms  {fl / t / 1e9:.1f} TFLOP/s  (TVMI_DCN_WAVES={os.environ.get('TVMI_DCN_WAVES', 'auto')})")
