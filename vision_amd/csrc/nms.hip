@@ -737,7 +737,7 @@ struct SmallSegWorkspace {
   int* sync_words;       // [0] finished workgroups, [1] error flag
   int* gcnt;             // [S] boxes per segment
   int* glist;            // [S][1024] global rank of the i-th box of the segment
-  unsigned char* flags;  // [n] keep flag per global rank
+  int* flags;            // [n] keep flag per global rank
   u64* tiles;            // [S][136][64]
 };
 inline size_t small_seg_workspace_layout(int64_t n, int64_t S, char* base, SmallSegWorkspace* w) {
@@ -750,13 +750,13 @@ inline size_t small_seg_workspace_layout(int64_t n, int64_t S, char* base, Small
   char* sw = take(2 * sizeof(int));
   char* gc = take((size_t)S * sizeof(int));
   char* gl = take((size_t)S * kSmallSegBoxes * sizeof(int));
-  char* fl = take((size_t)n);
+  char* fl = take((size_t)n * sizeof(int));
   char* tl = take((size_t)S * kSmallSegTiles * 64 * sizeof(u64));
   if (w) {
     w->sync_words = reinterpret_cast<int*>(sw);
     w->gcnt = reinterpret_cast<int*>(gc);
     w->glist = reinterpret_cast<int*>(gl);
-    w->flags = reinterpret_cast<unsigned char*>(fl);
+    w->flags = reinterpret_cast<int*>(fl);
     w->tiles = reinterpret_cast<u64*>(tl);
   }
   return off;
@@ -884,20 +884,22 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int6
   }
   // one flag per box of my segment, at its global rank
   const int* glist = ws.glist + (size_t)me * kSmallSegBoxes;
+  // Published with agent-scope (write-through) stores and read back with agent-scope loads instead of release /
+  // acquire fences: on the 8-XCD part a device-scope fence is a write-back / invalidate of the whole L2 slice,
+  // which costs more than this kernel's actual work.
   for (int i = tid; i < cnt; i += kSuper * kWave)
-    ws.flags[glist[i]] = (unsigned char)((s_keepbits[i >> 6] >> (i & 63)) & 1ull);
+    __hip_atomic_store(&ws.flags[glist[i]], (int)((s_keepbits[i >> 6] >> (i & 63)) & 1ull), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   // last workgroup out compacts the flags in global score order
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my flag stores are acknowledged
   __syncthreads();
   if (tid == 0) s_flag = atomicAdd(&ws.sync_words[0], 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_flag) return;
-  __threadfence();
-  const volatile unsigned char* vflags = ws.flags;
   int run = 0;
   for (int base = 0; base < n; base += 1024) {
     const int g = base + tid;
-    const bool kept = g < n && vflags[g] != 0;
+    const bool kept = g < n && __hip_atomic_load(&ws.flags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const u64 bal = __ballot(kept);
     if (lane == 0) s_wcnt[wave] = __popcll(bal);
     __syncthreads();
