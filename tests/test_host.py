@@ -187,3 +187,17 @@ def test_cpu_tensors_without_reference_have_no_silent_fallback():
         pytest.skip("reference CPU kernels are loaded in this process")
     with pytest.raises((NotImplementedError, RuntimeError)):
         vision_amd.nms(torch.rand(3, 4), torch.rand(3), 0.5)
+
+
+def test_transform_size_rule_matches_reference_golden():
+    """`vision_amd.transform.resized_size` (host arithmetic of GeneralizedRCNNTransform) vs the image_sizes the
+    reference module produced (tests/golden/detection.npz)."""
+    from helpers import golden
+    from vision_amd.transform import resized_size
+
+    G = golden("detection")
+    shapes = [G[f"xform_img{i}"].shape[-2:] for i in range(4)]
+    for tag, kw in (("a", dict(min_size=96, max_size=160)), ("b", dict(min_size=64, max_size=100)),
+                    ("c", dict(min_size=50, max_size=80, fixed_size=(72, 56)))):
+        got = [resized_size(int(h), int(w), **kw) for h, w in shapes]
+        assert got == [tuple(int(v) for v in s) for s in G[f"xform_{tag}_sizes"]]
