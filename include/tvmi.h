@@ -143,8 +143,8 @@ int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void*
 
 /* The same operation on channels_last feature maps (element (n,c,y,x) at ((n*H+y)*W+x)*C+c;
  * SURVEY.md §8f-2): lane = channel, taps are coalesced loads off a scalar base, no LDS window.
- * Output is still the reference's NCHW-contiguous [K,C,PH,PW].  float32, 7x7 bins,
- * sampling_ratio 2, every level H,W >= 2; a single level with k_min == k_max is plain
+ * Output is still the reference's NCHW-contiguous [K,C,PH,PW].  float32 (or float16 / bfloat16 with
+ * an even channel count: two channels per lane), 7x7 bins, sampling_ratio 2, every level H,W >= 2; a single level with k_min == k_max is plain
  * roi_align.  The reference instead copies every map to NCHW first
  * (cuda/roi_align_kernel.cu:365 `input.contiguous()`).
  */

@@ -709,6 +709,15 @@ def test_roi_align_channels_last_native_kernel(tv):
                  [b.to(DEV) for b in boxes], [(800, 1344)] * 2)
     assert b.is_contiguous()
     np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=1e-6)
+    # 16-bit channels_last maps: two channels per lane; same values as the 16-bit NCHW path (fp32 accumulation in both)
+    for dt in (torch.float16, torch.bfloat16):
+        for C in (64, 200):
+            x = torch.rand(2, C, 46, 61, generator=g).to(dt)
+            rois = rois_for(2, 120, 61 * 8, 46 * 8, 8, 300, g).to(dt)
+            y_cl = tv.roi_align(x.to(DEV).contiguous(memory_format=torch.channels_last), rois.to(DEV), 1 / 8, 7, 7, 2, False)
+            y_nc = tv.roi_align(x.to(DEV), rois.to(DEV), 1 / 8, 7, 7, 2, False)
+            assert y_cl.dtype == dt and y_cl.is_contiguous()
+            assert torch.equal(y_cl, y_nc)
 
 
 def test_boxes_to_rois_one_launch():

@@ -48,3 +48,8 @@ t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fl_nhwc, rois, scales, 7, 7, 
 print(f"channels_last multiscale roi_align 7x7: {t:.4f} ms  ({566.35e6 / t / 1e6:.0f} GB/s algorithmic, {566.35e6 / t / 1e6 / 8000:.3f} of HBM peak)")
 tc = tm(lambda: [f.contiguous() for f in fl_nhwc])
 print(f"(reference route: NHWC->NCHW copies of the 4 maps alone {tc:.4f} ms)")
+for dt in (torch.float16, torch.bfloat16):
+    fh = [f.to(dt).contiguous(memory_format=torch.channels_last) for f in fl]
+    rh = rois.to(dt)
+    t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fh, rh, scales, 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6))
+    print(f"channels_last multiscale roi_align 7x7 {dt}: {t:.4f} ms  ({283.2e6 / t / 1e6:.0f} GB/s algorithmic)")

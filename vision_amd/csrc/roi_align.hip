@@ -1726,27 +1726,45 @@ int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, 
 // block is contiguous in the NCHW output, so it leaves as one linear store stream.  Arithmetic per output is identical to the NCHW kernels (same separable
 // factors, same FMA order).  The reference has no such path: cuda/roi_align_kernel.cu:365
 // calls input.contiguous(), i.e. pays a full NHWC->NCHW copy of every feature map first.
-template <int PHT, int PWT, int SRT>
+template <typename T, int PHT, int PWT, int SRT>
 struct NhwcShared {
-  float t[64 * (PHT * PWT)];  // [channel][bin], pitch PH*PW (odd for 7x7: conflict-free both ways)
+  // [channel][bin] block of one unit (64 lanes x 4 bytes of channels: 64 fp32 or 128 16-bit channels), pitch PH*PW
+  // (odd for 7x7: conflict-free both ways)
+  T t[64 * (4 / (int)sizeof(T)) * (PHT * PWT)];
 };
 
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const float* __restrict__ rois,
-                                                               float* __restrict__ output, int C, int aligned,
+// one 32-bit word of channels -> CPL floats
+template <typename T>
+__device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)sizeof(T)]) {
+  if constexpr (std::is_same<T, float>::value) {
+    v[0] = __builtin_bit_cast(float, w);
+  } else if constexpr (std::is_same<T, __half>::value) {
+    v[0] = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu)));
+    v[1] = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+  } else {  // bfloat16: the upper half of an fp32
+    v[0] = __builtin_bit_cast(float, w << 16);
+    v[1] = __builtin_bit_cast(float, w & 0xffff0000u);
+  }
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const T* __restrict__ rois,
+                                                               T* __restrict__ output, int C, int aligned,
                                                                int ngroups, int64_t nunits) {
   constexpr int PHW = PHT * PWT;
   constexpr int NS = SRT * SRT;
-  __shared__ NhwcShared<PHT, PWT, SRT> sh[kThreads / 64];
+  constexpr int CPL = 4 / (int)sizeof(T);  // channels per lane: every tap is one 32-bit load per lane
+  constexpr int GC = 64 * CPL;             // channels per unit
+  __shared__ NhwcShared<T, PHT, PWT, SRT> sh[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int k, gi;
   if (!wave_unit(nunits / ngroups, ngroups, nullptr, k, gi)) return;
-  const int c0 = gi * 64;
+  const int c0 = gi * GC;
   // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
-  const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
+  const int l = __builtin_amdgcn_readfirstlane(fpn_level<T>(rois + (int64_t)k * 5, lv));
   const int H = lv.H[l], W = lv.W[l];
-  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
+  const RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
   const int batch = __builtin_amdgcn_readfirstlane(g.batch);
   // ---- per-RoI sample tables, one sample per lane: element offset of the low tap + the two factors
   int yoff = 0, xoff = 0;
@@ -1762,13 +1780,13 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
     xoff = lo * C;
   }
   const int rowC = W * C;
-  // byte offset of this lane's channel (lanes past the channel count re-read the last channel): the only
+  // byte offset of this lane's channel word (lanes past the channel count re-read the last word): the only
   // per-lane part of a tap address, everything else is scalar
-  const unsigned cl4 = 4u * (unsigned)min(c0 + lane, C - 1);
-  const float* nbase = static_cast<const float*>(lv.ptr[l]) + (int64_t)batch * H * W * C;
+  const unsigned cl4 = (unsigned)sizeof(T) * (unsigned)min(c0 + lane * CPL, C - CPL);
+  const T* nbase = static_cast<const T*>(lv.ptr[l]) + (int64_t)batch * H * W * C;
   constexpr bool kPow2 = (NS & (NS - 1)) == 0;
   const float inv_count = 1.f / (float)NS;
-  float* tl = sh[wave].t;
+  T* tl = sh[wave].t;
   // x-sample parameters are the same for every bin row: SGPRs for the whole unit
   int sx0[PWT * SRT];
   float shx[PWT * SRT], slx[PWT * SRT];
@@ -1779,59 +1797,73 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
     slx[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl), j));
   }
   for (int ph = 0; ph < PHT; ++ph) {
-    float acc[PWT];
+    float acc[PWT][CPL];
 #pragma unroll
-    for (int pw = 0; pw < PWT; ++pw) acc[pw] = 0.f;
+    for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) acc[pw][e] = 0.f;
 #pragma unroll
     for (int iy = 0; iy < SRT; ++iy) {
       const int sy = ph * SRT + iy;
       const int r0 = __builtin_amdgcn_readlane(yoff, sy);
       const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yh), sy));
       const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yl), sy));
-      const float* row0 = nbase + r0;
-      const float* row1 = row0 + rowC;
+      const T* row0 = nbase + r0;
+      const T* row1 = row0 + rowC;
 #pragma unroll
       for (int j = 0; j < PWT * SRT; ++j) {
         const char* p0 = reinterpret_cast<const char*>(row0 + sx0[j]);
         const char* p1 = reinterpret_cast<const char*>(row1 + sx0[j]);
         const char* q0 = reinterpret_cast<const char*>(row0 + sx0[j] + C);
         const char* q1 = reinterpret_cast<const char*>(row1 + sx0[j] + C);
-        const float v00 = *reinterpret_cast<const float*>(p0 + cl4), v01 = *reinterpret_cast<const float*>(q0 + cl4);
-        const float v10 = *reinterpret_cast<const float*>(p1 + cl4), v11 = *reinterpret_cast<const float*>(q1 + cl4);
-        const float t0 = __builtin_fmaf(slx[j], v01, shx[j] * v00);
-        const float t1 = __builtin_fmaf(slx[j], v11, shx[j] * v10);
-        float& a = acc[j / SRT];
-        a = __builtin_fmaf(hy, t0, a);
-        a = __builtin_fmaf(ly, t1, a);
+        float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
+        unpack_word<T>(*reinterpret_cast<const unsigned*>(p0 + cl4), v00);
+        unpack_word<T>(*reinterpret_cast<const unsigned*>(q0 + cl4), v01);
+        unpack_word<T>(*reinterpret_cast<const unsigned*>(p1 + cl4), v10);
+        unpack_word<T>(*reinterpret_cast<const unsigned*>(q1 + cl4), v11);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+          const float t0 = __builtin_fmaf(slx[j], v01[e], shx[j] * v00[e]);
+          const float t1 = __builtin_fmaf(slx[j], v11[e], shx[j] * v10[e]);
+          float& a = acc[j / SRT][e];
+          a = __builtin_fmaf(hy, t0, a);
+          a = __builtin_fmaf(ly, t1, a);
+        }
       }
     }
 #pragma unroll
-    for (int pw = 0; pw < PWT; ++pw) tl[lane * PHW + ph * PWT + pw] = kPow2 ? acc[pw] * inv_count : acc[pw] / (float)NS;
+    for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+      for (int e = 0; e < CPL; ++e)
+        st(tl + (lane * CPL + e) * PHW + ph * PWT + pw, kPow2 ? acc[pw][e] * inv_count : acc[pw][e] / (float)NS);
   }
-  // ---- the [channel][bin] block is contiguous in the NCHW output: one linear store stream
+  // ---- the [channel][bin] block is contiguous in the NCHW output: one linear stream of 32-bit words
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float* outk = output + ((int64_t)k * C + c0) * PHW;
-  const int nvalid = min(64, C - c0) * PHW;
+  unsigned* outw = reinterpret_cast<unsigned*>(output + ((int64_t)k * C + c0) * PHW);
+  const unsigned* tlw = reinterpret_cast<const unsigned*>(tl);
+  const int nwords = min(GC, C - c0) * PHW / CPL;  // C even for the 16-bit types (checked by the launcher)
 #pragma unroll 7
   for (int it = 0; it < PHW; ++it) {
     const int idx = it * 64 + lane;
-    if (idx < nvalid) __builtin_nontemporal_store(tl[idx], outk + idx);
+    if (idx < nwords) __builtin_nontemporal_store(tlw[idx], outw + idx);
   }
 }
 
+template <typename T>
 int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH, int64_t PW,
                        int64_t sr, int aligned, hipStream_t stream) {
   load_env_cfg();
-  const int ngroups = (int)ceil_div(C, 64);
+  constexpr int GC = 64 * (4 / (int)sizeof(T));
+  const int ngroups = (int)ceil_div(C, GC);
   const int64_t nunits = K * ngroups;
   const dim3 grid(wave_unit_grid(K, ngroups)), block(kThreads);
   if (!(PH == 7 && PW == 7 && sr == 2))
     return set_error((int)hipErrorInvalidValue,
                      "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
-  roi_align_fwd_nhwc<7, 7, 2><<<grid, block, 0, stream>>>(lv, static_cast<const float*>(rois), static_cast<float*>(output),
-                                                          (int)C, aligned, ngroups, nunits);
+  roi_align_fwd_nhwc<T, 7, 7, 2><<<grid, block, 0, stream>>>(lv, static_cast<const T*>(rois), static_cast<T*>(output), (int)C,
+                                                             aligned, ngroups, nunits);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward_nhwc");
 }
 
@@ -2045,7 +2077,8 @@ extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs,
   TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "roi_align (channels_last): 1..8 levels supported");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(inputs && heights && widths && spatial_scales && rois && output, "roi_align (channels_last): null pointer");
-  TVMI_CHECK_ARG(dt == TVMI_F32, "roi_align (channels_last): float32 only");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || ((dt == TVMI_F16 || dt == TVMI_BF16) && C % 2 == 0),
+                 "roi_align (channels_last): float32, or float16 / bfloat16 with an even channel count");
   TVMI_CHECK_ARG(pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2,
                  "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
   TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 64) < (1ll << 31), "roi_align (channels_last): size exceeds 32-bit launch limits");
@@ -2065,8 +2098,10 @@ extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs,
   lv.s0 = (float)canonical_scale;
   lv.lvl0 = (float)canonical_level;
   lv.eps = (float)eps;
-  return tvmi::launch_ms_fwd_nhwc(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned,
-                                  static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dt == TVMI_F32) return tvmi::launch_ms_fwd_nhwc<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
+  if (dt == TVMI_F16) return tvmi::launch_ms_fwd_nhwc<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
+  return tvmi::launch_ms_fwd_nhwc<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
 }
 
 // Tuning/debug knob, NOT part of the supported ABI (not declared in include/tvmi.h).

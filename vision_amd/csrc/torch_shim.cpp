@@ -166,7 +166,9 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
   const int64_t K = rois.size(0), C = input.size(1), H = input.size(2), W = input.size(3);
   at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, input.options().memory_format(at::MemoryFormat::Contiguous));
   if (output.numel() == 0) return output;
-  if (input.scalar_type() == at::kFloat && pooled_height == 7 && pooled_width == 7 && sampling_ratio == 2 && C > 1 &&
+  if ((input.scalar_type() == at::kFloat ||
+       ((input.scalar_type() == at::kHalf || input.scalar_type() == at::kBFloat16) && C % 2 == 0)) &&
+      pooled_height == 7 && pooled_width == 7 && sampling_ratio == 2 && C > 1 &&
       H >= 2 && W >= 2 && !input.is_contiguous() && input.is_contiguous(at::MemoryFormat::ChannelsLast) &&
       H * W * C < (1ll << 31)) {
     // channels_last input: native NHWC kernel instead of the reference's input.contiguous() copy
@@ -174,7 +176,7 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
     const double scale = spatial_scale;
     at::Tensor r = rois.contiguous();
     check_status(tvmi_multiscale_roi_align_forward_nhwc(&ptr, &H, &W, &scale, 1, r.const_data_ptr(), output.mutable_data_ptr(),
-                                                        TVMI_F32, input.size(0), C, K, 7, 7, 2, aligned ? 1 : 0, 0, 0, 224.0,
+                                                        dtype_of(input, "roi_align"), input.size(0), C, K, 7, 7, 2, aligned ? 1 : 0, 0, 0, 224.0,
                                                         4.0, 1e-6, current_stream(input)),
                  "roi_align");
     return output;
@@ -558,8 +560,9 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
   std::vector<int64_t> hs, ws;
   // channels_last maps (NHWC in memory) have their own kernel: lane = channel, no layout copy (the reference's
   // input.contiguous() would rewrite every map)
-  bool nhwc = f0.scalar_type() == at::kFloat && pooled_height == 7 && pooled_width == 7 && sampling_ratio == 2 &&
-              f0.size(1) > 1;
+  const bool low = f0.scalar_type() == at::kHalf || f0.scalar_type() == at::kBFloat16;
+  bool nhwc = (f0.scalar_type() == at::kFloat || (low && f0.size(1) % 2 == 0)) && pooled_height == 7 && pooled_width == 7 &&
+              sampling_ratio == 2 && f0.size(1) > 1;
   for (const at::Tensor& f : features)
     nhwc = nhwc && f.dim() == 4 && !f.is_contiguous() && f.is_contiguous(at::MemoryFormat::ChannelsLast) && f.size(2) >= 2 &&
            f.size(3) >= 2 && f.numel() / std::max<int64_t>(f.size(0), 1) < (1ll << 31);
@@ -572,12 +575,12 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
       hs.push_back(f.size(2));
       ws.push_back(f.size(3));
     }
-    at::Tensor r = rois.to(at::kFloat).contiguous();
+    at::Tensor r = rois.to(f0.scalar_type()).contiguous();
     at::Tensor out = at::empty({rois.size(0), f0.size(1), pooled_height, pooled_width}, f0.options().memory_format(at::MemoryFormat::Contiguous));
     if (out.numel() == 0) return out;
     check_status(tvmi_multiscale_roi_align_forward_nhwc(ptrs.data(), hs.data(), ws.data(), scales.data(),
                                                         (int64_t)features.size(), r.const_data_ptr(), out.mutable_data_ptr(),
-                                                        TVMI_F32, f0.size(0), f0.size(1), rois.size(0), pooled_height,
+                                                        dtype_of(f0, "multiscale_roi_align"), f0.size(0), f0.size(1), rois.size(0), pooled_height,
                                                         pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max,
                                                         canonical_scale, canonical_level, eps, current_stream(f0)),
                  "multiscale_roi_align");
