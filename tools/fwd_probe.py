@@ -53,3 +53,25 @@ for dt in (torch.float16, torch.bfloat16):
     rh = rois.to(dt)
     t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fh, rh, scales, 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6))
     print(f"channels_last multiscale roi_align 7x7 {dt}: {t:.4f} ms  ({283.2e6 / t / 1e6:.0f} GB/s algorithmic)")
+# locality experiment for the NHWC kernel: boxes sorted by (image, 64-px cell) before the call
+def lvl_sorted(bx):
+    out = []
+    for b in bx:
+        out.append(b[torch.argsort((b[:, 1] // 64) * 100 + b[:, 0] // 64)])
+    return out
+for name, bx in (("as given", boxes), ("sorted by 64px cell", lvl_sorted(boxes))):
+    r = _convert_to_roi_format(bx)
+    t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fl_nhwc, r, scales, 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6))
+    print(f"channels_last fp32, rois {name}: {t:.4f} ms")
+# sort by level first, then position (RoIs of one level share maps)
+from vision_amd.poolers import LevelMapper
+def lvl_pos_sorted(bx):
+    out = []
+    lm = LevelMapper(2, 5)
+    for b in bx:
+        lv = lm([b])
+        out.append(b[torch.argsort(lv * 10000 + (b[:, 1] // 64) * 100 + b[:, 0] // 64)])
+    return out
+r = _convert_to_roi_format(lvl_pos_sorted(boxes))
+t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fl_nhwc, r, scales, 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6))
+print(f"channels_last fp32, rois sorted by (level, cell): {t:.4f} ms")

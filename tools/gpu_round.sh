@@ -19,6 +19,8 @@ head -16 $OUT/prof/bench_kernel_stats.csv | cut -c1-160
 cd /tmp
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_fetch -o p -- python $ROOTDIR/tools/run_kernel.py roi7 6 > $ROOTDIR/$OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_write -o p -- python $ROOTDIR/tools/run_kernel.py roi7 6 > $ROOTDIR/$OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_fetch_cl -o p -- python $ROOTDIR/tools/run_kernel.py roi7cl 6 > $ROOTDIR/$OUT/pmc_fetch_cl.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_write_cl -o p -- python $ROOTDIR/tools/run_kernel.py roi7cl 6 > $ROOTDIR/$OUT/pmc_write_cl.log 2>&1
 cd $ROOTDIR
 # probe binaries are not tracked: build the calibration probe here if it did not travel with the snapshot
 [ -x $ROOTDIR/tools/probe/fetch_calib ] || hipcc --offload-arch=gfx950 -O3 -o $ROOTDIR/tools/probe/fetch_calib $ROOTDIR/tools/probe/fetch_calib.hip > /dev/null 2>&1

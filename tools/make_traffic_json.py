@@ -11,8 +11,9 @@ def mean_counter(sub, counter, kernel_pat):
                 vals.append(float(row["Counter_Value"]))
     return sum(vals) / len(vals) if vals else None
 out = {}
-for key, pat in (("roi_align_fwd_ms_dma", "roi_align_fwd_ms_dma"),):
-    f = mean_counter("pmc_fetch", "FETCH_SIZE", pat); w = mean_counter("pmc_write", "WRITE_SIZE", pat)
+for key, pat, fsub, wsub in (("roi_align_fwd_ms_dma", "roi_align_fwd_ms_dma", "pmc_fetch", "pmc_write"),
+                             ("roi_align_fwd_nhwc", "roi_align_fwd_nhwc", "pmc_fetch_cl", "pmc_write_cl")):
+    f = mean_counter(fsub, "FETCH_SIZE", pat); w = mean_counter(wsub, "WRITE_SIZE", pat)
     if f is None or w is None: continue
     out[key] = {"fetch_size_kb": f, "write_size_kb": w, "fetch_factor": fetch_factor, "write_factor": write_factor,
                 "hbm_bytes_per_launch": int(f * 1024 * fetch_factor + w * 1024 * write_factor),

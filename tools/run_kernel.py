@@ -13,6 +13,11 @@ with torch.no_grad():
         pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7 if which == "roi7" else 14, 2)
         for _ in range(reps):
             pool(feats, boxes, shapes)
+    elif which == "roi7cl":
+        pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+        cl = {k: v.contiguous(memory_format=torch.channels_last) for k, v in feats.items()}
+        for _ in range(reps):
+            pool(cl, boxes, shapes)
     elif which == "nms":
         b, s = torch.cat(boxes), torch.cat(scores)
         idx = torch.cat([torch.full((1000,), i, device=dev, dtype=torch.int64) for i in range(4)])
