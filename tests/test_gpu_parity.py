@@ -802,3 +802,34 @@ def test_transform_images_one_launch_golden():
     ref, rsizes = O.transform_images([b.numpy() for b in big], 800, 1333, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     assert sizes == rsizes and tuple(out.shape) == ref.shape
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("opname", ["roi_pool", "ps_roi_pool", "roi_align", "ps_roi_align"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.float64])
+@pytest.mark.parametrize("requires_grad", [True, False])
+def test_roi_opcheck(opname, dtype, requires_grad):
+    """The reference's `test_roi_opcheck` (test/test_ops.py:761-795) against OUR schema / fake / autograd
+    registrations and kernels: torch.library.opcheck = schema, autograd registration, fake tensor, AOT dispatch."""
+    op = getattr(torch.ops.torchvision, opname)
+    rois = torch.tensor([[0, 0, 0, 9, 9], [0, 0, 5, 4, 9], [0, 5, 5, 9, 9], [1, 0, 0, 9, 9]], dtype=dtype, device=DEV,
+                        requires_grad=requires_grad)
+    pool_size = 5
+    x = torch.rand(2, 2 * pool_size ** 2, 10, 10, dtype=dtype, device=DEV)
+    kwargs = dict(rois=rois, spatial_scale=1, pooled_height=pool_size, pooled_width=pool_size)
+    if opname in ("roi_align", "ps_roi_align"):
+        kwargs["sampling_ratio"] = -1
+    if opname == "roi_align":
+        kwargs["aligned"] = True
+    torch.library.opcheck(op, args=(x,), kwargs=kwargs)
+
+
+def test_nms_and_fused_ops_opcheck():
+    g = gen(3)
+    b = random_boxes(50, 100, 100, 2, 40, g).to(DEV)
+    s = torch.rand(50, generator=g).to(DEV)
+    torch.library.opcheck(torch.ops.torchvision.nms, args=(b, s, 0.5))
+    torch.library.opcheck(torch.ops.tvmi.nms_segmented, args=(b, s, torch.randint(0, 3, (50,), generator=g).to(DEV), 0.5))
+    feats = [torch.rand(1, 8, 64 // k, 64 // k, generator=g).to(DEV).requires_grad_(True) for k in (1, 2)]
+    rois = torch.cat([torch.zeros(50, 1), random_boxes(50, 64, 64, 2, 40, g)], 1).to(DEV)
+    torch.library.opcheck(torch.ops.tvmi.multiscale_roi_align,
+                          args=(feats, rois, [1.0, 0.5], 7, 7, 2, False, 0, 1, 224.0, 4.0, 1e-6))
