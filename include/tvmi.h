@@ -58,6 +58,13 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
              double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
              int64_t* keep_out, int64_t* num_keep_out, void* stream);
 
+/* The `order` input of the entries above for small inputs: indices of
+ * aten::sort(scores, stable=True, descending=True) (NaN first, ties by ascending index, -0 == +0) for
+ * float32 scores, n <= 4096, in one single-workgroup launch (the reference sorts with
+ * `scores.sort(0, descending=True)`, cuda/nms_kernel.cu:186-187).
+ */
+int tvmi_sort_scores_desc(const float* scores, int64_t n, int64_t* order, void* stream);
+
 /* Segment-major form of the same operation for batched_nms (ops/boxes.py:57-126): the caller
  * additionally provides the STABLE partition of the score order by segment id —
  *   perm     [n] int64: perm[p] = rank in `order` of the box at segment-major position p

@@ -833,3 +833,17 @@ def test_nms_and_fused_ops_opcheck():
     rois = torch.cat([torch.zeros(50, 1), random_boxes(50, 64, 64, 2, 40, g)], 1).to(DEV)
     torch.library.opcheck(torch.ops.tvmi.multiscale_roi_align,
                           args=(feats, rois, [1.0, 0.5], 7, 7, 2, False, 0, 1, 224.0, 4.0, 1e-6))
+
+
+def test_small_score_sort_equals_stable_descending_sort():
+    """tvmi::sort_scores_desc (what nms uses for <= 4096 float32 scores) == aten::sort(stable=True, descending=True)
+    indices: ties by ascending index, NaN first, +-inf, -0 == +0, every size class of the bitonic network."""
+    g = gen(11)
+    for n in (1, 2, 3, 63, 64, 65, 1000, 2048, 2049, 4096):
+        s = torch.randn(n, generator=g)
+        s = (s * 8).round() / 8                      # many exact ties
+        if n > 10:
+            s[3] = float("nan"); s[7] = float("inf"); s[8] = float("-inf"); s[5] = -0.0; s[6] = 0.0; s[9] = float("nan")
+        want = torch.sort(s, stable=True, descending=True)[1]
+        got = torch.ops.tvmi.sort_scores_desc(s.to(DEV)).cpu()
+        assert torch.equal(got, want), n

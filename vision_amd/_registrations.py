@@ -191,6 +191,7 @@ def _fake_boxes_to_rois(boxes):
 
 _FAKES = {
     "tvmi::boxes_to_rois": _fake_boxes_to_rois,
+    "tvmi::sort_scores_desc": lambda scores: scores.new_empty(scores.shape, dtype=torch.int64),
     "tvmi::normalize_resize_batch": _fake_normalize_resize_batch,
     "tvmi::box_iou_pairwise": _fake_box_iou_pairwise,
     "tvmi::nms_segmented_padded": _fake_nms_padded,

@@ -916,6 +916,73 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int6
   if (tid == 0) *num_keep = *(volatile int*)&ws.sync_words[1] ? -1 : run;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Score order for small inputs (n <= 4096, float32): order = aten::sort(scores, stable=True, descending=True)
+// indices — NaN first, ties by ascending index, -0 == +0 — as ONE single-workgroup launch (bitonic network over
+// 64-bit keys (order-preserving score bits << 32 | index) in LDS).  At these sizes torch's path is a radix-sort
+// kernel plus an index arange plus two copies (~40 us of launches for 4000 scores); this is ~half of that and has
+// no temporaries.  The unique index in the low word makes the (unstable) network produce the stable order.
+constexpr int kSortMax = 4096;
+__global__ __launch_bounds__(1024) void sort_scores_desc_small(const float* __restrict__ scores, int n, int N /*pow2 >= n*/,
+                                                               int64_t* __restrict__ order) {
+  __shared__ u64 keys[kSortMax];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N; i += 1024) {
+    u64 k = ~0ull;  // padding sorts last
+    if (i < n) {
+      const float f = scores[i];
+      unsigned b = __builtin_bit_cast(unsigned, f);
+      unsigned d;  // ascending d == descending score
+      if (f != f) {
+        d = 0u;  // NaN is the greatest value for aten::sort
+      } else {
+        if (f == 0.f) b = 0u;                                  // -0 == +0
+        const unsigned asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        d = ~asc;
+        if (d == 0u) d = 1u;  // cannot happen for non-NaN values (asc of +inf is 0xFF800000), kept for safety
+      }
+      k = ((u64)d << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  // Wave w owns the 128 compare-exchanges t in [128w, 128w+128) of every sub-stage, i.e. the 256 keys
+  // [256w, 256w+256): for j < 256 both keys of a pair are its own, so those sub-stages (58 of the 78 at N = 4096)
+  // need no workgroup barrier — LDS operations of one wave are ordered — only the j >= 256 ones do.
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool wide = j >= 256;
+      if (wide) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int t = wave * 128 + r * 64 + lane;
+        if (t < (N >> 1)) {
+          // t-th compare-exchange of this sub-stage: i has bit j clear
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int p = i | j;
+          const u64 a = keys[i], b = keys[p];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[p] = a;
+          }
+        }
+      }
+      if (wide) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) order[i] = (int64_t)(unsigned)keys[i];
+}
+
 struct SegWorkspace {
   u64* mask;
   u64* keepbits;
@@ -1055,4 +1122,14 @@ extern "C" int tvmi_nms_small_segments(const void* dets, const int64_t* order, c
   tvmi::nms_small_seg_sweep<<<dim3((unsigned)num_segments), dim3(tvmi::kSuper * tvmi::kWave), 0, s>>>(order, (int)n, w, keep_out,
                                                                                                     num_keep_out);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_small_segments");
+}
+
+extern "C" int tvmi_sort_scores_desc(const float* scores, int64_t n, int64_t* order, void* stream) {
+  TVMI_CHECK_ARG(n >= 0 && n <= tvmi::kSortMax, "sort_scores_desc: 0 <= n <= 4096");
+  if (n == 0) return 0;
+  TVMI_CHECK_ARG(scores && order, "sort_scores_desc: null pointer");
+  int N = 2;
+  while (N < n) N <<= 1;
+  tvmi::sort_scores_desc_small<<<dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream)>>>(scores, (int)n, N, order);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_sort_scores_desc");
 }

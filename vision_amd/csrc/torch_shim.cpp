@@ -78,7 +78,16 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
   TORCH_CHECK(boxes.scalar_type() == at::kFloat || boxes.scalar_type() == at::kDouble,
               "nms: boxes must be a floating point tensor");
   boxes = boxes.contiguous();
-  at::Tensor order = std::get<1>(at::sort(scores, /*stable=*/true, /*dim=*/0, /*descending=*/true));
+  at::Tensor order;
+  if (scores.scalar_type() == at::kFloat && n <= 4096) {
+    // detector-step sizes: the stable descending order in one launch instead of torch's sort + arange + copies
+    at::Tensor sc = scores.contiguous();
+    order = at::empty({n}, dets.options().dtype(at::kLong));
+    check_status(tvmi_sort_scores_desc(sc.const_data_ptr<float>(), n, order.mutable_data_ptr<int64_t>(), current_stream(dets)),
+                 "sort_scores_desc");
+  } else {
+    order = std::get<1>(at::sort(scores, /*stable=*/true, /*dim=*/0, /*descending=*/true));
+  }
   at::Tensor seg_c;
   const int64_t* seg_ptr = nullptr;
   if (seg.has_value() && seg->defined()) {
@@ -881,6 +890,18 @@ at::Tensor normalize_resize_batch(at::TensorList images, at::IntArrayRef out_hei
   return out;
 }
 
+at::Tensor sort_scores_desc(const at::Tensor& scores) {
+  TORCH_CHECK(scores.is_cuda() && scores.dim() == 1 && scores.scalar_type() == at::kFloat && scores.size(0) <= 4096,
+              "sort_scores_desc: a 1d float32 CUDA tensor with at most 4096 elements expected");
+  c10::DeviceGuard guard(scores.device());
+  at::Tensor sc = scores.contiguous();
+  at::Tensor order = at::empty({sc.size(0)}, sc.options().dtype(at::kLong));
+  check_status(tvmi_sort_scores_desc(sc.const_data_ptr<float>(), sc.size(0), order.mutable_data_ptr<int64_t>(),
+                                     current_stream(scores)),
+               "sort_scores_desc");
+  return order;
+}
+
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
 int64_t tvmi_abi_version() { return tvmi_version(); }
 
@@ -944,6 +965,8 @@ TORCH_LIBRARY(tvmi, m) {
   // models/detection/transform.py:119-255 (normalize + resize + zero-padded batching) as one launch
   m.def(
       "normalize_resize_batch(Tensor[] images, int[] out_heights, int[] out_widths, float[] mean, float[] std, int padded_h, int padded_w) -> Tensor");
+  // indices of aten::sort(scores, stable=True, descending=True) for <= 4096 float32 scores, one launch
+  m.def("sort_scores_desc(Tensor scores) -> Tensor");
   // ops/boxes.py:314-391 / 409-436 (box_iou / generalized_box_iou of xyxy boxes) as one launch
   m.def("box_iou_pairwise(Tensor boxes1, Tensor boxes2, bool generalized) -> Tensor");
   // ops/_utils.py:18-25 (cat + full_like per image + 2 cats) as one launch
@@ -979,6 +1002,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);
   m.impl("boxes_to_rois", &boxes_to_rois);
+  m.impl("sort_scores_desc", &sort_scores_desc);
   m.impl("normalize_resize_batch", &normalize_resize_batch);
   m.impl("box_iou_pairwise", &box_iou_pairwise);
   m.impl("detection_candidates", &detection_candidates);
