@@ -947,36 +947,64 @@ __global__ __launch_bounds__(1024) void sort_scores_desc_small(const float* __re
     keys[i] = k;
   }
   __syncthreads();
-  // Wave w owns the 128 compare-exchanges t in [128w, 128w+128) of every sub-stage, i.e. the 256 keys
-  // [256w, 256w+256): for j < 256 both keys of a pair are its own, so those sub-stages (58 of the 78 at N = 4096)
-  // need no workgroup barrier — LDS operations of one wave are ordered — only the j >= 256 ones do.
+  // Two sub-stages (j, j/2) per LDS round trip: a thread loads the quad {i, i|j/2, i|j, i|j|j/2}, does the four
+  // compare-exchanges in registers and stores it back (39 rounds instead of 78 at N = 4096).  Wave w owns quads
+  // [64w, 64w+64), i.e. the keys [256w, 256w+256): for j < 256 every quad is its own, so only the rounds with j >= 256
+  // need a workgroup barrier — LDS operations of one wave are ordered.
   const int wave = tid >> 6, lane = tid & 63;
+  auto cmpx = [](u64& a, u64& b, bool up) {
+    if ((a > b) == up) {
+      const u64 t = a;
+      a = b;
+      b = t;
+    }
+  };
+  auto sync_round = [&](bool wide) {
+    if (wide) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
   for (int k = 2; k <= N; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    int j = k >> 1;
+    for (; j >= 2; j >>= 2) {
+      const int j2 = j >> 1;
       const bool wide = j >= 256;
       if (wide) __syncthreads();
+      const int q = wave * 64 + lane;  // quad index
+      if (q < (N >> 2)) {
+        // insert zero bits at positions log2(j2) and log2(j)
+        const int t1 = ((q & ~(j2 - 1)) << 1) | (q & (j2 - 1));  // zero bit at log2(j2)
+        const int i = ((t1 & ~(j - 1)) << 1) | (t1 & (j - 1));   // zero bit at log2(j)
+        u64 a = keys[i], b = keys[i | j2], c = keys[i | j], d = keys[i | j | j2];
+        const bool up = (i & k) == 0;
+        cmpx(a, c, up);
+        cmpx(b, d, up);
+        cmpx(a, b, up);
+        cmpx(c, d, up);
+        keys[i] = a;
+        keys[i | j2] = b;
+        keys[i | j] = c;
+        keys[i | j | j2] = d;
+      }
+      sync_round(wide);
+    }
+    if (j == 1) {  // odd number of sub-stages for this k: the last one alone
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int t = wave * 128 + r * 64 + lane;
         if (t < (N >> 1)) {
-          // t-th compare-exchange of this sub-stage: i has bit j clear
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int p = i | j;
-          const u64 a = keys[i], b = keys[p];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            keys[i] = b;
-            keys[p] = a;
-          }
+          const int i = t << 1;
+          u64 a = keys[i], b = keys[i | 1];
+          cmpx(a, b, (i & k) == 0);
+          keys[i] = a;
+          keys[i | 1] = b;
         }
       }
-      if (wide) {
-        __syncthreads();
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+      sync_round(false);
     }
   }
   __syncthreads();
