@@ -1,0 +1,46 @@
+"""Randomised parity sweep against the oracle (NMS paths, RoIAlign NCHW / channels_last, backward); ~30 s on the box."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, vision_amd
+from oracle import oracle as O
+dev = torch.device("cuda:0"); tv = torch.ops.torchvision
+g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+def ri(a, b): return int(torch.randint(a, b + 1, (1,), generator=g))
+t0 = time.time(); cases = 0
+while time.time() - t0 < 25:
+    # ---- NMS / batched NMS
+    n = ri(1, 6000); canvas = float(ri(20, 800)); S = ri(1, 40)
+    xy = torch.rand(n, 2, generator=g) * canvas; wh = torch.rand(n, 2, generator=g) * ri(2, 120)
+    b = torch.cat([xy, xy + wh], 1)
+    s = torch.rand(n, generator=g)
+    if ri(0, 2) == 0: s = (s * ri(2, 50)).floor() / 16
+    idx = torch.randint(0, S, (n,), generator=g)
+    thr = [0.3, 0.5, 0.7, float(torch.rand(1, generator=g))][ri(0, 3)]
+    want = O.nms(b.numpy(), s.numpy(), thr)
+    got = tv.nms(b.to(dev), s.to(dev), thr).cpu().numpy()
+    assert np.array_equal(got, want), ("nms", n, canvas, thr)
+    wants = O.nms(b.numpy(), s.numpy(), thr, idx.numpy())
+    for hint in (-1, S):
+        gots = vision_amd.batched_nms(b.to(dev), s.to(dev), idx.to(dev), thr, num_segments=hint).cpu().numpy()
+        assert np.array_equal(gots, wants), ("batched", n, S, hint, thr)
+    # ---- RoIAlign forward NCHW vs channels_last vs oracle, backward vs oracle
+    N, C, H, W = ri(1, 3), ri(1, 70), ri(2, 60), ri(4, 70)
+    x = torch.rand(N, C, H, W, generator=g)
+    k = ri(1, 60); scale = [1.0, 0.5, 0.25][ri(0, 2)]
+    bx = torch.rand(k, 2, generator=g) * torch.tensor([W / scale, H / scale]) * 1.1 - 0.05 * W / scale
+    bw = torch.rand(k, 2, generator=g) * torch.tensor([W / scale, H / scale]) * [0.1, 0.5, 1.2][ri(0, 2)]
+    rois = torch.cat([torch.randint(0, N, (k, 1), generator=g).float(), bx, bx + bw], 1)
+    aligned = bool(ri(0, 1))
+    ref = O.roi_align(x.numpy(), rois.numpy(), scale, 7, 7, 2, aligned)
+    y = tv.roi_align(x.to(dev), rois.to(dev), scale, 7, 7, 2, aligned)
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-4, ("roi nchw", N, C, H, W)
+    if C > 1:
+        ycl = tv.roi_align(x.to(dev).contiguous(memory_format=torch.channels_last), rois.to(dev), scale, 7, 7, 2, aligned)
+        assert np.abs(ycl.cpu().numpy() - ref).max() < 1e-4, ("roi nhwc", N, C, H, W)
+    gr = torch.randn(ref.shape, generator=g)
+    gi = tv._roi_align_backward(gr.to(dev), rois.to(dev), scale, 7, 7, N, C, H, W, 2, aligned)
+    refb = O.roi_align_backward(gr.numpy(), rois.numpy(), scale, 7, 7, N, C, H, W, 2, aligned)
+    assert np.abs(gi.cpu().numpy() - refb).max() < 1e-4 * max(1.0, float(np.abs(refb).max())), ("roi bwd", N, C, H, W)
+    cases += 1
+print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, roi_align NCHW + channels_last + backward)")
