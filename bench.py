@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 IMG_H, IMG_W, CHANNELS, BATCH, PROPOSALS = 800, 1344, 256, 4, 1000
+N_SETS = 4  # rotated input sets
 STRIDES = (4, 8, 16, 32)
 POOL, SAMPLING, NMS_THR, MAX_DETS = 7, 2, 0.5, 100
 
@@ -90,20 +91,27 @@ def main():
     import vision_amd  # fails loudly if the HIP extension is missing
     from vision_amd import sharding
 
-    feats, boxes, scores = make_inputs(device, seed=1000 + rank)
+    # N_SETS independent input sets (1.46 GB of feature maps) are rotated step by step, so that the 256 MiB
+    # Infinity Cache cannot serve one step's maps to the next — the traffic is HBM traffic
+    sets = []
+    for i in range(N_SETS):
+        feats, boxes, scores = make_inputs(device, seed=1000 + rank + 97 * i)
+        sets.append(dict(feats=feats, boxes=boxes, scores=scores, all_boxes=torch.cat(boxes), all_scores=torch.cat(scores)))
+    feats, boxes, scores = sets[0]["feats"], sets[0]["boxes"], sets[0]["scores"]
     pool = vision_amd.MultiScaleRoIAlign([str(i) for i in range(len(STRIDES))], POOL, SAMPLING)
     image_shapes = [(IMG_H, IMG_W)] * BATCH
-    all_boxes = torch.cat(boxes)
-    all_scores = torch.cat(scores)
     img_idx = torch.cat([torch.full((PROPOSALS,), i, device=device, dtype=torch.int64) for i in range(BATCH)])
+    counter = {"i": 0}
 
-    def device_step():
+    def device_step(which=None):
         # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable)
-        pooled = pool(feats, boxes, image_shapes)                                          # [4000, 256, 7, 7], 1 launch
-        keep, num = vision_amd.boxes.batched_nms_padded(all_boxes, all_scores, img_idx, NMS_THR, BATCH)  # per-image NMS, 1 launch
+        d = sets[counter["i"] % N_SETS if which is None else which]
+        counter["i"] += 1
+        pooled = pool(d["feats"], d["boxes"], image_shapes)                                 # [4000, 256, 7, 7], 1 launch
+        keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
         # padded top-MAX_DETS detections per image, fixed shape, ONE launch, keep length read on the device
-        dets, counts = sharding.pack_kept_detections(all_boxes, all_scores, img_idx, keep, BATCH, MAX_DETS, num_keep=num)
-        return pooled, num, dets, counts
+        dets, counts = sharding.pack_kept_detections(d["all_boxes"], d["all_scores"], img_idx, keep, BATCH, MAX_DETS, num_keep=num)
+        return pooled, num, dets, counts, keep
 
     graph, static_out = None, None
     if args.graph:
@@ -113,12 +121,12 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
                 for _ in range(3):
-                    device_step()
+                    device_step(0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(graph):
-                static_out = device_step()
+                static_out = device_step(0)   # a captured graph replays ONE input set
         except Exception as exc:  # pragma: no cover - depends on the runtime
             print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             graph, static_out = None, None
@@ -128,9 +136,9 @@ def main():
         with torch.no_grad():
             if graph is not None:
                 graph.replay()
-                pooled, num, dets, counts = static_out
+                pooled, num, dets, counts, _ = static_out
             else:
-                pooled, num, dets, counts = device_step()
+                pooled, num, dets, counts, _ = device_step()
             gd, gc = sharding.all_gather_detections(dets, counts)   # the one collective (no-op at world 1)
         return pooled, num, gd, gc
 
@@ -155,45 +163,62 @@ def main():
     boxes_per_step = BATCH * PROPOSALS * world
     value = boxes_per_step / (ms_per_step / 1e3)
 
-    # ---- roofline of the dominant kernel, measured live with events on the launch stream
-    from vision_amd.poolers import _convert_to_roi_format
+    # ---- roofline of the dominant kernel, measured live with events on the launch stream (input sets rotated)
+    from vision_amd.poolers import LevelMapper, _convert_to_roi_format
 
-    rois5 = _convert_to_roi_format(boxes)
-    flist = [feats[str(i)] for i in range(len(STRIDES))]
     scales = [1.0 / s for s in STRIDES]
+    ms_args = (POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
+    for d in sets:
+        d["rois5"] = _convert_to_roi_format(d["boxes"]).float()
+        d["flist"] = [d["feats"][str(i)] for i in range(len(STRIDES))]
 
-    def roi_op():  # exactly what pool() launches, without its python-side roi formatting
-        return torch.ops.tvmi.multiscale_roi_align(flist, rois5, scales, POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
-
-    with torch.no_grad():
-        for _ in range(5):
-            roi_op()
+    def timed(fn, n_k=32, warm=4):
+        for i in range(warm):
+            fn(i)
         torch.cuda.synchronize()
-        n_k = 30
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(n_k):
-            roi_op()
+        for i in range(n_k):
+            fn(i)
         e1.record()
         torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / n_k
+        return e0.elapsed_time(e1) / n_k
+
+    with torch.no_grad():
+        # exactly what pool() launches, without its python-side roi formatting
+        k_ms = timed(lambda i: torch.ops.tvmi.multiscale_roi_align(sets[i % N_SETS]["flist"], sets[i % N_SETS]["rois5"], scales, *ms_args))
         # NMS alone, for the breakdown in `config`
-        e0.record()
-        for _ in range(n_k):
-            vision_amd.boxes.batched_nms_padded(all_boxes, all_scores, img_idx, NMS_THR, BATCH)
-        e1.record()
-        torch.cuda.synchronize()
-        nms_ms = e0.elapsed_time(e1) / n_k
+        nms_ms = timed(lambda i: vision_amd.boxes.batched_nms_padded(sets[i % N_SETS]["all_boxes"], sets[i % N_SETS]["all_scores"],
+                                                                      img_idx, NMS_THR, BATCH))
+        # dense variant: proposals clustered around 40 objects per image, most boxes are suppressed
+        dg = torch.Generator().manual_seed(5)
+        centers = torch.rand(BATCH, 40, 2, generator=dg) * torch.tensor([IMG_W - 200.0, IMG_H - 200.0])
+        pick = torch.randint(0, 40, (BATCH, PROPOSALS), generator=dg)
+        xy = torch.gather(centers, 1, pick[..., None].expand(-1, -1, 2)) + torch.randn(BATCH, PROPOSALS, 2, generator=dg) * 12
+        wh = 120 + torch.randn(BATCH, PROPOSALS, 2, generator=dg).abs() * 30
+        dense_boxes = torch.cat([xy, xy + wh], 2).reshape(-1, 4).to(device)
+        dense_scores = torch.rand(BATCH * PROPOSALS, generator=dg).to(device)
+        nms_dense_ms = timed(lambda i: vision_amd.boxes.batched_nms_padded(dense_boxes, dense_scores, img_idx, NMS_THR, BATCH))
+        dense_kept = int(vision_amd.boxes.batched_nms_padded(dense_boxes, dense_scores, img_idx, NMS_THR, BATCH)[1])
+        # the same step through the REFERENCE-SCHEMA ops only — what the unchanged torchvision python
+        # (ops/poolers.py:199-222 per-level roi_align + index_put, ops/boxes.py nms per image) launches on this library
+        tv = torch.ops.torchvision
+        mapper = LevelMapper(2, 5)
+        for d in sets:
+            lv = mapper(d["boxes"])
+            d["lvl_idx"] = [torch.where(lv == l)[0] for l in range(len(STRIDES))]
+
+        def schema_step(i):
+            d = sets[i % N_SETS]
+            result = torch.zeros(BATCH * PROPOSALS, CHANNELS, POOL, POOL, device=device)
+            for l in range(len(STRIDES)):
+                idx = d["lvl_idx"][l]
+                result[idx] = tv.roi_align(d["flist"][l], d["rois5"][idx], scales[l], POOL, POOL, SAMPLING, False)
+            return result, [tv.nms(b, sc, NMS_THR) for b, sc in zip(d["boxes"], d["scores"])]
+        schema_ms = timed(schema_step, n_k=16)
         # the same op on channels_last maps (native NHWC kernel) — reported, never part of `value`
-        flist_cl = [f.contiguous(memory_format=torch.channels_last) for f in flist]
-        for _ in range(3):
-            torch.ops.tvmi.multiscale_roi_align(flist_cl, rois5, scales, POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
-        e0.record()
-        for _ in range(n_k):
-            torch.ops.tvmi.multiscale_roi_align(flist_cl, rois5, scales, POOL, POOL, SAMPLING, False, 2, 5, 224.0, 4.0, 1e-6)
-        e1.record()
-        torch.cuda.synchronize()
-        cl_ms = e0.elapsed_time(e1) / n_k
+        flist_cl = [f.contiguous(memory_format=torch.channels_last) for f in sets[0]["flist"]]
+        cl_ms = timed(lambda i: torch.ops.tvmi.multiscale_roi_align(flist_cl, sets[0]["rois5"], scales, *ms_args))
         del flist_cl
     alg_bytes = algorithmic_bytes(feats, BATCH * PROPOSALS)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
@@ -226,6 +251,11 @@ def main():
             "nms_ms": round(nms_ms, 4),
             "roi_align_channels_last_ms": round(cl_ms, 4),
             "kept_boxes": int(out[1].item()),
+            "nms_dense_ms": round(nms_dense_ms, 4),
+            "nms_dense_kept_boxes": dense_kept,
+            "schema_ops_ms_per_step": round(schema_ms, 4),
+            "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
+            "rotated_input_sets": N_SETS,
             "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
         },
@@ -242,12 +272,29 @@ def main():
         },
     }
 
+    parity_ok = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(feats, boxes, scores)
+        base, ref_pooled, ref_keeps = cpu_baseline(feats, boxes, scores)
+        result["cpu_baseline"] = base
+        # parity of THIS run's outputs against what the CPU baseline just computed on the same inputs (input set 0)
+        with torch.no_grad():
+            pooled, num, _, _, keep = device_step(0)
+        torch.cuda.synchronize()
+        err = float((pooled.cpu() - ref_pooled).abs().max())
+        keep = keep[: int(num)].cpu()
+        same = True
+        for i in range(BATCH):
+            mine = keep[(keep >= i * PROPOSALS) & (keep < (i + 1) * PROPOSALS)] - i * PROPOSALS
+            same = same and torch.equal(mine, ref_keeps[i])
+        parity_ok = err <= 1e-4 and same
+        result["parity"] = {"roi_align_max_abs_err": err, "roi_align_tolerance": 1e-4, "nms_index_sets_equal": bool(same),
+                            "checked_against": base["kind"], "ok": bool(parity_ok)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit("bench.py: outputs differ from the CPU reference (see the parity block)")
 
 
 def cpu_baseline(feats, boxes, scores):
@@ -266,20 +313,30 @@ def cpu_baseline(feats, boxes, scores):
     scales = [1.0 / s for s in STRIDES]
     torch.set_num_threads(1)
 
+    ref_pooled = torch.zeros(BATCH * PROPOSALS, CHANNELS, POOL, POOL)
+    ref_keeps = [None] * BATCH
+
     def run_once():
         t0 = time.perf_counter()
+        outs = []
         for lvl in range(len(STRIDES)):
             sel = torch.nonzero(levels == lvl)[:, 0]
             if kind == "reference":
-                torch.ops.torchvision.roi_align(cpu_feats[str(lvl)], rois[sel], scales[lvl], POOL, POOL, SAMPLING, False)
+                outs.append((sel, torch.ops.torchvision.roi_align(cpu_feats[str(lvl)], rois[sel], scales[lvl], POOL, POOL, SAMPLING, False)))
             else:
-                O.roi_align(cpu_feats[str(lvl)].numpy(), rois[sel].numpy(), scales[lvl], POOL, POOL, SAMPLING, False)
+                outs.append((sel, torch.from_numpy(O.roi_align(cpu_feats[str(lvl)].numpy(), rois[sel].numpy(), scales[lvl], POOL, POOL,
+                                                               SAMPLING, False))))
+        keeps = []
         for b, s in zip(cpu_boxes, cpu_scores):
             if kind == "reference":
-                torch.ops.torchvision.nms(b, s, NMS_THR)
+                keeps.append(torch.ops.torchvision.nms(b, s, NMS_THR))
             else:
-                O.nms(b.numpy(), s.numpy(), NMS_THR)
-        return time.perf_counter() - t0
+                keeps.append(torch.from_numpy(O.nms(b.numpy(), s.numpy(), NMS_THR)))
+        dt = time.perf_counter() - t0
+        for sel, o in outs:   # kept for the parity block (outside the timed part)
+            ref_pooled[sel] = o
+        ref_keeps[:] = keeps
+        return dt
 
     times = [run_once()]  # first run doubles as warm-up and is kept if the budget is tight
     budget = 20.0
@@ -296,7 +353,7 @@ def cpu_baseline(feats, boxes, scores):
                   f"median of {len(times)} runs, {sum(times):.1f} s of CPU work, single-threaded reference kernels; "
                   f"host has {os.cpu_count()} logical CPUs",
         "seconds_per_step": round(med, 4),
-    }
+    }, ref_pooled, ref_keeps
 
 
 if __name__ == "__main__":

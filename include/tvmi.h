@@ -11,7 +11,7 @@
  *
  * Each function cites the reference interface it replaces (paths relative to the
  * pytorch/vision tree).  "rois" are always [K,5] = (batch_index, x1, y1, x2, y2) in the
- * same dtype as the feature tensor, feature tensors are contiguous NCHW.
+ * same dtype as the feature tensor (float32 for the multi-scale entries), feature tensors are contiguous NCHW.
  */
 #ifndef TVMI_H_
 #define TVMI_H_
@@ -98,21 +98,29 @@ int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_
  * torchvision/csrc/ops/cpu/roi_align_kernel.cpp:18-115,183-289 and
  * cpu/roi_align_common.h:32-124.
  *   input  [N,C,H,W]  output [K,C,PH,PW] (fully overwritten, no pre-zero needed)
- *   workspace (optional, may be NULL): 2*K*4 bytes of device scratch (RoI processing order +
- *   per-RoI "declined by the LDS-DMA kernel" flags).  Without it the fp32 fast path that needs
- *   the flags is not used; results do not depend on it.
- * backward: grad [K,C,PH,PW] read with the given element strides; grad_input
- * [N,C,H,W] must be zero-filled by the caller (the launcher accumulates atomically).
- * F16/BF16 accumulate in fp32.  backward workspace (optional, tvmi_roi_align_backward_workspace_bytes):
- * per-tile RoI lists of the tile-stationary (atomic-free) fp32 backward; without it the per-RoI
- * atomic kernel is used.
+ *   workspace (optional, may be NULL): K*4 bytes of device scratch (per-RoI "declined by the LDS-DMA
+ *   kernel" flags).  Without it the fast path that needs the flags is not used; results do not depend on it.
+ * backward: grad [K,C,PH,PW] read with the given element strides.  Two regimes:
+ *   - TILE-OWNER path (deterministic; what torchvision/ops/roi_align.py:276-281 reroutes to python for):
+ *     float32, 7x7 or 14x14 bins (any sampling_ratio), bins of a channel contiguous (w_stride 1, h_stride
+ *     PW), H, W <= 4096, and a workspace of tvmi_roi_align_backward_workspace_bytes(N, K, PH, PW) bytes.
+ *     Every 16x16 tile of grad_input is accumulated in registers by ONE workgroup and written exactly once
+ *     with plain stores: grad_input is FULLY OVERWRITTEN (no zero-fill needed), no atomics, bit-reproducible.
+ *     tvmi_roi_align_backward_overwrites(...) tells the caller whether a call takes this path.
+ *   - otherwise (fp64, 16-bit, other bin shapes, no workspace): accumulates with hardware atomics into a
+ *     grad_input the CALLER zero-filled, like cuda/roi_align_kernel.cu:304-327,440.
  */
 int tvmi_roi_align_forward(const void* input, const void* rois, void* output, tvmi_dtype dt,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                            int64_t pooled_h, int64_t pooled_w, double spatial_scale,
                            int64_t sampling_ratio, int aligned, void* workspace, size_t workspace_bytes,
                            void* stream);
-size_t tvmi_roi_align_backward_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t K);
+/* 0 when the pooled shape has no tile-owner kernel. */
+size_t tvmi_roi_align_backward_workspace_bytes(int64_t N, int64_t K, int64_t pooled_h, int64_t pooled_w);
+/* 1 if tvmi_roi_align_backward with these arguments overwrites grad_input (tile-owner path), 0 if it accumulates. */
+int tvmi_roi_align_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
+                                       int64_t pooled_h, int64_t pooled_w, int64_t c_stride, int64_t h_stride,
+                                       int64_t w_stride, size_t workspace_bytes);
 int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input, tvmi_dtype dt,
                             int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                             int64_t pooled_h, int64_t pooled_w, double spatial_scale,
@@ -123,7 +131,8 @@ int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input
 /* Multi-scale RoIAlign (FPN): replaces the per-level python loop of
  * torchvision/ops/poolers.py:147-227 (_multiscale_roi_align: LevelMapper -> torch.where ->
  * roi_align -> index_put per level) with ONE launch.  `inputs[l]` is level l's [N,C,H_l,W_l]
- * feature map (same N, C, dtype), `rois` [K,5] are in IMAGE coordinates; the level of a RoI
+ * feature map (same N, C, dtype), `rois` [K,5] are FLOAT32 image coordinates whatever the feature dtype
+ * (levels and sample positions are computed from the fp32 boxes, as the reference does); the level of a RoI
  * is floor(canonical_level + log2(sqrt(area)/canonical_scale) + eps) clamped to
  * [k_min, k_max], minus k_min (poolers.py:73-84).  output [K,C,PH,PW], fully overwritten.
  * F32 / F16 / BF16.
@@ -135,11 +144,16 @@ int tvmi_multiscale_roi_align_forward(const void* const* inputs, const int64_t* 
                                       int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
                                       double canonical_scale, double canonical_level, double eps,
                                       void* workspace, size_t workspace_bytes, void* stream);
-/* Backward of the multi-scale form in one launch: grad [K,C,PH,PW] (element strides given) is
- * scattered into the gradient map of each RoI's level, grad_inputs[l] = [N,C,H_l,W_l] (dt,
- * contiguous, ZERO-initialised by the caller).  Replaces the per-level autograd loop the
- * reference runs through poolers.py:199-222 + _roi_align_backward.  workspace: K ints.
+/* Backward of the multi-scale form in one launch (float32 grads and RoIs): grad [K,C,PH,PW] (element strides
+ * given) goes into the gradient map of each RoI's level, grad_inputs[l] = [N,C,H_l,W_l] contiguous.  Same two
+ * regimes as tvmi_roi_align_backward: with the tile-owner workspace every map is fully overwritten and the
+ * result is deterministic; otherwise the maps must be zero-filled by the caller.  Replaces the per-level
+ * autograd loop the reference runs through poolers.py:199-222 + _roi_align_backward.
  */
+int tvmi_multiscale_roi_align_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t K, const int64_t* heights,
+                                                  const int64_t* widths, int64_t n_levels, int64_t pooled_h,
+                                                  int64_t pooled_w, int64_t c_stride, int64_t h_stride, int64_t w_stride,
+                                                  size_t workspace_bytes);
 int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void* const* grad_inputs,
                                        const int64_t* heights, const int64_t* widths, const double* spatial_scales,
                                        int64_t n_levels, tvmi_dtype dt, int64_t N, int64_t C, int64_t K, int64_t pooled_h,
@@ -150,7 +164,7 @@ int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void*
 
 /* The same operation on channels_last feature maps (element (n,c,y,x) at ((n*H+y)*W+x)*C+c;
  * SURVEY.md §8f-2): lane = channel, taps are coalesced loads off a scalar base, no LDS window.
- * Output is still the reference's NCHW-contiguous [K,C,PH,PW].  float32 (or float16 / bfloat16 with
+ * Output is still the reference's NCHW-contiguous [K,C,PH,PW]; rois are float32.  float32 maps (or float16 / bfloat16 with
  * an even channel count: two channels per lane), 7x7 bins, sampling_ratio 2, every level H,W >= 2; a single level with k_min == k_max is plain
  * roi_align.  The reference instead copies every map to NCHW first
  * (cuda/roi_align_kernel.cu:365 `input.contiguous()`).

@@ -1,5 +1,6 @@
 """The drop-in boundary: the C-ABI library loads and exports every symbol include/tvmi.h
-declares; the dispatcher glue defines the reference's schemas verbatim.  No compute calls."""
+declares; the dispatcher glue defines the reference's schemas verbatim.  (No GPU here: the compute calls straight
+through the C ABI are in tests/test_gpu_abi.py.)"""
 import ctypes
 import os
 import re

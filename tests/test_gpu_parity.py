@@ -485,7 +485,8 @@ def test_resize_image_wrapper_uint8():
             ref = ref.clamp(0, 255)
         ref = ref.round().to(torch.uint8)[0]
         assert (out.cpu().int() - ref.int()).abs().max().item() <= 1
-    assert vision_amd.resize(img.to(DEV), [120, 160]).data_ptr() == img.to(DEV).data_ptr() or True
+    same = img.to(DEV)
+    assert vision_amd.resize(same, [120, 160]) is same          # identity size: no kernel, no copy (like F.resize)
 
 
 # ------------------------------------------------------------------------------ detection payload packing
@@ -555,7 +556,7 @@ def test_roi_align_16bit_dma_path(tv, dtype, tol, P):
     with torch.no_grad():
         out = pool({k: v.to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * N)
     assert out.dtype == dtype
-    ref32 = pool({k: v.float().to(DEV) for k, v in feats.items()}, [b.to(dtype).float().to(DEV) for b in boxes], [(800, 1344)] * N)
+    ref32 = pool({k: v.float().to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * N)   # fp32 boxes either way
     np.testing.assert_allclose(out.float().cpu().numpy(), ref32.cpu().numpy(), rtol=tol, atol=tol)
 
 
@@ -847,3 +848,95 @@ def test_small_score_sort_equals_stable_descending_sort():
         want = torch.sort(s, stable=True, descending=True)[1]
         got = torch.ops.tvmi.sort_scores_desc(s.to(DEV)).cpu()
         assert torch.equal(got, want), n
+
+
+# ------------------------------------------------------------------ tile-owner RoIAlign backward (deterministic)
+@pytest.mark.parametrize("P,sr,aligned", [(7, 2, False), (14, 2, True), (7, 0, False), (14, 3, False)])
+def test_roi_align_backward_owner_path_layouts(tv, P, sr, aligned):
+    """The tile-owner backward (fp32, 7x7 / 14x14): RoI lists longer than one scan round, unsorted batch indices, images
+    without RoIs, windows above 64 rows / columns (factors evaluated in the kernel), odd map sizes, adaptive sampling —
+    against the oracle; and the result must be bit-identical from run to run."""
+    g = gen(200 + P + sr)
+    N, C, H, W = 5, 37, 45, 83            # W odd, H / W not multiples of the 16-pixel tile, C not a multiple of 32
+    k = 2600
+    rois = rois_for(N, k, W * 8, H * 8, 4, 260, g)
+    rois[:, 0] = torch.randint(0, N, (k,), generator=g).float()
+    rois[rois[:, 0] == 3, 0] = 1.0                                   # image 3 has no RoI at all
+    rois[:1500, 1:] = torch.tensor([200.0, 120.0, 330.0, 250.0]) + torch.rand(1500, 4, generator=g) * 6   # > 1024 RoIs on one tile
+    rois[:1500, 0] = 2.0
+    rois[1500, 1:] = torch.tensor([-40.0, -30.0, 700.0, 400.0])     # window ~ 90 x 54 px: above the table capacity
+    rois[1501, 1:] = torch.tensor([0.0, 0.0, W * 8.0, H * 8.0])     # the whole map
+    rois[1502, 1:] = torch.tensor([300.0, 100.0, 100.0, 50.0])      # malformed (x2 < x1)
+    rois[1503, 1:] = torch.tensor([5000.0, 5000.0, 6000.0, 6000.0]) # outside
+    gr = torch.randn(k, C, P, P, generator=g)
+    a = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), 1 / 8, P, P, N, C, H, W, sr, aligned)
+    b = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), 1 / 8, P, P, N, C, H, W, sr, aligned)
+    assert torch.equal(a, b)
+    ref = O.roi_align_backward(gr.numpy(), rois.numpy(), 1 / 8, P, P, N, C, H, W, sr, aligned)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(ref).max())))
+    assert a[3].abs().max().item() == 0.0
+    # expanded (stride-0) and transposed gradients still arrive (the glue makes the bins contiguous)
+    ones = torch.ones(1, device=DEV).expand(k, C, P, P)
+    c = tv._roi_align_backward(ones, rois.to(DEV), 1 / 8, P, P, N, C, H, W, sr, aligned)
+    refc = O.roi_align_backward(np.ones((k, C, P, P), np.float32), rois.numpy(), 1 / 8, P, P, N, C, H, W, sr, aligned)
+    np.testing.assert_allclose(c.cpu().numpy(), refc, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(refc).max())))
+
+
+def test_roi_align_backward_is_deterministic_under_the_torch_flag(tv):
+    """torch.use_deterministic_algorithms(True): the reference reroutes roi_align to a python implementation
+    (torchvision/ops/roi_align.py:276-281) because its CUDA backward is atomic; ours is deterministic for the detector
+    shapes and must therefore not raise, and must raise for the shapes that still accumulate atomically."""
+    g = gen(231)
+    x = torch.randn(2, 16, 40, 60, generator=g).to(DEV)
+    rois = rois_for(2, 300, 480, 320, 8, 200, g).to(DEV)
+    feats = {str(i): torch.randn(2, 16, 320 // s, 480 // s, generator=g).to(DEV).requires_grad_(True) for i, s in enumerate((4, 8, 16))}
+    boxes = [random_boxes(200, 480, 320, 8, 300, g).to(DEV) for _ in range(2)]
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2"], 7, 2)
+    torch.use_deterministic_algorithms(True)
+    try:
+        xa = x.clone().requires_grad_(True)
+        vision_amd.roi_align(xa, rois, 7, 1 / 8, 2, False).square().sum().backward()
+        xb = x.clone().requires_grad_(True)
+        vision_amd.roi_align(xb, rois, 7, 1 / 8, 2, False).square().sum().backward()
+        assert torch.equal(xa.grad, xb.grad)
+        pool(feats, boxes, [(320, 480)] * 2).square().sum().backward()
+        g1 = [f.grad.clone() for f in feats.values()]
+        for f in feats.values():
+            f.grad = None
+        pool(feats, boxes, [(320, 480)] * 2).square().sum().backward()
+        assert all(torch.equal(a, f.grad) for a, f in zip(g1, feats.values()))
+        xc = x.clone().requires_grad_(True)
+        with pytest.raises(RuntimeError, match="roi_align_backward_kernel"):
+            vision_amd.roi_align(xc, rois, 5, 1 / 8, 2, False).sum().backward()
+    finally:
+        torch.use_deterministic_algorithms(False)
+
+
+def test_multiscale_roi_align_16bit_features_keep_fp32_boxes():
+    """fp16 / bf16 feature maps with fp32 proposals: levels and sample coordinates must come from the fp32 boxes (the
+    reference casts the RoIs to fp32 under autocast, _autograd_registrations.py:246) — boxes above 1024 px would move by
+    up to 8 px if they were rounded to bf16."""
+    g = gen(241)
+    B, C = 2, 32
+    feats = {str(i): torch.randn(B, C, 800 // s, 1344 // s, generator=g) for i, s in enumerate((4, 8, 16, 32))}
+    boxes = [random_boxes(200, 1344, 800, 8, 500, g) + torch.tensor([0.37, 0.21, 0.37, 0.21]) for _ in range(B)]
+    for b in boxes:
+        b[:100, 0::2] += 600.0                  # plenty of coordinates above 1024
+        b[:, 2].clamp_(max=1344.0)
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    levels = pool.map_levels(boxes) if pool.map_levels else None
+    for dt, tol in ((torch.bfloat16, 5e-3), (torch.float16, 4e-3)):
+        with torch.no_grad():
+            out = pool({k: v.to(dt).to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * B)
+        assert out.dtype == dt
+        levels = pool.map_levels(boxes)
+        rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+        for lvl in range(4):
+            sel = torch.nonzero(levels == lvl)[:, 0]
+            if sel.numel():
+                ref = O.roi_align(feats[str(lvl)].to(dt).float().numpy(), rois[sel].numpy(), pool.scales[lvl], 7, 7, 2, False)
+                np.testing.assert_allclose(out[sel.to(DEV)].float().cpu().numpy(), ref, rtol=tol, atol=tol)
+        # the autocast route gives the same tensor
+        with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+            out2 = pool({k: v.to(dt).to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * B)
+        assert torch.equal(out, out2)

@@ -1,0 +1,170 @@
+"""Measured config matrix (run on the GPU box): every timing quoted in DESIGN.md §6 comes from the JSON this writes
+(gpurun_out/<tag>/matrix.json, copied to profiles/).  Events on the current stream, inputs resident in HBM.
+
+    python tools/gpu_matrix.py [out.json] [section ...]      sections: c2 c1 c3 c4 resize post (default: all)
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+import bench
+import vision_amd
+from vision_amd.poolers import LevelMapper, _convert_to_roi_format
+
+dev = torch.device("cuda:0")
+tv = torch.ops.torchvision
+out_path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else None
+sections = [a for a in sys.argv[1:] if not a.endswith(".json")] or ["c2", "c1", "c3", "c4", "resize", "post"]
+res = {"device": torch.cuda.get_device_name(0), "torch": torch.__version__}
+
+
+def tm(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def put(key, ms, **kw):
+    res[key] = dict(ms=round(ms, 4), **kw)
+    extra = "  ".join(f"{k}={v}" for k, v in kw.items())
+    print(f"{key}: {ms:.4f} ms  {extra}", flush=True)
+
+
+if "c2" in sections:
+    feats, boxes, scores = bench.make_inputs(dev, 1000)
+    rois = _convert_to_roi_format(boxes).float()
+    levels = LevelMapper(2, 5)(boxes)
+    scales = [1 / s for s in bench.STRIDES]
+    ms_args = (2, 5, 224.0, 4.0, 1e-6)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        name = str(dt)[6:]
+        fl = [feats[str(i)].to(dt) for i in range(4)]
+        fcl = [f.contiguous(memory_format=torch.channels_last) for f in fl]
+        in_bytes = sum(f.numel() * f.element_size() for f in fl)
+        hs, ws = [f.shape[2] for f in fl], [f.shape[3] for f in fl]
+        for P in (7, 14):
+            out_bytes = 4000 * 256 * P * P * fl[0].element_size()
+            t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fl, rois, scales, P, P, 2, False, *ms_args))
+            put(f"c2_fwd_{P}x{P}_{name}", t, alg_GBs=round((in_bytes + out_bytes) / t / 1e6))
+            if P == 7:
+                t = tm(lambda: torch.ops.tvmi.multiscale_roi_align(fcl, rois, scales, P, P, 2, False, *ms_args))
+                put(f"c2_fwd_{P}x{P}_{name}_channels_last", t, alg_GBs=round((in_bytes + out_bytes) / t / 1e6))
+            # what the unchanged reference python launches: per-level roi_align + index_put (poolers.py:199-222)
+            sel = [torch.nonzero(levels == l)[:, 0] for l in range(4)]
+            rl = [rois[s].to(dt) for s in sel]
+
+            def per_level():
+                result = torch.zeros(4000, 256, P, P, dtype=dt, device=dev)
+                for l in range(4):
+                    result[sel[l]] = tv.roi_align(fl[l], rl[l], scales[l], P, P, 2, False)
+                return result
+            t = tm(per_level, n=10)
+            put(f"c2_fwd_{P}x{P}_{name}_schema_ops_per_level", t)
+            # backward: the per-level autograd path and the fused op; bytes = grad read + every map written once
+            grads = [torch.randn(len(s), 256, P, P, device=dev).to(dt) for s in sel]
+
+            def bwd_levels():
+                for l in range(4):
+                    f = fl[l]
+                    tv._roi_align_backward(grads[l], rl[l], scales[l], P, P, f.shape[0], 256, f.shape[2], f.shape[3], 2, False)
+            t = tm(bwd_levels, n=10)
+            put(f"c2_bwd_{P}x{P}_{name}_per_level", t, alg_GBs=round((out_bytes + in_bytes) / t / 1e6))
+            gall = torch.randn(4000, 256, P, P, device=dev).to(dt)
+            t = tm(lambda: torch.ops.tvmi.multiscale_roi_align_backward(gall, rois, hs, ws, scales, 4, P, P, 2, False, *ms_args), n=10)
+            put(f"c2_bwd_{P}x{P}_{name}_fused", t, alg_GBs=round((out_bytes + in_bytes) / t / 1e6))
+        del fl, fcl
+    ab, asc = torch.cat(boxes), torch.cat(scores)
+    img = torch.cat([torch.full((1000,), i, device=dev, dtype=torch.int64) for i in range(4)])
+    put("c2_nms_4x1000_batched_padded", tm(lambda: vision_amd.boxes.batched_nms_padded(ab, asc, img, 0.5, 4)))
+    put("c2_nms_4x1000_schema_ops", tm(lambda: [tv.nms(b, s, 0.5) for b, s in zip(boxes, scores)]))
+
+if "c1" in sections:
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 256, 200, 272, generator=g).to(dev)
+    xy = torch.rand(1000, 2, generator=g) * torch.tensor([1088 - 64.0, 800 - 64.0])
+    wh = 16 + torch.rand(1000, 2, generator=g) * 284
+    r1 = torch.cat([torch.zeros(1000, 1), xy, torch.minimum(xy + wh, torch.tensor([1088.0, 800.0]))], 1).to(dev)
+    sc = torch.rand(1000, generator=g).to(dev)
+    b1 = r1[:, 1:].contiguous()
+    t_roi = tm(lambda: tv.roi_align(x, r1, 0.25, 7, 7, 2, False))
+    t_nms = tm(lambda: tv.nms(b1, sc, 0.5))
+    put("c1_roi_align_7x7", t_roi)
+    put("c1_nms_1000", t_nms, boxes_per_s=round(1000 / (t_roi + t_nms) * 1e3))
+
+if "c3" in sections:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import random_boxes  # tests/helpers.py: the SURVEY.md §8d box generator
+    for canvas in (1000, 200):
+        g = torch.Generator().manual_seed(7)
+        n = 100_000
+        b = random_boxes(n, canvas, canvas, 1, 101, g).to(dev)
+        s = torch.rand(n, generator=g).to(dev)
+        idx = torch.randint(0, 80, (n,), generator=g).to(dev)
+        kept = tv.nms(b, s, 0.5).numel()
+        t = tm(lambda: tv.nms(b, s, 0.5), n=10)
+        pairs = n * (n - 1) / 2
+        put(f"c3_nms_100k_canvas{canvas}", t, kept=kept, Gpairs_per_s=round(pairs / t / 1e6, 1))
+        keptb = vision_amd.batched_nms(b, s, idx, 0.5).numel()
+        put(f"c3_batched_nms_100k_x80_canvas{canvas}", tm(lambda: vision_amd.batched_nms(b, s, idx, 0.5), n=10), kept=keptb)
+
+if "c4" in sections:
+    g = torch.Generator().manual_seed(0)
+    B, C, H, W = 2, 256, 100, 136
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    off = torch.randn(B, 18, H, W, generator=g).to(dev)
+    m = torch.rand(B, 9, H, W, generator=g).to(dev)
+    bias = torch.randn(256, generator=g).to(dev)
+    for groups in (1, 256):
+        w = (torch.randn(256, C // groups, 3, 3, generator=g) * 0.01).to(dev)
+        fl = 2.0 * B * 256 * (C // groups) * 9 * H * W
+        for mask in (None, m):
+            t = tm(lambda: vision_amd.deform_conv2d(x, off, w, bias, padding=1, mask=mask), n=10)
+            put(f"c4_deform_conv2d_g{groups}_{'mask' if mask is not None else 'nomask'}", t, TFLOPs=round(fl / t / 1e9, 2))
+        for dt in (torch.bfloat16, torch.float16):
+            t = tm(lambda: vision_amd.deform_conv2d(x.to(dt), off.to(dt), w.to(dt), bias.to(dt), padding=1), n=10)
+            put(f"c4_deform_conv2d_g{groups}_{str(dt)[6:]}", t, TFLOPs=round(fl / t / 1e9, 2))
+
+if "resize" in sections:
+    g = torch.Generator().manual_seed(0)
+    big = torch.rand(8, 3, 1080, 1920, generator=g).to(dev)
+    by = big.numel() * 4 + 8 * 3 * 800 * 1422 * 4
+    for mode, aa in (("bilinear", False), ("bilinear", True), ("bicubic", False), ("bicubic", True), ("nearest", False)):
+        t = tm(lambda: vision_amd.interpolate(big, size=(800, 1422), mode=mode, antialias=aa))
+        t2 = tm(lambda: F.interpolate(big, size=(800, 1422), mode=mode, antialias=aa))
+        put(f"resize_8x3x1080x1920_to_800x1422_{mode}{'_aa' if aa else ''}", t, GBs=round(by / t / 1e6), aten_ms=round(t2, 4))
+    small = torch.rand(3, 480, 640, generator=g).to(dev)[None]
+    for mode in ("bilinear", "bicubic"):
+        t = tm(lambda: vision_amd.interpolate(small, size=(800, 1067), mode=mode))
+        t2 = tm(lambda: F.interpolate(small, size=(800, 1067), mode=mode))
+        put(f"resize_3x480x640_to_800x1067_{mode}", t, aten_ms=round(t2, 4))
+
+if "post" in sections:
+    g = torch.Generator().manual_seed(0)
+    mk = torch.rand(100, 1, 28, 28, generator=g).to(dev)
+    xy = torch.rand(100, 2, generator=g) * torch.tensor([1200.0, 700.0])
+    mb = torch.cat([xy, xy + 20 + torch.rand(100, 2, generator=g) * 300], 1).to(dev)
+    t = tm(lambda: vision_amd.paste_masks_in_image(mk, mb, (800, 1333)))
+    put("paste_masks_100x28x28_to_800x1333", t, written_GBs=round(100 * 800 * 1333 * 4 / t / 1e6))
+    shapes = [(800, 1333)] * 4
+    props = [torch.cat([p, p + 30 + torch.rand(1000, 2, generator=g) * 300], 1).to(dev)
+             for p in (torch.rand(1000, 2, generator=g) * torch.tensor([1000.0, 500.0]) for _ in range(4))]
+    logits = (torch.randn(4000, 91, generator=g) * 3).to(dev)
+    reg = (torch.randn(4000, 364, generator=g) * 0.5).to(dev)
+    put("postprocess_detections_4x1000x91", tm(lambda: vision_amd.postprocess_detections(logits, reg, props, shapes, padded=True), n=10))
+
+if out_path:
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    json.dump(res, open(out_path, "w"), indent=1)
+    print("wrote", out_path)

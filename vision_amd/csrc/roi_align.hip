@@ -1,97 +1,28 @@
-// roi_align.hip — RoIAlign forward / backward for gfx950 (MI355X).
+// roi_align.hip — RoIAlign forward for gfx950 (MI355X).  (Backward: roi_align_bwd.hip.)
 //
-// Semantics: torchvision/csrc/ops/cpu/roi_align_kernel.cpp:18-115 (forward), :117-289
-// (backward) and cpu/roi_align_common.h:32-124 (sample -> 4 taps + weights).  The TU is
-// built with -ffp-contract=off so the sample-coordinate arithmetic rounds exactly like the
-// reference's x86 build; fused multiply-adds are only used where written explicitly.
+// Semantics: torchvision/csrc/ops/cpu/roi_align_kernel.cpp:18-115 and cpu/roi_align_common.h:32-124
+// (sample -> 4 taps + weights).  The TU is built with -ffp-contract=off so the sample-coordinate
+// arithmetic rounds exactly like the reference's x86 build; fused multiply-adds are only used where
+// written explicitly.
 //
 // Design (not the reference's one-thread-per-output gather, cuda/roi_align_kernel.cu:68):
-//   * one 256-thread workgroup per (RoI, chunk of CCH channels);
-//   * the RoI's PH*gh y-samples and PW*gw x-samples are decomposed ONCE into two small
-//     1-D tables in LDS (low index, low/high weight) — the bilinear weights are separable,
-//     so the reference's PH*PW*gh*gw PreCalc array is never materialised;
-//   * the RoI's bounding window of the feature map is staged per channel group into LDS
-//     with row-contiguous (coalesced along W) loads, and all 4 taps of every sample are
-//     gathered from LDS (ds_read2_b32 pairs), not from L1/L2;
-//   * outputs of a channel group are written as one contiguous run (K,C,PH,PW is
-//     contiguous in (c,ph,pw) for fixed k), fully coalesced.
-//   * RoIs whose tables or windows do not fit fall back, per workgroup, to table-driven
-//     global gathers or to on-the-fly arithmetic.
-// Backward mirrors this: gradients of a channel group are accumulated into the LDS window
-// with ds_add_f32 and flushed with ONE global atomic per touched pixel instead of 4 per
-// sample.
-#include <stdlib.h>
-
+//   * unit = one wave64 = (RoI, channel chunk), no workgroup barrier anywhere;
+//   * 7x7 / 14x14 bins with sampling_ratio 2: lane = output bin, its 4 samples live in registers, the
+//     RoI's window rows go HBM/L2 -> LDS by 16-byte LDS-DMA (double-buffered), taps are read from LDS
+//     (roi_align_fwd_dma / roi_align_fwd_ms_dma); what that kernel declines (windows above 8 DMA blocks
+//     per channel) is mopped up by a register-staged wave kernel;
+//   * other pooled shapes: per-wave axis tables in LDS + register-staged window (roi_align_fwd_wave);
+//   * channels_last maps: lane = channel kernel (roi_align_fwd_nhwc), no layout copy;
+//   * fp64: one thread per output element, arithmetic on the fly.
+// Multi-scale (FPN) entries pick the level of every RoI in the kernel and serve all levels with one launch.
 #include <type_traits>
 
-#include "tvmi_common.h"
+#include "roi_common.h"
 
 namespace tvmi {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxTab = 128;      // max PH*gh (and PW*gw) samples per axis kept in LDS
-constexpr int kWinFloats = 8192;  // LDS window capacity in floats (32 KiB)
-constexpr int kChunk = 32;        // channels per workgroup
-constexpr int kMaxLevels = 8;     // FPN levels served by one multi-scale launch
-
-template <typename A>
-struct RoiGeom {
-  A start_h, start_w, bin_h, bin_w, count;
-  int gh, gw, batch;
-};
-
-// cpu/roi_align_kernel.cpp:36-66
-template <typename T, typename A>
-__device__ __forceinline__ RoiGeom<A> roi_geom(const T* roi, A scale, int PH, int PW, int sr,
-                                               bool aligned) {
-  RoiGeom<A> g;
-  g.batch = (int)ld(roi);
-  const A offset = aligned ? (A)0.5 : (A)0.0;
-  const A sw = ld(roi + 1) * scale - offset;
-  const A sh = ld(roi + 2) * scale - offset;
-  const A ew = ld(roi + 3) * scale - offset;
-  const A eh = ld(roi + 4) * scale - offset;
-  A rw = ew - sw;
-  A rh = eh - sh;
-  if (!aligned) {
-    rw = rw > (A)1. ? rw : (A)1.;  // std::max(roi_width, 1)
-    rh = rh > (A)1. ? rh : (A)1.;
-  }
-  g.start_h = sh;
-  g.start_w = sw;
-  g.bin_h = rh / (A)PH;
-  g.bin_w = rw / (A)PW;
-  g.gh = sr > 0 ? sr : (int)ceil(rh / (A)PH);
-  g.gw = sr > 0 ? sr : (int)ceil(rw / (A)PW);
-  const int cnt = g.gh * g.gw;
-  g.count = (A)(cnt > 1 ? cnt : 1);
-  return g;
-}
-
-// One axis of cpu/roi_align_common.h:50-103.  Returns false when the coordinate is
-// outside [-1, dim] (the sample then contributes zero).
-template <typename A>
-__device__ __forceinline__ bool axis_sample(int dim, A start, A bin, int grid, int p, int i, int& lo,
-                                            int& hi, A& l, A& h) {
-  A c = start + (A)p * bin + (A)((float)i + .5f) * bin / (A)grid;
-  if (c < (A)-1.0 || c > (A)dim) {
-    lo = hi = 0;
-    l = h = (A)0;
-    return false;
-  }
-  if (c <= (A)0) c = (A)0;
-  lo = (int)c;
-  if (lo >= dim - 1) {
-    hi = lo = dim - 1;
-    c = (A)lo;
-  } else {
-    hi = lo + 1;
-  }
-  l = c - (A)lo;
-  h = (A)1. - l;
-  return true;
-}
 
 // ---------------------------------------------------------------------------------------
 // Generic forward: one thread per output element, arithmetic on the fly (any grid size,
@@ -138,264 +69,6 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_generic(
 }
 
 // ---------------------------------------------------------------------------------------
-// Tiled forward (fp32 accumulate): see the header comment.
-struct AxisTab {
-  int lo[kMaxTab];
-  int hi[kMaxTab];
-  float l[kMaxTab];
-  float h[kMaxTab];
-};
-
-struct TileShared {
-  AxisTab y, x;
-  int bounds[4];  // ymin, ymax, xmin, xmax over valid samples
-  float win[kWinFloats];
-};
-
-enum { MODE_LDS = 0, MODE_TAB = 1, MODE_GEN = 2, MODE_ZERO = 3 };
-
-// Builds both axis tables for this workgroup's RoI; returns the processing mode.
-// On MODE_LDS the table `lo` entries are rewritten as window-relative offsets
-// (y: row*wstride, x: col) and *G is the number of channels staged per pass.
-template <typename T>
-__device__ __forceinline__ int build_tables(TileShared& s, const RoiGeom<float>& g, int H, int W,
-                                            int PH, int PW, int chunk_c, int& y0, int& x0,
-                                            int& wh, int& ww, int& wstride, int& G) {
-  const int tid = threadIdx.x;
-  const int ny = PH * g.gh, nx = PW * g.gw;
-  if (ny > kMaxTab || nx > kMaxTab || g.gh <= 0 || g.gw <= 0) {
-    return (g.gh <= 0 || g.gw <= 0) ? MODE_ZERO : MODE_GEN;
-  }
-  if (tid == 0) {
-    s.bounds[0] = 0x7fffffff;
-    s.bounds[1] = -1;
-    s.bounds[2] = 0x7fffffff;
-    s.bounds[3] = -1;
-  }
-  __syncthreads();
-  if (tid < ny) {
-    int lo, hi;
-    float l, h;
-    const bool v = axis_sample<float>(H, g.start_h, g.bin_h, g.gh, tid / g.gh, tid % g.gh, lo, hi, l, h);
-    s.y.lo[tid] = v ? lo : -1;
-    s.y.hi[tid] = hi;
-    s.y.l[tid] = l;
-    s.y.h[tid] = h;
-    if (v) {
-      atomicMin(&s.bounds[0], lo);
-      atomicMax(&s.bounds[1], hi);
-    }
-  } else if (tid >= kMaxTab && tid - kMaxTab < nx) {
-    const int t = tid - kMaxTab;
-    int lo, hi;
-    float l, h;
-    const bool v = axis_sample<float>(W, g.start_w, g.bin_w, g.gw, t / g.gw, t % g.gw, lo, hi, l, h);
-    s.x.lo[t] = v ? lo : -1;
-    s.x.hi[t] = hi;
-    s.x.l[t] = l;
-    s.x.h[t] = h;
-    if (v) {
-      atomicMin(&s.bounds[2], lo);
-      atomicMax(&s.bounds[3], hi);
-    }
-  }
-  __syncthreads();
-  y0 = s.bounds[0];
-  x0 = s.bounds[2];
-  const int y1 = s.bounds[1], x1 = s.bounds[3];
-  if (y1 < 0 || x1 < 0) return MODE_ZERO;  // every sample of one axis is out of range
-  // Rows y0..y1+1 and cols x0..x1+1 are staged; the +1 pad only ever meets a zero weight.
-  wh = y1 - y0 + 2;
-  ww = x1 - x0 + 2;
-  wstride = ww | 1;
-  const int wsz = wh * wstride;
-  G = kWinFloats / wsz;
-  if (G > chunk_c) G = chunk_c;
-  const int mode = G >= 1 ? MODE_LDS : MODE_TAB;
-  // Second pass (same thread that wrote the entry): invalid samples get lo = origin and
-  // zero weights; LDS mode turns lo into a window-relative offset.
-  if (tid < ny) {
-    int lo = s.y.lo[tid];
-    if (lo < 0) {
-      lo = y0;
-      s.y.hi[tid] = y0;
-    }
-    s.y.lo[tid] = mode == MODE_LDS ? (lo - y0) * wstride : lo;
-  } else if (tid >= kMaxTab && tid - kMaxTab < nx) {
-    const int t = tid - kMaxTab;
-    int lo = s.x.lo[t];
-    if (lo < 0) {
-      lo = x0;
-      s.x.hi[t] = x0;
-    }
-    s.x.lo[t] = mode == MODE_LDS ? (lo - x0) : lo;
-  }
-  __syncthreads();
-  return mode;
-}
-
-// One workgroup = one (RoI k, channel chunk starting at c0) of one feature map.
-template <typename T, int PHT, int PWT, int SRT>
-__device__ __forceinline__ void roi_align_fwd_block(TileShared& s, const T* __restrict__ input,
-                                                    const T* __restrict__ rois, T* __restrict__ output,
-                                                    int C, int H, int W, int PH_, int PW_,
-                                                    float spatial_scale, int sr_, int aligned, int k, int c0) {
-  const int PH = PHT > 0 ? PHT : PH_;
-  const int PW = PWT > 0 ? PWT : PW_;
-  const int sr = SRT > 0 ? SRT : sr_;
-  const int PHW = PH * PW;
-  const int tid = threadIdx.x;
-  const int cc = min(kChunk, C - c0);
-
-  RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PH, PW, sr, aligned != 0);
-  if (SRT > 0) {
-    g.gh = SRT;
-    g.gw = SRT;
-  }
-  T* out = output + ((int64_t)k * C + c0) * PHW;
-  const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
-  const int64_t plane_sz = (int64_t)H * W;
-
-  int y0 = 0, x0 = 0, wh = 0, ww = 0, wstride = 0, G = 0;
-  const int mode = build_tables<T>(s, g, H, W, PH, PW, cc, y0, x0, wh, ww, wstride, G);
-
-  if (mode == MODE_ZERO) {
-    for (int o = tid; o < cc * PHW; o += kThreads) st(out + o, 0.f);
-    return;
-  }
-  if (mode == MODE_GEN) {
-    for (int o = tid; o < cc * PHW; o += kThreads) {
-      const int c = o / PHW, bin = o - c * PHW;
-      const int ph = bin / PW, pw = bin - ph * PW;
-      st(out + o, roi_align_point<T, float>(in0 + c * plane_sz, H, W, g, ph, pw));
-    }
-    return;
-  }
-  const float inv_count = g.count;  // divide (not multiply) to round like the reference
-  const int gh = g.gh, gw = g.gw;
-
-  if (mode == MODE_TAB) {
-    // Window too large for LDS: table-driven gathers straight from global memory.
-    for (int o = tid; o < cc * PHW; o += kThreads) {
-      const int c = o / PHW, bin = o - c * PHW;
-      const int ph = bin / PW, pw = bin - ph * PW;
-      const T* plane = in0 + c * plane_sz;
-      float acc = 0.f;
-      for (int iy = 0; iy < gh; ++iy) {
-        const int ty = ph * gh + iy;
-        const int ylo = s.y.lo[ty], yhi = s.y.hi[ty];
-        const float ly = s.y.l[ty], hy = s.y.h[ty];
-        for (int ix = 0; ix < gw; ++ix) {
-          const int tx = pw * gw + ix;
-          const int xlo = s.x.lo[tx], xhi = s.x.hi[tx];
-          const float lx = s.x.l[tx], hx = s.x.h[tx];
-          const float v1 = ld(plane + (int64_t)ylo * W + xlo), v2 = ld(plane + (int64_t)ylo * W + xhi);
-          const float v3 = ld(plane + (int64_t)yhi * W + xlo), v4 = ld(plane + (int64_t)yhi * W + xhi);
-          acc += (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
-        }
-      }
-      st(out + o, acc / inv_count);
-    }
-    return;
-  }
-
-  // MODE_LDS
-  const int wsz = wh * wstride;
-  const int wpix = wh * ww;
-  FastDiv16 div_wpix, div_ww;
-  div_wpix.init((unsigned)wpix);
-  div_ww.init((unsigned)ww);
-  for (int cg = 0; cg < cc; cg += G) {
-    const int gc = min(G, cc - cg);
-    // ---- stage gc channel windows (rows y0.., cols x0..; out-of-tensor pad = 0)
-    const int total = gc * wpix;
-    for (int e = tid; e < total; e += kThreads) {
-      const int ch = (int)div_wpix.div((unsigned)e);
-      const int rem = e - ch * wpix;
-      const int r = (int)div_ww.div((unsigned)rem);
-      const int col = rem - r * ww;
-      const int gy = y0 + r, gx = x0 + col;
-      float v = 0.f;
-      if (gy < H && gx < W) v = ld(in0 + (cg + ch) * plane_sz + (int64_t)gy * W + gx);
-      s.win[ch * wsz + r * wstride + col] = v;
-    }
-    __syncthreads();
-    // ---- gather from LDS
-    const int nout = gc * PHW;
-    for (int o = tid; o < nout; o += kThreads) {
-      const int ch = o / PHW, bin = o - ch * PHW;
-      const int ph = bin / PW, pw = bin - ph * PW;
-      const float* wbase = s.win + ch * wsz;
-      float acc = 0.f;
-      for (int iy = 0; iy < gh; ++iy) {
-        const int ty = ph * gh + iy;
-        const float* row = wbase + s.y.lo[ty];
-        const float ly = s.y.l[ty], hy = s.y.h[ty];
-        for (int ix = 0; ix < gw; ++ix) {
-          const int tx = pw * gw + ix;
-          const float* p = row + s.x.lo[tx];
-          const float lx = s.x.l[tx], hx = s.x.h[tx];
-          const float v1 = p[0], v2 = p[1], v3 = p[wstride], v4 = p[wstride + 1];
-          acc += (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4;
-        }
-      }
-      st(out + cg * PHW + o, acc / inv_count);
-    }
-    __syncthreads();
-  }
-}
-
-template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_tile(
-    const T* __restrict__ input, const T* __restrict__ rois, T* __restrict__ output, int C, int H,
-    int W, int PH_, int PW_, float spatial_scale, int sr_, int aligned, int nchunks) {
-  __shared__ TileShared s;
-  const int k = blockIdx.x / nchunks;
-  const int c0 = (blockIdx.x - k * nchunks) * kChunk;
-  roi_align_fwd_block<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
-                                        aligned, k, c0);
-}
-
-// ---------------------------------------------------------------------------------------
-// Multi-scale forward: the FPN level of every RoI is chosen IN the kernel
-// (torchvision/ops/poolers.py:47-84, LevelMapper: floor(k0 + log2(sqrt(area)/s0) + eps) clamped
-// to [k_min, k_max]) and all levels are served by ONE launch that writes straight into the
-// [K,C,PH,PW] result — no torch.where / index / index_put round trips per level
-// (poolers.py:199-222).
-struct MsLevels {
-  const void* ptr[kMaxLevels];
-  int H[kMaxLevels];
-  int W[kMaxLevels];
-  float scale[kMaxLevels];
-  int n_levels;
-  int k_min, k_max;
-  float s0, lvl0, eps;
-};
-
-template <typename T>
-__device__ __forceinline__ int fpn_level(const T* roi, const MsLevels& lv) {
-  const float x1 = ld(roi + 1), y1 = ld(roi + 2), x2 = ld(roi + 3), y2 = ld(roi + 4);
-  const float s = sqrtf((x2 - x1) * (y2 - y1));
-  float t = floorf(lv.lvl0 + log2f(s / lv.s0) + lv.eps);
-  t = fminf(fmaxf(t, (float)lv.k_min), (float)lv.k_max);  // NaN area -> k_min like torch.clamp? (clamp keeps NaN)
-  int l = (t == t) ? (int)t - lv.k_min : 0;
-  return min(max(l, 0), lv.n_levels - 1);
-}
-
-template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_tile(MsLevels lv, const T* __restrict__ rois,
-                                                                 T* __restrict__ output, int C, int PH_,
-                                                                 int PW_, int sr_, int aligned, int nchunks) {
-  __shared__ TileShared s;
-  const int k = blockIdx.x / nchunks;
-  const int c0 = (blockIdx.x - k * nchunks) * kChunk;
-  const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
-  roi_align_fwd_block<T, PHT, PWT, SRT>(s, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                        PH_, PW_, lv.scale[l], sr_, aligned, k, c0);
-}
-
-
-// ---------------------------------------------------------------------------------------
 // Wave-autonomous forward ("v3"): every wave owns one (RoI, channel chunk) unit end to end —
 // its own axis tables, its own LDS window, no workgroup barrier anywhere, so the 16 resident
 // waves of a CU drift apart and hide each other's memory latency.  The window is staged with a
@@ -411,8 +84,6 @@ struct WaveShared {
   float win[kWaveWin];
 };
 
-__device__ int g_roi_force_mode = 0;  // debug knob (tvmi_debug_set): 0 auto, 1 never stage through LDS
-__device__ int g_cfg_dma_sparse = 1;  // stage only the sampled rows of tall windows (TVMI_ROI_DMA_SPARSE=0: whole window)
 
 // Stages CH channel windows (rows y0.., cols x0.., clamped into the tensor) with RG row-groups
 // each: RG*CH independent loads are in flight per lane before the first LDS write.  Lanes
@@ -457,18 +128,18 @@ __device__ __forceinline__ void stage_window_setup(float* __restrict__ win, cons
   stage_window<T, RG, CH>(win, in_cg, plane_sz, gc, nrg, wsz, goff, loff);
 }
 
-template <typename T, int PHT, int PWT, int SRT>
+template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* __restrict__ input,
-                                                        const T* __restrict__ rois, T* __restrict__ output,
+                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                         int C, int H, int W, int PH_, int PW_, float spatial_scale,
-                                                        int sr_, int aligned, int k, int c0, int chunk, int force_mode) {
+                                                        int sr_, int aligned, int k, int c0, int chunk) {
   const int PH = PHT > 0 ? PHT : PH_;
   const int PW = PWT > 0 ? PWT : PW_;
   const int sr = SRT > 0 ? SRT : sr_;
   const int PHW = PH * PW;
   const int lane = threadIdx.x & 63;
   const int cc = min(chunk, C - c0);
-  RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PH, PW, sr, aligned != 0);
+  RoiGeom<float> g = roi_geom<R, float>(rois + (int64_t)k * 5, spatial_scale, PH, PW, sr, aligned != 0);
   if (SRT > 0) {
     g.gh = SRT;
     g.gw = SRT;
@@ -542,7 +213,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
   const int wsz = wh * wstride;
   const int rpi = wpad <= 64 ? 64 / wpad : 1;  // window rows staged per wave-instruction
   const int nrg = (wh + rpi - 1) / rpi;
-  int G = (ww <= 64 && nrg <= 16 && force_mode != 1) ? kWaveWin / wsz : 0;
+  int G = (ww <= 64 && nrg <= 16) ? kWaveWin / wsz : 0;
   if (G > cc) G = cc;
 
   if (G < 1) {
@@ -577,8 +248,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
   for (int cg = 0; cg < cc; cg += G) {
     const int gc = min(G, cc - cg);
     const T* in_cg = in0 + (int64_t)cg * plane_sz;
-    if (force_mode == 2) {
-    } else if (nrg <= 4)
+    if (nrg <= 4)
       stage_window_setup<T, 4, 4>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
     else if (nrg <= 8)
       stage_window_setup<T, 8, 2>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
@@ -587,7 +257,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nout = force_mode == 3 ? 0 : gc * PHW;
+    const int nout = gc * PHW;
     for (int o = lane; o < nout; o += 64) {
       const int ch = o / PHW, bin = o - ch * PHW;
       const int ph = bin / PW, pw = bin - ph * PW;
@@ -620,11 +290,11 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
 // store of the PH*PW outputs of that channel.  The bilinear form hy*(hx*v1+lx*v2) +
 // ly*(hx*v3+lx*v4) is evaluated with explicit fused multiply-adds; it differs from the
 // reference's (hy*hx)*v1+... association by rounding only (<1e-6 relative).
-template <typename T, int PHT, int PWT, int SRT>
+template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* __restrict__ input,
-                                                        const T* __restrict__ rois, T* __restrict__ output,
+                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                         int C, int H, int W, float spatial_scale, int aligned,
-                                                        int k, int c0, int chunk, int force_mode) {
+                                                        int k, int c0, int chunk) {
   constexpr int PHW = PHT * PWT;
   constexpr int NB = (PHW + 63) / 64;  // bins per lane
   constexpr int NS = SRT * SRT;        // samples per bin
@@ -632,7 +302,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
   static_assert(ny <= 64 && nx <= 64, "axis samples must fit one wave");
   const int lane = threadIdx.x & 63;
   const int cc = min(chunk, C - c0);
-  RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
+  RoiGeom<float> g = roi_geom<R, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
   T* out = output + ((int64_t)k * C + c0) * PHW;
   const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
   const int64_t plane_sz = (int64_t)H * W;
@@ -669,7 +339,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
   const int wsz = wh * wstride;
   const int rpi = wpad <= 64 ? 64 / wpad : 1;
   const int nrg = (wh + rpi - 1) / rpi;
-  int G = (ww <= 64 && nrg <= 16 && force_mode != 1) ? kWaveWin / wsz : 0;
+  int G = (ww <= 64 && nrg <= 16) ? kWaveWin / wsz : 0;
   if (G > cc) G = cc;
 
   // ---- per-lane sample set-up (registers)
@@ -865,7 +535,7 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   // A window taller than 2 rows per y-sample contains rows no sample touches (bins > 2 px): stage only the
   // sampled rows.  The kernel is bound by the bytes that cross L2 -> L1, and this drops ~1/3 of them on the
   // FPN workload (and pulls RoIs that were too tall for 8 DMA blocks per channel back onto this path).
-  if (g_cfg_dma_sparse && w.wh > 2 * ny) {
+  if (w.wh > 2 * ny) {
     w.sparse = 1;
     w.wh = 2 * ny;
   }
@@ -978,9 +648,9 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   }
 }
 
-template <typename T, int PHT, int PWT, int SRT>
+template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __restrict__ input,
-                                                       const T* __restrict__ rois, T* __restrict__ output,
+                                                       const R* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
                                                        int c0, int chunk, int* __restrict__ declined) {
   constexpr int PHW = PHT * PWT;
@@ -990,7 +660,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
   constexpr int BLK = kDmaBlkBytes / (int)sizeof(T);
   const int lane = threadIdx.x & 63;
   const int cc = min(chunk, C - c0);
-  const RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
+  const RoiGeom<float> g = roi_geom<R, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
   T* out = output + ((int64_t)k * C + c0) * PHW;
   const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
   const int64_t plane_sz = (int64_t)H * W;
@@ -1043,21 +713,20 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
     roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
 }
 
-template <typename T, int PHT, int PWT, int SRT>
+template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* __restrict__ input,
-                                                        const T* __restrict__ rois, T* __restrict__ output, int C,
+                                                        const R* __restrict__ rois, T* __restrict__ output, int C,
                                                         int H, int W, int PH_, int PW_, float spatial_scale, int sr_,
-                                                        int aligned, int k, int c0, int chunk, int force_mode,
+                                                        int aligned, int k, int c0, int chunk,
                                                         const int* __restrict__ declined) {
   if constexpr (PHT > 0 && PWT > 0 && SRT > 0) {
     // when the DMA launch ran first, this launch only mops up what it declined
     if (declined && declined[k] == 0) return;
-    roi_align_fwd_wave_fast<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, spatial_scale, aligned, k, c0, chunk,
-                                              force_mode);
+    roi_align_fwd_wave_fast<T, R, PHT, PWT, SRT>(s, input, rois, output, C, H, W, spatial_scale, aligned, k, c0, chunk);
   }
   else
-    roi_align_fwd_wave_unit<T, PHT, PWT, SRT>(s, input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_, aligned,
-                                              k, c0, chunk, force_mode);
+    roi_align_fwd_wave_unit<T, R, PHT, PWT, SRT>(s, input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_, aligned,
+                                              k, c0, chunk);
 }
 
 // XCD-aware work placement.  Workgroup b is observed to run on XCD b % 8 (a speed assumption
@@ -1065,7 +734,7 @@ __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* 
 // walks it channel-chunk by channel-chunk, so at any moment an XCD's private 4 MiB L2 is asked
 // for one thin channel slice of the feature maps (which fits) by ALL of its RoIs, and the
 // overlap between neighbouring RoI windows turns into L2 hits instead of HBM re-reads.
-__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const int* __restrict__ order, int& k,
+__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, int& k,
                                           int& chunk_idx, int wpb = kThreads / 64) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   const int xcd = blockIdx.x & 7;
@@ -1077,51 +746,7 @@ __device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const int* __r
   if (local >= Kx * nchunks) return false;
   chunk_idx = (int)(local / Kx);
   k = (int)(kstart + (local - (int64_t)chunk_idx * Kx));
-  if (order) k = order[k];
   return true;
-}
-
-// Locality order of the RoIs: a stable-enough counting sort by (image, 32-pixel band of the box
-// centre).  Cutting the sorted list into 8 contiguous ranges (one per XCD, see wave_unit) gives
-// every XCD a horizontal band of one image, i.e. a slice of every feature map that fits its L2.
-constexpr int kOrderBins = 4096;
-template <typename T>
-__global__ __launch_bounds__(1024) void roi_locality_order(const T* __restrict__ rois, int K, int* __restrict__ order) {
-  __shared__ int hist[kOrderBins];
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < kOrderBins; i += 1024) hist[i] = 0;
-  __syncthreads();
-  auto bin_of = [&](int k) {
-    const T* r = rois + (int64_t)k * 5;
-    int b = (int)ld(r);
-    const float cy = 0.5f * ((float)ld(r + 2) + (float)ld(r + 4));
-    int band = (cy == cy) ? (int)fminf(fmaxf(cy * (1.f / 32.f), 0.f), 63.f) : 0;
-    b = min(max(b, 0), 63);
-    return b * 64 + band;
-  };
-  for (int k = tid; k < K; k += 1024) atomicAdd(&hist[bin_of(k)], 1);
-  __syncthreads();
-  // exclusive scan of 4096 bins: 4 per thread + block scan
-  int loc[4], sum = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    loc[q] = sum;
-    sum += hist[tid * 4 + q];
-  }
-  part[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  const int base = part[tid] - sum;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) hist[tid * 4 + q] = base + loc[q];
-  __syncthreads();
-  for (int k = tid; k < K; k += 1024) order[atomicAdd(&hist[bin_of(k)], 1)] = k;
 }
 
 inline unsigned wave_unit_grid(int64_t K, int nchunks, int wpb = kThreads / 64) {
@@ -1134,479 +759,65 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restri
                                                                T* __restrict__ output, int C, int H, int W, int PH_,
                                                                int PW_, float spatial_scale, int sr_, int aligned,
                                                                int nchunks, int chunk, int64_t nunits,
-                                                               const int* __restrict__ declined,
-                                                               const int* __restrict__ order) {
+                                                               const int* __restrict__ declined) {
   __shared__ WaveShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
   const int c0 = ci * chunk;
-  roi_align_wave_dispatch<T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
-                                            aligned, k, c0, chunk, g_roi_force_mode, declined);
+  roi_align_wave_dispatch<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
+                                               aligned, k, c0, chunk, declined);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restrict__ input,
                                                               const T* __restrict__ rois, T* __restrict__ output,
                                                               int C, int H, int W, float spatial_scale, int aligned,
-                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
-                                                              const int* __restrict__ order) {
+                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ declined) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
-  roi_align_fwd_wave_dma<T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
-                                        chunk, declined);
+  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
+  roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
+                                              chunk, declined);
 }
 
-template <typename T, int PHT, int PWT, int SRT, int WPB = kThreads / 64>
-__global__ __launch_bounds__(64 * WPB) void roi_align_fwd_ms_dma(MsLevels lv, const T* __restrict__ rois,
+// Multi-scale entries: RoIs are float32 image coordinates whatever the feature dtype (roi_common.h).
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const float* __restrict__ rois,
                                                                  T* __restrict__ output, int C, int aligned,
-                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
-                                                                 const int* __restrict__ order) {
-  __shared__ DmaShared s[WPB];
+                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ declined) {
+  __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci, WPB)) return;
-  const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
-  roi_align_fwd_wave_dma<T, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                        lv.scale[l], aligned, k, ci * chunk, chunk, declined);
+  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
+  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                                  lv.scale[l], aligned, k, ci * chunk, chunk, declined);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, const T* __restrict__ rois,
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, const float* __restrict__ rois,
                                                                   T* __restrict__ output, int C, int PH_, int PW_,
                                                                   int sr_, int aligned, int nchunks, int chunk,
-                                                                  int64_t nunits, const int* __restrict__ declined,
-                                                                  const int* __restrict__ order) {
+                                                                  int64_t nunits, const int* __restrict__ declined) {
   __shared__ WaveShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, order, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
   const int c0 = ci * chunk;
-  const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
-  roi_align_wave_dispatch<T, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
-                                            lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, c0, chunk,
-                                            g_roi_force_mode, declined);
+  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+  roi_align_wave_dispatch<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
+                                                   lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, c0, chunk, declined);
 }
 
-// ---------------------------------------------------------------------------------------
-// Backward.  cpu/roi_align_kernel.cpp:183-289: every sample adds grad*w_i/count to its 4
-// taps.  Generic version: one thread per grad element, global atomics.
-template <typename T>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_generic(
-    const T* __restrict__ grad, const T* __restrict__ rois, T* __restrict__ grad_input,
-    int64_t total, int C, int H, int W, int PH, int PW, double spatial_scale, int sr, int aligned,
-    int64_t ns, int64_t cs, int64_t hs, int64_t ws) {
-  using A = typename Acc<T>::type;
-  for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * kThreads) {
-    const int pw = (int)(idx % PW);
-    const int ph = (int)((idx / PW) % PH);
-    const int c = (int)((idx / ((int64_t)PW * PH)) % C);
-    const int64_t k = idx / ((int64_t)PW * PH * C);
-    const RoiGeom<A> g = roi_geom<T, A>(rois + k * 5, (A)spatial_scale, PH, PW, sr, aligned != 0);
-    T* plane = grad_input + ((int64_t)g.batch * C + c) * H * W;
-    const A go = ld(grad + k * ns + c * cs + ph * hs + pw * ws);
-    for (int iy = 0; iy < g.gh; ++iy) {
-      int ylo, yhi;
-      A ly, hy;
-      const bool vy = axis_sample<A>(H, g.start_h, g.bin_h, g.gh, ph, iy, ylo, yhi, ly, hy);
-      for (int ix = 0; ix < g.gw; ++ix) {
-        int xlo, xhi;
-        A lx, hx;
-        const bool vx = axis_sample<A>(W, g.start_w, g.bin_w, g.gw, pw, ix, xlo, xhi, lx, hx);
-        if (!(vy && vx)) continue;
-        const A w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        atomic_accum(plane + (int64_t)ylo * W + xlo, go * w1 / g.count);
-        atomic_accum(plane + (int64_t)ylo * W + xhi, go * w2 / g.count);
-        atomic_accum(plane + (int64_t)yhi * W + xlo, go * w3 / g.count);
-        atomic_accum(plane + (int64_t)yhi * W + xhi, go * w4 / g.count);
-      }
-    }
-  }
-}
-
-// Tiled backward: accumulate a channel group's window in LDS, flush once per pixel.
-template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_tile(
-    const T* __restrict__ grad, const T* __restrict__ rois, T* __restrict__ grad_input, int C, int H,
-    int W, int PH_, int PW_, float spatial_scale, int sr_, int aligned, int nchunks, int64_t ns,
-    int64_t cs, int64_t hs, int64_t ws, const int* __restrict__ declined, MsLevels lv, int use_ms) {
-  __shared__ TileShared s;
-  const int PH = PHT > 0 ? PHT : PH_;
-  const int PW = PWT > 0 ? PWT : PW_;
-  const int sr = SRT > 0 ? SRT : sr_;
-  const int PHW = PH * PW;
-  const int tid = threadIdx.x;
-  const int k = blockIdx.x / nchunks;
-  if (declined && declined[k] == 0) return;  // this RoI was handled by the wave kernel
-  if (use_ms) {  // multi-scale form: the RoI picks its level's gradient map
-    const int l = fpn_level<T>(rois + (int64_t)k * 5, lv);
-    grad_input = static_cast<T*>(const_cast<void*>(lv.ptr[l]));
-    H = lv.H[l];
-    W = lv.W[l];
-    spatial_scale = lv.scale[l];
-  }
-  const int c0 = (blockIdx.x - k * nchunks) * kChunk;
-  const int cc = min(kChunk, C - c0);
-
-  RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, spatial_scale, PH, PW, sr, aligned != 0);
-  if (SRT > 0) {
-    g.gh = SRT;
-    g.gw = SRT;
-  }
-  const T* gk = grad + (int64_t)k * ns + (int64_t)c0 * cs;
-  T* gi0 = grad_input + ((int64_t)g.batch * C + c0) * H * W;
-  const int64_t plane_sz = (int64_t)H * W;
-
-  int y0 = 0, x0 = 0, wh = 0, ww = 0, wstride = 0, G = 0;
-  const int mode = build_tables<T>(s, g, H, W, PH, PW, cc, y0, x0, wh, ww, wstride, G);
-  if (mode == MODE_ZERO) return;
-  const float count = g.count;
-  const int gh = g.gh, gw = g.gw;
-
-  if (mode == MODE_GEN || mode == MODE_TAB) {
-    for (int o = tid; o < cc * PHW; o += kThreads) {
-      const int c = o / PHW, bin = o - c * PHW;
-      const int ph = bin / PW, pw = bin - ph * PW;
-      T* plane = gi0 + c * plane_sz;
-      const float go = ld(gk + c * cs + ph * hs + pw * ws);
-      for (int iy = 0; iy < gh; ++iy) {
-        int ylo, yhi;
-        float ly, hy;
-        const bool vy = axis_sample<float>(H, g.start_h, g.bin_h, gh, ph, iy, ylo, yhi, ly, hy);
-        for (int ix = 0; ix < gw; ++ix) {
-          int xlo, xhi;
-          float lx, hx;
-          const bool vx = axis_sample<float>(W, g.start_w, g.bin_w, gw, pw, ix, xlo, xhi, lx, hx);
-          if (!(vy && vx)) continue;
-          atomic_accum(plane + (int64_t)ylo * W + xlo, go * (hy * hx) / count);
-          atomic_accum(plane + (int64_t)ylo * W + xhi, go * (hy * lx) / count);
-          atomic_accum(plane + (int64_t)yhi * W + xlo, go * (ly * hx) / count);
-          atomic_accum(plane + (int64_t)yhi * W + xhi, go * (ly * lx) / count);
-        }
-      }
-    }
-    return;
-  }
-
-  const int wsz = wh * wstride;
-  const int wpix = wh * ww;
-  FastDiv16 div_wpix, div_ww;
-  div_wpix.init((unsigned)wpix);
-  div_ww.init((unsigned)ww);
-  for (int cg = 0; cg < cc; cg += G) {
-    const int gc = min(G, cc - cg);
-    for (int e = tid; e < gc * wsz; e += kThreads) s.win[e] = 0.f;
-    __syncthreads();
-    const int nout = gc * PHW;
-    for (int o = tid; o < nout; o += kThreads) {
-      const int ch = o / PHW, bin = o - ch * PHW;
-      const int ph = bin / PW, pw = bin - ph * PW;
-      const float go = ld(gk + (int64_t)(cg + ch) * cs + ph * hs + pw * ws);
-      float* wbase = s.win + ch * wsz;
-      for (int iy = 0; iy < gh; ++iy) {
-        const int ty = ph * gh + iy;
-        float* row = wbase + s.y.lo[ty];
-        const float ly = s.y.l[ty], hy = s.y.h[ty];
-        for (int ix = 0; ix < gw; ++ix) {
-          const int tx = pw * gw + ix;
-          float* p = row + s.x.lo[tx];
-          const float lx = s.x.l[tx], hx = s.x.h[tx];
-          atomicAdd(p, go * (hy * hx) / count);
-          atomicAdd(p + 1, go * (hy * lx) / count);
-          atomicAdd(p + wstride, go * (ly * hx) / count);
-          atomicAdd(p + wstride + 1, go * (ly * lx) / count);
-        }
-      }
-    }
-    __syncthreads();
-    const int total = gc * wpix;
-    for (int e = tid; e < total; e += kThreads) {
-      const int ch = (int)div_wpix.div((unsigned)e);
-      const int rem = e - ch * wpix;
-      const int r = (int)div_ww.div((unsigned)rem);
-      const int col = rem - r * ww;
-      const int gy = y0 + r, gx = x0 + col;
-      const float v = s.win[ch * wsz + r * wstride + col];
-      if (gy < H && gx < W && v != 0.f) atomic_accum(gi0 + (cg + ch) * plane_sz + (int64_t)gy * W + gx, v);
-    }
-    __syncthreads();
-  }
-}
-
-// debug / tuning knobs (tvmi_debug_set): [0] kernel variant 0 = block-tiled, 1 = wave-autonomous;
-// [1] channels per unit for the wave variant; [2] force mode (device side)
-int g_cfg_variant = 1;
-int g_cfg_chunk = 32;
-int g_cfg_dma = 1;
-int g_cfg_order = 0;
-int g_cfg_bwd_dense = 1;
-int g_cfg_dma_wpb = 4;
-int g_cfg_dma_extra_lds = 0;  // analysis knob: unused dynamic LDS per workgroup (lowers occupancy)
-
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-static void load_env_cfg() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-  g_cfg_variant = env_int("TVMI_ROI_VARIANT", g_cfg_variant);
-  g_cfg_chunk = env_int("TVMI_ROI_CHUNK", g_cfg_chunk);
-  g_cfg_dma = env_int("TVMI_ROI_DMA", g_cfg_dma);
-  g_cfg_order = env_int("TVMI_ROI_ORDER", g_cfg_order);
-  g_cfg_bwd_dense = env_int("TVMI_ROI_BWD_DENSE", g_cfg_bwd_dense);
-  g_cfg_dma_wpb = env_int("TVMI_ROI_DMA_WPB", g_cfg_dma_wpb);
-  {
-    const int v = env_int("TVMI_ROI_DMA_SPARSE", -1);
-    if (v >= 0) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cfg_dma_sparse), &v, sizeof(int));
-  }
-  g_cfg_dma_extra_lds = env_int("TVMI_ROI_DMA_EXTRA_LDS", g_cfg_dma_extra_lds);
-}
-
-// ---------------------------------------------------------------------------------------
-// Wave-autonomous backward (fp32, compile-time shapes): same unit decomposition and LDS window
-// image as the DMA forward.  Lane = bin with its 4 samples in registers; per channel the wave
-// loads the 49 (196) grads coalesced, scatters the 16 tap contributions of every bin into the
-// zeroed LDS window with ds_add_f32, then flushes the window ROW-WISE: one lane = 4 consecutive
-// pixels, so the global float atomics of a wave hit whole row segments (few cache lines per
-// instruction) and there is ONE atomic per touched pixel per RoI instead of 4 per sample
-// (reference: cuda/roi_align_kernel.cu:304-327).
-template <int PHT, int PWT, int SRT, int NRG>
-__device__ __forceinline__ void roi_align_bwd_passes(DmaShared& s, const float* __restrict__ gk, float* __restrict__ gi0,
-                                                     int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
-                                                     int64_t cs, const int (&goffs)[(PHT * PWT + 63) / 64],
-                                                     const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
-                                                     const float (&fy)[(PHT * PWT + 63) / 64][SRT][2],
-                                                     const float (&fx)[(PHT * PWT + 63) / 64][SRT][2]) {
-  constexpr int PHW = PHT * PWT;
-  constexpr int NB = (PHW + 63) / 64;
-  constexpr int NS = SRT * SRT;
-  constexpr int G = NRG <= 2 * kDmaPerPass ? (2 * kDmaPerPass) / NRG : 1;  // channels per pass (both buffers)
-  const float inv_count = 1.f / (float)NS;
-  const int lane = threadIdx.x & 63;
-  const int rsub = lane / dw.lpr, q = lane - rsub * dw.lpr;
-  const bool flush_lane = rsub < dw.rpi && q < dw.nq;
-  const int gx = dw.x0 + 4 * q;
-  for (int cg = 0; cg < cc; cg += G) {
-    const int gc = min(G, cc - cg);
-    // zero the pass' window images
-    for (int i = lane; i < gc * NRG * (kDmaBlk / 4); i += 64) reinterpret_cast<float4*>(s.buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int ch = 0; ch < gc; ++ch) {
-      float* wbase = s.buf + ch * (NRG * kDmaBlk);
-      const float* gch = gk + (int64_t)(cg + ch) * cs;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int bin = lane + 64 * b;
-        if (bin >= PHW) continue;
-        const float gsc = gch[goffs[b]] * inv_count;  // count is 4 here: exact
-#pragma unroll
-        for (int iy = 0; iy < SRT; ++iy) {
-          const float a = gsc * fy[b][iy][1], bb = gsc * fy[b][iy][0];
-#pragma unroll
-          for (int ix = 0; ix < SRT; ++ix) {
-            float* q0 = wbase + off[b][iy * SRT + ix][0];
-            float* q1 = wbase + off[b][iy * SRT + ix][1];
-            atomicAdd(q0, a * fx[b][ix][1]);
-            atomicAdd(q0 + 1, a * fx[b][ix][0]);
-            atomicAdd(q1, bb * fx[b][ix][1]);
-            atomicAdd(q1 + 1, bb * fx[b][ix][0]);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // flush: lane (rsub, q) owns 4 consecutive pixels of window row rg*rpi+rsub
-    if (flush_lane) {
-      for (int ch = 0; ch < gc; ++ch) {
-        float* plane = gi0 + (int64_t)(cg + ch) * plane_sz;
-#pragma unroll
-        for (int rg = 0; rg < NRG; ++rg) {
-          const int r = rg * dw.rpi + rsub;
-          if (r < dw.wh) {
-            const float4 v = *reinterpret_cast<const float4*>(s.buf + (ch * NRG + rg) * kDmaBlk + rsub * 4 * dw.lpr + 4 * q);
-            float* dst = plane + (int64_t)(dw.y0 + r) * W + gx;
-            if (v.x != 0.f) unsafeAtomicAdd(dst, v.x);
-            if (v.y != 0.f) unsafeAtomicAdd(dst + 1, v.y);
-            if (v.z != 0.f) unsafeAtomicAdd(dst + 2, v.z);
-            if (v.w != 0.f) unsafeAtomicAdd(dst + 3, v.w);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Dense-separable backward (fp32, compile-time shapes) — no LDS atomics.
-// ds_add_f32 turned out to be the bottleneck of every scatter-style backward on this chip
-// (measured ~3 cycles per lane-operation per CU: 4.5-7 ms on config 2 in three different
-// kernels).  The gradient of a RoI window is a separable product,
-//     dWindow[r][c] = sum_ph AyD[r][ph] * ( sum_pw G[ph][pw] * AxD[pw][c] ),
-// with AyD / AxD the (tiny, mostly zero) matrices of bilinear row / column factors summed over
-// the samples of a bin and divided by count.  A wave handles (RoI, channel chunk): lane = window
-// column (several channels side by side when the window is narrow), AxD's column lives in
-// registers, AyD rows and the grads sit in LDS and are read as broadcasts; every window pixel
-// is produced by exactly one lane with plain FMAs and leaves with ONE global float atomic,
-// issued as contiguous row segments.
-constexpr int kDenseMaxWH = 48;
-
-template <int PHT, int PWT, int SRT>
-struct DenseShared {
-  static constexpr int PHP = (PHT + 3) & ~3;   // padded to float4
-  static constexpr int PWP = (PWT + 3) & ~3;
-  __attribute__((aligned(16))) float ayd[kDenseMaxWH][PHP];
-  __attribute__((aligned(16))) float gs[8][PHT][PWP];  // up to 8 channels side by side
-};
-
-template <int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_dense(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                                float* __restrict__ grad_input, int C, int H, int W,
-                                                                float spatial_scale, int aligned, int nchunks, int chunk,
-                                                                int64_t nunits, int64_t ns, int64_t cs, int64_t hs,
-                                                                int64_t ws, int* __restrict__ declined, MsLevels lv,
-                                                                int use_ms) {
-  using DS = DenseShared<PHT, PWT, SRT>;
-  __shared__ DS sh[kThreads / 64];
-  constexpr int ny = PHT * SRT, nx = PWT * SRT;
-  constexpr int NS = SRT * SRT;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, nullptr, k, ci)) return;
-  const int c0 = ci * chunk;
-  const int cc = min(chunk, C - c0);
-  if (use_ms) {  // multi-scale form: the RoI picks its level's gradient map (poolers.py:73-84)
-    const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-    grad_input = static_cast<float*>(const_cast<void*>(lv.ptr[l]));
-    H = lv.H[l];
-    W = lv.W[l];
-    spatial_scale = lv.scale[l];
-  }
-  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
-  // ---- window bounds (shifted samples: lo + 1 is always inside the map)
-  int y0 = 0, wh = 0, x0 = 0, ww = 0, state = 2;
-  if (H >= 2 && W >= 2) {
-    int lo = 0, lo2 = 0;
-    float l, h;
-    bool v = false, v2 = false;
-    if (lane < ny) v = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, l, h);
-    if (lane < nx) v2 = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo2, l, h);
-    const unsigned long long by = __ballot(v), bx = __ballot(v2);
-    if (by == 0ull || bx == 0ull) {
-      state = 0;  // no sample inside the map: no gradient
-    } else {
-      const int ya = __builtin_amdgcn_readlane(lo, __builtin_ctzll(by)), yb = __builtin_amdgcn_readlane(lo, 63 - __builtin_clzll(by));
-      const int xa = __builtin_amdgcn_readlane(lo2, __builtin_ctzll(bx)), xb = __builtin_amdgcn_readlane(lo2, 63 - __builtin_clzll(bx));
-      y0 = min(ya, yb);
-      wh = max(ya, yb) + 1 - y0 + 1;
-      x0 = min(xa, xb);
-      ww = max(xa, xb) + 1 - x0 + 1;
-      state = (wh <= kDenseMaxWH && ww <= 64) ? 1 : 2;
-    }
-  }
-  if (c0 == 0 && lane == 0) declined[k] = state == 2;
-  if (state != 1) return;
-  int wpad = 4;
-  while (wpad < ww) wpad <<= 1;
-  const int cpl = min(64 / wpad, 8);  // channels processed side by side
-  const int slot = lane / wpad, col = lane - slot * wpad;
-  const bool col_ok = col < ww && slot < cpl;
-  const float inv_count = 1.f / (float)NS;
-  DS& s = sh[wave];
-  // ---- AxD column of this lane (registers) and AyD rows (LDS), both already divided by count
-  float axd[PWT];
-  {
-    const int gcol = x0 + col;
-#pragma unroll
-    for (int pw = 0; pw < PWT; ++pw) {
-      float a = 0.f;
-#pragma unroll
-      for (int i = 0; i < SRT; ++i) {
-        int lo;
-        float l, h;
-        if (axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h)) {
-          if (lo == gcol) a += h;
-          if (lo + 1 == gcol) a += l;
-        }
-      }
-      axd[pw] = col_ok ? a : 0.f;
-    }
-    if (lane < wh) {
-      const int grow = y0 + lane;
-#pragma unroll
-      for (int ph = 0; ph < DS::PHP; ++ph) {
-        float a = 0.f;
-        if (ph < PHT) {
-#pragma unroll
-          for (int i = 0; i < SRT; ++i) {
-            int lo;
-            float l, h;
-            if (axis_sample_shifted(H, g.start_h, g.bin_h, SRT, ph, i, lo, l, h)) {
-              if (lo == grow) a += h;
-              if (lo + 1 == grow) a += l;
-            }
-          }
-        }
-        s.ayd[lane][ph] = a * inv_count;
-      }
-    }
-  }
-  const float* gk = grad + (int64_t)k * ns + (int64_t)c0 * cs;
-  float* gi0 = grad_input + ((int64_t)g.batch * C + c0) * H * W;
-  const int64_t plane_sz = (int64_t)H * W;
-  for (int cg = 0; cg < cc; cg += cpl) {
-    const int gc = min(cpl, cc - cg);
-    // 1. grads of gc channels -> LDS (coalesced within a channel)
-    for (int e = lane; e < gc * PHT * PWT; e += 64) {
-      const int ch = e / (PHT * PWT), bin = e - ch * (PHT * PWT);
-      const int ph = bin / PWT, pw = bin - ph * PWT;
-      s.gs[ch][ph][pw] = gk[(int64_t)(cg + ch) * cs + ph * hs + pw * ws];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // 2. t[ph] = sum_pw G[ph][pw] * AxD[pw][col]
-    float t[PHT];
-    const int myslot = min(slot, gc - 1);
-#pragma unroll
-    for (int ph = 0; ph < PHT; ++ph) {
-      float a = 0.f;
-#pragma unroll
-      for (int pw = 0; pw < PWT; ++pw) a = __builtin_fmaf(s.gs[myslot][ph][pw], axd[pw], a);
-      t[ph] = a;
-    }
-    // 3. window rows: one global atomic per pixel, contiguous along the row
-    const bool write_ok = col_ok && slot < gc;
-    float* plane = gi0 + (int64_t)(cg + myslot) * plane_sz + (int64_t)y0 * W + x0 + col;
-    for (int r = 0; r < wh; ++r) {
-      float v = 0.f;
-#pragma unroll
-      for (int ph = 0; ph < PHT; ++ph) v = __builtin_fmaf(s.ayd[r][ph], t[ph], v);
-      if (write_ok && v != 0.f) unsafeAtomicAdd(plane + (int64_t)r * W, v);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-}
+constexpr int kUnitChunk = 32;  // channels per wave unit
+constexpr int kMopChunk = 64;   // channels per unit of the launch that mops up what the DMA kernel declined (almost always empty)
 
 template <typename T>
 int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int* order, int* declined, hipStream_t stream) {
-  load_env_cfg();
+               int* declined, hipStream_t stream) {
   const T* in = static_cast<const T*>(input);
   const T* r = static_cast<const T*>(rois);
   T* out = static_cast<T*>(output);
@@ -1617,104 +828,32 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
         in, r, out, total, (int)C, (int)H, (int)W, (int)PH, (int)PW, scale, (int)sr, aligned);
   } else {
     const float fs = (float)scale;
-    const bool wavev = g_cfg_variant == 1;
-    if (order && wavev && g_cfg_order) {
-      roi_locality_order<T><<<dim3(1), dim3(1024), 0, stream>>>(r, (int)K, order);
-    } else {
-      order = nullptr;
-    }
-    const int chunk = wavev ? g_cfg_chunk : kChunk;
-    const int nchunks = (int)ceil_div(C, chunk);
-    const int64_t nunits = K * nchunks;
-    const dim3 grid(wavev ? wave_unit_grid(K, nchunks) : (unsigned)nunits), block(kThreads);
-    // fallback launch (what the DMA launch declined): coarser units, it is almost always empty
-    const int fb_chunk = 64, fb_nchunks = (int)ceil_div(C, fb_chunk);
-    const int64_t fb_nunits = K * fb_nchunks;
-    const dim3 fb_grid(wave_unit_grid(K, fb_nchunks));
-#define TVMI_FWD(PHT, PWT, SRT)                                                                              \
-  if (wavev) {                                                                                               \
-    bool dma = false;                                                                                        \
-    if constexpr ((PHT) > 0) {                                                                               \
-      if (g_cfg_dma && declined) {                                                                           \
-        roi_align_fwd_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, \
-                                                                     aligned, nchunks, chunk, nunits, declined, order); \
-        dma = true;                                                                                          \
-      }                                                                                                      \
-    }                                                                                                        \
-    if (dma)                                                                                                 \
-      roi_align_fwd_wave<T, PHT, PWT, SRT><<<fb_grid, block, 0, stream>>>(                                   \
-          in, r, out, (int)C, (int)H, (int)W, (int)PH, (int)PW, fs, (int)sr, aligned, fb_nchunks, fb_chunk,  \
-          fb_nunits, declined, order);                                                                       \
-    else                                                                                                     \
-      roi_align_fwd_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W,   \
-                                                                       (int)PH, (int)PW, fs, (int)sr, aligned, \
-                                                                       nchunks, chunk, nunits, nullptr, order); \
-  } else                                                                                                     \
-    roi_align_fwd_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W,     \
-                                                                     (int)PH, (int)PW, fs, (int)sr, aligned, nchunks)
+    const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
+    const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
+    const dim3 grid(wave_unit_grid(K, nchunks)), mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
+#define TVMI_FWD(PHT, PWT, SRT)                                                                                   \
+  if (declined) {                                                                                                 \
+    roi_align_fwd_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, aligned, \
+                                                                    nchunks, kUnitChunk, nunits, declined);       \
+    roi_align_fwd_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH, \
+                                                                         (int)PW, fs, (int)sr, aligned, mop_nchunks, \
+                                                                         kMopChunk, mop_nunits, declined);        \
+  } else                                                                                                          \
+    roi_align_fwd_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH,  \
+                                                                     (int)PW, fs, (int)sr, aligned, nchunks,      \
+                                                                     kUnitChunk, nunits, nullptr)
     if (PH == 7 && PW == 7 && sr == 2) {
       TVMI_FWD(7, 7, 2);
     } else if (PH == 14 && PW == 14 && sr == 2) {
       TVMI_FWD(14, 14, 2);
     } else {
-      TVMI_FWD(0, 0, 0);
+      roi_align_fwd_wave<T, 0, 0, 0><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH, (int)PW, fs,
+                                                                 (int)sr, aligned, nchunks, kUnitChunk, nunits, nullptr);
     }
 #undef TVMI_FWD
   }
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_forward");
 }
-
-template <typename T>
-int launch_bwd(const void* grad, const void* rois, void* grad_input, int64_t N, int64_t C, int64_t H,
-               int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int64_t ns, int64_t cs, int64_t hs, int64_t ws, int* declined, hipStream_t stream,
-               const MsLevels* ms = nullptr) {
-  load_env_cfg();
-  const T* g = static_cast<const T*>(grad);
-  const T* r = static_cast<const T*>(rois);
-  T* gi = static_cast<T*>(grad_input);
-  const int64_t total = K * C * PH * PW;
-  MsLevels lv{};
-  const int use_ms = ms != nullptr;
-  if (ms) lv = *ms;
-  if constexpr (std::is_same<T, double>::value) {
-    if (ms) return set_error((int)hipErrorInvalidValue, "multiscale_roi_align_backward: float64 is not supported");
-    const int64_t blocks = std::min<int64_t>(ceil_div(total, kThreads), 1 << 20);
-    roi_align_bwd_generic<T><<<dim3((unsigned)blocks), dim3(kThreads), 0, stream>>>(
-        g, r, gi, total, (int)C, (int)H, (int)W, (int)PH, (int)PW, scale, (int)sr, aligned, ns, cs,
-        hs, ws);
-  } else {
-    const int nchunks = (int)ceil_div(C, kChunk);
-    const dim3 grid((unsigned)(K * nchunks)), block(kThreads);
-    const float fs = (float)scale;
-    const int wchunk = g_cfg_chunk, wnchunks = (int)ceil_div(C, wchunk);
-    const int64_t wnunits = K * wnchunks;
-#define TVMI_BWD(PHT, PWT, SRT)                                                                            \
-  {                                                                                                        \
-    const int* dflags = nullptr;                                                                           \
-    if constexpr (std::is_same<T, float>::value && (PHT) > 0) {                                            \
-      if (g_cfg_bwd_dense && declined && H * W * C < (1ll << 31)) {                                        \
-        roi_align_bwd_dense<PHT, PWT, SRT><<<dim3(wave_unit_grid(K, wnchunks)), block, 0, stream>>>(       \
-            g, r, gi, (int)C, (int)H, (int)W, fs, aligned, wnchunks, wchunk, wnunits, ns, cs, hs, ws, declined, lv, use_ms); \
-        dflags = declined;                                                                                 \
-      }                                                                                                    \
-    }                                                                                                      \
-    roi_align_bwd_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(g, r, gi, (int)C, (int)H, (int)W,     \
-                                                                     (int)PH, (int)PW, fs, (int)sr, aligned, \
-                                                                     nchunks, ns, cs, hs, ws, dflags, lv, use_ms); \
-  }
-    if (PH == 7 && PW == 7 && sr == 2) {
-      TVMI_BWD(7, 7, 2);
-    } else if (PH == 14 && PW == 14 && sr == 2) {
-      TVMI_BWD(14, 14, 2);
-    } else {
-      TVMI_BWD(0, 0, 0);
-    }
-#undef TVMI_BWD
-  }
-  TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_backward");
-}
-
 
 // ---------------------------------------------------------------------------------------
 // channels_last (NHWC) forward.  With the channel as the fastest dimension a
@@ -1748,7 +887,7 @@ __device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)size
 }
 
 template <typename T, int PHT, int PWT, int SRT>
-__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const T* __restrict__ rois,
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const float* __restrict__ rois,
                                                                T* __restrict__ output, int C, int aligned,
                                                                int ngroups, int64_t nunits) {
   constexpr int PHW = PHT * PWT;
@@ -1759,12 +898,12 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int k, gi;
-  if (!wave_unit(nunits / ngroups, ngroups, nullptr, k, gi)) return;
+  if (!wave_unit(nunits / ngroups, ngroups, k, gi)) return;
   const int c0 = gi * GC;
   // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
-  const int l = __builtin_amdgcn_readfirstlane(fpn_level<T>(rois + (int64_t)k * 5, lv));
+  const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
   const int H = lv.H[l], W = lv.W[l];
-  const RoiGeom<float> g = roi_geom<T, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
+  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
   const int batch = __builtin_amdgcn_readfirstlane(g.batch);
   // ---- per-RoI sample tables, one sample per lane: element offset of the low tap + the two factors
   int yoff = 0, xoff = 0;
@@ -1854,7 +993,6 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
 template <typename T>
 int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH, int64_t PW,
                        int64_t sr, int aligned, hipStream_t stream) {
-  load_env_cfg();
   constexpr int GC = 64 * (4 / (int)sizeof(T));
   const int ngroups = (int)ceil_div(C, GC);
   const int64_t nunits = K * ngroups;
@@ -1862,65 +1000,57 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
   if (!(PH == 7 && PW == 7 && sr == 2))
     return set_error((int)hipErrorInvalidValue,
                      "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
-  roi_align_fwd_nhwc<T, 7, 7, 2><<<grid, block, 0, stream>>>(lv, static_cast<const T*>(rois), static_cast<T*>(output), (int)C,
+  roi_align_fwd_nhwc<T, 7, 7, 2><<<grid, block, 0, stream>>>(lv, static_cast<const float*>(rois), static_cast<T*>(output), (int)C,
                                                              aligned, ngroups, nunits);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward_nhwc");
 }
 
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
-                  int64_t PW, int64_t sr, int aligned, int* order, int* declined, hipStream_t stream) {
-  load_env_cfg();
-  const T* r = static_cast<const T*>(rois);
+                  int64_t PW, int64_t sr, int aligned, int* declined, hipStream_t stream) {
+  const float* r = static_cast<const float*>(rois);
   T* out = static_cast<T*>(output);
-  const bool wavev = g_cfg_variant == 1;
-  if (order && wavev && g_cfg_order) {
-    roi_locality_order<T><<<dim3(1), dim3(1024), 0, stream>>>(r, (int)K, order);
-  } else {
-    order = nullptr;
-  }
-  const int chunk = wavev ? g_cfg_chunk : kChunk;
-  const int nchunks = (int)ceil_div(C, chunk);
-  const int64_t nunits = K * nchunks;
-  const dim3 grid(wavev ? wave_unit_grid(K, nchunks) : (unsigned)nunits), block(kThreads);
-  const int fb_chunk = 64, fb_nchunks = (int)ceil_div(C, fb_chunk);
-  const int64_t fb_nunits = K * fb_nchunks;
-  const dim3 fb_grid(wave_unit_grid(K, fb_nchunks));
-#define TVMI_MS(PHT, PWT, SRT)                                                                                  \
-  if (wavev) {                                                                                                  \
-    bool dma = false;                                                                                           \
-    if constexpr ((PHT) > 0) {                                                                                  \
-      if (g_cfg_dma && declined) {                                                                              \
-        if (g_cfg_dma_wpb == 1)                                                                                 \
-          roi_align_fwd_ms_dma<T, PHT, PWT, SRT, 1><<<dim3(wave_unit_grid(K, nchunks, 1)), dim3(64), 0, stream>>>( \
-              lv, r, out, (int)C, aligned, nchunks, chunk, nunits, declined, order);                            \
-        else if (g_cfg_dma_wpb == 2)                                                                            \
-          roi_align_fwd_ms_dma<T, PHT, PWT, SRT, 2><<<dim3(wave_unit_grid(K, nchunks, 2)), dim3(128), 0, stream>>>( \
-              lv, r, out, (int)C, aligned, nchunks, chunk, nunits, declined, order);                            \
-        else                                                                                                    \
-          roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, g_cfg_dma_extra_lds, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
-                                                                          chunk, nunits, declined, order);      \
-        dma = true;                                                                                             \
-      }                                                                                                         \
-    }                                                                                                           \
-    if (dma)                                                                                                    \
-      roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<fb_grid, block, 0, stream>>>(                                   \
-          lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, aligned, fb_nchunks, fb_chunk, fb_nunits, declined, order); \
-    else                                                                                                        \
-      roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(                                      \
-          lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, aligned, nchunks, chunk, nunits, nullptr, order);      \
-  } else                                                                                                        \
-    roi_align_fwd_ms_tile<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW,   \
-                                                                        (int)sr, aligned, nchunks)
+  const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
+  const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
+  const dim3 grid(wave_unit_grid(K, nchunks)), mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
+#define TVMI_MS(PHT, PWT, SRT)                                                                                      \
+  if (declined) {                                                                                                   \
+    roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
+                                                                       nunits, declined);                           \
+    roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
+                                                                            aligned, mop_nchunks, kMopChunk, mop_nunits, \
+                                                                            declined);                              \
+  } else                                                                                                            \
+    roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
+                                                                        aligned, nchunks, kUnitChunk, nunits, nullptr)
   if (PH == 7 && PW == 7 && sr == 2) {
     TVMI_MS(7, 7, 2);
   } else if (PH == 14 && PW == 14 && sr == 2) {
     TVMI_MS(14, 14, 2);
   } else {
-    TVMI_MS(0, 0, 0);
+    roi_align_fwd_ms_wave<T, 0, 0, 0><<<grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, aligned,
+                                                                  nchunks, kUnitChunk, nunits, nullptr);
   }
 #undef TVMI_MS
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward");
+}
+
+int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, const int64_t* widths, const double* scales,
+                int64_t n_levels, int64_t k_min, int64_t k_max, double s0, double lvl0, double eps) {
+  for (int i = 0; i < kMaxLevels; ++i) {
+    const int j = i < n_levels ? i : 0;
+    lv.ptr[i] = ptrs[j];
+    lv.H[i] = (int)heights[j];
+    lv.W[i] = (int)widths[j];
+    lv.scale[i] = (float)scales[j];
+  }
+  lv.n_levels = (int)n_levels;
+  lv.k_min = (int)k_min;
+  lv.k_max = (int)k_max;
+  lv.s0 = (float)s0;
+  lv.lvl0 = (float)lvl0;
+  lv.eps = (float)eps;
+  return 0;
 }
 
 }  // namespace
@@ -1932,8 +1062,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
                                       double spatial_scale, int64_t sampling_ratio, int aligned,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
-  int* order = (workspace && workspace_bytes >= 2 * (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
-  int* declined = order ? order + K : nullptr;
+  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
   TVMI_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0, "roi_align: negative size");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(input && rois && output, "roi_align: null pointer");
@@ -1943,33 +1072,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
   TVMI_DISPATCH_FLOAT(dt, "roi_align_forward",
                       return tvmi::launch_fwd<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h,
                                                         pooled_w, spatial_scale, sampling_ratio,
-                                                        aligned, order, declined, s));
-  return 0;
-}
-
-extern "C" size_t tvmi_roi_align_backward_workspace_bytes(int64_t N, int64_t H, int64_t W, int64_t K) {
-  if (N <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
-  return (size_t)K * sizeof(int);  // one "left to the fallback launch" flag per RoI
-}
-
-extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void* grad_input,
-                                       tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W,
-                                       int64_t K, int64_t pooled_h, int64_t pooled_w,
-                                       double spatial_scale, int64_t sampling_ratio, int aligned,
-                                       int64_t n_stride, int64_t c_stride, int64_t h_stride,
-                                       int64_t w_stride, void* workspace, size_t workspace_bytes, void* stream) {
-  TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
-  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int)) ? static_cast<int*>(workspace) : nullptr;
-  if (K * C * pooled_h * pooled_w == 0 || N * H * W == 0) return 0;
-  TVMI_CHECK_ARG(grad && rois && grad_input, "roi_align_backward: null pointer");
-  TVMI_CHECK_ARG(H * W < (1ll << 31) && K * tvmi::ceil_div(C, 32) < (1ll << 31),
-                 "roi_align_backward: size exceeds 32-bit launch limits");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TVMI_DISPATCH_FLOAT(dt, "roi_align_backward",
-                      return tvmi::launch_bwd<scalar_t>(grad, rois, grad_input, N, C, H, W, K,
-                                                        pooled_h, pooled_w, spatial_scale,
-                                                        sampling_ratio, aligned, n_stride, c_stride,
-                                                        h_stride, w_stride, declined, s));
+                                                        aligned, declined, s));
   return 0;
 }
 
@@ -1988,82 +1091,19 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
   TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16,
                  "multiscale_roi_align: float32 / float16 / bfloat16 only");
   TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align: size exceeds 32-bit launch limits");
+  for (int64_t i = 0; i < n_levels; ++i)
+    TVMI_CHECK_ARG(inputs[i] != nullptr && heights[i] * widths[i] < (1ll << 31), "multiscale_roi_align: bad level");
   tvmi::MsLevels lv;
-  for (int i = 0; i < tvmi::kMaxLevels; ++i) {
-    const int j = i < n_levels ? i : 0;
-    TVMI_CHECK_ARG(inputs[j] != nullptr && heights[j] * widths[j] < (1ll << 31), "multiscale_roi_align: bad level");
-    lv.ptr[i] = inputs[j];
-    lv.H[i] = (int)heights[j];
-    lv.W[i] = (int)widths[j];
-    lv.scale[i] = (float)spatial_scales[j];
-  }
-  lv.n_levels = (int)n_levels;
-  lv.k_min = (int)k_min;
-  lv.k_max = (int)k_max;
-  lv.s0 = (float)canonical_scale;
-  lv.lvl0 = (float)canonical_level;
-  lv.eps = (float)eps;
+  tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* order = (workspace && workspace_bytes >= 2 * (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
-  int* declined = order ? order + K : nullptr;
+  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
   switch (dt) {
     case TVMI_F32:
-      return tvmi::launch_ms_fwd<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, order, declined, s);
+      return tvmi::launch_ms_fwd<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, s);
     case TVMI_F16:
-      return tvmi::launch_ms_fwd<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, order, declined, s);
+      return tvmi::launch_ms_fwd<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, s);
     default:
-      return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned,
-                                                 order, declined, s);
-  }
-}
-
-extern "C" int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void* const* grad_inputs,
-                                                  const int64_t* heights, const int64_t* widths,
-                                                  const double* spatial_scales, int64_t n_levels, tvmi_dtype dt, int64_t N,
-                                                  int64_t C, int64_t K, int64_t pooled_h, int64_t pooled_w,
-                                                  int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
-                                                  double canonical_scale, double canonical_level, double eps,
-                                                  int64_t n_stride, int64_t c_stride, int64_t h_stride, int64_t w_stride,
-                                                  void* workspace, size_t workspace_bytes, void* stream) {
-  TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "multiscale_roi_align_backward: pooled size must be positive");
-  TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "multiscale_roi_align_backward: 1..8 levels supported");
-  if (K * C * pooled_h * pooled_w == 0 || N == 0) return 0;
-  TVMI_CHECK_ARG(grad && rois && grad_inputs && heights && widths && spatial_scales, "multiscale_roi_align_backward: null pointer");
-  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16, "multiscale_roi_align_backward: float32 / float16 / bfloat16 only");
-  TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align_backward: size exceeds 32-bit launch limits");
-  tvmi::MsLevels lv;
-  int64_t hmax = 1, wmax = 1;
-  for (int i = 0; i < tvmi::kMaxLevels; ++i) {
-    const int j = i < n_levels ? i : 0;
-    TVMI_CHECK_ARG(grad_inputs[j] != nullptr && heights[j] > 0 && widths[j] > 0 && heights[j] * widths[j] * C < (1ll << 31),
-                   "multiscale_roi_align_backward: bad level");
-    lv.ptr[i] = grad_inputs[j];
-    lv.H[i] = (int)heights[j];
-    lv.W[i] = (int)widths[j];
-    lv.scale[i] = (float)spatial_scales[j];
-    hmax = std::max(hmax, heights[j]);
-    wmax = std::max(wmax, widths[j]);
-  }
-  lv.n_levels = (int)n_levels;
-  lv.k_min = (int)k_min;
-  lv.k_max = (int)k_max;
-  lv.s0 = (float)canonical_scale;
-  lv.lvl0 = (float)canonical_level;
-  lv.eps = (float)eps;
-  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int)) ? static_cast<int*>(workspace) : nullptr;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // H / W / scale / grad_input of the single-level signature are placeholders: every RoI takes them from its level
-  switch (dt) {
-    case TVMI_F32:
-      return tvmi::launch_bwd<float>(grad, rois, grad_inputs[0], N, C, hmax, wmax, K, pooled_h, pooled_w, spatial_scales[0],
-                                     sampling_ratio, aligned, n_stride, c_stride, h_stride, w_stride, declined, s, &lv);
-    case TVMI_F16:
-      return tvmi::launch_bwd<__half>(grad, rois, grad_inputs[0], N, C, hmax, wmax, K, pooled_h, pooled_w, spatial_scales[0],
-                                      sampling_ratio, aligned, n_stride, c_stride, h_stride, w_stride, declined, s, &lv);
-    default:
-      return tvmi::launch_bwd<__hip_bfloat16>(grad, rois, grad_inputs[0], N, C, hmax, wmax, K, pooled_h, pooled_w,
-                                              spatial_scales[0], sampling_ratio, aligned, n_stride, c_stride, h_stride,
-                                              w_stride, declined, s, &lv);
+      return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, s);
   }
 }
 
@@ -2082,37 +1122,13 @@ extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs,
   TVMI_CHECK_ARG(pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2,
                  "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
   TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 64) < (1ll << 31), "roi_align (channels_last): size exceeds 32-bit launch limits");
-  tvmi::MsLevels lv;
-  for (int i = 0; i < tvmi::kMaxLevels; ++i) {
-    const int j = i < n_levels ? i : 0;
-    TVMI_CHECK_ARG(inputs[j] != nullptr && heights[j] >= 2 && widths[j] >= 2 && heights[j] * widths[j] * C < (1ll << 31),
+  for (int64_t i = 0; i < n_levels; ++i)
+    TVMI_CHECK_ARG(inputs[i] != nullptr && heights[i] >= 2 && widths[i] >= 2 && heights[i] * widths[i] * C < (1ll << 31),
                    "roi_align (channels_last): every level needs H, W >= 2 and H*W*C < 2^31");
-    lv.ptr[i] = inputs[j];
-    lv.H[i] = (int)heights[j];
-    lv.W[i] = (int)widths[j];
-    lv.scale[i] = (float)spatial_scales[j];
-  }
-  lv.n_levels = (int)n_levels;
-  lv.k_min = (int)k_min;
-  lv.k_max = (int)k_max;
-  lv.s0 = (float)canonical_scale;
-  lv.lvl0 = (float)canonical_level;
-  lv.eps = (float)eps;
+  tvmi::MsLevels lv;
+  tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dt == TVMI_F32) return tvmi::launch_ms_fwd_nhwc<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
   if (dt == TVMI_F16) return tvmi::launch_ms_fwd_nhwc<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
   return tvmi::launch_ms_fwd_nhwc<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
-}
-
-// Tuning/debug knob, NOT part of the supported ABI (not declared in include/tvmi.h).
-extern "C" int tvmi_debug_set(int key, int value) {
-  if (key == 0) tvmi::g_cfg_variant = value;
-  if (key == 1 && value > 0) tvmi::g_cfg_chunk = value;
-  if (key == 3) tvmi::g_cfg_dma = value;
-  if (key == 4) tvmi::g_cfg_order = value;
-  if (key == 2) {
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(tvmi::g_roi_force_mode), &value, sizeof(int));
-    return (int)e;
-  }
-  return 0;
 }

@@ -1,0 +1,115 @@
+// roi_common.h — RoI geometry shared by the RoIAlign forward (roi_align.hip) and backward
+// (roi_align_bwd.hip) translation units.  Arithmetic follows the reference's CPU kernels op by op
+// (torchvision/csrc/ops/cpu/roi_align_kernel.cpp:36-66, cpu/roi_align_common.h:50-103); both TUs are
+// built with -ffp-contract=off so that sample coordinates round like the reference's x86 build.
+#pragma once
+
+#include "tvmi_common.h"
+
+namespace tvmi {
+
+constexpr int kMaxLevels = 8;  // FPN levels served by one multi-scale launch
+
+template <typename A>
+struct RoiGeom {
+  A start_h, start_w, bin_h, bin_w, count;
+  int gh, gw, batch;
+};
+
+// cpu/roi_align_kernel.cpp:36-66
+template <typename T, typename A>
+__device__ __forceinline__ RoiGeom<A> roi_geom(const T* roi, A scale, int PH, int PW, int sr, bool aligned) {
+  RoiGeom<A> g;
+  g.batch = (int)ld(roi);
+  const A offset = aligned ? (A)0.5 : (A)0.0;
+  const A sw = ld(roi + 1) * scale - offset;
+  const A sh = ld(roi + 2) * scale - offset;
+  const A ew = ld(roi + 3) * scale - offset;
+  const A eh = ld(roi + 4) * scale - offset;
+  A rw = ew - sw;
+  A rh = eh - sh;
+  if (!aligned) {
+    rw = rw > (A)1. ? rw : (A)1.;  // std::max(roi_width, 1)
+    rh = rh > (A)1. ? rh : (A)1.;
+  }
+  g.start_h = sh;
+  g.start_w = sw;
+  g.bin_h = rh / (A)PH;
+  g.bin_w = rw / (A)PW;
+  g.gh = sr > 0 ? sr : (int)ceil(rh / (A)PH);
+  g.gw = sr > 0 ? sr : (int)ceil(rw / (A)PW);
+  const int cnt = g.gh * g.gw;
+  g.count = (A)(cnt > 1 ? cnt : 1);
+  return g;
+}
+
+// One axis of cpu/roi_align_common.h:50-103.  Returns false when the coordinate is
+// outside [-1, dim] (the sample then contributes zero).
+template <typename A>
+__device__ __forceinline__ bool axis_sample(int dim, A start, A bin, int grid, int p, int i, int& lo, int& hi, A& l,
+                                            A& h) {
+  A c = start + (A)p * bin + (A)((float)i + .5f) * bin / (A)grid;
+  if (c < (A)-1.0 || c > (A)dim) {
+    lo = hi = 0;
+    l = h = (A)0;
+    return false;
+  }
+  if (c <= (A)0) c = (A)0;
+  lo = (int)c;
+  if (lo >= dim - 1) {
+    hi = lo = dim - 1;
+    c = (A)lo;
+  } else {
+    hi = lo + 1;
+  }
+  l = c - (A)lo;
+  h = (A)1. - l;
+  return true;
+}
+
+// lo/l/h of one axis sample in "shifted" form (dim >= 2): a sample on the last row / column (where the
+// reference uses x_high = x_low with weight 0) is re-expressed on the pair (dim-2, dim-1) with factors
+// (0, 1) — the same value, and lo + 1 is always inside the map.
+__device__ __forceinline__ bool axis_sample_shifted(int dim, float start, float bin, int grid, int p, int i, int& lo,
+                                                    float& l, float& h) {
+  int hi;
+  const bool v = axis_sample<float>(dim, start, bin, grid, p, i, lo, hi, l, h);
+  if (!v) {
+    lo = 0;
+    l = h = 0.f;
+    return false;
+  }
+  if (lo > dim - 2) {  // lo == dim-1: value is in[dim-1]
+    lo = dim - 2;
+    l = 1.f;
+    h = 0.f;
+  }
+  return true;
+}
+
+// Multi-scale (FPN) launches: the level of every RoI is chosen IN the kernel
+// (torchvision/ops/poolers.py:47-84, LevelMapper: floor(k0 + log2(sqrt(area)/s0) + eps) clamped to
+// [k_min, k_max]).  RoIs of the multi-scale entries are always float32 image coordinates, whatever the
+// feature dtype: the reference computes levels and sample coordinates from the fp32 boxes too
+// (poolers.py:199-222, and _autograd_registrations.py:246 under autocast).
+struct MsLevels {
+  const void* ptr[kMaxLevels];
+  int H[kMaxLevels];
+  int W[kMaxLevels];
+  float scale[kMaxLevels];
+  int n_levels;
+  int k_min, k_max;
+  float s0, lvl0, eps;
+};
+
+template <typename R>
+__device__ __forceinline__ int fpn_level(const R* roi, const MsLevels& lv) {
+  const float x1 = ld(roi + 1), y1 = ld(roi + 2), x2 = ld(roi + 3), y2 = ld(roi + 4);
+  const float s = sqrtf((x2 - x1) * (y2 - y1));
+  float t = floorf(lv.lvl0 + log2f(s / lv.s0) + lv.eps);
+  t = fminf(fmaxf(t, (float)lv.k_min), (float)lv.k_max);
+  int l = (t == t) ? (int)t - lv.k_min : 0;  // NaN area (torch.clamp keeps NaN, .to(int64) of NaN is the minimum): level 0
+  return min(max(l, 0), lv.n_levels - 1);
+}
+
+}  // namespace tvmi

@@ -183,7 +183,7 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
     // channels_last input: native NHWC kernel instead of the reference's input.contiguous() copy
     const void* ptr = input.const_data_ptr();
     const double scale = spatial_scale;
-    at::Tensor r = rois.contiguous();
+    at::Tensor r = rois.to(at::kFloat).contiguous();  // the multi-scale entries take float32 RoIs (exact upcast)
     check_status(tvmi_multiscale_roi_align_forward_nhwc(&ptr, &H, &W, &scale, 1, r.const_data_ptr(), output.mutable_data_ptr(),
                                                         dtype_of(input, "roi_align"), input.size(0), C, K, 7, 7, 2, aligned ? 1 : 0, 0, 0, 224.0,
                                                         4.0, 1e-6, current_stream(input)),
@@ -191,11 +191,11 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
     return output;
   }
   at::Tensor input_ = input.contiguous(), rois_ = rois.contiguous();
-  at::Tensor ws = at::empty({2 * K}, input.options().dtype(at::kInt));  // order + declined-flag scratch
+  at::Tensor ws = at::empty({K}, input.options().dtype(at::kInt));  // "declined by the LDS-DMA kernel" flags
   check_status(tvmi_roi_align_forward(input_.const_data_ptr(), rois_.const_data_ptr(), output.mutable_data_ptr(),
                                       dtype_of(input, "roi_align"), input.size(0), C, H, W, K, pooled_height,
                                       pooled_width, spatial_scale, sampling_ratio, aligned ? 1 : 0,
-                                      ws.mutable_data_ptr(), 2 * (size_t)K * sizeof(int32_t), current_stream(input)),
+                                      ws.mutable_data_ptr(), (size_t)K * sizeof(int32_t), current_stream(input)),
                "roi_align");
   return output;
 }
@@ -218,18 +218,29 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
                               batch_size, channels, height, width, sampling_ratio, aligned)
         .to(grad.scalar_type());
   }
-  at::Tensor grad_input = at::zeros({batch_size, channels, height, width}, grad.options());
-  if (grad.numel() == 0) return grad_input;
-  at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
+  if (batch_size * channels * height * width == 0 || rois.size(0) == 0)
+    return at::zeros({batch_size, channels, height, width}, grad.options());
   at::Tensor rois_ = rois.contiguous();
-  const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, height, width, rois.size(0));
-  at::Tensor ws = at::empty({(int64_t)ws_bytes}, grad.options().dtype(at::kByte));
-  check_status(tvmi_roi_align_backward(grad.const_data_ptr(), rois_.const_data_ptr(), grad_input.mutable_data_ptr(),
-                                       dtype_of(grad, "_roi_align_backward"), batch_size, channels, height,
-                                       width, rois.size(0), pooled_height, pooled_width, spatial_scale,
-                                       sampling_ratio, aligned ? 1 : 0, grad.stride(0), grad.stride(1),
-                                       grad.stride(2), grad.stride(3), ws.mutable_data_ptr(), ws_bytes,
-                                       current_stream(grad)),
+  // The tile-owner backward (fp32, 7x7 / 14x14 bins) wants the bins of a channel contiguous; it writes every pixel
+  // of grad_input exactly once (no zero-fill, no atomics, deterministic).  Everything else accumulates atomically
+  // into a zero-filled tensor like the reference (cuda/roi_align_kernel.cu:440).
+  at::Tensor g = grad;
+  const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, rois.size(0), pooled_height, pooled_width);
+  if (ws_bytes != 0 && grad.scalar_type() == at::kFloat &&
+      !(grad.stride(3) == 1 && grad.stride(2) == pooled_width && grad.stride(1) >= pooled_height * pooled_width))
+    g = grad.contiguous();
+  const tvmi_dtype dt = dtype_of(g, "_roi_align_backward");
+  const bool overwrites = ws_bytes != 0 && tvmi_roi_align_backward_overwrites(dt, batch_size, channels, height, width, rois.size(0),
+                                                                              pooled_height, pooled_width, g.stride(1), g.stride(2),
+                                                                              g.stride(3), ws_bytes) != 0;
+  at::Tensor grad_input = overwrites ? at::empty({batch_size, channels, height, width}, g.options())
+                                     : at::zeros({batch_size, channels, height, width}, g.options());
+  if (!overwrites) at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
+  at::Tensor ws = at::empty({(int64_t)(overwrites ? ws_bytes : 0)}, g.options().dtype(at::kByte));
+  check_status(tvmi_roi_align_backward(g.const_data_ptr(), rois_.const_data_ptr(), grad_input.mutable_data_ptr(), dt, batch_size,
+                                       channels, height, width, rois.size(0), pooled_height, pooled_width, spatial_scale,
+                                       sampling_ratio, aligned ? 1 : 0, g.stride(0), g.stride(1), g.stride(2), g.stride(3),
+                                       overwrites ? ws.mutable_data_ptr() : nullptr, overwrites ? ws_bytes : 0, current_stream(grad)),
                "_roi_align_backward");
   return grad_input;
 }
@@ -584,7 +595,7 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
       hs.push_back(f.size(2));
       ws.push_back(f.size(3));
     }
-    at::Tensor r = rois.to(f0.scalar_type()).contiguous();
+    at::Tensor r = rois.to(at::kFloat).contiguous();
     at::Tensor out = at::empty({rois.size(0), f0.size(1), pooled_height, pooled_width}, f0.options().memory_format(at::MemoryFormat::Contiguous));
     if (out.numel() == 0) return out;
     check_status(tvmi_multiscale_roi_align_forward_nhwc(ptrs.data(), hs.data(), ws.data(), scales.data(),
@@ -604,17 +615,19 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
     hs.push_back(f.size(2));
     ws.push_back(f.size(3));
   }
-  at::Tensor rois_ = rois.to(f0.scalar_type()).contiguous();
+  // RoIs stay float32 whatever the feature dtype: levels and sample coordinates are computed from the fp32 boxes,
+  // as the reference does (poolers.py:199-222; under autocast _autograd_registrations.py:246 casts them to fp32)
+  at::Tensor rois_ = rois.to(at::kFloat).contiguous();
   const int64_t K = rois.size(0), C = f0.size(1);
   at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, f0.options());
   if (output.numel() == 0) return output;
-  at::Tensor order_ws = at::empty({2 * K}, f0.options().dtype(at::kInt));  // order + declined-flag scratch
+  at::Tensor order_ws = at::empty({K}, f0.options().dtype(at::kInt));  // "declined by the LDS-DMA kernel" flags
   check_status(tvmi_multiscale_roi_align_forward(ptrs.data(), hs.data(), ws.data(), scales.data(),
                                                  (int64_t)features.size(), rois_.const_data_ptr(),
                                                  output.mutable_data_ptr(), dtype_of(f0, "multiscale_roi_align"),
                                                  f0.size(0), C, K, pooled_height, pooled_width, sampling_ratio,
                                                  aligned ? 1 : 0, k_min, k_max, canonical_scale, canonical_level, eps,
-                                                 order_ws.mutable_data_ptr(), 2 * (size_t)K * sizeof(int32_t),
+                                                 order_ws.mutable_data_ptr(), (size_t)K * sizeof(int32_t),
                                                  current_stream(f0)),
                "multiscale_roi_align");
   return output;
@@ -635,25 +648,33 @@ std::vector<at::Tensor> multiscale_roi_align_backward(const at::Tensor& grad, co
   const bool low = grad.scalar_type() == at::kHalf || grad.scalar_type() == at::kBFloat16;
   // 16-bit gradients accumulate in fp32 and are rounded once (see roi_align_backward)
   at::Tensor g = low ? grad.to(at::kFloat) : grad;
-  at::Tensor r = rois.to(g.scalar_type()).contiguous();
+  at::Tensor r = rois.to(at::kFloat).contiguous();
   TORCH_CHECK(g.scalar_type() == at::kFloat, "multiscale_roi_align_backward: float32 / float16 / bfloat16 only");
   const int64_t K = g.size(0), C = g.size(1);
+  std::vector<int64_t> hs(heights.begin(), heights.end()), ws(widths.begin(), widths.end());
+  const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, K, pooled_height, pooled_width);
+  if (ws_bytes != 0 && !(g.stride(3) == 1 && g.stride(2) == pooled_width && g.stride(1) >= pooled_height * pooled_width))
+    g = g.contiguous();
+  const bool overwrites = ws_bytes != 0 && K != 0 && C != 0 && batch_size != 0 &&
+                          tvmi_multiscale_roi_align_backward_overwrites(TVMI_F32, batch_size, C, K, hs.data(), ws.data(),
+                                                                        (int64_t)hs.size(), pooled_height, pooled_width, g.stride(1),
+                                                                        g.stride(2), g.stride(3), ws_bytes) != 0;
   std::vector<at::Tensor> outs;
   std::vector<void*> ptrs;
-  std::vector<int64_t> hs(heights.begin(), heights.end()), ws(widths.begin(), widths.end());
   for (size_t i = 0; i < heights.size(); ++i) {
-    outs.push_back(at::zeros({batch_size, C, heights[i], widths[i]}, g.options()));
+    outs.push_back(overwrites ? at::empty({batch_size, C, heights[i], widths[i]}, g.options())
+                              : at::zeros({batch_size, C, heights[i], widths[i]}, g.options()));
     ptrs.push_back(outs.back().mutable_data_ptr());
   }
   if (g.numel() != 0 && batch_size != 0) {
-    at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
-    at::Tensor wsp = at::empty({K}, g.options().dtype(at::kInt));
+    if (!overwrites) at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
+    at::Tensor wsp = at::empty({(int64_t)(overwrites ? ws_bytes : 0)}, g.options().dtype(at::kByte));
     check_status(tvmi_multiscale_roi_align_backward(g.const_data_ptr(), r.const_data_ptr(), ptrs.data(), hs.data(), ws.data(),
                                                     scales.data(), (int64_t)heights.size(), TVMI_F32, batch_size, C, K,
                                                     pooled_height, pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max,
                                                     canonical_scale, canonical_level, eps, g.stride(0), g.stride(1),
-                                                    g.stride(2), g.stride(3), wsp.mutable_data_ptr(), (size_t)K * sizeof(int32_t),
-                                                    current_stream(grad)),
+                                                    g.stride(2), g.stride(3), overwrites ? wsp.mutable_data_ptr() : nullptr,
+                                                    overwrites ? ws_bytes : 0, current_stream(grad)),
                  "multiscale_roi_align_backward");
   }
   if (low)

@@ -71,7 +71,7 @@ def _multiscale_roi_align(x_filtered: List[Tensor], boxes: List[Tensor], output_
         # directly in the [K, C, PH, PW] output (no torch.where / index_put per level); the
         # registered autograd formula is one launch too (tvmi::multiscale_roi_align_backward)
         return torch.ops.tvmi.multiscale_roi_align(
-            list(x_filtered), rois.to(first.dtype), [float(s) for s in scales], int(output_size[0]),
+            list(x_filtered), rois.float(), [float(s) for s in scales], int(output_size[0]),
             int(output_size[1]), int(sampling_ratio), False, int(mapper.k_min), int(mapper.k_max), float(mapper.s0),
             float(mapper.lvl0), float(mapper.eps))
     levels = mapper(boxes)
