@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
+                    "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
+                    "as a SECOND JSON object; never mixed into `value`")
     ap.add_argument("--graph", action="store_true", help="replay the per-rank chain from a captured hipGraph (measured: no gain "
                     "over eager sync-free launches on this stack, so off by default)")
     args = ap.parse_args()
@@ -295,6 +298,26 @@ def main():
         dist.destroy_process_group()
     if not parity_ok:
         sys.exit("bench.py: outputs differ from the CPU reference (see the parity block)")
+    if args.e2e and rank == 0 and world == 1:
+        print(json.dumps(e2e_config5()), flush=True)
+
+
+def e2e_config5():
+    """BASELINE config 5 in fresh processes (tools/e2e_maskrcnn.py): the overlay of the reference python needs its own
+    interpreter state.  For N > 1 launch that script under torchrun directly (it shards the images over the ranks)."""
+    import subprocess
+
+    out = {"metric": "MaskRCNN-R50 img/s (BASELINE config 5)", "n_gpus": 1, "runs": []}
+    for variant in ("reference", "fused"):
+        for thresh in ("0.0", "0.05"):
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_maskrcnn.py"), "--variant", variant, "--score-thresh", thresh]
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                out["runs"].append(json.loads(line[-1]) if line else {"variant": variant, "error": p.stderr[-800:]})
+            except Exception as exc:  # pragma: no cover
+                out["runs"].append({"variant": variant, "error": f"{type(exc).__name__}: {exc}"})
+    return out
 
 
 def cpu_baseline(feats, boxes, scores):

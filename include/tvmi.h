@@ -254,7 +254,9 @@ int tvmi_pack_detections(const float* boxes, const float* scores, const int64_t*
                          int64_t max_dets, float* dets, int32_t* counts, void* stream);
 /* Same, with the length of `keep` read on the device (num_keep_dev [1] int64, e.g. tvmi_nms's
  * num_keep_out on the same stream; clamped to [0, keep_capacity]): NMS -> packed payload with
- * no host synchronisation in between, so the chain can be captured in a hipGraph. */
+ * no host synchronisation in between, so the chain can be captured in a hipGraph.  A NEGATIVE
+ * length — the error sentinel of the sync-free NMS entries (segment above its size limit, id
+ * outside the promised range) — is passed on: counts[b] = -1 for every image, zero payload. */
 int tvmi_pack_detections_devcount(const float* boxes, const float* scores, const int64_t* labels,
                                   const int64_t* image_idx, const int64_t* keep, int64_t keep_capacity,
                                   const int64_t* num_keep_dev, int64_t num_images, int64_t max_dets, float* dets,

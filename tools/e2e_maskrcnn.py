@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 at N GPUs of one node: Mask R-CNN ResNet50-FPN inference, random-init weights, synthetic
+3x800x1333 images, the batch sharded over the ranks (images are independent), ONE fixed-shape all-gather of the
+padded detections per step (vision_amd.sharding).  Runs the UNCHANGED reference python package
+(models/detection/generalized_rcnn.py:53-133, mask_rcnn.py) laid over our operator library
+(vision_amd.integration.make_overlay); the backbone / heads are MIOpen + hipBLASLt through torch, outside our kernels.
+
+    python tools/e2e_maskrcnn.py --variant reference|fused [--batch 2] [--steps 8] [--warmup 3] [--score-thresh 0.0]
+
+variant reference : nothing swapped — every torchvision.ops call of the reference python lands in the
+                    `torchvision::` schema kernels of this library (and, with the opt-in aten override, every
+                    F.interpolate in resize.hip)
+variant fused     : vision_amd.{MultiScaleRoIAlign, postprocess_detections, filter_proposals, paste_masks_in_image,
+                    transform_images} swapped in
+Prints one JSON object.  Launched by `bench.py --e2e` in a fresh process (the overlay needs TVMI_NO_PY_REGISTRATIONS=1
+before vision_amd is imported: the reference package brings its own fake / autograd registrations)."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["TVMI_NO_PY_REGISTRATIONS"] = "1"
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="reference", choices=["reference", "fused", "check"],
+                    help="check: run the SAME model both ways on the same images and compare the detections")
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU and step")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--score-thresh", type=float, default=0.0,
+                    help="box_score_thresh; random-init class scores are ~1/91, so 0.0 keeps the post-processing busy "
+                         "(100 detections per image) and the default 0.05 of the reference keeps none")
+    ap.add_argument("--no-aten-override", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
+    world = max(world, 1)
+    assert torch.cuda.is_available(), "config 5 is measured on the GPU"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import vision_amd
+    from vision_amd import integration, sharding
+    from tools.stage_reference_python import reference_package
+
+    scratch = tempfile.mkdtemp(prefix="tvmi_e2e_")
+    pkg = reference_package(scratch)
+    if pkg is None:
+        print(json.dumps({"e2e": None, "reason": "reference python package neither present nor staged"}))
+        return
+    sys.path.insert(0, integration.make_overlay(os.path.join(scratch, "overlay"), pkg))
+    import torchvision  # the reference package, unmodified
+    from torchvision import extension
+    from torchvision.models.detection import maskrcnn_resnet50_fpn
+
+    assert extension._has_ops(), "the reference loader did not find our library as _C / _C_stable"
+    if not args.no_aten_override:
+        vision_amd.override_aten_upsample(True)
+
+    torch.manual_seed(0)
+    model = maskrcnn_resnet50_fpn(weights=None, weights_backbone=None, box_score_thresh=args.score_thresh).eval().to(device)
+    def apply_fused():
+        import torchvision.models.detection.transform as T
+        from torchvision.models.detection.image_list import ImageList
+
+        names = ["0", "1", "2", "3"]
+        model.roi_heads.box_roi_pool = vision_amd.MultiScaleRoIAlign(names, 7, 2)
+        model.roi_heads.mask_roi_pool = vision_amd.MultiScaleRoIAlign(names, 14, 2)
+        rh, rpn, tr = model.roi_heads, model.rpn, model.transform
+        rh.postprocess_detections = lambda logits, reg, props, shapes: vision_amd.postprocess_detections(
+            logits, reg, props, shapes, bbox_reg_weights=rh.box_coder.weights, score_thresh=rh.score_thresh,
+            nms_thresh=rh.nms_thresh, detections_per_img=rh.detections_per_img)
+        rpn.filter_proposals = lambda props, obj, shapes, per_level: vision_amd.filter_proposals(
+            props, obj, shapes, per_level, pre_nms_top_n=rpn.pre_nms_top_n(), post_nms_top_n=rpn.post_nms_top_n(),
+            nms_thresh=rpn.nms_thresh, score_thresh=rpn.score_thresh, min_size=rpn.min_size)
+        T.paste_masks_in_image = vision_amd.paste_masks_in_image
+
+        def fused_transform(images, targets=None):
+            tensors, sizes = vision_amd.transform_images(images, tr.min_size, tr.max_size, tr.image_mean, tr.image_std,
+                                                         tr.size_divisible)
+            return ImageList(tensors, [tuple(s) for s in sizes]), targets
+        tr.forward = fused_transform
+
+    if args.variant == "fused":
+        apply_fused()
+
+    g = torch.Generator().manual_seed(100 + rank)
+    batches = [[torch.rand(3, 800, 1333, generator=g).to(device) for _ in range(args.batch)] for _ in range(2)]
+
+    if args.variant == "check":
+        # same weights, same images: unchanged reference python vs the fused pieces
+        with torch.no_grad():
+            ref = model(batches[0])
+            apply_fused()
+            fus = model(batches[0])
+        rep = {"e2e_check": "reference python vs fused vision_amd pieces, same model and images", "images": []}
+        ok = True
+        for a, b in zip(ref, fus):
+            n = min(len(a["scores"]), len(b["scores"]))
+            same_n = len(a["scores"]) == len(b["scores"])
+            lab = bool(torch.equal(a["labels"][:n], b["labels"][:n]))
+            ds = float((a["scores"][:n] - b["scores"][:n]).abs().max()) if n else 0.0
+            db = float((a["boxes"][:n] - b["boxes"][:n]).abs().max()) if n else 0.0
+            dm = float((a["masks"][:n] - b["masks"][:n]).abs().max()) if n else 0.0
+            rep["images"].append({"detections": [len(a["scores"]), len(b["scores"])], "labels_equal": lab, "max_score_diff": ds,
+                                  "max_box_diff_px": db, "max_mask_diff": dm})
+            # same detections in the same order; values differ by fp32 rounding carried through a random-init network
+            ok = ok and same_n and lab and ds < 1e-4 and db < 5e-2 and dm < 5e-3
+        rep["ok"] = ok
+        print(json.dumps(rep), flush=True)
+        sys.exit(0 if ok else 1)
+
+    def step(i):
+        with torch.no_grad():
+            out = model(batches[i % 2])
+        # fixed-shape detection payload of this rank's images and its one all-gather
+        B = len(out)
+        n = torch.tensor([o["boxes"].shape[0] for o in out])
+        dets = torch.zeros(B, 100, 6, device=device)
+        for j, o in enumerate(out):
+            k = min(int(n[j]), 100)
+            dets[j, :k, :4], dets[j, :k, 4], dets[j, :k, 5] = o["boxes"][:k], o["scores"][:k], o["labels"][:k].float()
+        sharding.all_gather_detections(dets, n.to(device=device, dtype=torch.int32).clamp(max=100))
+        return out
+
+    for i in range(args.warmup):
+        out = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    calls0 = int(torch.ops.tvmi.aten_upsample_calls())
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    res = {
+        "e2e": "maskrcnn_resnet50_fpn inference (BASELINE config 5)",
+        "variant": args.variant,
+        "value": round(args.batch * world * args.steps / dt, 3),
+        "unit": "img/s",
+        "n_gpus": world,
+        "images_per_gpu_per_step": args.batch,
+        "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "box_score_thresh": args.score_thresh,
+        "detections_per_image": [int(o["boxes"].shape[0]) for o in out],
+        "mask_shape": list(out[0]["masks"].shape),
+        "aten_upsample_override": not args.no_aten_override,
+        "aten_upsample_calls_per_step": (int(torch.ops.tvmi.aten_upsample_calls()) - calls0) / max(args.steps, 1),
+        "reference_python": torchvision.__file__,
+        "data": "synthetic", "weights": "random init (seed 0)", "dtype": "f32",
+    }
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,19 +9,33 @@ __version__ = "0.1.0"
 
 
 def load(register_python: bool = True):
-    """Load the native libraries and (optionally) the python-level fake/autograd/autocast
-    registrations.  Pass register_python=False when the reference `torchvision` python
-    package is going to be imported over this library: it brings its own
-    _meta_registrations / _autograd_registrations for the same schemas."""
+    """Load the native libraries and the python-level fake/autograd/autocast registrations.
+    Pass register_python=False (or set TVMI_NO_PY_REGISTRATIONS=1) when the reference `torchvision`
+    python package is going to be imported over this library: it brings its own
+    _meta_registrations / _autograd_registrations for the `torchvision::` schemas, so only the
+    `tvmi::` namespace is registered here then."""
     _loader.load()
-    if register_python:
-        from . import _registrations
+    from . import _registrations
 
-        _registrations.register_all()
+    _registrations.register_all(torchvision_schemas=bool(register_python))
+
+
+def override_aten_upsample(enable: bool = True) -> bool:
+    """Opt-in: put our resize kernels on the CUDA key of aten::upsample_{nearest,bilinear,bicubic}2d,
+    _upsample_{bilinear,bicubic}2d_aa and _upsample_nearest_exact2d (functional + .out), so that every
+    F.interpolate call of the unchanged reference python (models/detection/transform.py:65-72,
+    ops/feature_pyramid_network.py:194, roi_heads.py:427, transforms/v2/functional/_geometry.py:344) lands in
+    vision_amd/csrc/resize.hip.  Returns the previous state.  Also enabled by TVMI_OVERRIDE_ATEN_UPSAMPLE=1."""
+    import torch
+
+    _loader.assert_has_ops()
+    return bool(torch.ops.tvmi.override_aten_upsample(bool(enable)))
 
 
 try:
     load(register_python=_os.environ.get("TVMI_NO_PY_REGISTRATIONS", "0") != "1")
+    if _os.environ.get("TVMI_OVERRIDE_ATEN_UPSAMPLE", "0") == "1":
+        override_aten_upsample(True)
 except _loader.ExtensionMissing:
     if _os.environ.get("TVMI_ALLOW_MISSING", "0") != "1":
         raise

@@ -298,14 +298,21 @@ def _make_autocast(op_name, n_tensor_args, restore):
     return wrapper
 
 
-def register_all():
-    """Idempotent; skipped entirely if another package already registered these ops."""
+def register_all(torchvision_schemas: bool = True):
+    """Idempotent.  `torchvision_schemas=False` registers only what belongs to the `tvmi::` namespace (fake kernels,
+    the autograd formula of the fused multi-scale op): the mode for processes in which the reference's python package
+    is imported over this library and brings its own registrations for the `torchvision::` schemas."""
     global _AUTOCAST_KEYS
     if _done["v"]:
         return
     _done["v"] = True
     for name, fn in _FAKES.items():
-        torch.library.register_fake(name, fn)
+        if torchvision_schemas or name.startswith("tvmi::"):
+            torch.library.register_fake(name, fn)
+    torch.library.register_autograd("tvmi::multiscale_roi_align", _multiscale_backward, setup_context=_multiscale_setup)
+    torch.library.register_autograd("tvmi::multiscale_roi_align_backward", _no_double_backward("multiscale_roi_align"))
+    if not torchvision_schemas:
+        return
 
     tv = "torchvision::"
     for fwd, bwd, nb, tail, aux in (
@@ -317,8 +324,6 @@ def register_all():
         setup, backward = _make_roi_autograd(fwd, bwd, nb, tail, aux)
         torch.library.register_autograd(tv + fwd, backward, setup_context=setup)
         torch.library.register_autograd(tv + bwd, _no_double_backward(fwd))
-    torch.library.register_autograd("tvmi::multiscale_roi_align", _multiscale_backward, setup_context=_multiscale_setup)
-    torch.library.register_autograd("tvmi::multiscale_roi_align_backward", _no_double_backward("multiscale_roi_align"))
     torch.library.register_autograd(tv + "deform_conv2d", _deform_backward, setup_context=_deform_setup)
     torch.library.register_autograd(tv + "_deform_conv2d_backward", _no_double_backward("deform_conv2d"))
 

@@ -187,7 +187,9 @@ __device__ __forceinline__ void suppression_row(const float* __restrict__ rows, 
   if (KEYS) word &= __ballot(jkey == row_keys[I]);
   // gfx9 takes the lane select of v_writelane from an SGPR or M0 (an inline constant assembles but selects the wrong
   // lane for I >= 32 — measured), and only one SGPR may sit on the constant bus: the row index goes through M0,
-  // which the caller saves and restores around the 64 rows.
+  // which the caller saves and restores around the 64 rows.  (M0 is a reserved register for this compiler: naming it
+  // in the clobber list is rejected with "clobber list contains reserved registers", so the save / restore pair it is;
+  // nothing between the pair can be given an M0 use by the compiler — this TU has no LDS-DMA, movrel or GWS code.)
   asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
                : "+v"(mine_lo), "+v"(mine_hi)
                : "s"((int)(unsigned)word), "n"(I), "s"((int)(unsigned)(word >> 32)));

@@ -20,7 +20,11 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
     const int64_t* __restrict__ image_idx, const int64_t* __restrict__ keep, int64_t num_keep,
     const int64_t* __restrict__ num_keep_dev, int num_images, int max_dets, float* __restrict__ dets,
     int32_t* __restrict__ counts) {
-  // the keep list may come straight from an NMS launch on the same stream: its length then lives on the device
+  // the keep list may come straight from an NMS launch on the same stream: its length then lives on the device.
+  // A negative length is the sync-free NMS's error sentinel (a segment above its size limit, an id outside the
+  // promised range): the keep list is then unspecified, and the sentinel is passed on as counts[b] = -1 (zero
+  // payload) instead of being mistaken for "nothing kept".
+  const bool poisoned = num_keep_dev && *num_keep_dev < 0;
   if (num_keep_dev) num_keep = min(max(*num_keep_dev, (int64_t)0), num_keep);
   __shared__ int s_cnt[kPackMaxImages];                 // kept so far per image
   __shared__ int s_wave[kPackWaves][kPackMaxImages];    // this chunk: kept per (wave, image)
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
     }
     __syncthreads();
   }
-  for (int i = tid; i < num_images; i += kPackThreads) counts[i] = min(s_cnt[i], max_dets);
+  for (int i = tid; i < num_images; i += kPackThreads) counts[i] = poisoned ? -1 : min(s_cnt[i], max_dets);
 }
 
 

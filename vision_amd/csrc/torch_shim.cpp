@@ -13,7 +13,17 @@
 // torchvision.ops wrapper bind to this library unchanged.
 // Define TVMI_NO_SCHEMA_DEFS when another library in the process already owns the m.def()s.
 #include <ATen/ATen.h>
+#include <ATen/ops/_upsample_bicubic2d_aa_cuda_dispatch.h>
+#include <ATen/ops/_upsample_bilinear2d_aa_cuda_dispatch.h>
+#include <ATen/ops/_upsample_nearest_exact2d_cuda_dispatch.h>
+#include <ATen/ops/upsample_bicubic2d_cuda_dispatch.h>
+#include <ATen/ops/upsample_bilinear2d_cuda_dispatch.h>
+#include <ATen/ops/upsample_nearest2d_cuda_dispatch.h>
+#include <ATen/native/Resize.h>
+#include <atomic>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <c10/core/DeviceGuard.h>
 #include <torch/csrc/inductor/aoti_torch/c/shim.h>
 #include <torch/library.h>
@@ -564,6 +574,96 @@ at::Tensor interpolate2d(const at::Tensor& input, int64_t out_h, int64_t out_w, 
   return out;
 }
 
+// ---- the resize boundary of the reference: torchvision resizes through F.interpolate
+// (models/detection/transform.py:65-72, ops/feature_pyramid_network.py:194, models/detection/roi_heads.py:427,453,
+// transforms/v2/functional/_geometry.py:344-350), i.e. through aten::upsample_*.  `tvmi::override_aten_upsample(True)`
+// (opt-in; TVMI_OVERRIDE_ATEN_UPSAMPLE=1 at import) puts our kernels on the CUDA key of those aten ops, functional and
+// .out overloads, so the unchanged reference python lands in resize.hip.  Only the forward is taken over (autograd keeps
+// calling aten's *_backward); inputs our kernels do not serve (channels_last, integer dtypes, 0-sized) go to ATen's own
+// CUDA kernel through its static-dispatch entry.  The handle is dropped again by override_aten_upsample(False).
+namespace upsample_override {
+
+std::unique_ptr<torch::Library> g_lib;
+std::mutex g_mutex;
+std::atomic<int64_t> g_calls{0};  // how many aten::upsample_* calls were served by tvmi kernels (tests read it)
+
+bool ours(const at::Tensor& self, at::IntArrayRef size) {
+  const auto t = self.scalar_type();
+  return self.is_cuda() && self.dim() == 4 && size.size() == 2 && self.numel() > 0 && size[0] > 0 && size[1] > 0 &&
+         (t == at::kFloat || t == at::kHalf || t == at::kBFloat16 || t == at::kDouble) && self.is_contiguous();
+}
+
+double sc(const std::optional<double>& v) { return v.has_value() ? *v : -1.0; }
+
+#define TVMI_UPSAMPLE_LINEAR(NAME, ATEN, MODE, AA)                                                                      \
+  at::Tensor NAME(const at::Tensor& self, at::IntArrayRef size, bool align_corners, std::optional<double> sh,          \
+                  std::optional<double> sw) {                                                                          \
+    if (!ours(self, size)) return at::cuda::ATEN(self, size, align_corners, sh, sw);                                   \
+    ++g_calls;                                                                                                         \
+    return interpolate2d(self, size[0], size[1], MODE, align_corners, AA, sc(sh), sc(sw));                             \
+  }                                                                                                                    \
+  at::Tensor& NAME##_out(const at::Tensor& self, at::IntArrayRef size, bool align_corners, std::optional<double> sh,   \
+                         std::optional<double> sw, at::Tensor& out) {                                                  \
+    if (!ours(self, size)) return at::cuda::ATEN##_outf(self, size, align_corners, sh, sw, out);                       \
+    ++g_calls;                                                                                                         \
+    at::Tensor r = interpolate2d(self, size[0], size[1], MODE, align_corners, AA, sc(sh), sc(sw));                     \
+    at::native::resize_output(out, r.sizes());                                                                         \
+    out.copy_(r);                                                                                                      \
+    return out;                                                                                                        \
+  }
+#define TVMI_UPSAMPLE_NEAREST(NAME, ATEN, MODE)                                                                        \
+  at::Tensor NAME(const at::Tensor& self, at::IntArrayRef size, std::optional<double> sh, std::optional<double> sw) {  \
+    if (!ours(self, size)) return at::cuda::ATEN(self, size, sh, sw);                                                  \
+    ++g_calls;                                                                                                         \
+    return interpolate2d(self, size[0], size[1], MODE, false, false, sc(sh), sc(sw));                                  \
+  }                                                                                                                    \
+  at::Tensor& NAME##_out(const at::Tensor& self, at::IntArrayRef size, std::optional<double> sh,                       \
+                         std::optional<double> sw, at::Tensor& out) {                                                  \
+    if (!ours(self, size)) return at::cuda::ATEN##_outf(self, size, sh, sw, out);                                      \
+    ++g_calls;                                                                                                         \
+    at::Tensor r = interpolate2d(self, size[0], size[1], MODE, false, false, sc(sh), sc(sw));                          \
+    at::native::resize_output(out, r.sizes());                                                                         \
+    out.copy_(r);                                                                                                      \
+    return out;                                                                                                        \
+  }
+
+TVMI_UPSAMPLE_LINEAR(bilinear, upsample_bilinear2d, 2, false)
+TVMI_UPSAMPLE_LINEAR(bicubic, upsample_bicubic2d, 3, false)
+TVMI_UPSAMPLE_LINEAR(bilinear_aa, _upsample_bilinear2d_aa, 2, true)
+TVMI_UPSAMPLE_LINEAR(bicubic_aa, _upsample_bicubic2d_aa, 3, true)
+TVMI_UPSAMPLE_NEAREST(nearest, upsample_nearest2d, 0)
+TVMI_UPSAMPLE_NEAREST(nearest_exact, _upsample_nearest_exact2d, 1)
+#undef TVMI_UPSAMPLE_LINEAR
+#undef TVMI_UPSAMPLE_NEAREST
+
+bool set(bool enable) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  const bool was = g_lib != nullptr;
+  if (enable && !g_lib) {
+    g_lib = std::make_unique<torch::Library>(torch::Library::IMPL, "aten", c10::make_optional(c10::DispatchKey::CUDA), __FILE__,
+                                             __LINE__);
+    g_lib->impl("upsample_bilinear2d", &bilinear);
+    g_lib->impl("upsample_bilinear2d.out", &bilinear_out);
+    g_lib->impl("upsample_bicubic2d", &bicubic);
+    g_lib->impl("upsample_bicubic2d.out", &bicubic_out);
+    g_lib->impl("_upsample_bilinear2d_aa", &bilinear_aa);
+    g_lib->impl("_upsample_bilinear2d_aa.out", &bilinear_aa_out);
+    g_lib->impl("_upsample_bicubic2d_aa", &bicubic_aa);
+    g_lib->impl("_upsample_bicubic2d_aa.out", &bicubic_aa_out);
+    g_lib->impl("upsample_nearest2d", &nearest);
+    g_lib->impl("upsample_nearest2d.out", &nearest_out);
+    g_lib->impl("_upsample_nearest_exact2d", &nearest_exact);
+    g_lib->impl("_upsample_nearest_exact2d.out", &nearest_exact_out);
+  } else if (!enable) {
+    g_lib.reset();
+  }
+  return was;
+}
+
+int64_t calls() { return g_calls.load(); }
+
+}  // namespace upsample_override
+
 // ---- multi-scale RoIAlign in one launch (torchvision/ops/poolers.py:147-227)
 at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois, at::ArrayRef<double> scales,
                                 int64_t pooled_height, int64_t pooled_width, int64_t sampling_ratio, bool aligned,
@@ -963,6 +1063,9 @@ TORCH_LIBRARY_FRAGMENT(torchvision, m) {
 // loops in the reference); they live in their own namespace.
 TORCH_LIBRARY(tvmi, m) {
   m.def("abi_version", &tvmi_abi_version);
+  // opt-in: our resize kernels on the CUDA key of aten::upsample_* (returns the previous state)
+  m.def("override_aten_upsample", &upsample_override::set);
+  m.def("aten_upsample_calls", &upsample_override::calls);
   // batched NMS without the per-class python loop of torchvision/ops/boxes.py:113-126; num_segments > 0 promises
   // ids in [0, num_segments) and unlocks the single-launch path for n <= 4096
   m.def("nms_segmented(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold, int num_segments=-1) -> Tensor");

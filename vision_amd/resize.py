@@ -53,6 +53,11 @@ def interpolate(input: Tensor, size=None, scale_factor=None, mode: str = "neares
         oh, ow = int(math.floor(float(ih) * sf[0])), int(math.floor(float(iw) * sf[1]))
         if not recompute_scale_factor:
             scale_h, scale_w = float(sf[0]), float(sf[1])
+    if input.requires_grad and torch.is_grad_enabled():
+        # tvmi::interpolate2d is the forward kernel only; silently dropping the gradient would be worse than refusing
+        raise RuntimeError("vision_amd.interpolate is inference-only (no backward kernel): call it under torch.no_grad(), or "
+                           "use torch.nn.functional.interpolate with vision_amd.override_aten_upsample(True), which keeps "
+                           "aten's autograd formula and runs our forward kernel")
     return torch.ops.tvmi.interpolate2d(input, oh, ow, _MODES[mode], align, bool(antialias), scale_h, scale_w)
 
 

@@ -52,7 +52,9 @@ def pack_kept_detections(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep:
     all images of this rank; returns the same (`dets`, `counts`) payload as pack_detections.  On CUDA
     tensors this is ONE launch (`tvmi::pack_detections`).  With `num_keep` (a [1] int64 device tensor,
     from `tvmi::nms_segmented_padded`) only the first num_keep[0] entries of `keep` are read and no host
-    synchronisation happens between the NMS and the packing — the chain is hipGraph-capturable."""
+    synchronisation happens between the NMS and the packing — the chain is hipGraph-capturable.  If the sync-free
+    NMS reported its error sentinel (num_keep < 0: a segment above its size limit or an id outside the promised range)
+    every count comes back as -1 — `unpack_detections` raises on it — instead of "no detections"."""
     if num_keep is not None:
         return torch.ops.tvmi.pack_detections_devcount(boxes, scores, labels, image_idx, keep, num_keep,
                                                        int(num_images), int(max_dets))
@@ -87,6 +89,9 @@ def all_gather_detections(dets: Tensor, counts: Tensor, group=None) -> Tuple[Ten
 def unpack_detections(dets: Tensor, counts: Tensor) -> List[dict]:
     out = []
     for d, n in zip(dets, counts.tolist()):
+        if n < 0:
+            raise RuntimeError("detection payload carries the sync-free NMS error sentinel (count -1): a segment exceeded the "
+                               "size limit of the no-sync path or an id was outside the promised range; use batched_nms()")
         d = d[:n]
         out.append({"boxes": d[:, :4], "scores": d[:, 4], "labels": d[:, 5].to(torch.int64)})
     return out
