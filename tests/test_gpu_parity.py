@@ -864,7 +864,7 @@ def test_roi_align_backward_owner_path_layouts(tv, P, sr, aligned):
     rois[rois[:, 0] == 3, 0] = 1.0                                   # image 3 has no RoI at all
     rois[:1500, 1:] = torch.tensor([200.0, 120.0, 330.0, 250.0]) + torch.rand(1500, 4, generator=g) * 6   # > 1024 RoIs on one tile
     rois[:1500, 0] = 2.0
-    rois[1500, 1:] = torch.tensor([-40.0, -30.0, 700.0, 400.0])     # window ~ 90 x 54 px: above the table capacity
+    rois[1500, 1:] = torch.tensor([-40.0, -30.0, 700.0, 400.0])     # window ~ 90 x 54 px
     rois[1501, 1:] = torch.tensor([0.0, 0.0, W * 8.0, H * 8.0])     # the whole map
     rois[1502, 1:] = torch.tensor([300.0, 100.0, 100.0, 50.0])      # malformed (x2 < x1)
     rois[1503, 1:] = torch.tensor([5000.0, 5000.0, 6000.0, 6000.0]) # outside
@@ -880,6 +880,28 @@ def test_roi_align_backward_owner_path_layouts(tv, P, sr, aligned):
     c = tv._roi_align_backward(ones, rois.to(DEV), 1 / 8, P, P, N, C, H, W, sr, aligned)
     refc = O.roi_align_backward(np.ones((k, C, P, P), np.float32), rois.numpy(), 1 / 8, P, P, N, C, H, W, sr, aligned)
     np.testing.assert_allclose(c.cpu().numpy(), refc, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(refc).max())))
+
+
+@pytest.mark.parametrize("nbig", [5, 1300])
+def test_roi_align_backward_owner_oversized_windows(tv, nbig):
+    """Windows above the 128-row / -column coefficient tables take the second pass (factors evaluated in the kernel, tile
+    read-add-written): a handful of them (sorted short list) and more than the list holds (full descriptor scan)."""
+    g = gen(260 + nbig)
+    N, C, H, W, P = 2, 6, 150, 171, 7
+    k = nbig + 300
+    rois = rois_for(N, k, W * 4, H * 4, 8, 200, g)
+    big = torch.rand(nbig, 4, generator=g)
+    rois[:nbig, 1] = big[:, 0] * 60
+    rois[:nbig, 2] = big[:, 1] * 40
+    rois[:nbig, 3] = rois[:nbig, 1] + 540 + big[:, 2] * 80          # 135..155 px wide on the map
+    rois[:nbig, 4] = rois[:nbig, 2] + 200 + big[:, 3] * 380         # 50..145 px tall
+    rois = rois[torch.randperm(k, generator=g)]
+    gr = torch.randn(k, C, P, P, generator=g)
+    a = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), 0.25, P, P, N, C, H, W, 2, False)
+    b = tv._roi_align_backward(gr.to(DEV), rois.to(DEV), 0.25, P, P, N, C, H, W, 2, False)
+    assert torch.equal(a, b)
+    ref = O.roi_align_backward(gr.numpy(), rois.numpy(), 0.25, P, P, N, C, H, W, 2, False)
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(ref).max())))
 
 
 def test_roi_align_backward_is_deterministic_under_the_torch_flag(tv):

@@ -18,6 +18,22 @@ with torch.no_grad():
         cl = {k: v.contiguous(memory_format=torch.channels_last) for k, v in feats.items()}
         for _ in range(reps):
             pool(cl, boxes, shapes)
+    elif which in ("bwd7", "bwd14"):
+        from vision_amd.poolers import _convert_to_roi_format
+        P = 7 if which == "bwd7" else 14
+        rois = _convert_to_roi_format(boxes).float()
+        fl = [feats[str(i)] for i in range(4)]
+        gall = torch.randn(4000, 256, P, P, device=dev)
+        for _ in range(reps):
+            torch.ops.tvmi.multiscale_roi_align_backward(gall, rois, [f.shape[2] for f in fl], [f.shape[3] for f in fl],
+                                                         [1 / s for s in bench.STRIDES], 4, P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6)
+    elif which == "nms100k":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import random_boxes
+        g = torch.Generator().manual_seed(7)
+        b = random_boxes(100_000, 1000, 1000, 1, 101, g).to(dev); s = torch.rand(100_000, generator=g).to(dev)
+        for _ in range(reps):
+            torch.ops.torchvision.nms(b, s, 0.5)
     elif which == "nms":
         b, s = torch.cat(boxes), torch.cat(scores)
         idx = torch.cat([torch.full((1000,), i, device=dev, dtype=torch.int64) for i in range(4)])

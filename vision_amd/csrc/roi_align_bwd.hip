@@ -13,7 +13,7 @@
 //         dWin[r][c] = sum_ph AyD[r][ph] * ( sum_pw G[ph][pw] * AxD[pw][c] ),
 //     AyD / AxD being the (tiny) matrices of bilinear row / column factors summed over the samples of a bin
 //     and divided by the grid size.  A pre-pass expands them once per RoI into window-relative tables
-//     (<= 64 rows / columns; larger windows are evaluated on the fly), together with the RoI's level,
+//     (<= 128 rows / columns; larger windows are evaluated on the fly by a second pass), together with the RoI's level,
 //     tile rectangle and window;
 //   * lane = (column pair, channel slot): G (the PH*PW grads of the lane's channel) and the AxD columns live
 //     in VGPRs, the AyD row of a tile row is WAVE-UNIFORM and is fetched with scalar loads (SGPR operands
@@ -32,10 +32,11 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTile = 16;      // tile edge (pixels) owned by one workgroup
 constexpr int kOwnChunk = 32;  // channels per workgroup: 4 waves x 8 channel slots x 1 channel per lane
-constexpr int kRCap = 64;      // window rows / columns with precomputed coefficient rows
+constexpr int kRCap = 128;     // window rows / columns with precomputed coefficient rows
 constexpr int kAyRows = kTile + kRCap + kTile;  // rows of a RoI's AyD table (zero rows on both sides: any tile row offset is readable)
 constexpr int kScanChunk = 1024;
 constexpr int kBigBit = 1 << 30;   // descriptor key bit: window above the table capacity (second pass)
+constexpr int kBigCap = 1024;       // oversized-window RoIs listed for the second pass (more: it scans every descriptor)
 constexpr int kUnset = 0x7f7f7f7f;  // memset pattern of the per-image RoI ranges and of the oversized-window counter  // RoI descriptors scanned per list round (256 per wave)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -45,7 +46,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct OwnWorkspace {
   int2* scan;     // [K] {key = (level << 24) | batch (| kBigBit), or -1; tile rect ty0 | ty1<<8 | tx0<<16 | tx1<<24}
   int4* win;      // [K] {y0, x0, wh, ww}
-  int* imgrange;  // [2N + 1] {min RoI index of image n, -(max index + 1)} ..., count of oversized windows; memset to kUnset
+  int* imgrange;  // [2N + 1] {first RoI index of image n, -(last index + 1)} ..., kUnset + count of oversized windows; memset to kUnset
+  int* biglist;   // [kBigCap] indices of the RoIs with oversized windows (unordered; the second pass sorts them)
   float* ayt;     // [K][kTile + kRCap + kTile][PH]  AyD rows, window-relative, 16 zero rows before and behind
   float* axt;     // [K][kRCap][PWP]  AxD columns (stored as rows), window-relative
 };
@@ -54,7 +56,7 @@ constexpr int pad4(int v) { return (v + 3) & ~3; }
 
 inline size_t own_workspace_bytes(int64_t N, int64_t K, int PH, int PW) {
   const size_t tab = (size_t)K * ((size_t)kAyRows * PH + (size_t)kRCap * pad4(PW)) * sizeof(float);
-  return (size_t)K * (sizeof(int2) + sizeof(int4)) + (size_t)(2 * N + 4) * sizeof(int) + tab + 512;
+  return (size_t)K * (sizeof(int2) + sizeof(int4)) + (size_t)(2 * N + 4 + kBigCap) * sizeof(int) + tab + 512;
 }
 
 inline OwnWorkspace carve_workspace(void* base, int64_t N, int64_t K, int PH, int PW) {
@@ -68,6 +70,8 @@ inline OwnWorkspace carve_workspace(void* base, int64_t N, int64_t K, int PH, in
   p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~uintptr_t(15));
   w.imgrange = reinterpret_cast<int*>(p);
   p += (size_t)(2 * N + 4) * sizeof(int);
+  w.biglist = reinterpret_cast<int*>(p);
+  p += (size_t)kBigCap * sizeof(int);
   p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~uintptr_t(63));
   w.ayt = reinterpret_cast<float*>(p);
   p += (size_t)K * kAyRows * PH * sizeof(float);
@@ -137,7 +141,16 @@ __global__ __launch_bounds__(kThreads) void roi_bwd_prepass(const float* __restr
   const int H = lv.ms.H[l], W = lv.ms.W[l];
   const RoiGeom<float> g = roi_geom<float, float>(roi, lv.ms.scale[l], PH, PW, sr, aligned != 0);
   int y0 = 0, y1 = -1, x0 = 0, x1 = -1;
-  bool ok = g.batch >= 0 && g.batch < lv.N && g.gh > 0 && g.gw > 0;
+  const bool batch_ok = g.batch >= 0 && g.batch < lv.N;
+  if (batch_ok && lane == 0) {
+    // RoI index range of every image, from the run boundaries of the batch column only: RoI lists are normally
+    // grouped by image, and thousands of same-address atomics would cost more than the rest of this kernel
+    const int prevb = k > 0 ? (int)rois[(int64_t)(k - 1) * 5] : -1;
+    const int nextb = k + 1 < K ? (int)rois[(int64_t)(k + 1) * 5] : -1;
+    if (prevb != g.batch) atomicMin(&ws.imgrange[2 * g.batch], k);
+    if (nextb != g.batch) atomicMin(&ws.imgrange[2 * g.batch + 1], -(k + 1));
+  }
+  bool ok = batch_ok && g.gh > 0 && g.gw > 0;
   ok = ok && axis_window(H, g.start_h, g.bin_h, g.gh, PH, y0, y1);
   ok = ok && axis_window(W, g.start_w, g.bin_w, g.gw, PW, x0, x1);
   if (!ok) {  // no sample inside the map (or a batch index outside the tensor): no gradient
@@ -153,27 +166,29 @@ __global__ __launch_bounds__(kThreads) void roi_bwd_prepass(const float* __restr
     const int rect = (y0 / kTile) | ((y1 / kTile) << 8) | ((x0 / kTile) << 16) | ((x1 / kTile) << 24);
     ws.scan[k] = make_int2((l << 24) | g.batch | (big ? kBigBit : 0), rect);
     ws.win[k] = make_int4(y0, x0, wh, ww);
-    if (big) atomicAdd(&ws.imgrange[2 * lv.N], 1);
-    atomicMin(&ws.imgrange[2 * g.batch], k);
-    atomicMin(&ws.imgrange[2 * g.batch + 1], -(k + 1));
+    if (big) {
+      const int slot = atomicAdd(&ws.imgrange[2 * lv.N], 1) - kUnset;
+      if (slot >= 0 && slot < kBigCap) ws.biglist[slot] = k;
+    }
   }
   if (big) return;
-  for (int t = lane; t < kAyRows; t += 64) {  // table row t <-> window row t - 16
+  // table row t <-> window row t - 16; rows past wh + 16 + 15 are never read (the tile overlaps the window)
+  for (int t = lane; t < wh + 2 * kTile; t += 64) {
     float* row = ws.ayt + ((int64_t)k * kAyRows + t) * PH;
     const int r = t - kTile;
     const bool in = r >= 0 && r < wh;
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) row[ph] = in ? axis_coef(H, g.start_h, g.bin_h, g.gh, ph, y0 + r) : 0.f;
   }
-  if (lane < ww) {
-    float* row = ws.axt + ((int64_t)k * kRCap + lane) * PWP;
+  for (int c = lane; c < ww; c += 64) {
+    float* row = ws.axt + ((int64_t)k * kRCap + c) * PWP;
 #pragma unroll
     for (int p0 = 0; p0 < PWP; p0 += 4) {
       float4 v;
-      v.x = p0 + 0 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 0, x0 + lane) : 0.f;
-      v.y = p0 + 1 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 1, x0 + lane) : 0.f;
-      v.z = p0 + 2 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 2, x0 + lane) : 0.f;
-      v.w = p0 + 3 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 3, x0 + lane) : 0.f;
+      v.x = p0 + 0 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 0, x0 + c) : 0.f;
+      v.y = p0 + 1 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 1, x0 + c) : 0.f;
+      v.z = p0 + 2 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 2, x0 + c) : 0.f;
+      v.w = p0 + 3 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 3, x0 + c) : 0.f;
       *reinterpret_cast<float4*>(row + p0) = v;
     }
   }
@@ -274,7 +289,7 @@ struct OwnShared {
 template <bool kBig, int PH, int PW>
 __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float* __restrict__ grad, const float* __restrict__ rois,
                                            const OwnLevels& lv, int C, int K, int nchunks, int sr, int aligned, int64_t ns,
-                                           int64_t cs, const OwnWorkspace& ws) {
+                                           int64_t cs, const OwnWorkspace& ws, const int* klist = nullptr, int nlist = 0) {
   constexpr int PWP = pad4(PW);
   constexpr int RB = PH <= 7 ? 4 : 2;  // tile rows per scalar-load batch (RB * PH coefficient SGPRs, two batches in flight)
   const int tid = threadIdx.x;
@@ -315,6 +330,10 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
     rs = 0;
     re = 0;
   }
+  if (klist) {  // scan domain = positions of a sorted RoI index list instead of the image's index range
+    rs = 0;
+    re = nlist;
+  }
   rs = TVMI_UNIFORM(rs);
   re = TVMI_UNIFORM(re);
 
@@ -324,9 +343,10 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < kScanChunk / 256; ++j) {
-      const int k = base + wave * (kScanChunk / 4) + j * 64 + lane;
+      const int pos = base + wave * (kScanChunk / 4) + j * 64 + lane;
+      const int k = (klist && pos < re) ? klist[pos] : pos;
       bool hit = false;
-      if (k < re) {
+      if (pos < re) {
         const int2 d = ws.scan[k];
         const int r = d.y;
         hit = d.x == key && ty >= (r & 255) && ty <= ((r >> 8) & 255) && tx >= ((r >> 16) & 255) && tx <= ((r >> 24) & 255);
@@ -450,9 +470,23 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_owner_big(const float*
                                                                     OwnLevels lv, int C, int K, int nchunks, int nitems, int sr,
                                                                     int aligned, int64_t ns, int64_t cs, OwnWorkspace ws) {
   __shared__ OwnShared sh;
-  if (ws.imgrange[2 * lv.N] == kUnset) return;  // no oversized window anywhere
+  __shared__ int s_raw[kBigCap], s_sorted[kBigCap];
+  const int nbig = ws.imgrange[2 * lv.N] - kUnset;
+  if (nbig <= 0) return;  // no oversized window anywhere
+  const bool listed = nbig <= kBigCap;
+  if (listed) {  // ascending RoI index = the fixed summation order: rank sort of the (short) list
+    for (int i = threadIdx.x; i < nbig; i += kThreads) s_raw[i] = ws.biglist[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbig; i += kThreads) {
+      const int v = s_raw[i];
+      int rank = 0;
+      for (int j = 0; j < nbig; ++j) rank += s_raw[j] < v ? 1 : 0;
+      s_sorted[rank] = v;
+    }
+    __syncthreads();
+  }
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    owner_item<true, PH, PW>(sh, item, grad, rois, lv, C, K, nchunks, sr, aligned, ns, cs, ws);
+    owner_item<true, PH, PW>(sh, item, grad, rois, lv, C, K, nchunks, sr, aligned, ns, cs, ws, listed ? s_sorted : nullptr, nbig);
     __syncthreads();
   }
 }
