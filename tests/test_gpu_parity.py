@@ -179,6 +179,29 @@ def test_batched_nms_single_launch_small_path():
     assert int(num) == -1                                                                           # sync-free form reports it
 
 
+def test_nms_large_path_dependency_chains(tv):
+    """n > 4096 (chunked mask kernels, sweep on a second stream, parallel fixed-point rounds per 1024-box group): a
+    chain of boxes in which every box is suppressed only by its predecessor (keep, drop, keep, drop, ...) is as deep as
+    a dependency gets — far beyond the fixed-point round budget, so the serial walk has to take over — mixed with
+    ordinary random boxes; index lists must equal the oracle's."""
+    g = gen(97)
+    n_chain, n_rand = 5000, 3000
+    x = torch.arange(n_chain, dtype=torch.float32) * 4.0                    # 10-wide boxes every 4 px: IoU(i, i+1) = 6/14
+    chain = torch.stack([x, torch.zeros(n_chain), x + 10.0, torch.full((n_chain,), 10.0)], 1)
+    rand = random_boxes(n_rand, 20000, 400, 5, 60, g)
+    rand[:, 1] += 50.0                                                      # keep them off the chain's row
+    rand[:, 3] += 50.0
+    boxes = torch.cat([chain, rand])
+    scores = torch.cat([torch.linspace(1.0, 0.5, n_chain), torch.rand(n_rand, generator=g) * 0.4])
+    perm = torch.randperm(n_chain + n_rand, generator=g)
+    boxes, scores = boxes[perm], scores[perm]
+    for thr in (0.4, 0.45):
+        keep = tv.nms(boxes.to(DEV), scores.to(DEV), thr).cpu().numpy()
+        want = O.nms(boxes.numpy(), scores.numpy(), thr)
+        assert np.array_equal(keep, want), thr
+    assert len(want) > n_chain // 2
+
+
 def test_nms_100k_properties(tv):
     # BASELINE config 3 size; oracle too slow here -> size-independent properties
     g = gen(7)

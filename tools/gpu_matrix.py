@@ -1,7 +1,7 @@
 """Measured config matrix (run on the GPU box): every timing quoted in DESIGN.md §6 comes from the JSON this writes
 (gpurun_out/<tag>/matrix.json, copied to profiles/).  Events on the current stream, inputs resident in HBM.
 
-    python tools/gpu_matrix.py [out.json] [section ...]      sections: c2 c1 c3 c4 resize post (default: all)
+    python tools/gpu_matrix.py [out.json] [section ...]      sections: c2 c1 c3 c4 resize post roipool (default: all)
 """
 import json
 import os
@@ -19,7 +19,7 @@ from vision_amd.poolers import LevelMapper, _convert_to_roi_format
 dev = torch.device("cuda:0")
 tv = torch.ops.torchvision
 out_path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else None
-sections = [a for a in sys.argv[1:] if not a.endswith(".json")] or ["c2", "c1", "c3", "c4", "resize", "post"]
+sections = [a for a in sys.argv[1:] if not a.endswith(".json")] or ["c2", "c1", "c3", "c4", "resize", "post", "roipool"]
 res = {"device": torch.cuda.get_device_name(0), "torch": torch.__version__}
 
 
@@ -163,6 +163,29 @@ if "post" in sections:
     logits = (torch.randn(4000, 91, generator=g) * 3).to(dev)
     reg = (torch.randn(4000, 364, generator=g) * 0.5).to(dev)
     put("postprocess_detections_4x1000x91", tm(lambda: vision_amd.postprocess_detections(logits, reg, props, shapes, padded=True), n=10))
+
+if "roipool" in sections:
+    # RoIPool family on a config-2-shaped single-level workload: 4 x 256 x 100 x 168 map (stride 8), 4000 RoIs, 7x7
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import rois_for
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 256, 100, 168, generator=g).to(dev)
+    rois = rois_for(4, 4000, 1344, 800, 32, 400, g).to(dev)
+    in_b, out_b = x.numel() * 4, 4000 * 256 * 49 * 4
+    y, am = tv.roi_pool(x, rois, 0.125, 7, 7)
+    t = tm(lambda: tv.roi_pool(x, rois, 0.125, 7, 7))
+    put("roi_pool_fwd_4x256x100x168_4000rois_7x7", t, alg_GBs=round((in_b + out_b * 2) / 1e6 / t))
+    gr = torch.randn_like(y)
+    put("roi_pool_bwd", tm(lambda: tv._roi_pool_backward(gr, rois, am, 0.125, 7, 7, 4, 256, 100, 168), n=10))
+    xp = torch.randn(4, 245, 100, 168, generator=g).to(dev)   # 5 output channels x 49 position-sensitive planes
+    yp, mp = tv.ps_roi_align(xp, rois, 0.125, 7, 7, 2)
+    put("ps_roi_align_fwd_4x245x100x168_4000rois_7x7", tm(lambda: tv.ps_roi_align(xp, rois, 0.125, 7, 7, 2)))
+    gp = torch.randn_like(yp)
+    put("ps_roi_align_bwd", tm(lambda: tv._ps_roi_align_backward(gp, rois, mp, 0.125, 7, 7, 2, 4, 245, 100, 168), n=10))
+    yq, mq = tv.ps_roi_pool(xp, rois, 0.125, 7, 7)
+    put("ps_roi_pool_fwd", tm(lambda: tv.ps_roi_pool(xp, rois, 0.125, 7, 7)))
+    put("ps_roi_pool_bwd", tm(lambda: tv._ps_roi_pool_backward(gp, rois, mq, 0.125, 7, 7, 4, 245, 100, 168), n=10))
+    put("roi_align_fwd_same_workload_for_scale", tm(lambda: tv.roi_align(x, rois, 0.125, 7, 7, 2, False)))
 
 if out_path:
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)

@@ -33,6 +33,8 @@
 #include <type_traits>
 #include <utility>
 
+#include <vector>
+
 #include "tvmi_common.h"
 
 namespace tvmi {
@@ -231,12 +233,12 @@ __device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, cons
 template <typename T>
 __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     const T* __restrict__ dets, const int64_t* __restrict__ order, const int64_t* __restrict__ seg, int n, int CB,
-    double thr, ThrBand band, u64* __restrict__ mask) {
+    double thr, ThrBand band, u64* __restrict__ mask, int rb0) {
   __shared__ T s_row[64][5];  // x1,y1,x2,y2,area of the row block
   __shared__ long long s_seg[64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int rb = blockIdx.y;
+  const int rb = rb0 + blockIdx.y;  // large problems are launched in chunks of row blocks (see launch())
   const int cb = blockIdx.x * kMaskWaves + wave;
   if ((int)(blockIdx.x * kMaskWaves + kMaskWaves - 1) < rb) return;  // whole workgroup left of the diagonal
   const int row0 = rb * 64;
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
 // K2: fold the rows kept in super-blocks before `b0` into removed[cb] for cb in [b0, b1).
 __global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mask, const u64* __restrict__ keepbits,
                                                      u64* __restrict__ removed, int CB, int b0, int b1) {
+  __builtin_amdgcn_s_setprio(2);  // on the sweep's critical path, under the mask kernels of later chunks
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int cb = b0 + blockIdx.x;
@@ -303,79 +306,142 @@ __global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mas
   if (lane == 0 && red) atomicOr(&removed[cb], red);
 }
 
-// K3: resolve the (up to) kSuper blocks [b0, b1) of one super-block.
-__global__ __launch_bounds__(kSuper * kWave) void nms_resolve(const u64* __restrict__ mask,
-                                                              const int64_t* __restrict__ order,
-                                                              const u64* __restrict__ removed,
-                                                              u64* __restrict__ keepbits, int n, int CB, int b0, int b1,
-                                                              int64_t* __restrict__ keep_out,
-                                                              int64_t* __restrict__ num_keep) {
-  __shared__ u64 s_keep[kSuper];
+// K3 for large problems: ONE workgroup resolves a WIDE super-block of up to kWide 64-box blocks [b0, b1): it walks it
+// in mini super-blocks of kSuper blocks; removed[] (filled by nms_colreduce) carries what every earlier wide super-block
+// suppresses, the rows of earlier mini super-blocks of THIS wide block are pulled here by the wave that owns the
+// column (keep bits in LDS), then the same register-resident resolve chain as nms_resolve.  4x fewer launch pairs on the
+// serial chain than with 16-block super-blocks.
+constexpr int kWide = 64;
+constexpr int kJacobiRounds = 24;  // parallel fixed-point rounds tried per mini super-block before the serial walk
+__global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __restrict__ mask,
+                                                                   const int64_t* __restrict__ order,
+                                                                   const u64* __restrict__ removed,
+                                                                   u64* __restrict__ keepbits, int n, int CB, int b0, int b1,
+                                                                   int64_t* __restrict__ keep_out,
+                                                                   int64_t* __restrict__ num_keep) {
+  __shared__ u64 s_keep[kWide];
+  __shared__ u64 s_jac[2][kSuper];
+  __shared__ int s_changed[3];
+  __shared__ int s_base[kWide + 1];
+  // this workgroup is the serial link of the sweep and shares the chip with the mask kernels of later chunks:
+  // its waves take issue priority over whatever else is resident on the CU
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
-  // wave-uniform by construction; readfirstlane tells the compiler, so the whole resolve chain
-  // (candidate word, ctz, readlane index) is scalar code instead of an exec-masked VALU loop
-  const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's block in the super-block
-  const int cb = b0 + c_loc;
-  const bool have = cb < b1;
-  // prefetch: diagonal tile word of this lane's row + the tiles above it inside the super-block
-  u64 diag = 0ull, above[kSuper - 1];
-  u64 rem = 0ull;
-  if (have) {
-    diag = mask[((size_t)cb * CB + cb) * 64 + lane];
-    rem = removed[cb];
-  }
+  const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nb = b1 - b0;
+  for (int m0 = 0; m0 < nb; m0 += kSuper) {
+    const int lb = m0 + c_loc;  // local block of this wave in the wide super-block
+    const int cb = b0 + lb;
+    const bool have = lb < nb;
+    u64 diag = 0ull, above[kSuper - 1];
+    u64 rem = 0ull;
+    if (have) {
+      diag = mask[((size_t)cb * CB + cb) * 64 + lane];
+      rem = removed[cb];
+    }
 #pragma unroll
-  for (int q = 0; q < kSuper - 1; ++q) {
-    above[q] = 0ull;
-    if (have && q < c_loc) above[q] = mask[((size_t)(b0 + q) * CB + cb) * 64 + lane];
-  }
-  rem = uniform64(rem);
-  const int rows_here = have ? min(64, n - cb * 64) : 0;
-  const u64 valid = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
-  u64 my_keep = 0ull;
+    for (int q = 0; q < kSuper - 1; ++q) {
+      above[q] = 0ull;
+      if (have && q < c_loc) above[q] = mask[((size_t)(b0 + m0 + q) * CB + cb) * 64 + lane];
+    }
+    u64 acc = 0ull;
+    if (have) {
+      // earlier mini super-blocks of this wide block: keep bits are final, in LDS.  16 independent tile loads per
+      // round (one coalesced 512-byte access each) so that the memory latency is paid once per round, not per tile.
+      // (Requesting all of them up front was measured: 128 VGPRs + spills at 1024 threads, slower.)
+      for (int r0 = 0; r0 < m0; r0 += kSuper) {
+        u64 w[kSuper];
 #pragma unroll
-  for (int step = 0; step < kSuper; ++step) {
-    if (step == c_loc && have) {
-      // every earlier block of the super-block is folded in: resolve my 64 boxes
-      // Only boxes whose diagonal row is non-empty can change the outcome, and a box's removed
-      // bit is final once every lower-indexed non-empty row has been handled — so the serial
-      // (wave-uniform, scalar) loop visits just the surviving non-empty rows, in order.
-      u64 r = uniform64(rem);
-      u64 active = uniform64(__ballot(diag != 0ull)) & ~r & valid;
-      while (active) {
-        const int k = __builtin_ctzll(active);
-        r |= readlane64(diag, k);          // box k is kept: apply its row
-        active &= ~(r | (1ull << k));      // drop k and everything it (or earlier rows) removed
-      }
-      const u64 keep = ~r & valid;
-      my_keep = keep;
-      if (lane == 0) {
-        s_keep[c_loc] = keep;
-        keepbits[cb] = keep;
+        for (int q = 0; q < kSuper; ++q) w[q] = mask[((size_t)(b0 + r0 + q) * CB + cb) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < kSuper; ++q) acc |= ((s_keep[r0 + q] >> lane) & 1ull) ? w[q] : 0ull;
       }
     }
-    __syncthreads();
-    if (step < kSuper - 1 && have && step < c_loc) {
-      const u64 kb = s_keep[step];
-      const u64 contrib = ((kb >> lane) & 1ull) ? above[step] : 0ull;
-      rem |= wave_or64(contrib);
+    rem = uniform64(rem) | (m0 > 0 ? wave_or64(acc) : 0ull);
+    const int rows_here = have ? min(64, n - cb * 64) : 0;
+    const u64 valid = rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+    // ---- the kSuper x kSuper tiles of this mini super-block form a strictly upper-triangular system
+    //          keep_c = ~(rem_c | OR over kept rows r of blocks q <= c of tile(q, c)[r]) & valid,
+    // whose unique solution is the greedy sweep's answer.  Instead of walking its 16 blocks one barrier-separated step
+    // at a time, iterate it in parallel (all 16 waves at once, Jacobi): after t rounds every box whose chain of
+    // "suppressed by a box that is itself suppressed by ..." is at most t long is final, and a round without change
+    // is the fixed point.  Real detections need a handful of rounds; a chain longer than kJacobiRounds falls back to
+    // the serial walk below (same answer, old speed).
+    u64 my_keep = ~rem & valid;
+    bool converged = false;
+    if (lane == 0) s_jac[0][c_loc] = have ? my_keep : 0ull;
+    if (threadIdx.x == 0) s_changed[0] = 0;
+    for (int it = 0; it < kJacobiRounds; ++it) {
+      if (threadIdx.x == 0) s_changed[(it + 1) % 3] = 0;
+      __syncthreads();
+      const u64* cur = s_jac[it & 1];
+      u64 contrib = 0ull;
+#pragma unroll
+      for (int q = 0; q < kSuper - 1; ++q) contrib |= ((cur[q] >> lane) & 1ull) ? above[q] : 0ull;  // above[q] = 0 for q >= c_loc
+      contrib |= ((cur[c_loc] >> lane) & 1ull) ? diag : 0ull;
+      const u64 nk = have ? (~(rem | wave_or64(contrib)) & valid) : 0ull;
+      if (lane == 0) {
+        s_jac[(it + 1) & 1][c_loc] = nk;
+        if (nk != my_keep) s_changed[it % 3] = 1;
+      }
+      my_keep = nk;
+      __syncthreads();
+      if (s_changed[it % 3] == 0) {
+        converged = true;
+        break;
+      }
+    }
+    if (converged) {
+      if (lane == 0 && have) {
+        s_keep[lb] = my_keep;
+        keepbits[cb] = my_keep;
+      }
+      __syncthreads();
+      continue;
+    }
+#pragma unroll
+    for (int step = 0; step < kSuper; ++step) {
+      if (step == c_loc && have) {
+        u64 r = uniform64(rem);
+        u64 active = uniform64(__ballot(diag != 0ull)) & ~r & valid;
+        while (active) {
+          const int k = __builtin_ctzll(active);
+          r |= readlane64(diag, k);
+          active &= ~(r | (1ull << k));
+        }
+        if (lane == 0) {
+          s_keep[lb] = ~r & valid;
+          keepbits[cb] = ~r & valid;
+        }
+      }
+      __syncthreads();
+      if (step < kSuper - 1 && have && step < c_loc) {
+        const u64 kb = s_keep[m0 + step];
+        const u64 contrib = ((kb >> lane) & 1ull) ? above[step] : 0ull;
+        rem |= wave_or64(contrib);
+      }
     }
   }
   // append the kept original indices in score order
-  if (have) {
-    int64_t base = *num_keep;
-    for (int q = 0; q < c_loc; ++q) base += __popcll(s_keep[q]);
-    if ((my_keep >> lane) & 1ull) {
-      const u64 below = my_keep & ((1ull << lane) - 1ull);
-      keep_out[base + __popcll(below)] = order[(int64_t)cb * 64 + lane];
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int b = 0; b < nb; ++b) {
+      s_base[b] = run;
+      run += __popcll(s_keep[b]);
+    }
+    s_base[nb] = run;
+  }
+  __syncthreads();
+  const int64_t base = *num_keep;
+  for (int b = c_loc; b < nb; b += kSuper) {
+    const u64 kb = s_keep[b];
+    if ((kb >> lane) & 1ull) {
+      const u64 below = kb & ((1ull << lane) - 1ull);
+      keep_out[base + s_base[b] + __popcll(below)] = order[(int64_t)(b0 + b) * 64 + lane];
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int64_t total = *num_keep;
-    for (int q = 0; q < b1 - b0; ++q) total += __popcll(s_keep[q]);
-    *num_keep = total;
-  }
+  if (threadIdx.x == 0) *num_keep = base + s_base[nb];
 }
 
 // K3': the whole sweep of a small problem (CB <= kSmallCB column blocks, i.e. N <= 4096) in ONE
@@ -455,6 +521,40 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __r
   }
 }
 
+// Fork / join helpers of the large-problem path.  The mask kernel (throughput-bound, fills the chip) is launched in
+// chunks of kWide row blocks on one internal stream; the sweep of chunk c (latency-bound: one resolve workgroup plus
+// a modest column reduction) runs on a second, higher-priority stream as soon as chunk c of the mask is complete —
+// i.e. UNDER the mask kernels of the later chunks instead of after them.  Both streams are forked from and joined back
+// into the caller's stream with events, so the caller sees ordinary stream-ordered behaviour (and the pattern is
+// capturable).  Streams / events are cached per host thread and device.
+struct SweepStreams {
+  int device = -1;
+  hipStream_t mask_stream = nullptr, sweep_stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::vector<hipEvent_t> chunk_done;
+  bool ensure(int nchunks) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev != device) {  // first use on this thread / device (handles of another device are simply abandoned)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&mask_stream, hipStreamNonBlocking, lo) != hipSuccess) return false;
+      if (hipStreamCreateWithPriority(&sweep_stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+      chunk_done.clear();
+      device = dev;
+    }
+    while ((int)chunk_done.size() < nchunks) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+      chunk_done.push_back(e);
+    }
+    return true;
+  }
+};
+thread_local SweepStreams g_sweep_streams;
+
 template <typename T>
 int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr, void* workspace,
            int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
@@ -462,25 +562,52 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   u64* mask = static_cast<u64*>(workspace);
   u64* removed = mask + (size_t)CB * CB * 64;
   u64* keepbits = removed + CB;
-  const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
-  nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), order, seg, (int)n, CB,
-                                                                   thr, thr_band(thr), mask);
-  if (CB <= kSmallCB) {  // latency-bound sizes: the whole sweep is one launch
+  const T* d = static_cast<const T*>(dets);
+  const ThrBand band = thr_band(thr);
+  if (CB <= kSmallCB) {  // latency-bound sizes: one mask launch, the whole sweep is one more
+    const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
+    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(d, order, seg, (int)n, CB, thr, band, mask, 0);
     nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, (int)n, CB, keep_out, num_keep);
     TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
   }
   hipError_t e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
   if (e == hipSuccess) e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
-  for (int b0 = 0; b0 < CB; b0 += kSuper) {
-    const int b1 = std::min(CB, b0 + kSuper);
+  const int nchunks = (int)ceil_div(CB, kWide);
+  SweepStreams& ss = g_sweep_streams;
+  const bool forked = ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
+                      hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
+                      hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess;
+  hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream;
+  auto mask_chunk = [&](int c) {
+    const int r0 = c * kWide, r1 = std::min(CB, r0 + kWide);
+    // row block r only has tiles for column blocks >= r: workgroups left of the chunk's first row block exit at once
+    const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)(r1 - r0));
+    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, ms>>>(d, order, seg, (int)n, CB, thr, band, mask, r0);
+  };
+  auto sweep_chunk = [&](int c) {
+    const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
     if (b0 > 0) {
       const dim3 rgrid((unsigned)(b1 - b0), (unsigned)ceil_div(b0, 4 * kReduceRows));
-      nms_colreduce<<<rgrid, dim3(256), 0, stream>>>(mask, keepbits, removed, CB, b0, b1);
+      nms_colreduce<<<rgrid, dim3(256), 0, sw>>>(mask, keepbits, removed, CB, b0, b1);
     }
-    nms_resolve<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, removed, keepbits, (int)n, CB, b0, b1, keep_out,
-                                                              num_keep);
+    nms_resolve_wide<<<dim3(1), dim3(kSuper * kWave), 0, sw>>>(mask, order, removed, keepbits, (int)n, CB, b0, b1, keep_out,
+                                                               num_keep);
+  };
+  bool ok = true;
+  if (forked) {
+    for (int c = 0; c < nchunks; ++c) {
+      mask_chunk(c);
+      ok = ok && hipEventRecord(ss.chunk_done[c], ms) == hipSuccess && hipStreamWaitEvent(sw, ss.chunk_done[c], 0) == hipSuccess;
+      sweep_chunk(c);
+    }
+    // the sweep stream has waited for every mask chunk: joining it joins both
+    ok = ok && hipEventRecord(ss.join, sw) == hipSuccess && hipStreamWaitEvent(stream, ss.join, 0) == hipSuccess;
+  } else {  // no side streams (creation failed): same kernels, serially on the caller's stream
+    for (int c = 0; c < nchunks; ++c) mask_chunk(c);
+    for (int c = 0; c < nchunks; ++c) sweep_chunk(c);
   }
+  if (!ok) return set_error((int)hipErrorUnknown, "tvmi_nms: stream fork / join failed");
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
 }
 

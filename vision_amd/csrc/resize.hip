@@ -191,11 +191,52 @@ __global__ void aa_table_kernel(float* __restrict__ table, int out_size, int in_
   row[1] = __int_as_float(min(xsize, taps));
 }
 
-template <typename T>
+// Output-stationary, one lane per output column.  The x weights of the lane's column live in registers for the
+// whole block (MAXT compile-time taps, zero beyond xsize — the table rows are zero padded), the y weights of the
+// block's output row are wave-uniform (scalar loads), and the tap loop is fully unrolled: ysize x MAXT independent
+// loads + FMAs per output and plane, no table traffic inside the loops.  Indices past the row end are clamped (their
+// weight is zero).  Neighbouring lanes' windows overlap by (1 - 1/scale), so the taps are L1 hits.
+template <typename T, int MAXT>
 __global__ __launch_bounds__(kThreads) void aa2d_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                         const float* __restrict__ ytab, const float* __restrict__ xtab,
                                                         int NC, int IH, int IW, int OH, int OW, int ytaps, int xtaps,
                                                         int nc_per_block) {
+  const int ox = blockIdx.x * kThreads + threadIdx.x;
+  const int oy = blockIdx.y;
+  if (ox >= OW) return;
+  const float* yr = ytab + (int64_t)oy * (ytaps + 2);
+  const float* xr = xtab + (int64_t)ox * (xtaps + 2);
+  const int ymin = __float_as_int(yr[0]), ysize = __float_as_int(yr[1]);
+  const int xmin = __float_as_int(xr[0]);
+  float wx[MAXT];
+  int xo[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    wx[i] = i < xtaps ? xr[2 + i] : 0.f;
+    xo[i] = min(xmin + i, IW - 1);
+  }
+  const int nc0 = blockIdx.z * nc_per_block, nc1 = min(NC, nc0 + nc_per_block);
+  const int64_t iplane = (int64_t)IH * IW, oplane = (int64_t)OH * OW;
+  for (int nc = nc0; nc < nc1; ++nc) {
+    const T* p = in + nc * iplane + (int64_t)ymin * IW;
+    float acc = 0.f;
+    for (int j = 0; j < ysize; ++j) {
+      const T* row = p + (int64_t)j * IW;
+      float r = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) r += ld(row + xo[i]) * wx[i];
+      acc += r * yr[2 + j];
+    }
+    st(out + nc * oplane + (int64_t)oy * OW + ox, acc);
+  }
+}
+
+// arbitrary tap counts (downscale factors above ~7.5x bicubic / 15x bilinear): same loops with run-time bounds
+template <typename T>
+__global__ __launch_bounds__(kThreads) void aa2d_kernel_any(const T* __restrict__ in, T* __restrict__ out,
+                                                            const float* __restrict__ ytab, const float* __restrict__ xtab,
+                                                            int NC, int IH, int IW, int OH, int OW, int ytaps, int xtaps,
+                                                            int nc_per_block) {
   const int ox = blockIdx.x * kThreads + threadIdx.x;
   const int oy = blockIdx.y;
   if (ox >= OW) return;
@@ -426,10 +467,20 @@ extern "C" int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt
                                                                          align_corners);
   aa_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, sw, mode, xt,
                                                                          align_corners);
-  TVMI_DISPATCH_FLOAT(dt, "upsample_aa2d",
-                      aa2d_kernel<scalar_t><<<L.grid, dim3(kThreads), 0, s>>>(
-                          (const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)NC, (int)IH, (int)IW, (int)OH,
-                          (int)OW, yt, xt, L.nc_per_block));
+#define TVMI_AA(KERNEL)                                                                                       \
+  KERNEL<<<L.grid, dim3(kThreads), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)NC, (int)IH, \
+                                           (int)IW, (int)OH, (int)OW, yt, xt, L.nc_per_block)
+  TVMI_DISPATCH_FLOAT(dt, "upsample_aa2d", {
+    if (xt <= 4)
+      TVMI_AA((aa2d_kernel<scalar_t, 4>));
+    else if (xt <= 8)
+      TVMI_AA((aa2d_kernel<scalar_t, 8>));
+    else if (xt <= 16)
+      TVMI_AA((aa2d_kernel<scalar_t, 16>));
+    else
+      TVMI_AA(aa2d_kernel_any<scalar_t>);
+  });
+#undef TVMI_AA
   TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_aa2d");
 }
 
