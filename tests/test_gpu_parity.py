@@ -351,6 +351,27 @@ def test_roi_pool_and_ps_ops_vs_oracle(tv):
         tv.ps_roi_align(torch.rand(1, 10, 8, 8, device=DEV), torch.rand(2, 5, device=DEV), 1.0, 3, 3, 2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_roi_pool_wave_kernel_windows_and_bin_counts(tv, dtype):
+    """LDS-staged RoIPool: more than 64 bins (9x9), windows that do not fit the wave's LDS region (scanned from global
+    memory), RoIs sticking out of the map, empty bins, equal maxima (first one wins: argmax must match) — value and
+    argmax identical to the reference arithmetic (16-bit inputs: on the rounded values)."""
+    g = gen(51)
+    N, C, H, W = 2, 45, 60, 90
+    x = (torch.randn(N, C, H, W, generator=g) * 4).round().to(dtype)        # many exact ties
+    rois = rois_for(N, 200, W * 8, H * 8, 4, 300, g)
+    rois[0, 1:] = torch.tensor([0.0, 0.0, W * 8.0, H * 8.0])                # whole map: 5400-pixel window
+    rois[1, 1:] = torch.tensor([-100.0, -80.0, 900.0, 600.0])
+    rois[2, 1:] = torch.tensor([300.0, 200.0, 300.0, 200.0])                # one pixel
+    rois[3, 1:] = torch.tensor([5000.0, 5000.0, 6000.0, 6000.0])            # outside: empty bins
+    rois[4, 1:] = torch.tensor([400.0, 300.0, 100.0, 50.0])                 # malformed
+    for P in (7, 9, 2):
+        y, a = tv.roi_pool(x.to(DEV), rois.to(dtype).to(DEV), 0.125, P, P)
+        ry, ra = O.roi_pool(x.float().numpy(), rois.to(dtype).float().numpy(), 0.125, P, P)
+        assert y.dtype == dtype
+        assert np.array_equal(y.float().cpu().numpy(), ry) and np.array_equal(a.cpu().numpy(), ra), P
+
+
 def test_roi_ops_autograd_on_gpu(tv):
     g = gen(12)
     x = torch.rand(1, 8, 9, 9, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)

@@ -27,6 +27,14 @@ with torch.no_grad():
         for _ in range(reps):
             torch.ops.tvmi.multiscale_roi_align_backward(gall, rois, [f.shape[2] for f in fl], [f.shape[3] for f in fl],
                                                          [1 / s for s in bench.STRIDES], 4, P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6)
+    elif which == "roipool":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import rois_for
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 256, 100, 168, generator=g).to(dev)
+        rois = rois_for(4, 4000, 1344, 800, 32, 400, g).to(dev)
+        for _ in range(reps):
+            torch.ops.torchvision.roi_pool(x, rois, 0.125, 7, 7)
     elif which == "nms100k":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import random_boxes
