@@ -294,14 +294,18 @@ int tvmi_rpn_candidates(const float* objectness, const float* boxes_in, const fl
                         float bbox_xform_clip, float score_thresh, float min_size, float* out_boxes, float* out_scores,
                         int64_t* out_levels, uint8_t* out_valid, void* stream);
 
-/* Pairwise axis-aligned IoU (generalized = 0; torchvision/ops/boxes.py:314-391) or generalized
- * IoU (generalized = 1; :409-436) of xyxy boxes: boxes1 [N,4], boxes2 [M,4] -> out [N,M], dt F32
- * or F64.  16-bit boxes are upcast by the caller like ops/_utils.py:72-84; source_16bit = 1 (float16)
- * / 2 (bfloat16) / 0 then makes the kernel round rb - lt to that type first, as the reference's
- * `_upcast(rb - lt)` does.  One launch instead of ~10 broadcast tensor ops; same operations, same order.
+/* Pairwise axis-aligned IoU of xyxy boxes: boxes1 [N,4], boxes2 [M,4] -> out [N,M], dt F32 or F64.
+ *   mode 0  box_iou               torchvision/ops/boxes.py:314-391
+ *   mode 1  generalized_box_iou   :409-436
+ *   mode 2  distance_box_iou      :469-515 (`eps` added to the squared enclosing diagonal)
+ *   mode 3  complete_box_iou      :439-466 (alpha = v / (1 - iou + v + eps))
+ * 16-bit boxes are upcast by the caller like ops/_utils.py:72-84; for modes 0 / 1 source_16bit = 1 (float16) / 2
+ * (bfloat16) makes the kernel round rb - lt to that type first, as the reference's `_upcast(rb - lt)` does (modes
+ * 2 / 3 upcast the boxes before any arithmetic: pass 0).  One launch instead of ~10-25 broadcast tensor ops; same
+ * operations, same order.
  */
 int tvmi_box_iou_pairwise(const void* boxes1, const void* boxes2, void* out, tvmi_dtype dt, int64_t N, int64_t M,
-                          int generalized, int source_16bit, void* stream);
+                          int mode, int source_16bit, double eps, void* stream);
 
 /* ---------------------------------------------------------- box_iou_rotated ------------
  * Replaces: cuda/box_iou_rotated_kernel.cu:41-188; semantics of box_iou_rotated_utils.h:67-383

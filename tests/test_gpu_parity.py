@@ -828,6 +828,27 @@ def test_box_iou_pairwise_bit_identical_to_reference_tensor_math():
     assert torch.allclose(vision_amd.box_iou(kat1.to(DEV), kat2.to(DEV)).cpu(), expected, atol=1e-4)
 
 
+def test_distance_and_complete_box_iou_fused_kernel():
+    """distance_box_iou / complete_box_iou (ops/boxes.py:439-515) in the fused pairwise kernel vs the same formulas in
+    torch CPU tensor math: DIoU is the same operations in the same order (1e-6 covers the device division), CIoU adds
+    atan (device libm vs the CPU's: 1e-5); plus the reference's known-answer matrix (test/test_ops.py:1781-1788)."""
+    g = gen(23)
+    b1 = random_boxes(41, 500, 400, 2, 200, g)
+    b2 = random_boxes(700, 500, 400, 2, 200, g)
+    b2[3] = b1[7]
+    for a, b in ((b1, b2), (b1.double(), b2.double()), (b1.half(), b2.half())):
+        for fn, tol in ((vision_amd.distance_box_iou, 1e-6), (vision_amd.complete_box_iou, 1e-5)):
+            want = fn(a, b)                                 # CPU tensors: the tensor-math form
+            got = fn(a.to(DEV), b.to(DEV)).cpu()
+            assert got.dtype == want.dtype and got.shape == (41, 700)
+            torch.testing.assert_close(got, want, rtol=0, atol=tol)
+    f = torch.tensor([[285.3538, 185.5758, 1193.5110, 851.4551], [285.1472, 188.7374, 1192.4984, 851.0669],
+                      [279.2440, 197.9812, 1189.4746, 849.2019]])
+    expected = torch.tensor([[1.0, 0.9933, 0.9673], [0.9933, 1.0, 0.9737], [0.9673, 0.9737, 1.0]])
+    assert torch.allclose(vision_amd.distance_box_iou(f.to(DEV), f.to(DEV)).cpu(), expected, atol=1e-3)
+    assert torch.allclose(vision_amd.complete_box_iou(f.to(DEV), f.to(DEV)).cpu(), expected, atol=1e-3)
+
+
 def test_transform_images_one_launch_golden():
     """Fused normalize + resize + batching vs the reference GeneralizedRCNNTransform's own output (eval mode): same
     image_sizes and padded shape, values within 2e-5 (fp32 bilinear on normalised taps), padding exactly zero."""

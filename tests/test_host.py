@@ -247,3 +247,17 @@ def test_nms_band_test_never_contradicts_the_exact_predicate():
         assert not np.any(exact[sure_f]), thr
         # and the band is narrow: almost everything is decided without the division
         assert (sure_t | sure_f).mean() > 0.45
+
+
+def test_distance_and_complete_box_iou_known_answers():
+    """Host mirrors of distance_box_iou / complete_box_iou reproduce the reference's known-answer matrices
+    (test/test_ops.py:1781-1788, 1811-1818), integer boxes included (tensor-math form on CPU)."""
+    import torch
+    import vision_amd
+
+    ints1 = torch.tensor([[0, 0, 100, 100], [0, 0, 50, 50], [200, 200, 300, 300], [0, 0, 25, 25]])
+    ints2 = torch.tensor([[0, 0, 100, 100], [0, 0, 50, 50], [200, 200, 300, 300]])
+    int_expected = torch.tensor([[1.0, 0.1875, -0.4444], [0.1875, 1.0, -0.5625], [-0.4444, -0.5625, 1.0], [-0.0781, 0.1875, -0.6267]])
+    for dt in (torch.int16, torch.int32, torch.int64):
+        assert torch.allclose(vision_amd.distance_box_iou(ints1.to(dt), ints2.to(dt)), int_expected, atol=1e-4)
+        assert torch.allclose(vision_amd.complete_box_iou(ints1.to(dt), ints2.to(dt)), int_expected, atol=1e-4)

@@ -45,6 +45,8 @@ from .boxes import (  # noqa: E402,F401
     box_area,
     box_iou,
     clip_boxes_to_image,
+    complete_box_iou,
+    distance_box_iou,
     generalized_box_iou,
     nms,
     remove_small_boxes,

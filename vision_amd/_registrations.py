@@ -176,7 +176,7 @@ def _fake_pack_devcount(boxes, scores, labels, image_idx, keep, num_keep, num_im
     return boxes.new_empty((num_images, max_dets, 6), dtype=torch.float32), boxes.new_empty((num_images,), dtype=torch.int32)
 
 
-def _fake_box_iou_pairwise(boxes1, boxes2, generalized):
+def _fake_box_iou_pairwise(boxes1, boxes2, mode, eps=1e-7):
     dt = torch.float64 if torch.float64 in (boxes1.dtype, boxes2.dtype) else torch.float32
     return boxes1.new_empty((boxes1.shape[0], boxes2.shape[0]), dtype=dt)
 

@@ -101,7 +101,7 @@ def box_iou(boxes1: Tensor, boxes2: Tensor, fmt: str = "xyxy") -> Tensor:
     if fmt != "xyxy":
         raise ValueError(f"Unsupported box format {fmt!r}; convert to xyxy or cxcywhr first")
     if _native_pairwise(boxes1, boxes2):
-        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, False)
+        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, 0)
     inter, union = _box_inter_union(boxes1, boxes2)
     return inter / union
 
@@ -115,7 +115,7 @@ def _native_pairwise(boxes1: Tensor, boxes2: Tensor) -> bool:
 def generalized_box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
     """Pairwise generalized IoU [N, M] of xyxy boxes (ops/boxes.py:409-436)."""
     if _native_pairwise(boxes1, boxes2):
-        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, True)
+        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, 1)
     inter, union = _box_inter_union(boxes1, boxes2)
     iou = inter / union
     lti = torch.min(boxes1[..., :, None, :2], boxes2[..., None, :, :2])
@@ -123,6 +123,43 @@ def generalized_box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
     whi = _upcast(rbi - lti).clamp(min=0)
     areai = whi[..., 0] * whi[..., 1]
     return iou - (areai - union) / areai
+
+
+def _box_diou_iou(boxes1: Tensor, boxes2: Tensor, eps: float = 1e-7) -> Tuple[Tensor, Tensor]:
+    # ops/boxes.py:494-515 (tensor-math form: CPU tensors and inputs that need grad)
+    inter, union = _box_inter_union(boxes1, boxes2)
+    iou = inter / union
+    lti = torch.min(boxes1[..., :, None, :2], boxes2[..., None, :, :2])
+    rbi = torch.max(boxes1[..., :, None, 2:], boxes2[..., None, :, 2:])
+    whi = _upcast(rbi - lti).clamp(min=0)
+    diagonal_distance_squared = (whi[..., 0] ** 2) + (whi[..., 1] ** 2) + eps
+    x_p, y_p = (boxes1[..., 0] + boxes1[..., 2]) / 2, (boxes1[..., 1] + boxes1[..., 3]) / 2
+    x_g, y_g = (boxes2[..., 0] + boxes2[..., 2]) / 2, (boxes2[..., 1] + boxes2[..., 3]) / 2
+    centers_distance_squared = (_upcast(x_p[..., :, None] - x_g[..., None, :]) ** 2) + (
+        _upcast(y_p[..., :, None] - y_g[..., None, :]) ** 2)
+    return iou - (centers_distance_squared / diagonal_distance_squared), iou
+
+
+def distance_box_iou(boxes1: Tensor, boxes2: Tensor, eps: float = 1e-7) -> Tensor:
+    """Pairwise distance IoU [N, M] of xyxy boxes (ops/boxes.py:469-491); one launch on device tensors."""
+    boxes1, boxes2 = _upcast(boxes1), _upcast(boxes2)
+    if _native_pairwise(boxes1, boxes2):
+        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, 2, float(eps))
+    return _box_diou_iou(boxes1, boxes2, eps)[0]
+
+
+def complete_box_iou(boxes1: Tensor, boxes2: Tensor, eps: float = 1e-7) -> Tensor:
+    """Pairwise complete IoU [N, M] of xyxy boxes (ops/boxes.py:439-466); one launch on device tensors."""
+    boxes1, boxes2 = _upcast(boxes1), _upcast(boxes2)
+    if _native_pairwise(boxes1, boxes2):
+        return torch.ops.tvmi.box_iou_pairwise(boxes1, boxes2, 3, float(eps))
+    diou, iou = _box_diou_iou(boxes1, boxes2, eps)
+    w_pred, h_pred = boxes1[..., :, None, 2] - boxes1[..., :, None, 0], boxes1[..., :, None, 3] - boxes1[..., :, None, 1]
+    w_gt, h_gt = boxes2[..., None, :, 2] - boxes2[..., None, :, 0], boxes2[..., None, :, 3] - boxes2[..., None, :, 1]
+    v = (4 / (torch.pi ** 2)) * torch.pow(torch.atan(w_pred / h_pred) - torch.atan(w_gt / h_gt), 2)
+    with torch.no_grad():
+        alpha = v / (1 - iou + v + eps)
+    return diou - alpha * v
 
 
 def clip_boxes_to_image(boxes: Tensor, size: Tuple[int, int]) -> Tensor:

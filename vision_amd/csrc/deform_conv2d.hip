@@ -565,14 +565,10 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
       <<<dim3((unsigned)ceil_div(npix, 32 * NI * WN), (unsigned)ceil_div(p.OCg, 32 * MI * WM), (unsigned)p.groups), \
          dim3(64 * WM * WN), 0, s>>>((const float*)input, wt, (const float*)offset, (const float*)mask,              \
                                      (const float*)bias, (float*)output, p, ICg_pad, OCg_pad)
-    // same workgroup tiles as before (256x64 / 128x128 / 64x256); when the tiles fill the chip less than ~3 times,
-    // 8 smaller waves per tile instead of 4 (TVMI_DCN_WAVES=4 / 8 forces either)
-    static const int force_waves = []() {
-      const char* e = getenv("TVMI_DCN_WAVES");
-      return e ? atoi(e) : 0;
-    }();
+    // 256x64 / 128x128 / 64x256 workgroup tiles; when the tiles fill the chip less than ~3 times, 8 smaller waves
+    // per tile instead of 4 (more waves per SIMD to hide the gather latency behind)
     const int64_t ntiles = ceil_div(npix, p.OCg > 128 ? 64 : (p.OCg > 64 ? 128 : 256)) * ceil_div(p.OCg, p.OCg > 128 ? 256 : (p.OCg > 64 ? 128 : 64)) * p.groups;
-    const bool eight = force_waves ? force_waves == 8 : ntiles < 3 * 768;
+    const bool eight = ntiles < 3 * 768;
     if (p.OCg > 128) {
       if (eight) TVMI_DCN(4, 2, 2, 1); else TVMI_DCN(4, 1, 2, 2);
     } else if (p.OCg > 64) {

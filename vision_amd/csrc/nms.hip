@@ -102,11 +102,7 @@ struct ThrBand {
 };
 inline ThrBand thr_band(double thr) {
   ThrBand b{-INFINITY, INFINITY};  // = "always take the exact path"
-  static const bool force_exact = []() {
-    const char* e = getenv("TVMI_NMS_EXACT");  // analysis knob: evaluate the division for every pair
-    return e && e[0] == '1';
-  }();
-  if (force_exact || !(thr > 1e-30 && thr < 1e30)) return b;
+  if (!(thr > 1e-30 && thr < 1e30)) return b;
   float d = (float)thr;
   if ((double)d > thr) d = nextafterf(d, -INFINITY);  // largest float <= thr
   const float u = nextafterf(d, INFINITY);            // smallest float > thr

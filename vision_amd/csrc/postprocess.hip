@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void boxes_to_rois_kernel(BoxLists bl, T* __re
   r[4] = b[3];
 }
 
-// Pairwise axis-aligned IoU / generalized IoU (ops/boxes.py:314-391, 409-436): the reference builds
+// Pairwise axis-aligned IoU / generalized / distance / complete IoU (ops/boxes.py:314-391, 409-436, 439-515): the reference builds
 // [N,M,2] temporaries with ~10 elementwise launches; here one thread per (i, j), j fastest, same
 // operations in the same order (this TU has no FP contraction), so values are bit-identical to the
 // reference's CPU tensor math.
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void boxes_to_rois_kernel(BoxLists bl, T* __re
 // BEFORE upcasting (`_upcast(rb - lt)`), so the difference is rounded to 16 bits here too.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void box_iou_pairwise_kernel(const T* __restrict__ b1, const T* __restrict__ b2,
-                                                               T* __restrict__ out, int N, int M, int src16) {
+                                                               T* __restrict__ out, int N, int M, int src16, T eps) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i = blockIdx.y;
   if (j >= M) return;
@@ -242,6 +242,25 @@ __global__ __launch_bounds__(256) void box_iou_pairwise_kernel(const T* __restri
     const T wi = clamp0(r16(tmax(ax2, bx2) - tmin(ax1, bx1))), hi = clamp0(r16(tmax(ay2, by2) - tmin(ay1, by1)));
     const T areai = wi * hi;
     r = r - (areai - uni) / areai;
+  }
+  if (MODE >= 2) {
+    // _box_diou_iou (ops/boxes.py:494-515), the boxes are already upcast there: no 16-bit rounding of differences.
+    // torch.min / max of the corner tensors: lti = min(lt1, lt2), rbi = max(rb1, rb2); whi = clamp(rbi - lti, 0)
+    const T wi = clamp0(tmax(ax2, bx2) - tmin(ax1, bx1)), hi = clamp0(tmax(ay2, by2) - tmin(ay1, by1));
+    const T diag2 = (wi * wi) + (hi * hi) + eps;
+    const T xp = (ax1 + ax2) / (T)2, yp = (ay1 + ay2) / (T)2, xg = (bx1 + bx2) / (T)2, yg = (by1 + by2) / (T)2;
+    const T dx = xp - xg, dy = yp - yg;
+    const T cdist2 = (dx * dx) + (dy * dy);
+    const T iou = r;
+    r = iou - (cdist2 / diag2);
+    if (MODE == 3) {
+      // complete_box_iou (:439-466): v = 4/pi^2 * (atan(w_p/h_p) - atan(w_g/h_g))^2, alpha = v / (1 - iou + v + eps)
+      const T wp = ax2 - ax1, hp = ay2 - ay1, wg = bx2 - bx1, hg = by2 - by1;
+      const T d = atan(wp / hp) - atan(wg / hg);
+      const T v = (T)(4.0 / (3.141592653589793 * 3.141592653589793)) * (d * d);
+      const T alpha = v / ((T)1 - iou + v + eps);
+      r = r - alpha * v;
+    }
   }
   out[(int64_t)i * M + j] = r;
 }
@@ -335,11 +354,12 @@ extern "C" int tvmi_boxes_to_rois(const void* const* boxes, const int64_t* count
 }
 
 extern "C" int tvmi_box_iou_pairwise(const void* boxes1, const void* boxes2, void* out, tvmi_dtype dt, int64_t N, int64_t M,
-                                     int generalized, int source_16bit, void* stream) {
+                                     int mode, int source_16bit, double eps, void* stream) {
   TVMI_CHECK_ARG(N >= 0 && M >= 0, "box_iou_pairwise: negative size");
   if (N * M == 0) return 0;
   TVMI_CHECK_ARG(boxes1 && boxes2 && out, "box_iou_pairwise: null pointer");
   TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "box_iou_pairwise: float32 / float64 (upcast 16-bit boxes first)");
+  TVMI_CHECK_ARG(mode >= 0 && mode <= 3, "box_iou_pairwise: mode 0 IoU, 1 generalized, 2 distance, 3 complete");
   TVMI_CHECK_ARG(N <= 65535 * 64ll && M < (1ll << 31), "box_iou_pairwise: size too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)((M + 255) / 256), (unsigned)std::min<int64_t>(N, 65535));
@@ -350,12 +370,20 @@ extern "C" int tvmi_box_iou_pairwise(const void* boxes1, const void* boxes2, voi
 #define TVMI_IOU(T_, MODE_)                                                                                         \
   tvmi::box_iou_pairwise_kernel<T_, MODE_><<<g, dim3(256), 0, s>>>(static_cast<const T_*>(boxes1) + r0 * 4,          \
                                                                    static_cast<const T_*>(boxes2),                   \
-                                                                   static_cast<T_*>(out) + r0 * M, rows, (int)M, source_16bit)
+                                                                   static_cast<T_*>(out) + r0 * M, rows, (int)M, source_16bit, (T_)eps)
+#define TVMI_IOU_MODES(T_)                      \
+  switch (mode) {                               \
+    case 0: TVMI_IOU(T_, 0); break;             \
+    case 1: TVMI_IOU(T_, 1); break;             \
+    case 2: TVMI_IOU(T_, 2); break;             \
+    default: TVMI_IOU(T_, 3); break;            \
+  }
     if (dt == TVMI_F32) {
-      if (generalized) TVMI_IOU(float, 1); else TVMI_IOU(float, 0);
+      TVMI_IOU_MODES(float)
     } else {
-      if (generalized) TVMI_IOU(double, 1); else TVMI_IOU(double, 0);
+      TVMI_IOU_MODES(double)
     }
+#undef TVMI_IOU_MODES
 #undef TVMI_IOU
   }
   (void)grid;

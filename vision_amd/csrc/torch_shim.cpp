@@ -107,11 +107,7 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
   }
   at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
   at::Tensor num = at::empty({1}, dets.options().dtype(at::kLong));
-  static const bool seg_major = []() {
-    const char* e = std::getenv("TVMI_NMS_SEGMAJOR");
-    return !(e && e[0] == '0');
-  }();
-  if (seg_ptr && seg_major && n <= 4096 && num_segments >= 1 && num_segments <= 1024) {
+  if (seg_ptr && n <= 4096 && num_segments >= 1 && num_segments <= 1024) {
     // detector-step sizes with a known id range: per-segment tiles + concurrent per-segment sweeps, no second sort
     const size_t sb = tvmi_nms_small_segments_workspace_bytes(n, num_segments);
     at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
@@ -123,7 +119,7 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
     if (!allow_sync || num.item<int64_t>() >= 0) return std::make_tuple(keep, num);
     // a segment above 1024 boxes or an id outside [0, num_segments): general path below
   }
-  if (seg_ptr && seg_major && n > 4096) {  // up to 4096 boxes the single-launch global sweep is as fast
+  if (seg_ptr && n > 4096) {  // up to 4096 boxes the single-launch global sweep is as fast
     // segment-major path: stable partition of the score order by segment (a second sort), block-diagonal
     // masks, one sweep workgroup per segment
     auto parted = at::sort(seg_c.index_select(0, order), /*stable=*/true, /*dim=*/0, /*descending=*/false);
@@ -964,21 +960,23 @@ at::Tensor boxes_to_rois(at::TensorList boxes) {
   return rois;
 }
 
-// ---- pairwise IoU / GIoU in one launch (ops/boxes.py:314-391, 409-436)
-at::Tensor box_iou_pairwise(const at::Tensor& boxes1, const at::Tensor& boxes2, bool generalized) {
+// ---- pairwise IoU / GIoU / DIoU / CIoU in one launch (ops/boxes.py:314-391, 409-436, 439-515)
+at::Tensor box_iou_pairwise(const at::Tensor& boxes1, const at::Tensor& boxes2, int64_t mode, double eps) {
+  TORCH_CHECK(mode >= 0 && mode <= 3, "box_iou_pairwise: mode 0 IoU, 1 generalized, 2 distance, 3 complete");
   TORCH_CHECK(boxes1.is_cuda() && boxes2.is_cuda() && boxes1.dim() == 2 && boxes2.dim() == 2 && boxes1.size(1) == 4 &&
                   boxes2.size(1) == 4,
               "box_iou_pairwise: boxes1 [N,4] and boxes2 [M,4] CUDA tensors expected");
   c10::DeviceGuard guard(boxes1.device());
   // _upcast (ops/_utils.py:72-84) + type promotion of the two inputs
   auto dt = at::promote_types(boxes1.scalar_type(), boxes2.scalar_type());
-  const int src16 = dt == at::kHalf ? 1 : (dt == at::kBFloat16 ? 2 : 0);
+  // modes 2 / 3 upcast the boxes before any arithmetic (distance_box_iou / complete_box_iou start with _upcast)
+  const int src16 = mode >= 2 ? 0 : (dt == at::kHalf ? 1 : (dt == at::kBFloat16 ? 2 : 0));
   if (dt != at::kDouble) dt = at::kFloat;
   at::Tensor a = boxes1.to(dt).contiguous(), b = boxes2.to(dt).contiguous();
   at::Tensor out = at::empty({a.size(0), b.size(0)}, a.options());
   if (out.numel() == 0) return out;
   check_status(tvmi_box_iou_pairwise(a.const_data_ptr(), b.const_data_ptr(), out.mutable_data_ptr(), dtype_of(a, "box_iou"),
-                                     a.size(0), b.size(0), generalized ? 1 : 0, src16, current_stream(boxes1)),
+                                     a.size(0), b.size(0), (int)mode, src16, eps, current_stream(boxes1)),
                "box_iou_pairwise");
   return out;
 }
@@ -1102,7 +1100,7 @@ TORCH_LIBRARY(tvmi, m) {
   // indices of aten::sort(scores, stable=True, descending=True) for <= 4096 float32 scores, one launch
   m.def("sort_scores_desc(Tensor scores) -> Tensor");
   // ops/boxes.py:314-391 / 409-436 (box_iou / generalized_box_iou of xyxy boxes) as one launch
-  m.def("box_iou_pairwise(Tensor boxes1, Tensor boxes2, bool generalized) -> Tensor");
+  m.def("box_iou_pairwise(Tensor boxes1, Tensor boxes2, int mode, float eps=1e-07) -> Tensor");
   // ops/_utils.py:18-25 (cat + full_like per image + 2 cats) as one launch
   m.def("boxes_to_rois(Tensor[] boxes) -> Tensor");
   // python loop of roi_heads.py:486-500 (pad + expand + resize + paste per detection) as one launch
