@@ -102,8 +102,8 @@ int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_
  *   kernel" flags).  Without it the fast path that needs the flags is not used; results do not depend on it.
  * backward: grad [K,C,PH,PW] read with the given element strides.  Two regimes:
  *   - TILE-OWNER path (deterministic; what torchvision/ops/roi_align.py:276-281 reroutes to python for):
- *     float32, 7x7 or 14x14 bins (any sampling_ratio), bins of a channel contiguous (w_stride 1, h_stride
- *     PW), H, W <= 4096, and a workspace of tvmi_roi_align_backward_workspace_bytes(N, K, PH, PW) bytes.
+ *     float32, 7x7 or 14x14 bins (any sampling_ratio), the [C,PH,PW] block of a RoI contiguous (w_stride 1,
+ *     h_stride PW, c_stride PH*PW), H, W <= 4096, and a workspace of tvmi_roi_align_backward_workspace_bytes(N, K, PH, PW) bytes.
  *     Every 16x16 tile of grad_input is accumulated in registers by ONE workgroup and written exactly once
  *     with plain stores: grad_input is FULLY OVERWRITTEN (no zero-fill needed), no atomics, bit-reproducible.
  *     tvmi_roi_align_backward_overwrites(...) tells the caller whether a call takes this path.

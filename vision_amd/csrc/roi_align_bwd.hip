@@ -49,13 +49,13 @@ struct OwnWorkspace {
   int* imgrange;  // [2N + 1] {first RoI index of image n, -(last index + 1)} ..., kUnset + count of oversized windows; memset to kUnset
   int* biglist;   // [kBigCap] indices of the RoIs with oversized windows (unordered; the second pass sorts them)
   float* ayt;     // [K][kTile + kRCap + kTile][PH]  AyD rows, window-relative, 16 zero rows before and behind
-  float* axt;     // [K][kRCap][PWP]  AxD columns (stored as rows), window-relative
+  float* axt;     // [K][PW][kTile + kRCap + kTile]  AxD rows (column index fastest), window-relative, zero columns on both sides
 };
 
 constexpr int pad4(int v) { return (v + 3) & ~3; }
 
 inline size_t own_workspace_bytes(int64_t N, int64_t K, int PH, int PW) {
-  const size_t tab = (size_t)K * ((size_t)kAyRows * PH + (size_t)kRCap * pad4(PW)) * sizeof(float);
+  const size_t tab = (size_t)K * ((size_t)kAyRows * PH + (size_t)kAyRows * PW) * sizeof(float);
   return (size_t)K * (sizeof(int2) + sizeof(int4)) + (size_t)(2 * N + 4 + kBigCap) * sizeof(int) + tab + 512;
 }
 
@@ -132,7 +132,6 @@ __device__ __forceinline__ bool axis_window(int dim, float start, float bin, int
 template <int PH, int PW>
 __global__ __launch_bounds__(kThreads) void roi_bwd_prepass(const float* __restrict__ rois, int K, OwnLevels lv, int sr,
                                                             int aligned, OwnWorkspace ws) {
-  constexpr int PWP = pad4(PW);
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (k >= K) return;
@@ -180,17 +179,14 @@ __global__ __launch_bounds__(kThreads) void roi_bwd_prepass(const float* __restr
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) row[ph] = in ? axis_coef(H, g.start_h, g.bin_h, g.gh, ph, y0 + r) : 0.f;
   }
-  for (int c = lane; c < ww; c += 64) {
-    float* row = ws.axt + ((int64_t)k * kRCap + c) * PWP;
+  // x table: [pw][column], table column t <-> window column t - 16 (zeros outside [0, ww): a lane's two adjacent
+  // columns are ONE 8-byte load per pw, without range tests); columns past ww + 16 + 15 are never read
+  for (int t = lane; t < ww + 2 * kTile; t += 64) {
+    const int c = t - kTile;
+    const bool in = c >= 0 && c < ww;
 #pragma unroll
-    for (int p0 = 0; p0 < PWP; p0 += 4) {
-      float4 v;
-      v.x = p0 + 0 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 0, x0 + c) : 0.f;
-      v.y = p0 + 1 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 1, x0 + c) : 0.f;
-      v.z = p0 + 2 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 2, x0 + c) : 0.f;
-      v.w = p0 + 3 < PW ? axis_coef(W, g.start_w, g.bin_w, g.gw, p0 + 3, x0 + c) : 0.f;
-      *reinterpret_cast<float4*>(row + p0) = v;
-    }
+    for (int pw = 0; pw < PW; ++pw)
+      ws.axt[((int64_t)k * PW + pw) * kAyRows + t] = in ? axis_coef(W, g.start_w, g.bin_w, g.gw, pw, x0 + c) : 0.f;
   }
 }
 
@@ -269,12 +265,13 @@ __device__ __forceinline__ void rows_fma(v2f* acc, const float (&cf)[RB * PH], c
 // One entry of a tile's RoI list, copied into LDS by the scanning lane: everything the accumulation needs
 // that is per-RoI (so that the walk over the list has ONE dependent LDS read in front of its loads).
 struct OwnEntry {
-  int k, y0, x0, ww;
+  int k, y0, x0, wh;
 };
 
 struct OwnShared {
   OwnEntry list[4][kScanChunk / 4];  // per-wave segments of the tile's RoI list (ascending RoI index)
   int count[4];
+  __attribute__((aligned(16))) float gstage[4][2][400];  // per wave: two buffers of 8 channels x 7x7 grads (392 floats)
 };
 
 #define TVMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -290,7 +287,6 @@ template <bool kBig, int PH, int PW>
 __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float* __restrict__ grad, const float* __restrict__ rois,
                                            const OwnLevels& lv, int C, int K, int nchunks, int sr, int aligned, int64_t ns,
                                            int64_t cs, const OwnWorkspace& ws, const int* klist = nullptr, int nlist = 0) {
-  constexpr int PWP = pad4(PW);
   constexpr int RB = PH <= 7 ? 4 : 2;  // tile rows per scalar-load batch (RB * PH coefficient SGPRs, two batches in flight)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -358,7 +354,7 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
         e.k = k;
         e.y0 = wi.x;
         e.x0 = wi.y;
-        e.ww = wi.w;
+        e.wh = wi.z;
         sh.list[wave][cnt + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = e;
       }
       cnt += __builtin_popcountll(b);
@@ -366,12 +362,123 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
     if (lane == 0) sh.count[wave] = cnt;
     __syncthreads();
     // ---- accumulate the listed RoIs (every wave walks all four segments, in order)
+    if constexpr (!kBig && PH <= 7) {
+      {
+        // The grads of the wave's 8 channels are ONE contiguous run of 8 * PH*PW floats: the wave fetches it with two
+        // coalesced 16-byte-per-lane loads (13 cache lines) into its private LDS region and every lane reads its channel
+        // from there — instead of 13 loads per lane whose 64 lanes ask for 8 scattered 16-byte pieces each (104 line
+        // requests per RoI and wave at the texture addresser, 50 VGPRs in flight).  The loads of entry e + 1 are issued
+        // as soon as entry e sits in LDS, so their latency runs under the ~160 packed FMAs of entry e.
+        constexpr int NGW = 8 * PH * PW;             // floats per wave and RoI
+        constexpr int NPIECE = (NGW + 3) / 4;        // 16-byte pieces (98 for 7x7)
+        constexpr int NLD = (NPIECE + 63) / 64;      // load instructions per lane (2)
+        static_assert(NGW <= 400, "the per-wave staging buffers hold 7x7 bins");
+        const int n0 = TVMI_UNIFORM(sh.count[0]), n1 = n0 + TVMI_UNIFORM(sh.count[1]), n2 = n1 + TVMI_UNIFORM(sh.count[2]);
+        const int total = n2 + TVMI_UNIFORM(sh.count[3]);
+        touched += total;
+        const int ch0w = chunk * kOwnChunk + wave * 8;            // first channel of this wave
+        const int nvalid = max(0, min(8, C - ch0w)) * PH * PW;    // floats of the run that exist
+        float* gl = &sh.gstage[wave][0][0];
+        auto entry_at = [&](int e, int& k, int& y0, int& x0, int& wh) {
+          const int seg = (e >= n0 ? 1 : 0) + (e >= n1 ? 1 : 0) + (e >= n2 ? 1 : 0);
+          const int idx = e - (seg == 0 ? 0 : seg == 1 ? n0 : seg == 2 ? n1 : n2);
+          const OwnEntry en = sh.list[seg][idx];
+          k = TVMI_UNIFORM(en.k);
+          y0 = TVMI_UNIFORM(en.y0);
+          x0 = TVMI_UNIFORM(en.x0);
+          wh = TVMI_UNIFORM(en.wh);
+        };
+        float4 gin[NLD];
+        auto issue_run = [&](int k) {
+          const float* run = grad + (int64_t)k * ns + (int64_t)ch0w * cs;
+#pragma unroll
+          for (int u = 0; u < NLD; ++u) {
+            const int f0 = 4 * (u * 64 + lane);  // first float of this lane's piece
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f0 + 4 <= nvalid) {
+              v = *reinterpret_cast<const float4*>(run + f0);
+            } else if (f0 < nvalid) {  // the piece that straddles the end of the run (never read past the tensor)
+              v.x = run[f0];
+              if (f0 + 1 < nvalid) v.y = run[f0 + 1];
+              if (f0 + 2 < nvalid) v.z = run[f0 + 2];
+            }
+            gin[u] = v;
+          }
+        };
+        int k = 0, y0 = 0, x0 = 0, wh = 0;
+        if (total > 0) {
+          entry_at(0, k, y0, x0, wh);
+          issue_run(k);
+        }
+        for (int e = 0; e < total; ++e) {
+          float* gb = gl + (e & 1) * 400;
+#pragma unroll
+          for (int u = 0; u < NLD; ++u)
+            if (u * 64 + lane < NPIECE) *reinterpret_cast<float4*>(gb + 4 * (u * 64 + lane)) = gin[u];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          int kn = 0, y0n = 0, x0n = 0, whn = 0;
+          if (e + 1 < total) {
+            entry_at(e + 1, kn, y0n, x0n, whn);
+            issue_run(kn);
+          }
+          // -- coefficient rows (scalar loads), AxD columns (vector loads), grads of this lane's channel (LDS)
+          const float* arow = ws.ayt + ((int64_t)k * kAyRows + (ybase - y0 + kTile)) * PH;
+          float cfa[RB * PH], cfb[RB * PH];
+          load_coefs<RB * PH>(cfa, arow);
+          load_coefs<RB * PH>(cfb, arow + RB * PH);
+          // AxD of this lane's two adjacent pixels: one 8-byte load per pw from the zero-padded [pw][column] table
+          v2f axd[PW];
+          const float* xt = ws.axt + (int64_t)k * PW * kAyRows + (xl - x0 + kTile);
+#pragma unroll
+          for (int pw = 0; pw < PW; ++pw) axd[pw] = *reinterpret_cast<const v2f*>(xt + pw * kAyRows);
+          // grads row by row out of LDS, one row ahead of the FMAs that consume it (14 VGPRs instead of 49)
+          const float* gch = gb + cslot * (PH * PW);
+          v2f t[PH];
+          float grow[2][PW];
+#pragma unroll
+          for (int pw = 0; pw < PW; ++pw) grow[0][pw] = gch[pw];
+#pragma unroll
+          for (int ph = 0; ph < PH; ++ph) {
+            if (ph + 1 < PH) {
+#pragma unroll
+              for (int pw = 0; pw < PW; ++pw) grow[(ph + 1) & 1][pw] = gch[(ph + 1) * PW + pw];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v2f a = {0.f, 0.f};
+#pragma unroll
+            for (int pw = 0; pw < PW; ++pw) a = pk_fma_bcast(grow[ph & 1][pw], axd[pw], a);
+            t[ph] = a;  // lanes of channels past C carry zeros (staged run) and are never stored
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // groups of RB tile rows that lie entirely outside the window have all-zero coefficient rows: their FMAs are
+          // skipped (uniform branch); the scalar loads stay unconditional so that they remain two batches ahead
+          const int rrel0 = ybase - y0;
+#pragma unroll
+          for (int r0 = 0; r0 < kTile; r0 += 2 * RB) {
+            if (rrel0 + r0 + RB > 0 && rrel0 + r0 < wh) rows_fma<RB, PH>(acc + r0, cfa, t);
+            if (r0 + 2 * RB < kTile) load_coefs<RB * PH>(cfa, arow + (r0 + 2 * RB) * PH);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rrel0 + r0 + 2 * RB > 0 && rrel0 + r0 + RB < wh) rows_fma<RB, PH>(acc + r0 + RB, cfb, t);
+            if (r0 + 3 * RB < kTile) load_coefs<RB * PH>(cfb, arow + (r0 + 3 * RB) * PH);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          k = kn;
+          y0 = y0n;
+          x0 = x0n;
+          wh = whn;
+        }
+        __syncthreads();
+        continue;
+      }
+    }
     for (int seg = 0; seg < 4; ++seg) {
       const int nseg = TVMI_UNIFORM(sh.count[seg]);
       touched += nseg;
       for (int i = 0; i < nseg; ++i) {
         const OwnEntry e = sh.list[seg][i];
-        const int k = TVMI_UNIFORM(e.k), y0 = TVMI_UNIFORM(e.y0), x0 = TVMI_UNIFORM(e.x0), ww = TVMI_UNIFORM(e.ww);
+        const int k = TVMI_UNIFORM(e.k), y0 = TVMI_UNIFORM(e.y0), x0 = TVMI_UNIFORM(e.x0), wh = TVMI_UNIFORM(e.wh);
         const float* gp = grad + (int64_t)k * ns + (int64_t)chc * cs;
         if constexpr (!kBig) {
           // tile row r <-> table row (ybase - y0) + 16 + r: one base address per RoI, immediate offsets per row.
@@ -381,29 +488,23 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
           load_coefs<RB * PH>(cfa, arow);
           load_coefs<RB * PH>(cfb, arow + RB * PH);
           // -- AxD columns of this lane's two pixels (table rows; zero outside the window)
+          // AxD of this lane's two adjacent pixels: one 8-byte load per pw from the zero-padded [pw][column] table
           v2f axd[PW];
-          const int c0 = xl - x0, c1 = c0 + 1;
-          const bool v0 = c0 >= 0 && c0 < ww, v1 = c1 >= 0 && c1 < ww;
-          const float* t0 = ws.axt + ((int64_t)k * kRCap + (v0 ? c0 : 0)) * PWP;
-          const float* t1 = ws.axt + ((int64_t)k * kRCap + (v1 ? c1 : 0)) * PWP;
+          const float* xt = ws.axt + (int64_t)k * PW * kAyRows + (xl - x0 + kTile);
 #pragma unroll
-          for (int p0 = 0; p0 < PWP; p0 += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(t0 + p0);
-            const float4 b = *reinterpret_cast<const float4*>(t1 + p0);
-            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (p0 + q < PW) axd[p0 + q] = v2f{v0 ? av[q] : 0.f, v1 ? bv[q] : 0.f};
-          }
+          for (int pw = 0; pw < PW; ++pw) axd[pw] = *reinterpret_cast<const v2f*>(xt + pw * kAyRows);
           v2f t[PH];
           grads_times_axd<PH, PW>(t, gp, axd, ch_ok);
           // -- acc[r] += sum_ph AyD[r][ph] * t[ph]
+          // groups of RB tile rows that lie entirely outside the window have all-zero coefficient rows: their FMAs are
+          // skipped (uniform branch); the scalar loads stay unconditional so that they remain two batches ahead
+          const int rrel0 = ybase - y0;
 #pragma unroll
           for (int r0 = 0; r0 < kTile; r0 += 2 * RB) {
-            rows_fma<RB, PH>(acc + r0, cfa, t);
+            if (rrel0 + r0 + RB > 0 && rrel0 + r0 < wh) rows_fma<RB, PH>(acc + r0, cfa, t);
             if (r0 + 2 * RB < kTile) load_coefs<RB * PH>(cfa, arow + (r0 + 2 * RB) * PH);
             __builtin_amdgcn_sched_barrier(0);
-            rows_fma<RB, PH>(acc + r0 + RB, cfb, t);
+            if (rrel0 + r0 + 2 * RB > 0 && rrel0 + r0 + RB < wh) rows_fma<RB, PH>(acc + r0 + RB, cfb, t);
             if (r0 + 3 * RB < kTile) load_coefs<RB * PH>(cfb, arow + (r0 + 3 * RB) * PH);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -739,7 +840,7 @@ bool owner_shape(int64_t PH, int64_t PW) { return (PH == 7 && PW == 7) || (PH ==
 bool owner_applies(tvmi_dtype dt, int64_t N, int64_t C, int64_t K, int64_t PH, int64_t PW, const int64_t* heights,
                    const int64_t* widths, int64_t n_levels, int64_t cs, int64_t hs, int64_t ws, size_t workspace_bytes) {
   if (dt != TVMI_F32 || !owner_shape(PH, PW) || N <= 0 || N >= (1 << 24) || C <= 0 || K < 0 || K >= (1ll << 30)) return false;
-  if (ws != 1 || hs != PW || cs < PH * PW) return false;  // bins of a channel must be contiguous
+  if (ws != 1 || hs != PW || cs != PH * PW) return false;  // the [C, PH, PW] block of a RoI must be contiguous
   if (n_levels < 1 || n_levels > kMaxLevels) return false;
   int64_t tiles = 0;
   for (int64_t i = 0; i < n_levels; ++i) {

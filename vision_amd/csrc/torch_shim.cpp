@@ -233,7 +233,7 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
   at::Tensor g = grad;
   const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, rois.size(0), pooled_height, pooled_width);
   if (ws_bytes != 0 && grad.scalar_type() == at::kFloat &&
-      !(grad.stride(3) == 1 && grad.stride(2) == pooled_width && grad.stride(1) >= pooled_height * pooled_width))
+      !(grad.stride(3) == 1 && grad.stride(2) == pooled_width && grad.stride(1) == pooled_height * pooled_width))
     g = grad.contiguous();
   const tvmi_dtype dt = dtype_of(g, "_roi_align_backward");
   const bool overwrites = ws_bytes != 0 && tvmi_roi_align_backward_overwrites(dt, batch_size, channels, height, width, rois.size(0),
@@ -759,7 +759,7 @@ std::vector<at::Tensor> multiscale_roi_align_backward(const at::Tensor& grad, co
   const int64_t K = g.size(0), C = g.size(1);
   std::vector<int64_t> hs(heights.begin(), heights.end()), ws(widths.begin(), widths.end());
   const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, K, pooled_height, pooled_width);
-  if (ws_bytes != 0 && !(g.stride(3) == 1 && g.stride(2) == pooled_width && g.stride(1) >= pooled_height * pooled_width))
+  if (ws_bytes != 0 && !(g.stride(3) == 1 && g.stride(2) == pooled_width && g.stride(1) == pooled_height * pooled_width))
     g = g.contiguous();
   const bool overwrites = ws_bytes != 0 && K != 0 && C != 0 && batch_size != 0 &&
                           tvmi_multiscale_roi_align_backward_overwrites(TVMI_F32, batch_size, C, K, hs.data(), ws.data(),
