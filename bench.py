@@ -21,6 +21,16 @@ Besides the contract line it reports
                  per launch from a separate rocprofv3 --pmc pass (profiles/roofline_traffic.json) or null.
   cpu_baseline : the reference's own CPU kernels (oracle/_ref, kind "reference") — or the C port when
                  that library is absent — timed on this host on the same workload, rank 0 at N=1 only.
+  parity       : outside the timed region, the pooled output and the per-image keep lists of the timed
+                 configuration are compared with what cpu_baseline computed on the same inputs (max abs
+                 error against the 1e-4 bar; index lists equal).  A failed parity check exits non-zero.
+  config       : also the time of the same step through the reference-schema ops alone (per-level
+                 torchvision::roi_align + torchvision::nms), the channels_last kernel, the dense NMS variant
+                 — reported beside `value`, never part of it.  Inputs rotate over N_SETS sets so the 256 MiB
+                 Infinity Cache cannot carry one step's feature maps into the next.
+--e2e prints a SECOND JSON line: BASELINE config 5 (Mask R-CNN R50-FPN inference img/s through the unchanged
+reference python laid over this library, and with the fused vision_amd pieces swapped in) — tools/e2e_maskrcnn.py,
+run in fresh processes; needs the staged reference python package (tools/stage_reference_python.py).
 """
 import argparse
 import json

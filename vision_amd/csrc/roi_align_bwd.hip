@@ -34,10 +34,10 @@ constexpr int kTile = 16;      // tile edge (pixels) owned by one workgroup
 constexpr int kOwnChunk = 32;  // channels per workgroup: 4 waves x 8 channel slots x 1 channel per lane
 constexpr int kRCap = 128;     // window rows / columns with precomputed coefficient rows
 constexpr int kAyRows = kTile + kRCap + kTile;  // rows of a RoI's AyD table (zero rows on both sides: any tile row offset is readable)
-constexpr int kScanChunk = 1024;
+constexpr int kScanChunk = 1024;  // RoI descriptors scanned per list round (256 per wave)
 constexpr int kBigBit = 1 << 30;   // descriptor key bit: window above the table capacity (second pass)
 constexpr int kBigCap = 1024;       // oversized-window RoIs listed for the second pass (more: it scans every descriptor)
-constexpr int kUnset = 0x7f7f7f7f;  // memset pattern of the per-image RoI ranges and of the oversized-window counter  // RoI descriptors scanned per list round (256 per wave)
+constexpr int kUnset = 0x7f7f7f7f;  // memset pattern of the per-image RoI ranges and of the oversized-window counter
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
