@@ -114,6 +114,41 @@ def test_nms_threshold_edge_is_exact_without_the_division(tv):
         assert np.array_equal(vision_amd.batched_nms(big.to(DEV), sbig.to(DEV), ibig.to(DEV), thr).cpu().numpy(), want), thr
 
 
+def test_nms_area_range_of_the_fast_path(tv):
+    """The division-free tile loop is only taken for tiles whose boxes all have an area in [2^-60, 2^60]; boxes scaled
+    to 2^-70 / 2^+70 areas, NaN / inf coordinates, zero-area and inverted boxes, normalised (0..1) coordinates — alone
+    and mixed into otherwise ordinary tiles — must give the reference's index lists (exact path or fast path alike)."""
+    g = gen(31)
+    n = 3000
+    base = random_boxes(n, 64, 64, 2, 30, g)
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, 4, (n,), generator=g)
+    variants = {"normalised": base / 64.0, "tiny": base * 2.0 ** -38, "huge": base * 2.0 ** 33, "edge_lo": base * 2.0 ** -32,
+                "edge_hi": base * 2.0 ** 27}
+    mixed = base.clone()
+    mixed[7::61] *= 2.0 ** -38                   # a few out-of-range boxes per tile
+    mixed[11::173] *= 2.0 ** 34
+    mixed[13::211, 2] = float("nan")
+    mixed[17::223, 3] = float("inf")
+    mixed[19::227, 0] = float("-inf")
+    mixed[23::97, 2:] = mixed[23::97, :2]        # zero area
+    mixed[29::131, 2] = mixed[29::131, 0] - 1.0  # inverted
+    variants["mixed"] = mixed
+    for name, b in variants.items():
+        for thr in (0.5, 0.3):
+            want = O.nms(b.numpy(), scores.numpy(), thr)
+            assert np.array_equal(tv.nms(b.to(DEV), scores.to(DEV), thr).cpu().numpy(), want), (name, thr)
+            wseg = O.nms(b.numpy(), scores.numpy(), thr, idxs.numpy())
+            got = vision_amd.batched_nms(b.to(DEV), scores.to(DEV), idxs.to(DEV), thr, num_segments=4).cpu().numpy()
+            assert np.array_equal(got, wseg), (name, thr)
+    big = torch.cat([mixed, base, mixed * 0.5])  # n > 4096: chunked mask kernels / segment-major kernel
+    sbig = torch.rand(big.shape[0], generator=g)
+    ibig = torch.randint(0, 6, (big.shape[0],), generator=g)
+    assert np.array_equal(tv.nms(big.to(DEV), sbig.to(DEV), 0.5).cpu().numpy(), O.nms(big.numpy(), sbig.numpy(), 0.5))
+    assert np.array_equal(vision_amd.batched_nms(big.to(DEV), sbig.to(DEV), ibig.to(DEV), 0.5).cpu().numpy(),
+                          O.nms(big.numpy(), sbig.numpy(), 0.5, ibig.numpy()))
+
+
 def test_batched_nms_native_segmented_path():
     g = gen(6)
     n = 30000  # numel 120k > 100k -> "vanilla" semantics via tvmi::nms_segmented

@@ -204,49 +204,56 @@ def test_transform_size_rule_matches_reference_golden():
 
 
 def test_nms_band_test_never_contradicts_the_exact_predicate():
-    """The NMS tile kernels (vision_amd/csrc/nms.hip: thr_band / suppression_row) decide a pair without the division
-    when  union > 0 and inter > t_hi * union  (suppressed)  or  inter < t_lo * union  (not suppressed), and fall back
-    to the reference's `(double)(inter / union) > thr` otherwise.  Emulate exactly that float32 arithmetic here and
-    check, on random and on adversarial (within a few ulps of the threshold) pairs, that a decided pair always agrees
-    with the exact predicate — i.e. the margins of the band are sufficient."""
+    """The NMS tile kernels (vision_amd/csrc/nms.hip: thr_band / suppression_row_pair) decide a pair without the
+    division:  t = fma(-c, union, inter), ru = r * union;  t > ru -> suppressed, t < -ru -> not suppressed, and fall
+    back to the reference's `(double)(inter / union) > thr` otherwise (also for unions / thresholds outside the
+    fast-path range).  Emulate that float32 arithmetic here (the fma through float64: 24x24-bit product exact, one
+    rounding of the sum, one to float — off from a true fma by at most a double-rounding tie) and check, on random and
+    on adversarial (within a few ulps of the threshold) pairs, that a decided pair always agrees with the exact
+    predicate — i.e. the margins of the band are sufficient."""
     f = np.float32
     rng = np.random.default_rng(0)
 
     def band(thr):
-        if not (thr > 1e-30 and thr < 1e30):
-            return f(-np.inf), f(np.inf)
+        if not (thr >= 1.0 / 1048576.0 and thr <= 1048576.0):
+            return f(0), f(np.inf)
         d = f(thr)
         if float(d) > thr:
             d = np.nextafter(d, f(-np.inf))
         u = np.nextafter(d, f(np.inf))
         hi = np.nextafter(f(float(u) * (1.0 + 1.0 / 1048576.0)), f(np.inf))
         lo = np.nextafter(f(float(d) * (1.0 - 1.0 / 1048576.0)), f(-np.inf))
-        return lo, hi
+        return f(f(0.5) * f(hi + lo)), f(f(0.75) * f(hi - lo))
 
-    thrs = [0.5, 0.3, 0.7, 1.0 / 3.0, 0.05, 0.95, 1.0, 1e-6, float(np.nextafter(f(0.5), f(1))), 0.5000000001, 0.4999999999]
+    thrs = [0.5, 0.3, 0.7, 1.0 / 3.0, 0.05, 0.95, 1.0, 1e-5, float(np.nextafter(f(0.5), f(1))), 0.5000000001, 0.4999999999]
     for thr in thrs:
-        lo, hi = band(thr)
-        union = (rng.random(400_000) * 1e4 + 1e-3).astype(f)
-        # inter spread over [0, union] plus a cloud concentrated within a few ulps of thr * union
-        inter_a = (rng.random(200_000).astype(f) * union[:200_000]).astype(f)
-        base = (f(thr) * union[200_000:]).astype(f)
-        steps = rng.integers(-40, 41, size=base.shape)
-        inter_b = base.copy()
-        for _ in range(40):
-            up = steps > 0
-            dn = steps < 0
-            inter_b = np.where(up, np.nextafter(inter_b, f(np.inf)), np.where(dn, np.nextafter(inter_b, f(-np.inf)), inter_b))
-            steps = steps - np.sign(steps)
-        inter = np.concatenate([inter_a, np.maximum(inter_b, f(0))]).astype(f)
-        with np.errstate(over="ignore", invalid="ignore"):
-            sure_t = (union > 0) & (inter > (hi * union).astype(f))
-            sure_f = (union > 0) & (inter < (lo * union).astype(f))
-            exact = (inter / union).astype(f).astype(np.float64) > thr
-        assert not np.any(sure_t & sure_f)
-        assert np.all(exact[sure_t]), thr
-        assert not np.any(exact[sure_f]), thr
-        # and the band is narrow: almost everything is decided without the division
-        assert (sure_t | sure_f).mean() > 0.45
+        c, r = band(thr)
+        assert np.isfinite(r) and r > 0
+        for scale in (1e4, 2.0 ** -50, 2.0 ** 50):          # unions across the fast-path range [2^-60, 2^60]
+            union = ((rng.random(400_000) + 1e-3) * scale).astype(f)
+            # inter spread over [0, union] plus a cloud concentrated within a few ulps of thr * union
+            inter_a = (rng.random(200_000).astype(f) * union[:200_000]).astype(f)
+            base = (f(thr) * union[200_000:]).astype(f)
+            steps = rng.integers(-40, 41, size=base.shape)
+            inter_b = base.copy()
+            for _ in range(40):
+                up = steps > 0
+                dn = steps < 0
+                inter_b = np.where(up, np.nextafter(inter_b, f(np.inf)), np.where(dn, np.nextafter(inter_b, f(-np.inf)), inter_b))
+                steps = steps - np.sign(steps)
+            inter = np.concatenate([inter_a, np.maximum(inter_b, f(0))]).astype(f)
+            with np.errstate(over="ignore", invalid="ignore"):
+                t = (inter.astype(np.float64) - float(c) * union.astype(np.float64)).astype(f)
+                ru = (r * union).astype(f)
+                sure_t = t > ru
+                sure_f = t < -ru
+                exact = (inter / union).astype(f).astype(np.float64) > thr
+            assert not np.any(sure_t & sure_f)
+            assert np.all(exact[sure_t]), (thr, scale)
+            assert not np.any(exact[sure_f]), (thr, scale)
+            # and the band is narrow: almost everything is decided without the division
+            assert (sure_t | sure_f).mean() > 0.45
+    assert band(1e-7) == (f(0), f(np.inf)) and band(float("nan"))[1] == f(np.inf)    # outside the range: never decided
 
 
 def test_distance_and_complete_box_iou_known_answers():

@@ -89,51 +89,55 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
          (u64)(unsigned int)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // The suppression predicate `(double)(inter / union) > thr` (cpu/nms_kernel.cpp:88) without the IEEE division in
 // the common case.  With u = the smallest float above thr and d = the largest float at or below it, RN(q) > thr
-// <=> RN(q) >= u, which q >= u guarantees, and RN(q) <= d is guaranteed by q <= d.  The host passes
-// t_hi >= u (1 + 2^-20) and t_lo <= d (1 - 2^-20), margins that swallow the rounding of the two float products, so
-//   union > 0 && inter > t_hi * union  => certainly suppressed,   union > 0 && inter < t_lo * union => certainly not,
-// and only lanes inside the 2^-19-wide band (or with a non-positive / NaN union) take the exact division.  The
-// result is bit-identical to evaluating the division everywhere; the mask kernels are VALU-bound and the
-// division + double compare were ~40 % of their instructions.
+// <=> RN(q) >= u, which q >= u guarantees, and RN(q) <= d is guaranteed by q <= d.  Take hi >= u (1 + 2^-20),
+// lo <= d (1 - 2^-20), c = (hi + lo) / 2, r = 0.75 (hi - lo) and evaluate, in float,
+//       t = fma(-c, union, inter)        (one rounding),        ru = r * union:
+//   t >  ru  =>  inter > (c + r (1 - 2^-22)) union >= hi union > u union   => certainly suppressed,
+//   t < -ru  =>  inter < (c - r (1 - 2^-22)) union <= lo union < d union   => certainly not,
+// (the extra quarter of the band width in r swallows the roundings of c, t and ru: they are ~2^-24 relative, the band is
+// 2^-19 relative), and only pairs with |t| <= ru — IoU within ~2^-19 of the threshold — need the exact division.  The
+// relative-error argument needs normal numbers and a positive union: the fast path is only taken for a tile whose boxes
+// all have an area in [2^-60, 2^60] (then every coordinate is finite, inter <= min(area_i, area_j) by monotonic
+// rounding, union >= max(area_i, area_j) (1 - 2^-23) > 0 and r * union >= 2^-101), and for thresholds in
+// [2^-20, 2^20]; everything else is evaluated with the reference's expression.  The result is bit-identical to
+// evaluating the division everywhere; the mask kernels are VALU-bound and the division + double compare were ~40 % of
+// their instructions.
 struct ThrBand {
-  float lo, hi;
+  float c, r;
 };
 inline ThrBand thr_band(double thr) {
-  ThrBand b{-INFINITY, INFINITY};  // = "always take the exact path"
-  if (!(thr > 1e-30 && thr < 1e30)) return b;
+  ThrBand b{0.f, INFINITY};  // = "always take the exact path" (|t| <= inf)
+  if (!(thr >= 1.0 / 1048576.0 && thr <= 1048576.0)) return b;
   float d = (float)thr;
   if ((double)d > thr) d = nextafterf(d, -INFINITY);  // largest float <= thr
   const float u = nextafterf(d, INFINITY);            // smallest float > thr
-  b.hi = nextafterf((float)((double)u * (1.0 + 1.0 / 1048576.0)), INFINITY);
-  b.lo = nextafterf((float)((double)d * (1.0 - 1.0 / 1048576.0)), -INFINITY);
+  const float hi = nextafterf((float)((double)u * (1.0 + 1.0 / 1048576.0)), INFINITY);
+  const float lo = nextafterf((float)((double)d * (1.0 - 1.0 / 1048576.0)), -INFINITY);
+  b.c = 0.5f * (hi + lo);
+  b.r = 0.75f * (hi - lo);
   return b;
 }
-template <typename T>
-__device__ __forceinline__ bool iou_over(T inter, T uni, double thr, ThrBand band) {
-  if constexpr (std::is_same<T, float>::value) {
-    const bool pos = uni > 0.f;
-    const bool sure_t = pos && inter > band.hi * uni;
-    const bool sure_f = pos && inter < band.lo * uni;
-    if (sure_t || sure_f) return sure_t;
-  }
-  return (double)(inter / uni) > thr;
-}
+constexpr float kAreaMin = 0x1p-60f, kAreaMax = 0x1p60f;  // fast-path range of box areas (see above)
 
-// One 64x64 suppression tile: lane = column box (registers), the row boxes come from LDS (`rows`, 64 rows of 5
-// values: x1,y1,x2,y2,area; `row_keys` = their segment ids or nullptr).  Returns, in lane r, the 64-bit word of row r.
+// One 64x64 suppression tile: lane = column box (registers), the row boxes come from LDS in component-major form
+// (`rows[k * RS + i]`, k = x1,y1,x2,y2,area, i = row: two consecutive rows are one 8-byte read; `row_keys` = their
+// segment ids or nullptr).  `nrows` = rows of the block that exist (the others hold zeros or anything at all: their
+// words are never consumed).  Returns, in lane r, the 64-bit word of row r.
 //
 // exact form: the reference's expression for every pair (also the only form for float64 boxes)
-template <typename T>
+template <typename T, int RS>
 __device__ __forceinline__ u64 suppression_tile_exact(const T* __restrict__ rows, const long long* __restrict__ row_keys,
                                                       T jx1, T jy1, T jx2, T jy2, T jarea, long long jkey, u64 valid_cols,
                                                       bool diag, double thr) {
   const int lane = threadIdx.x & 63;
   u64 mine = 0ull;
   for (int i = 0; i < 64; ++i) {
-    const T ix1 = rows[i * 5 + 0], iy1 = rows[i * 5 + 1], ix2 = rows[i * 5 + 2], iy2 = rows[i * 5 + 3];
-    const T iarea = rows[i * 5 + 4];
+    const T ix1 = rows[0 * RS + i], iy1 = rows[1 * RS + i], ix2 = rows[2 * RS + i], iy2 = rows[3 * RS + i];
+    const T iarea = rows[4 * RS + i];
     const T xx1 = ix1 > jx1 ? ix1 : jx1;  // std::max(ix1, x1[j])
     const T yy1 = iy1 > jy1 ? iy1 : jy1;
     const T xx2 = jx2 < ix2 ? jx2 : ix2;  // std::min(ix2, x2[j])
@@ -151,38 +155,55 @@ __device__ __forceinline__ u64 suppression_tile_exact(const T* __restrict__ rows
   return mine;
 }
 
-// fast form (float32): the loop is fully unrolled and written for the machine's real bottleneck.  A CU has ONE
-// scalar ALU for its four SIMDs, so a scalar instruction costs as much issue time as a vector one; the per-row work
-// is therefore kept on the vector side: the band test of iou_over() (the union is replaced by NaN when it is not
-// positive, which makes both comparisons false = undecided), raw v_max / v_min (the builtins would canonicalise each
-// LDS operand with an extra instruction; they differ from std::max / std::min only for NaN operands, and a NaN
-// coordinate makes that box's area, the union and the predicate NaN / false either way), the row word parked with
-// v_writelane (lane select through M0).  Per row that leaves three scalar ops (M0, collecting the undecided lanes); a tile
-// with any undecided pair — IoU within 2^-19 of the threshold, or a non-positive union — is simply redone in the
-// exact form, so the result is bit-identical to evaluating the division everywhere.
-template <int I, bool DIAG, bool KEYS>
-__device__ __forceinline__ void suppression_row(const float* __restrict__ rows, const long long* __restrict__ row_keys,
-                                                float jx1, float jy1, float jx2, float jy2, float jarea, long long jkey,
-                                                ThrBand band, int& mine_lo, int& mine_hi, u64& undecided) {
-  const float ix1 = rows[I * 5 + 0], iy1 = rows[I * 5 + 1], ix2 = rows[I * 5 + 2], iy2 = rows[I * 5 + 3];
-  const float iarea = rows[I * 5 + 4];
-  float xx1, yy1, xx2, yy2;
-  asm("v_max_f32 %0, %1, %2" : "=v"(xx1) : "v"(ix1), "v"(jx1));
-  asm("v_max_f32 %0, %1, %2" : "=v"(yy1) : "v"(iy1), "v"(jy1));
-  asm("v_min_f32 %0, %1, %2" : "=v"(xx2) : "v"(ix2), "v"(jx2));
-  asm("v_min_f32 %0, %1, %2" : "=v"(yy2) : "v"(iy2), "v"(jy2));
-  const float dw = xx2 - xx1, dh = yy2 - yy1;
-  const float w = 0.f < dw ? dw : 0.f;
-  const float h = 0.f < dh ? dh : 0.f;
-  const float inter = w * h;
-  float uni = iarea + jarea - inter;
-  uni = uni > 0.f ? uni : __builtin_nanf("");
-  const u64 over = __ballot(inter > band.hi * uni);
-  const u64 under = __ballot(inter < band.lo * uni);
-  undecided |= ~(over | under);
-  u64 word = over;
-  if (DIAG) word &= I < 63 ? (~0ull << ((I + 1) & 63)) : 0ull;  // only columns after the row
-  if (KEYS) word &= __ballot(jkey == row_keys[I]);
+// fast form (float32): fully unrolled, TWO rows per step, written for the machine's real bottleneck.  The mask kernels
+// are bound by instruction issue (a wave64 VALU instruction occupies its SIMD for 4 cycles, and a CU has ONE scalar ALU
+// for its four SIMDs, so a scalar instruction costs as much issue time as a vector one).  With the rows of a pair side
+// by side in a register pair, everything except min / max / compare runs as packed fp32 (v_pk_add / v_pk_mul /
+// v_pk_fma: two rows per instruction): the differences, the product, the union and the band test of thr_band().  The
+// "undecided" bookkeeping stays on the vector side too: each lane keeps the minimum of |t| - r*union over the rows
+// (positive <=> every pair of the lane was decided) — one v_sub with |.| per row and one v_min3 per row pair, no
+// scalar mask arithmetic.  Raw v_max / v_min (the builtins would canonicalise each LDS operand with an extra
+// instruction; they differ from std::max / std::min only for NaN operands, which the area check of the fast path
+// excludes).  The row word is parked with v_writelane (lane select through M0).  Per row pair: 8 min/max, 4 max(0,.),
+// 7 packed ops, 2 compares, 2 |t| - ru, 1 min3, 4 writelanes, 2 M0 moves; a tile with any undecided pair is simply
+// redone in the exact form, so the result is bit-identical to evaluating the division everywhere.
+template <int I, bool DIAG, bool KEYS, int RS>
+__device__ __forceinline__ void suppression_row_pair(const float* __restrict__ rows, const long long* __restrict__ row_keys,
+                                                     float jx1, float jy1, float jx2, float jy2, v2f jarea2, long long jkey,
+                                                     v2f negc, v2f r2, int& mine_lo, int& mine_hi, float& margin) {
+  const v2f ix1 = *reinterpret_cast<const v2f*>(rows + 0 * RS + I), iy1 = *reinterpret_cast<const v2f*>(rows + 1 * RS + I);
+  const v2f ix2 = *reinterpret_cast<const v2f*>(rows + 2 * RS + I), iy2 = *reinterpret_cast<const v2f*>(rows + 3 * RS + I);
+  const v2f iarea = *reinterpret_cast<const v2f*>(rows + 4 * RS + I);
+  float a0, a1, b0, b1, c0, c1, d0, d1;
+  asm("v_max_f32 %0, %1, %2" : "=v"(a0) : "v"(ix1.x), "v"(jx1));
+  asm("v_max_f32 %0, %1, %2" : "=v"(a1) : "v"(ix1.y), "v"(jx1));
+  asm("v_max_f32 %0, %1, %2" : "=v"(b0) : "v"(iy1.x), "v"(jy1));
+  asm("v_max_f32 %0, %1, %2" : "=v"(b1) : "v"(iy1.y), "v"(jy1));
+  asm("v_min_f32 %0, %1, %2" : "=v"(c0) : "v"(ix2.x), "v"(jx2));
+  asm("v_min_f32 %0, %1, %2" : "=v"(c1) : "v"(ix2.y), "v"(jx2));
+  asm("v_min_f32 %0, %1, %2" : "=v"(d0) : "v"(iy2.x), "v"(jy2));
+  asm("v_min_f32 %0, %1, %2" : "=v"(d1) : "v"(iy2.y), "v"(jy2));
+  const v2f dw = v2f{c0, c1} - v2f{a0, a1}, dh = v2f{d0, d1} - v2f{b0, b1};
+  v2f w, h;
+  w.x = 0.f < dw.x ? dw.x : 0.f;
+  w.y = 0.f < dw.y ? dw.y : 0.f;
+  h.x = 0.f < dh.x ? dh.x : 0.f;
+  h.y = 0.f < dh.y ? dh.y : 0.f;
+  const v2f inter = w * h;
+  const v2f uni = (iarea + jarea2) - inter;
+  const v2f t = __builtin_elementwise_fma(negc, uni, inter);
+  const v2f ru = r2 * uni;
+  u64 word0 = __ballot(t.x > ru.x), word1 = __ballot(t.y > ru.y);
+  const float m0 = __builtin_fabsf(t.x) - ru.x, m1 = __builtin_fabsf(t.y) - ru.y;
+  asm("v_min3_f32 %0, %0, %1, %2" : "+v"(margin) : "v"(m0), "v"(m1));
+  if (DIAG) {
+    word0 &= ~0ull << ((I + 1) & 63);                          // only columns after the row
+    word1 &= I + 1 < 63 ? (~0ull << ((I + 2) & 63)) : 0ull;
+  }
+  if (KEYS) {
+    word0 &= __ballot(jkey == row_keys[I]);
+    word1 &= __ballot(jkey == row_keys[I + 1]);
+  }
   // gfx9 takes the lane select of v_writelane from an SGPR or M0 (an inline constant assembles but selects the wrong
   // lane for I >= 32 — measured), and only one SGPR may sit on the constant bus: the row index goes through M0,
   // which the caller saves and restores around the 64 rows.  (M0 is a reserved register for this compiler: naming it
@@ -190,39 +211,53 @@ __device__ __forceinline__ void suppression_row(const float* __restrict__ rows, 
   // nothing between the pair can be given an M0 use by the compiler — this TU has no LDS-DMA, movrel or GWS code.)
   asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
                : "+v"(mine_lo), "+v"(mine_hi)
-               : "s"((int)(unsigned)word), "n"(I), "s"((int)(unsigned)(word >> 32)));
+               : "s"((int)(unsigned)word0), "n"(I), "s"((int)(unsigned)(word0 >> 32)));
+  asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+               : "+v"(mine_lo), "+v"(mine_hi)
+               : "s"((int)(unsigned)word1), "n"(I + 1), "s"((int)(unsigned)(word1 >> 32)));
 }
 
-template <bool DIAG, bool KEYS, int... Is>
+template <bool DIAG, bool KEYS, int RS, int... Is>
 __device__ __forceinline__ void suppression_rows(std::integer_sequence<int, Is...>, const float* __restrict__ rows,
                                                  const long long* __restrict__ row_keys, float jx1, float jy1, float jx2,
-                                                 float jy2, float jarea, long long jkey, ThrBand band, int& mine_lo,
-                                                 int& mine_hi, u64& undecided) {
-  (suppression_row<Is, DIAG, KEYS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided), ...);
+                                                 float jy2, v2f jarea2, long long jkey, v2f negc, v2f r2, int& mine_lo,
+                                                 int& mine_hi, float& margin) {
+  (suppression_row_pair<2 * Is, DIAG, KEYS, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi,
+                                                margin),
+   ...);
 }
 
-template <typename T>
-__device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, const long long* __restrict__ row_keys,
+template <typename T, int RS>
+__device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, const long long* __restrict__ row_keys, int nrows,
                                                 T jx1, T jy1, T jx2, T jy2, T jarea, long long jkey, bool jvalid, bool diag,
                                                 double thr, ThrBand band) {
   const u64 valid_cols = __ballot(jvalid);
   if constexpr (std::is_same<T, float>::value) {
-    int mine_lo = 0, mine_hi = 0, m0_save;
-    u64 undecided = 0ull;
-    const auto seq = std::make_integer_sequence<int, 64>{};
-    asm volatile("s_mov_b32 %0, m0" : "=s"(m0_save));
-    if (row_keys) {
-      if (diag) suppression_rows<true, true>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
-      else suppression_rows<false, true>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
-    } else {
-      if (diag) suppression_rows<true, false>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
-      else suppression_rows<false, false>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, band, mine_lo, mine_hi, undecided);
+    const int lane = threadIdx.x & 63;
+    const float rarea = rows[4 * RS + lane];
+    const bool out_of_range = (jvalid && !(jarea >= kAreaMin && jarea <= kAreaMax)) ||
+                              (lane < nrows && !(rarea >= kAreaMin && rarea <= kAreaMax));
+    if (__ballot(out_of_range) == 0ull) {
+      int mine_lo = 0, mine_hi = 0, m0_save;
+      float margin = INFINITY;
+      const v2f jarea2 = {jarea, jarea}, negc = {-band.c, -band.c}, r2 = {band.r, band.r};
+      const auto seq = std::make_integer_sequence<int, 32>{};
+      asm volatile("s_mov_b32 %0, m0" : "=s"(m0_save));
+      if (row_keys) {
+        if (diag) suppression_rows<true, true, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+        else suppression_rows<false, true, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+      } else {
+        if (diag) suppression_rows<true, false, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+        else suppression_rows<false, false, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+      }
+      asm volatile("s_mov_b32 m0, %0" : : "s"(m0_save));
+      // rows that do not exist hold zeros in the mask kernels (decided: inter = 0) or leftovers in the small-segment
+      // kernel (may or may not be decided: at worst a spurious exact evaluation of a last block)
+      if ((__ballot(!(margin > 0.f)) & valid_cols) == 0ull)
+        return (((u64)(unsigned)mine_hi << 32) | (u64)(unsigned)mine_lo) & valid_cols;
     }
-    asm volatile("s_mov_b32 m0, %0" : : "s"(m0_save));
-    if ((undecided & valid_cols) == 0ull)
-      return (((u64)(unsigned)mine_hi << 32) | (u64)(unsigned)mine_lo) & valid_cols;
   }
-  return suppression_tile_exact<T>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, valid_cols, diag, thr);
+  return suppression_tile_exact<T, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, valid_cols, diag, thr);
 }
 
 // mask layout: tile (rb, cb) = 64 words at mask + (rb*CB + cb)*64; word r = row rb*64+r.
@@ -230,7 +265,7 @@ template <typename T>
 __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     const T* __restrict__ dets, const int64_t* __restrict__ order, const int64_t* __restrict__ seg, int n, int CB,
     double thr, ThrBand band, u64* __restrict__ mask, int rb0) {
-  __shared__ T s_row[64][5];  // x1,y1,x2,y2,area of the row block
+  __shared__ __attribute__((aligned(16))) T s_row[5][64];  // x1,y1,x2,y2,area of the row block, component-major
   __shared__ long long s_seg[64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -251,11 +286,11 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
       y2 = b.y2;
       if (seg) sg = seg[oi];
     }
-    s_row[lane][0] = x1;
-    s_row[lane][1] = y1;
-    s_row[lane][2] = x2;
-    s_row[lane][3] = y2;
-    s_row[lane][4] = (x2 - x1) * (y2 - y1);
+    s_row[0][lane] = x1;
+    s_row[1][lane] = y1;
+    s_row[2][lane] = x2;
+    s_row[3][lane] = y2;
+    s_row[4][lane] = (x2 - x1) * (y2 - y1);
     s_seg[lane] = sg;
   }
   __syncthreads();
@@ -274,8 +309,8 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     if (seg) jseg = seg[oj];
   }
   const T jarea = (jx2 - jx1) * (jy2 - jy1);
-  const u64 mine = suppression_tile<T>(&s_row[0][0], seg ? s_seg : nullptr, jx1, jy1, jx2, jy2, jarea, jseg, jvalid,
-                                       cb == rb, thr, band);
+  const u64 mine = suppression_tile<T, 64>(&s_row[0][0], seg ? s_seg : nullptr, min(64, n - row0), jx1, jy1, jx2, jy2, jarea,
+                                           jseg, jvalid, cb == rb, thr, band);
   mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
 }
 
@@ -649,7 +684,7 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
                                                                          const int64_t* __restrict__ oidx,
                                                                          const int64_t* __restrict__ keys, int n, int CB,
                                                                          double thr, ThrBand band, u64* __restrict__ mask) {
-  __shared__ T s_row[64][5];
+  __shared__ __attribute__((aligned(16))) T s_row[5][64];
   __shared__ long long s_key[64];
   __shared__ int s_cbmax;
   const int lane = threadIdx.x & 63;
@@ -668,11 +703,11 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
       y2 = b.y2;
       k = keys[r];
     }
-    s_row[lane][0] = x1;
-    s_row[lane][1] = y1;
-    s_row[lane][2] = x2;
-    s_row[lane][3] = y2;
-    s_row[lane][4] = (x2 - x1) * (y2 - y1);
+    s_row[0][lane] = x1;
+    s_row[1][lane] = y1;
+    s_row[2][lane] = x2;
+    s_row[3][lane] = y2;
+    s_row[4][lane] = (x2 - x1) * (y2 - y1);
     s_key[lane] = k;
     if (lane == 0) {
       // column blocks that share a segment with this row block end with the segment of its last row; a
@@ -699,7 +734,8 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
       jkey = keys[j];
     }
     const T jarea = (jx2 - jx1) * (jy2 - jy1);
-    const u64 mine = suppression_tile<T>(&s_row[0][0], s_key, jx1, jy1, jx2, jy2, jarea, jkey, jvalid, cb == rb, thr, band);
+    const u64 mine = suppression_tile<T, 64>(&s_row[0][0], s_key, min(64, n - row0), jx1, jy1, jx2, jy2, jarea, jkey, jvalid,
+                                             cb == rb, thr, band);
     mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
   }
 }
@@ -891,7 +927,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict__ dets, const int64_t* __restrict__ order,
                                                             const int64_t* __restrict__ seg, int n, int S, double thr, ThrBand band,
                                                             SmallSegWorkspace ws) {
-  __shared__ T s_box[kSmallSegBoxes][5];
+  __shared__ __attribute__((aligned(16))) T s_box[5][kSmallSegBoxes];  // component-major
   __shared__ int s_wcnt[16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -923,11 +959,11 @@ __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict_
     const int pos = cnt + before + __popcll(bal & ((1ull << lane) - 1ull));
     if (mine && pos < kSmallSegBoxes) {
       const Box<T> b = load_box<T>(dets, oi);
-      s_box[pos][0] = b.x1;
-      s_box[pos][1] = b.y1;
-      s_box[pos][2] = b.x2;
-      s_box[pos][3] = b.y2;
-      s_box[pos][4] = (b.x2 - b.x1) * (b.y2 - b.y1);
+      s_box[0][pos] = b.x1;
+      s_box[1][pos] = b.y1;
+      s_box[2][pos] = b.x2;
+      s_box[3][pos] = b.y2;
+      s_box[4][pos] = (b.x2 - b.x1) * (b.y2 - b.y1);
       if (scribe) glist[pos] = g;
     }
     cnt += total;
@@ -954,9 +990,9 @@ __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict_
   const int j = cb * 64 + lane;
   const bool jvalid = j < cnt;
   const int jj = jvalid ? j : 0;
-  const T jx1 = s_box[jj][0], jy1 = s_box[jj][1], jx2 = s_box[jj][2], jy2 = s_box[jj][3], jarea = s_box[jj][4];
-  const u64 mine = suppression_tile<T>(&s_box[rb * 64][0], nullptr, jx1, jy1, jx2, jy2, jarea, 0, jvalid, cb == rb, thr,
-                                       band);
+  const T jx1 = s_box[0][jj], jy1 = s_box[1][jj], jx2 = s_box[2][jj], jy2 = s_box[3][jj], jarea = s_box[4][jj];
+  const u64 mine = suppression_tile<T, kSmallSegBoxes>(&s_box[0][rb * 64], nullptr, min(64, cnt - rb * 64), jx1, jy1, jx2, jy2,
+                                                       jarea, 0, jvalid, cb == rb, thr, band);
   ws.tiles[((size_t)me * kSmallSegTiles + t) * 64 + lane] = mine;
 }
 
