@@ -388,9 +388,10 @@ def test_roi_pool_and_ps_ops_vs_oracle(tv):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_roi_pool_wave_kernel_windows_and_bin_counts(tv, dtype):
-    """LDS-staged RoIPool: more than 64 bins (9x9), windows that do not fit the wave's LDS region (scanned from global
-    memory), RoIs sticking out of the map, empty bins, equal maxima (first one wins: argmax must match) — value and
-    argmax identical to the reference arithmetic (16-bit inputs: on the rounded values)."""
+    """Column-lane RoIPool kernel (7x7) and the lane-per-output kernel (other shapes): windows wider than a wave (64
+    columns: scanned bin by bin), RoIs sticking out of the map, empty bins, equal maxima (first one in (h, w) order
+    wins: argmax must match) — value and argmax identical to the reference arithmetic (16-bit inputs: on the rounded
+    values)."""
     g = gen(51)
     N, C, H, W = 2, 45, 60, 90
     x = (torch.randn(N, C, H, W, generator=g) * 4).round().to(dtype)        # many exact ties
@@ -405,6 +406,26 @@ def test_roi_pool_wave_kernel_windows_and_bin_counts(tv, dtype):
         ry, ra = O.roi_pool(x.float().numpy(), rois.to(dtype).float().numpy(), 0.125, P, P)
         assert y.dtype == dtype
         assert np.array_equal(y.float().cpu().numpy(), ry) and np.array_equal(a.cpu().numpy(), ra), P
+
+
+@pytest.mark.parametrize("C", [7, 33, 70, 130, 256, 300])
+def test_roi_pool_column_kernel_channel_partitions(tv, C):
+    """The 7x7 kernel deals (RoI, 32-channel chunk) units to 8 partitions (chunk = partition mod 8 when there are 8 or
+    more chunks, RoI slices when chunks divides 8, plain order otherwise): every channel count class, partial last
+    chunks, narrow windows (2 / 4 / 8 channels side by side in a wave), -inf / NaN / -FLT_MAX pixels."""
+    g = gen(60 + C)
+    N, H, W = 3, 40, 56
+    x = (torch.randn(N, C, H, W, generator=g) * 3).round()
+    x[:, ::5, ::7, ::3] = float("-inf")
+    x[:, 1::6, 3::11, 1::5] = float("nan")
+    x[:, 2::9, :, :] = -3.4028234663852886e38                                    # whole planes at -FLT_MAX: argmax -1
+    rois = rois_for(N, 150, W * 4, H * 4, 2, 200, g)
+    rois[:20, 3] = rois[:20, 1] + torch.rand(20, generator=g) * 24                # narrow windows: <= 8 columns
+    rois[20:40, 3] = rois[20:40, 1] + 30 + torch.rand(20, generator=g) * 30       # 8..16 columns
+    y, a = tv.roi_pool(x.to(DEV), rois.to(DEV), 0.25, 7, 7)
+    ry, ra = O.roi_pool(x.numpy(), rois.numpy(), 0.25, 7, 7)
+    assert np.array_equal(a.cpu().numpy(), ra)
+    assert np.array_equal(y.cpu().numpy(), ry, equal_nan=True)
 
 
 def test_roi_ops_autograd_on_gpu(tv):

@@ -170,7 +170,8 @@ if "roipool" in sections:
     from helpers import rois_for
     g = torch.Generator().manual_seed(3)
     x = torch.randn(4, 256, 100, 168, generator=g).to(dev)
-    rois = rois_for(4, 4000, 1344, 800, 32, 400, g).to(dev)
+    rois = rois_for(4, 4000, 1344, 800, 32, 400, g)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)].to(dev)      # grouped by image, as convert_boxes_to_roi_format emits them
     in_b, out_b = x.numel() * 4, 4000 * 256 * 49 * 4
     y, am = tv.roi_pool(x, rois, 0.125, 7, 7)
     t = tm(lambda: tv.roi_pool(x, rois, 0.125, 7, 7))

@@ -32,7 +32,8 @@ with torch.no_grad():
         from helpers import rois_for
         g = torch.Generator().manual_seed(3)
         x = torch.randn(4, 256, 100, 168, generator=g).to(dev)
-        rois = rois_for(4, 4000, 1344, 800, 32, 400, g).to(dev)
+        rois = rois_for(4, 4000, 1344, 800, 32, 400, g)
+        rois = rois[torch.argsort(rois[:, 0], stable=True)].to(dev)
         for _ in range(reps):
             torch.ops.torchvision.roi_pool(x, rois, 0.125, 7, 7)
     elif which == "nms100k":
