@@ -11,14 +11,15 @@
 //                RoI with roundf)
 // Work decomposition.
 //   roi_pool forward, 7x7, fp32 / fp16 / bf16 (`roi_pool_fwd_cols`): one wave64 per (RoI, 32-channel chunk), LANE =
-//   WINDOW COLUMN.  The reference shape — one thread per output scanning its own bin — leaves a wave executing the
-//   longest bin of its 64 lanes with dependent scalar-width loads; here the rows of the RoI window are walked once
-//   per pooled row `ph` (a window row is contiguous: one coalesced load per row, 2-8 channels side by side when the
-//   window is narrower than 32 / 16 / 8 columns, four rows in flight), every lane keeps the running (max, first
-//   index) of ITS column for the 7 pooled rows in registers, and the columns of a bin are then folded across lanes
-//   through a per-wave LDS transposition by the lane that owns the output (ties -> smaller index, which is the
-//   reference's first-in-scan-order).  Outputs and argmax leave as contiguous 49-element runs.  Windows wider than
-//   64 columns, other pooled shapes and fp64 take the lane-per-output kernel `roi_pool_fwd`.
+//   FOUR WINDOW COLUMNS of one of 4 / 8 channels.  The reference shape — one thread per output scanning its own bin —
+//   leaves a wave executing the longest bin of its 64 lanes with dependent 4-byte loads (measured: VALU-bound on
+//   574 M instructions, 1.29 ms).  Here the rows of the RoI window are walked once per pooled row `ph` (a window row is
+//   contiguous: one 16-byte load per lane and row, four rows in flight), every lane keeps the running (max, first
+//   row) of its four columns in registers, the columns of a pooled row are folded into its 7 bins across lanes through
+//   a 2 KB per-wave LDS transposition (double-buffered, so the fold of row ph overlaps the walk of ph + 1; ties ->
+//   smaller index, which is the reference's first-in-scan-order), and a lane keeps its 7 results until the pass ends.
+//   Channel chunks are pinned to XCDs (a chunk's planes fit one 4 MB L2), outputs leave as non-temporal stores.
+//   Windows wider than 64 columns, other pooled shapes and fp64 take the lane-per-output kernel `roi_pool_fwd`.
 //   Everything else: one lane per pooled output element with `pw` fastest, so a wave covers one or more complete
 //   pooled rows of one (roi, channel) — output / argmax / channel_mapping stores are contiguous, and the lanes of a
 //   wave read neighbouring input bins of the same plane (shared cache lines).  Backward kernels scatter with hardware
@@ -83,48 +84,70 @@ __global__ __launch_bounds__(kThreads) void roi_pool_fwd(const T* __restrict__ i
   }
 }
 
-// ---- roi_pool forward, lane = window column (see the header) -------------------------------------------------
-constexpr int kPoolChunk = 32;  // channels per wave
+// ---- roi_pool forward, lane = four window columns (see the header) -------------------------------------------
+constexpr int kPoolChunk = 32;     // channels per wave
+constexpr int kPoolThreads = 256;
 
-// one window row: every lane loads the pixel of its column (SGPR row pointer + a fixed 32-bit lane offset: no vector
-// address arithmetic per row) and keeps (max, ROW of the first maximum) — the row is a scalar operand of the select
+// four consecutive pixels of a row with ONE load per lane (16 bytes fp32 / 8 bytes 16-bit; element alignment is enough
+// on this memory path): the texture path retires a wave load in ~16 cycles whatever its width, so bytes per load are
+// what the row walk is bound by (measured with dword loads: data-return path 94 % busy)
 template <typename T>
-__device__ __forceinline__ float ld_row(const T* __restrict__ rowp, unsigned vbyte) {
-  // uniform 64-bit base + zero-extended 32-bit lane byte offset = the SGPR-base form of global_load
-  return ld(reinterpret_cast<const T*>(reinterpret_cast<const char*>(rowp) + vbyte));
+struct Quad;
+template <>
+struct Quad<float> {
+  typedef float raw __attribute__((ext_vector_type(4))) __attribute__((aligned(4)));
+  static __device__ __forceinline__ float cvt(float v) { return v; }
+};
+template <>
+struct Quad<__half> {
+  typedef unsigned short raw __attribute__((ext_vector_type(4))) __attribute__((aligned(2)));
+  static __device__ __forceinline__ float cvt(unsigned short v) { return __half2float(__ushort_as_half(v)); }
+};
+template <>
+struct Quad<__hip_bfloat16> {
+  typedef unsigned short raw __attribute__((ext_vector_type(4))) __attribute__((aligned(2)));
+  static __device__ __forceinline__ float cvt(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+};
+template <typename T>
+__device__ __forceinline__ typename Quad<T>::raw ld_quad(const T* __restrict__ rowp, unsigned vbyte) {
+  // uniform 64-bit row pointer + zero-extended 32-bit lane byte offset
+  return *reinterpret_cast<const typename Quad<T>::raw*>(reinterpret_cast<const char*>(rowp) + vbyte);
 }
+// (max, ROW of the first maximum) of the lane's four columns; strict compare, NaN never wins (cpu/roi_pool_kernel.cpp:83-88)
 template <typename T>
-__device__ __forceinline__ void pool_row(const T* __restrict__ rowp, unsigned vbyte, int h, float& av, int& ah) {
-  const float v = ld_row(rowp, vbyte);
-  const bool gt = v > av;  // strict, NaN never wins: cpu/roi_pool_kernel.cpp:83-88
-  ah = gt ? h : ah;
-  av = gt ? v : av;
+__device__ __forceinline__ void pool_quad(const typename Quad<T>::raw q, int h, float (&av)[4], int (&ah)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = Quad<T>::cvt(q[j]);
+    const bool gt = v > av[j];
+    ah[j] = gt ? h : ah[j];
+    av[j] = gt ? v : av[j];
+  }
 }
 
 template <typename T, int PH, int PW>
-__global__ __launch_bounds__(kThreads) void roi_pool_fwd_cols(const T* __restrict__ input, const T* __restrict__ rois,
-                                                              T* __restrict__ output, int* __restrict__ argmax, int K,
-                                                              int C, int H, int W, double spatial_scale) {
+__global__ __launch_bounds__(kPoolThreads) void roi_pool_fwd_cols(const T* __restrict__ input, const T* __restrict__ rois,
+                                                                  T* __restrict__ output, int* __restrict__ argmax, int K,
+                                                                  int C, int H, int W, double spatial_scale) {
   constexpr int kBins = PH * PW;
-  constexpr int kWaves = kThreads / 64;
-  __shared__ float2 s_col[kWaves][PH][64];  // per column: (max, bit pattern of its first index)
-  __shared__ int s_w[kWaves][8];            // per pw: w0 | w1 << 16 (window-relative), bit 31: bin row/col range empty
-  __shared__ int s_h[kWaves][8];            // per ph: 1 if the row range is empty
+  constexpr int kWaves = kPoolThreads / 64;
+  __shared__ float2 s_col[kWaves][2][256];   // per (channel slot, column): (max, bit pattern of its first index); one pooled row, double-buffered
+  __shared__ int s_w[kWaves][8];             // per pw: w0 | w1 << 16 (window-relative), negative: empty column range
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // unit -> (RoI k, channel chunk): the feature planes of one channel chunk of one image are a few MB — they fit the
   // 4 MB L2 of an XCD, the whole map does not.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 —
   // observed, a speed assumption only), so partition p = blockIdx % 8 owns the chunks c = p (mod 8) and walks the RoIs
-  // (sorted by image in every caller we know) in order, 4 consecutive RoIs per workgroup: an XCD's L2 then serves
-  // every re-read of a window instead of the fabric (measured: L2 hit 20 % -> see DESIGN.md).  With fewer than 8
-  // chunks the RoI list is split into 8 / chunks contiguous slices instead.
+  // (grouped by image in every caller we know) in order: an XCD's L2 then serves every re-read of a window instead of
+  // the fabric (measured: L2 hit 20 % -> 91 %).  With fewer than 8 chunks the RoI list is split into
+  // 8 / chunks contiguous slices instead.
   const int chunks = (C + kPoolChunk - 1) / kPoolChunk;
   int k, chunk;
   {
     const int part = blockIdx.x & 7, slot = blockIdx.x >> 3;
     if (chunks >= 8) {
-      const int mine = (chunks - part + 7) >> 3;           // chunks owned by this partition: part, part + 8, ...
-      const int64_t e = (int64_t)slot * kWaves + wave;     // entry in the partition's list, RoI fastest
+      const int mine = (chunks - part + 7) >> 3;        // chunks owned by this partition: part, part + 8, ...
+      const int64_t e = (int64_t)slot * kWaves + wave;  // entry in the partition's list, RoI fastest
       if (e >= (int64_t)mine * K) return;
       chunk = part + 8 * (int)(e / K);
       k = (int)(e % K);
@@ -192,100 +215,100 @@ __global__ __launch_bounds__(kThreads) void roi_pool_fwd_cols(const T* __restric
     return;
   }
 
-  // bin tables of this RoI (lanes 0..PW-1 / 0..PH-1 compute one entry each)
+  // bin tables of this RoI (lanes 0..7 compute one entry each)
   if (lane < 8) {
     const int w0 = clampi((int)floor((float)lane * bin_w) + rsw, 0, W), w1 = clampi((int)ceil((float)(lane + 1) * bin_w) + rsw, 0, W);
-    const int h0 = clampi((int)floor((float)lane * bin_h) + rsh, 0, H), h1 = clampi((int)ceil((float)(lane + 1) * bin_h) + rsh, 0, H);
     s_w[wave][lane] = w1 <= w0 ? (int)0x80000000 : ((w0 - X0) | ((w1 - X0) << 16));
-    s_h[wave][lane] = h1 <= h0;
   }
-  // G channels side by side: lane = (channel slot g, column)
-  const int wp = ww <= 8 ? 8 : (ww <= 16 ? 16 : (ww <= 32 ? 32 : 64));
-  const int G = 64 / wp;
-  const int g = lane / wp, col = lane % wp;
-  // lanes beyond the window / beyond C read a valid pixel (column X0 / channel c0) whose result is never consumed
-  const int x = X0 + (col < ww ? col : 0);
-  const int xs = min(x, W - 1);
+  // G channels side by side: lane = (channel slot g, column quad q); a channel has cw = 4 * wpq column slots in LDS
+  const int wq = (ww + 3) >> 2;
+  const int wpq = wq <= 8 ? 8 : 16;
+  const int G = 64 / wpq, cw = wpq * 4;  // 8 or 4 channels per pass
+  const int g = lane / wpq, q = lane % wpq;
+  // a quad never leaves its row (the last one is shifted left; re-read columns carry identical values); lanes beyond
+  // the window / beyond C read a valid quad whose result is never stored
+  const bool qvalid = q < wq;
+  const int xl = min(X0 + (qvalid ? 4 * q : 0), W - 4);
+  const int slot0 = xl - X0;  // window-relative column of the lane's first pixel (may be negative after the shift)
+  // fold stage: lane = (channel slot g2, pooled column pw) for lanes below 7 G (<= 56)
+  const int g2 = lane / PW, pw2 = lane % PW;
+  const bool folds = lane < PW * G;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int wr = s_w[wave][folds ? pw2 : 0];
+  const int fq0 = wr & 0xffff, fq1 = wr < 0 ? 0 : (wr >> 16);  // the bin's window-relative column range (empty: none)
   for (int cc = 0; cc < kPoolChunk; cc += G) {
     const int c = c0 + cc + g;
-    const unsigned voff = (unsigned)((c < C ? c : c0) * H * W + xs) * (unsigned)sizeof(T);  // bytes
-    float accv[PH];
-    int acch[PH];
+    const unsigned voff = (unsigned)((c < C ? c : c0) * H * W + xl) * (unsigned)sizeof(T);  // bytes
+    float resv[PH];
+    int resi[PH];
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
-      float av = -FLT_MAX;
-      int ah = -1;
+      float av[4] = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+      int ah[4] = {-1, -1, -1, -1};
       int h = hs[ph];
       const int e = he[ph];
       const T* rowp = img + (int64_t)h * W;
       for (; h + 4 <= e; h += 4) {  // four independent loads in flight
-        const float v0 = ld_row(rowp, voff), v1 = ld_row(rowp + W, voff), v2 = ld_row(rowp + 2 * W, voff), v3 = ld_row(rowp + 3 * W, voff);
-        bool gt = v0 > av;
-        ah = gt ? h : ah;
-        av = gt ? v0 : av;
-        gt = v1 > av;
-        ah = gt ? h + 1 : ah;
-        av = gt ? v1 : av;
-        gt = v2 > av;
-        ah = gt ? h + 2 : ah;
-        av = gt ? v2 : av;
-        gt = v3 > av;
-        ah = gt ? h + 3 : ah;
-        av = gt ? v3 : av;
+        const auto q0 = ld_quad(rowp, voff), q1 = ld_quad(rowp + W, voff), q2 = ld_quad(rowp + 2 * W, voff),
+                   q3 = ld_quad(rowp + 3 * W, voff);
+        pool_quad<T>(q0, h, av, ah);
+        pool_quad<T>(q1, h + 1, av, ah);
+        pool_quad<T>(q2, h + 2, av, ah);
+        pool_quad<T>(q3, h + 3, av, ah);
         rowp += 4 * (int64_t)W;
       }
       for (; h < e; ++h) {
-        pool_row(rowp, voff, h, av, ah);
+        pool_quad<T>(ld_quad(rowp, voff), h, av, ah);
         rowp += W;
       }
-      accv[ph] = av;
-      acch[ph] = ah;
-    }
+      float2* dst = &s_col[wave][ph & 1][g * cw];
+      if (qvalid) {
 #pragma unroll
-    for (int ph = 0; ph < PH; ++ph)
-      s_col[wave][ph][lane] = make_float2(accv[ph], __int_as_float(acch[ph] < 0 ? -1 : acch[ph] * W + x));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // fold the columns of each bin: lane = (channel slot, bin)
-    const int nout = kBins * G;
-    for (int o = lane; o < nout; o += 64) {
-      const int g2 = o / kBins, bin = o % kBins;
-      const int ph = bin / PW, pw = bin % PW;
-      const int wr = s_w[wave][pw];
-      const bool empty = wr < 0 || s_h[wave][ph] != 0;
+        for (int j = 0; j < 4; ++j)
+          if (slot0 + j >= 0) dst[slot0 + j] = make_float2(av[j], __int_as_float(ah[j] < 0 ? -1 : ah[j] * W + xl + j));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // fold the columns of bin (ph, pw2) of channel slot g2; the other buffer is being filled by the next pooled row
+      const bool empty = wr < 0 || e <= hs[ph];
       float best = empty ? 0.f : -FLT_MAX;
       int besti = -1;
-      if (!empty) {
-        const float2* sc = &s_col[wave][ph][g2 * wp];
-        const int q1 = wr >> 16;
-        for (int q = wr & 0xffff; q < q1; ++q) {
-          const float2 e = sc[q];
-          const int i = __float_as_int(e.y);
+      if (folds && !empty) {
+        const float2* sc = &s_col[wave][ph & 1][g2 * cw];
+        for (int qq = fq0; qq < fq1; ++qq) {
+          const float2 t = sc[qq];
+          const int i = __float_as_int(t.y);
           // larger value wins; equal values: the smaller index = the earlier position of the reference's (h, w) scan
-          if (e.x > best || (e.x == best && (unsigned)i < (unsigned)besti)) {
-            best = e.x;
+          if (t.x > best || (t.x == best && (unsigned)i < (unsigned)besti)) {
+            best = t.x;
             besti = i;
           }
         }
       }
-      if (c0 + cc + g2 < C) {
-        // write-once streams (2 x 200 MB at the measured shape) must not evict the feature planes from L2
+      resv[ph] = best;
+      resi[ph] = besti;
+    }
+    if (folds && c0 + cc + g2 < C) {
+      // write-once streams (2 x 200 MB at the measured shape) must not evict the feature planes from L2.  The seven
+      // stores of a lane are 28 bytes apart; together the wave fills G x 196 contiguous bytes.
+      const int64_t o0 = out0 + (int64_t)(cc + g2) * kBins + pw2;
+#pragma unroll
+      for (int ph = 0; ph < PH; ++ph) {
         T outv;
-        st(&outv, best);
+        st(&outv, resv[ph]);
         if constexpr (sizeof(T) == 2) {
           unsigned short bits;
           __builtin_memcpy(&bits, &outv, 2);
-          __builtin_nontemporal_store(bits, reinterpret_cast<unsigned short*>(output + out0 + (int64_t)cc * kBins + o));
+          __builtin_nontemporal_store(bits, reinterpret_cast<unsigned short*>(output + o0 + ph * PW));
         } else {
-          __builtin_nontemporal_store(outv, output + out0 + (int64_t)cc * kBins + o);
+          __builtin_nontemporal_store(outv, output + o0 + ph * PW);
         }
-        __builtin_nontemporal_store(besti, argmax + out0 + (int64_t)cc * kBins + o);
+        __builtin_nontemporal_store(resi[ph], argmax + o0 + ph * PW);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -474,17 +497,17 @@ extern "C" int tvmi_roi_pool_forward(const void* input, const void* rois, void* 
   TVMI_CHECK_ARG(input && rois && output && argmax, "roi_pool: null pointer");
   TVMI_CHECK_ARG(H * W < (1ll << 31), "roi_pool: plane too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (pooled_h == 7 && pooled_w == 7 && dt != TVMI_F64 && C * H * W < (1ll << 29) && W >= 1 && H >= 1 &&
+  if (pooled_h == 7 && pooled_w == 7 && dt != TVMI_F64 && C * H * W < (1ll << 29) && W >= 4 && H >= 1 &&
       K * ((C + tvmi::kPoolChunk - 1) / tvmi::kPoolChunk) < (1ll << 31)) {
     // grid: 8 partitions (see the kernel) x the workgroups of the longest partition
-    const int64_t chunks = (C + tvmi::kPoolChunk - 1) / tvmi::kPoolChunk, wpb = kThreads / 64;
+    const int64_t chunks = (C + tvmi::kPoolChunk - 1) / tvmi::kPoolChunk, wpb = tvmi::kPoolThreads / 64;
     int64_t blocks;
     if (chunks >= 8) blocks = 8 * ((((chunks + 7) / 8) * K + wpb - 1) / wpb);
     else if (8 % chunks == 0) blocks = 8 * (((K + (8 / chunks) - 1) / (8 / chunks) + wpb - 1) / wpb);
     else blocks = (K * chunks + wpb - 1) / wpb;
     const dim3 grid((unsigned)blocks);
 #define TVMI_POOL_COLS(scalar_t)                                                                                      \
-  tvmi::roi_pool_fwd_cols<scalar_t, 7, 7><<<grid, dim3(kThreads), 0, s>>>((const scalar_t*)input, (const scalar_t*)rois, \
+  tvmi::roi_pool_fwd_cols<scalar_t, 7, 7><<<grid, dim3(tvmi::kPoolThreads), 0, s>>>((const scalar_t*)input, (const scalar_t*)rois, \
                                                                           (scalar_t*)output, argmax, (int)K, (int)C,    \
                                                                           (int)H, (int)W, spatial_scale)
     if (dt == TVMI_F32) TVMI_POOL_COLS(float);
