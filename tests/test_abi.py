@@ -69,6 +69,26 @@ def test_kernel_library_is_pure_c_abi():
     assert not any("torch" in n or "c10" in n for n in needed), needed
 
 
+def test_stable_glue_is_stable_abi_only():
+    """tvmi_torch_stable.so (the `_C_stable` role: CUDA kernels of nms and box_iou_rotated, the two ops the reference keeps
+    on the stable ABI — cuda/nms_kernel.cu:262, cuda/box_iou_rotated_kernel.cu:192) must reach torch only through the C
+    shim: no ATen / c10 C++ symbol among its undefined symbols, no libc10 among its dependencies."""
+    import subprocess
+
+    import vision_amd
+
+    so = vision_amd._loader.STABLE_SHIM_SO
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", so], text=True).split("\n")
+    cxx_torch = [u for u in undefined if "_ZN2at" in u or "_ZN3c10" in u or "_ZNK2at" in u or "_ZNK3c10" in u or "_ZN5torch" in u]
+    assert not cxx_torch, cxx_torch[:5]
+    assert any("torch_call_dispatcher" in u or "aoti_torch_" in u for u in undefined)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", subprocess.check_output(["readelf", "-d", so], text=True))
+    assert not any("c10" in n for n in needed), needed
+    # and the classic glue no longer carries those two kernels: they are registered exactly once
+    assert torch._C._dispatch_has_kernel_for_dispatch_key("torchvision::nms", "CUDA")
+    assert torch._C._dispatch_has_kernel_for_dispatch_key("torchvision::box_iou_rotated", "CUDA")
+
+
 def test_schemas_are_the_reference_strings(tv):
     for name, schema in REFERENCE_SCHEMAS.items():
         op = getattr(tv, name).default

@@ -27,7 +27,7 @@ def t(a, dtype=None):
 def test_native_library_is_the_one_running():
     assert torch.cuda.is_available()
     maps = open("/proc/self/maps").read()
-    assert "libtvmi_kernels.so" in maps and "tvmi_torch.so" in maps
+    assert "libtvmi_kernels.so" in maps and "tvmi_torch.so" in maps and "tvmi_torch_stable.so" in maps
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 

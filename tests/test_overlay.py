@@ -80,7 +80,7 @@ def test_reference_python_on_the_gpu_lands_in_our_kernels(tmp_path):
         import vision_amd                               # TVMI_NO_PY_REGISTRATIONS=1: the reference's registrations rule
         from oracle import oracle as O
         maps = open("/proc/self/maps").read()
-        assert "libtvmi_kernels.so" in maps and "tvmi_torch.so" in maps
+        assert "libtvmi_kernels.so" in maps and "tvmi_torch.so" in maps and "tvmi_torch_stable.so" in maps
         dev = "cuda"
         g = torch.Generator().manual_seed(0)
         b = torch.rand(3000, 4, generator=g) * 300; b[:, 2:] += b[:, :2]

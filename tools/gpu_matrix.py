@@ -1,7 +1,7 @@
 """Measured config matrix (run on the GPU box): every timing quoted in DESIGN.md §6 comes from the JSON this writes
 (gpurun_out/<tag>/matrix.json, copied to profiles/).  Events on the current stream, inputs resident in HBM.
 
-    python tools/gpu_matrix.py [out.json] [section ...]      sections: c2 c1 c3 c4 resize post roipool (default: all)
+    python tools/gpu_matrix.py [out.json] [section ...]      sections: c2 c1 c3 c4 resize post roipool iou (default: all)
 """
 import json
 import os
@@ -19,7 +19,7 @@ from vision_amd.poolers import LevelMapper, _convert_to_roi_format
 dev = torch.device("cuda:0")
 tv = torch.ops.torchvision
 out_path = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".json") else None
-sections = [a for a in sys.argv[1:] if not a.endswith(".json")] or ["c2", "c1", "c3", "c4", "resize", "post", "roipool"]
+sections = [a for a in sys.argv[1:] if not a.endswith(".json")] or ["c2", "c1", "c3", "c4", "resize", "post", "roipool", "iou"]
 res = {"device": torch.cuda.get_device_name(0), "torch": torch.__version__}
 
 
@@ -187,6 +187,34 @@ if "roipool" in sections:
     put("ps_roi_pool_fwd", tm(lambda: tv.ps_roi_pool(xp, rois, 0.125, 7, 7)))
     put("ps_roi_pool_bwd", tm(lambda: tv._ps_roi_pool_backward(gp, rois, mq, 0.125, 7, 7, 4, 245, 100, 168), n=10))
     put("roi_align_fwd_same_workload_for_scale", tm(lambda: tv.roi_align(x, rois, 0.125, 7, 7, 2, False)))
+
+if "iou" in sections:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import random_boxes
+    g = torch.Generator().manual_seed(5)
+    a = random_boxes(4000, 1333, 800, 8, 400, g).to(dev)
+    b = random_boxes(4000, 1333, 800, 8, 400, g).to(dev)
+    for name, fn in (("box_iou", vision_amd.box_iou), ("generalized_box_iou", vision_amd.generalized_box_iou),
+                     ("distance_box_iou", vision_amd.distance_box_iou), ("complete_box_iou", vision_amd.complete_box_iou)):
+        t = tm(lambda: fn(a, b))
+        put(f"{name}_4000x4000", t, Gpairs_per_s=round(16e6 / t / 1e6, 1), out_GBs=round(64e6 / 1e6 / t))
+
+    def tensor_math_iou(x, y):     # the reference's broadcast formulation (ops/boxes.py:314-391) on the same GPU
+        area1 = (x[:, 2] - x[:, 0]) * (x[:, 3] - x[:, 1])
+        area2 = (y[:, 2] - y[:, 0]) * (y[:, 3] - y[:, 1])
+        lt = torch.max(x[:, None, :2], y[:, :2])
+        rb = torch.min(x[:, None, 2:], y[:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, :, 0] * wh[:, :, 1]
+        return inter / (area1[:, None] + area2 - inter)
+    put("box_iou_4000x4000_torch_tensor_math", tm(lambda: tensor_math_iou(a, b), n=10))
+    # rotated boxes (cx, cy, w, h, angle)
+    ra = torch.cat([torch.rand(2000, 2, generator=g) * 800, torch.rand(2000, 2, generator=g) * 200 + 4,
+                    (torch.rand(2000, 1, generator=g) - 0.5) * 180], 1).to(dev)
+    rb_ = torch.cat([torch.rand(2000, 2, generator=g) * 800, torch.rand(2000, 2, generator=g) * 200 + 4,
+                     (torch.rand(2000, 1, generator=g) - 0.5) * 180], 1).to(dev)
+    t = tm(lambda: tv.box_iou_rotated(ra, rb_), n=10)
+    put("box_iou_rotated_2000x2000", t, Mpairs_per_s=round(4e6 / t / 1e3, 1))
 
 if out_path:
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)

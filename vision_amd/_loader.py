@@ -1,8 +1,10 @@
-"""Locates and loads the two in-tree native libraries of vision_amd.
+"""Locates and loads the three in-tree native libraries of vision_amd.
 
-    _lib/libtvmi_kernels.so   hand-written gfx950 kernels behind the C ABI of include/tvmi.h
-    _lib/tvmi_torch.so        dispatcher glue registering the `torchvision::` schemas
-                              (role of `_C` / `_C_stable` in torchvision/extension.py:8-33)
+    _lib/libtvmi_kernels.so    hand-written gfx950 kernels behind the C ABI of include/tvmi.h
+    _lib/tvmi_torch.so         dispatcher glue: the `torchvision::` schemas + the classic-ABI CUDA-key kernels
+                               (role of `_C` in torchvision/extension.py:8-33)
+    _lib/tvmi_torch_stable.so  stable-ABI glue: the CUDA-key kernels of `nms` and `box_iou_rotated`
+                               (role of `_C_stable`; the same two ops the reference keeps on the stable ABI)
 
 There is deliberately NO python / eager fallback: if the extension is missing the import
 fails loudly (`TVMI_ALLOW_MISSING=1` only lets pure-host helpers import for docs/tooling).
@@ -16,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "_lib")
 KERNELS_SO = os.path.join(LIB_DIR, "libtvmi_kernels.so")
 SHIM_SO = os.path.join(LIB_DIR, "tvmi_torch.so")
+STABLE_SHIM_SO = os.path.join(LIB_DIR, "tvmi_torch_stable.so")
 
 _state = {"loaded": False, "kernels": None}
 
@@ -29,10 +32,10 @@ def is_loaded() -> bool:
 
 
 def load():
-    """Load libtvmi_kernels.so + tvmi_torch.so (idempotent)."""
+    """Load libtvmi_kernels.so, tvmi_torch.so and tvmi_torch_stable.so (idempotent)."""
     if _state["loaded"]:
         return
-    for path in (KERNELS_SO, SHIM_SO):
+    for path in (KERNELS_SO, SHIM_SO, STABLE_SHIM_SO):
         if not os.path.exists(path):
             raise ExtensionMissing(
                 f"vision_amd native extension not built: {path} is missing. "
@@ -41,7 +44,8 @@ def load():
     # torch is imported above, so its libamdhip64.so.7 is already mapped; the kernels
     # library binds to that single HIP runtime (same SONAME) instead of a second copy.
     _state["kernels"] = ctypes.CDLL(KERNELS_SO, mode=ctypes.RTLD_GLOBAL)
-    torch.ops.load_library(SHIM_SO)
+    torch.ops.load_library(SHIM_SO)         # defines the schemas: first
+    torch.ops.load_library(STABLE_SHIM_SO)
     _state["loaded"] = True
 
 

@@ -160,9 +160,6 @@ std::tuple<at::Tensor, at::Tensor> nms_segmented_padded(const at::Tensor& dets, 
 }
 
 
-at::Tensor nms(const at::Tensor& dets, const at::Tensor& scores, double iou_threshold) {
-  return nms_segmented(dets, scores, c10::nullopt, iou_threshold, -1);
-}
 
 // ---- roi_align: cuda/roi_align_kernel.cu:334-466
 at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, double spatial_scale,
@@ -519,27 +516,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_co
   return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
 }
 
-// ---- box_iou_rotated: cuda/box_iou_rotated_kernel.cu:92-188
-at::Tensor box_iou_rotated(const at::Tensor& boxes1, const at::Tensor& boxes2) {
-  TORCH_CHECK(boxes1.is_cuda(), "boxes1 must be a CUDA tensor");
-  TORCH_CHECK(boxes2.is_cuda(), "boxes2 must be a CUDA tensor");
-  TORCH_CHECK(boxes1.dim() == 2 && boxes1.size(1) == 5, "boxes1 must have shape (N, 5)");
-  TORCH_CHECK(boxes2.dim() == 2 && boxes2.size(1) == 5, "boxes2 must have shape (M, 5)");
-  TORCH_CHECK(boxes1.scalar_type() == boxes2.scalar_type(), "boxes1 and boxes2 must have the same dtype");
-  c10::DeviceGuard guard(boxes1.device());
-  at::Tensor b1 = boxes1.contiguous(), b2 = boxes2.contiguous();
-  if (b1.scalar_type() == at::kHalf || b1.scalar_type() == at::kBFloat16) {
-    b1 = b1.to(at::kFloat);
-    b2 = b2.to(at::kFloat);
-  }
-  const int64_t N = b1.size(0), M = b2.size(0);
-  at::Tensor ious = at::empty({N, M}, b1.options().dtype(at::kFloat));
-  if (N > 0 && M > 0)
-    check_status(tvmi_box_iou_rotated(b1.const_data_ptr(), b2.const_data_ptr(), ious.mutable_data_ptr<float>(),
-                                      dtype_of(b1, "box_iou_rotated"), N, M, current_stream(boxes1)),
-                 "box_iou_rotated");
-  return ious;
-}
+// ---- box_iou_rotated, nms: stable-ABI kernels, torch_shim_stable.cpp (as in the reference: cuda/box_iou_rotated_kernel.cu:192,
+// cuda/nms_kernel.cu:262)
 
 // ---- resize (aten::upsample_* arithmetic; see include/tvmi.h).  mode: 0 nearest, 1 nearest-exact,
 // 2 bilinear, 3 bicubic.  Input [N,C,H,W] (any strides; made contiguous), output [N,C,OH,OW].
@@ -1110,7 +1088,6 @@ TORCH_LIBRARY(tvmi, m) {
 }
 
 TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
-  m.impl("nms", &nms);
   m.impl("roi_align", &roi_align_forward);
   m.impl("_roi_align_backward", &roi_align_backward);
   m.impl("roi_pool", &roi_pool_forward);
@@ -1121,7 +1098,6 @@ TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
   m.impl("_ps_roi_pool_backward", &ps_roi_pool_backward);
   m.impl("deform_conv2d", &deform_conv2d_forward);
   m.impl("_deform_conv2d_backward", &deform_conv2d_backward);
-  m.impl("box_iou_rotated", &box_iou_rotated);
 }
 
 TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
