@@ -1,4 +1,5 @@
-"""Randomised parity sweep against the oracle (NMS paths, RoIAlign NCHW / channels_last, backward); ~30 s on the box."""
+"""Randomised parity sweep against the oracle (NMS paths incl. the chunked large path and degenerate boxes, RoIAlign NCHW /
+channels_last / tile-owner backward 7x7 + 14x14, RoIPool column kernel); ~45 s on the box.  python tools/fuzz_gpu.py [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,11 +9,16 @@ dev = torch.device("cuda:0"); tv = torch.ops.torchvision
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 def ri(a, b): return int(torch.randint(a, b + 1, (1,), generator=g))
 t0 = time.time(); cases = 0
-while time.time() - t0 < 25:
+while time.time() - t0 < 40:
     # ---- NMS / batched NMS
-    n = ri(1, 6000); canvas = float(ri(20, 800)); S = ri(1, 40)
+    n = ri(1, 6000) if ri(0, 7) else ri(6000, 25000); canvas = float(ri(20, 800)); S = ri(1, 40)
     xy = torch.rand(n, 2, generator=g) * canvas; wh = torch.rand(n, 2, generator=g) * ri(2, 120)
     b = torch.cat([xy, xy + wh], 1)
+    if ri(0, 5) == 0:                                     # degenerate boxes: zero area, inverted, tiny / huge scale
+        k0 = ri(3, 50); b[::k0, 2:] = b[::k0, :2]
+        k1 = ri(3, 50); b[1::k1, 2] = b[1::k1, 0] - 1.0
+        if ri(0, 1): b[2::ri(5, 60)] *= 2.0 ** -38
+        if ri(0, 1): b[3::ri(5, 60)] *= 2.0 ** 33
     s = torch.rand(n, generator=g)
     if ri(0, 2) == 0: s = (s * ri(2, 50)).floor() / 16
     idx = torch.randint(0, S, (n,), generator=g)
@@ -42,5 +48,19 @@ while time.time() - t0 < 25:
     gi = tv._roi_align_backward(gr.to(dev), rois.to(dev), scale, 7, 7, N, C, H, W, 2, aligned)
     refb = O.roi_align_backward(gr.numpy(), rois.numpy(), scale, 7, 7, N, C, H, W, 2, aligned)
     assert np.abs(gi.cpu().numpy() - refb).max() < 1e-4 * max(1.0, float(np.abs(refb).max())), ("roi bwd", N, C, H, W)
+    if ri(0, 3) == 0:                                     # 14x14 backward (owner kernel, 14x14 instantiation)
+        gr = torch.randn(k, C, 14, 14, generator=g)
+        gi = tv._roi_align_backward(gr.to(dev), rois.to(dev), scale, 14, 14, N, C, H, W, 2, aligned)
+        refb = O.roi_align_backward(gr.numpy(), rois.numpy(), scale, 14, 14, N, C, H, W, 2, aligned)
+        assert np.abs(gi.cpu().numpy() - refb).max() < 1e-4 * max(1.0, float(np.abs(refb).max())), ("roi bwd14", N, C, H, W)
+    # ---- RoIPool 7x7 (column kernel): value and argmax bit-exact, ties from rounded values
+    C2 = [ri(1, 40), ri(40, 130), ri(250, 300)][ri(0, 2)]
+    xp = (torch.randn(N, C2, H, W, generator=g) * 2).round()
+    if ri(0, 1): rois_p = rois[torch.argsort(rois[:, 0], stable=True)]
+    else: rois_p = rois
+    dt = [torch.float32, torch.float16, torch.bfloat16][ri(0, 2)]
+    yp, ap = tv.roi_pool(xp.to(dt).to(dev), rois_p.to(dt).to(dev), scale, 7, 7)
+    ryp, rap = O.roi_pool(xp.to(dt).float().numpy(), rois_p.to(dt).float().numpy(), scale, 7, 7)
+    assert np.array_equal(ap.cpu().numpy(), rap) and np.array_equal(yp.float().cpu().numpy(), ryp), ("roi_pool", N, C2, H, W, dt)
     cases += 1
-print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, roi_align NCHW + channels_last + backward)")
+print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, roi_align NCHW + channels_last + backward, roi_pool)")
