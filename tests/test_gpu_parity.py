@@ -572,6 +572,27 @@ def test_resize_vs_installed_torch_cpu(mode, aa):
         np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("align", [False, True])
+def test_resize_bilinear_tile_kernel_shapes(align):
+    """The LDS-tiled bilinear kernel (256 x 4 output tiles, patch staged with 16-byte loads) at its corner cases: widths
+    that are no multiple of 4 / 256, rows that are no multiple of 4, inputs 4..9 pixels wide (shifted last quad), up- and
+    down-scales up to its limits (1.49 / 2.3; beyond: the per-output kernel), align_corners — against torch CPU."""
+    g = gen(71)
+    cases = [((5, 4), (7, 9)), ((9, 7), (4, 4)), ((33, 257), (40, 258)), ((61, 301), (50, 203)), ((64, 511), (30, 345)),
+             ((135, 240), (100, 178)), ((37, 53), (111, 160)), ((20, 300), (9, 201)), ((50, 1000), (23, 700)),
+             ((17, 260), (17, 260)), ((12, 9), (30, 1031))]
+    for (ih, iw), (oh, ow) in cases:
+        # the launcher takes the tiled kernel from 16384 tile-planes on: enough planes for every shape
+        tiles = -(-ow // 256) * -(-oh // 4)
+        img = torch.rand(1, -(-16384 // tiles) + 3, ih, iw, generator=g)
+        ref = F.interpolate(img, size=(oh, ow), mode="bilinear", align_corners=align)
+        out = vision_amd.interpolate(img.to(DEV), size=(oh, ow), mode="bilinear", align_corners=align)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=TOL, err_msg=f"{ih}x{iw}->{oh}x{ow}")
+        out16 = vision_amd.interpolate(img.to(DEV, torch.bfloat16), size=(oh, ow), mode="bilinear", align_corners=align)
+        ref16 = F.interpolate(img.to(torch.bfloat16).float(), size=(oh, ow), mode="bilinear", align_corners=align)
+        np.testing.assert_allclose(out16.float().cpu().numpy(), ref16.numpy(), rtol=0, atol=2e-2)
+
+
 def test_resize_image_wrapper_uint8():
     g = gen(19)
     img = torch.randint(0, 256, (3, 120, 160), generator=g, dtype=torch.uint8)
