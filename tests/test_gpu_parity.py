@@ -593,6 +593,27 @@ def test_resize_bilinear_tile_kernel_shapes(align):
         np.testing.assert_allclose(out16.float().cpu().numpy(), ref16.numpy(), rtol=0, atol=2e-2)
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_resize_antialias_tile_kernel_shapes(mode):
+    """The LDS-tiled anti-aliased kernel (separable inside a 256 x 4 output tile; both axes <= 8 taps) at its corner
+    cases — ragged widths / heights, narrow inputs, image edges inside a tile, up- and down-scales up to its limits —
+    against torch CPU F.interpolate(antialias=True)."""
+    g = gen(72)
+    cases = [((9, 8), (7, 6)), ((33, 257), (30, 200)), ((61, 301), (50, 223)), ((64, 340), (48, 255)), ((135, 240), (100, 178)),
+             ((37, 53), (111, 160)), ((40, 300), (17, 230)), ((50, 1000), (40, 700)), ((17, 260), (17, 260)), ((24, 9), (30, 1031)),
+             ((100, 128), (29, 100))]
+    for (ih, iw), (oh, ow) in cases:
+        tiles = -(-ow // 256) * -(-oh // 4)
+        img = torch.rand(1, -(-16384 // tiles) + 3, ih, iw, generator=g)
+        ref = F.interpolate(img, size=(oh, ow), mode=mode, align_corners=False, antialias=True)
+        out = vision_amd.interpolate(img.to(DEV), size=(oh, ow), mode=mode, align_corners=False, antialias=True)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=TOL, err_msg=f"{mode} {ih}x{iw}->{oh}x{ow}")
+    img = torch.rand(1, 5000, 61, 301, generator=g)
+    out16 = vision_amd.interpolate(img.to(DEV, torch.float16), size=(50, 223), mode=mode, align_corners=False, antialias=True)
+    ref16 = F.interpolate(img.to(torch.float16).float(), size=(50, 223), mode=mode, align_corners=False, antialias=True)
+    np.testing.assert_allclose(out16.float().cpu().numpy(), ref16.numpy(), rtol=0, atol=4e-3)
+
+
 def test_resize_image_wrapper_uint8():
     g = gen(19)
     img = torch.randint(0, 256, (3, 120, 160), generator=g, dtype=torch.uint8)

@@ -300,6 +300,135 @@ __global__ void aa_table_kernel(float* __restrict__ table, int out_size, int in_
   row[1] = __int_as_float(min(xsize, taps));
 }
 
+// ---- anti-aliased, LDS-tiled: one wave = 256 output columns x 4 output rows of a few planes -------------------------
+// Separable inside the tile: the input patch (<= 16 rows x 380 columns) is staged with 16-byte loads, every lane forms
+// the HORIZONTAL sums of its four output columns for every patch row (taps from LDS, weights in registers — the same
+// operations in the same order as aa2d_kernel), then the four output rows are the VERTICAL combinations of those row
+// sums; the vertical weights of the tile are one 4 x 16 matrix held across the lanes of a VGPR and enter as scalars
+// (v_readlane), rows outside an output row's support are skipped (their weight is exactly 0).  The per-output
+// kernels issue taps_y x taps_x gathers per output (20-56 at a 1.35x downscale) and are bound by the texture path;
+// here a patch pixel is fetched once per tile.  Both axes <= 8 taps (scale <= 3.5 bilinear, <= 1.75 bicubic).
+constexpr int kAATaps = 8, kAARows = 16;
+
+template <typename T>
+__global__ __launch_bounds__(64) void aa2d_tile_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                       const float* __restrict__ ytab, const float* __restrict__ xtab,
+                                                       int NC, int IH, int IW, int OH, int OW, int ytaps, int xtaps,
+                                                       int nc_per_block) {
+  typedef typename Vec4<T>::raw raw4;
+  __shared__ float patch[kAARows][kPatchCols];
+  const int lane = threadIdx.x;
+  const int ox0 = blockIdx.x * kTileW, oy0 = blockIdx.y * kTileRows;
+  // cells right of the image edge are read with weight 0 (the table rows are zero padded): make them finite once
+  for (int i = lane; i < kAARows * kPatchCols; i += 64) (&patch[0][0])[i] = 0.f;
+  // the lane's four output columns: first tap and weights
+  int cx[4];
+  float wx[4][kAATaps];
+  const int nx = min(4, OW - (ox0 + 4 * lane));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* xr = xtab + (int64_t)min(ox0 + 4 * lane + j, OW - 1) * (xtaps + 2);
+    cx[j] = __float_as_int(xr[0]);
+#pragma unroll
+    for (int i = 0; i < kAATaps; ++i) wx[j][i] = i < xtaps ? xr[2 + i] : 0.f;
+  }
+  const int xin0 = __builtin_amdgcn_readfirstlane(__float_as_int(xtab[(int64_t)ox0 * (xtaps + 2)]));
+  const int xlast = __builtin_amdgcn_readfirstlane(__float_as_int(xtab[(int64_t)min(ox0 + kTileW - 1, OW - 1) * (xtaps + 2)]));
+  const int ncols = min(xlast + kAATaps, IW) - xin0;  // staged columns (every tap index below stays inside the patch)
+  const int nq = (ncols + 3) >> 2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cx[j] -= xin0;
+  // rows: patch origin, and the 4 x 16 matrix of vertical weights: lane (ro * 16 + r) holds the weight of patch row r
+  // in output row ro (0 outside its support)
+  const int ylo = min(oy0, OH - 1), yhi = min(oy0 + kTileRows - 1, OH - 1);
+  const int yin0 = __builtin_amdgcn_readfirstlane(__float_as_int(ytab[(int64_t)ylo * (ytaps + 2)]));
+  const float* ylr = ytab + (int64_t)yhi * (ytaps + 2);
+  const int nrows = __builtin_amdgcn_readfirstlane(__float_as_int(ylr[0]) + __float_as_int(ylr[1])) - yin0;
+  float wv;
+  {
+    const int ro = lane >> 4, r = lane & 15;
+    const float* yr = ytab + (int64_t)min(oy0 + ro, OH - 1) * (ytaps + 2);
+    const int t = r - (__float_as_int(yr[0]) - yin0);
+    wv = (t >= 0 && t < __float_as_int(yr[1])) ? yr[2 + t] : 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nc0 = blockIdx.z * nc_per_block, nc1 = min(NC, nc0 + nc_per_block);
+  const int64_t iplane = (int64_t)IH * IW, oplane = (int64_t)OH * OW;
+  for (int nc = nc0; nc < nc1; ++nc) {
+    const T* p = in + nc * iplane + (int64_t)yin0 * IW;
+    for (int q = lane; q < nq; q += 64) {
+      // a quad never leaves its row: the last one is shifted left, re-written columns carry identical values
+      const int xsrc = min(xin0 + 4 * q, IW - 4);
+      const int c = xsrc - xin0;
+#pragma unroll
+      for (int r0 = 0; r0 < kAARows; r0 += 8) {  // eight rows in flight
+        raw4 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r0 + r < nrows) v[r] = *reinterpret_cast<const raw4*>(p + (int64_t)(r0 + r) * IW + xsrc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r0 + r < nrows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (c + j >= 0) patch[r0 + r][c + j] = Vec4<T>::up(v[r][j]);
+          }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float acc[kTileRows][4];
+#pragma unroll
+    for (int ro = 0; ro < kTileRows; ++ro)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ro][j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < kAARows; ++r) {
+      if (r < nrows) {
+        float h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* row = &patch[r][cx[j]];
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < kAATaps; ++i) t += row[i] * wx[j][i];
+          h[j] = t;
+        }
+#pragma unroll
+        for (int ro = 0; ro < kTileRows; ++ro) {
+          const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wv), ro * 16 + r));
+          if (w != 0.f) {  // wave-uniform: outside the output row's support
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ro][j] += h[j] * w;
+          }
+        }
+      }
+    }
+    if (nx > 0) {
+#pragma unroll
+      for (int ro = 0; ro < kTileRows; ++ro) {
+        if (oy0 + ro < OH) {
+          raw4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = Vec4<T>::down(acc[ro][j]);
+          T* dst = out + nc * oplane + (int64_t)(oy0 + ro) * OW + ox0 + 4 * lane;
+          if (nx == 4) {
+            __builtin_nontemporal_store(o, reinterpret_cast<raw4*>(dst));
+          } else {
+            for (int j = 0; j < nx; ++j) reinterpret_cast<decltype(Vec4<T>::down(0.f))*>(dst)[j] = o[j];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // Output-stationary, one lane per output column.  The x weights of the lane's column live in registers for the
 // whole block (MAXT compile-time taps, zero beyond xsize — the table rows are zero padded), the y weights of the
 // block's output row are wave-uniform (scalar loads), and the tap loop is fully unrolled: ysize x MAXT independent
@@ -596,6 +725,26 @@ extern "C" int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt
                                                                          align_corners);
   aa_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, sw, mode, xt,
                                                                          align_corners);
+  // LDS-tiled kernel: both axes within 8 taps, the patch of a 256 x 4 output tile within its LDS block, enough tiles
+  {
+    const double need_cols = std::ceil((double)(kTileW - 1) * (double)sw) + kAATaps + 2.0;
+    const double need_rows = std::ceil((double)(kTileRows - 1) * (double)sh) + yt + 2.0;
+    const int64_t tiles = ceil_div(OW, kTileW) * ceil_div(OH, kTileRows);
+    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(8, NC * tiles / 8192));
+    const dim3 grid((unsigned)ceil_div(OW, kTileW), (unsigned)ceil_div(OH, kTileRows), (unsigned)ceil_div(NC, per));
+    if (dt != TVMI_F64 && IW >= 4 && xt <= kAATaps && yt <= kAATaps && need_cols <= (double)(kPatchCols - 4) &&
+        need_rows <= (double)kAARows && grid.z <= 65535 && NC * tiles >= 16384) {
+#define TVMI_AA_TILE(scalar_t)                                                                                          \
+  aa2d_tile_kernel<scalar_t><<<grid, dim3(64), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)NC, (int)IH, \
+                                                      (int)IW, (int)OH, (int)OW, yt, xt, per)
+      if (dt == TVMI_F32) TVMI_AA_TILE(float);
+      else if (dt == TVMI_F16) TVMI_AA_TILE(__half);
+      else if (dt == TVMI_BF16) TVMI_AA_TILE(__hip_bfloat16);
+      else return ::tvmi::set_error(hipErrorInvalidValue, "upsample_aa2d: unsupported dtype");
+#undef TVMI_AA_TILE
+      TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_aa2d");
+    }
+  }
 #define TVMI_AA(KERNEL)                                                                                       \
   KERNEL<<<L.grid, dim3(kThreads), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)NC, (int)IH, \
                                            (int)IW, (int)OH, (int)OW, yt, xt, L.nc_per_block)
