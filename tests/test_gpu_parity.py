@@ -572,9 +572,10 @@ def test_resize_vs_installed_torch_cpu(mode, aa):
         np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
 @pytest.mark.parametrize("align", [False, True])
-def test_resize_bilinear_tile_kernel_shapes(align):
-    """The LDS-tiled bilinear kernel (256 x 4 output tiles, patch staged with 16-byte loads) at its corner cases: widths
+def test_resize_bilinear_tile_kernel_shapes(align, mode):
+    """The LDS-tiled bilinear / bicubic kernels (256 x 4 output tiles, patch staged with 16-byte loads) at their corner cases: widths
     that are no multiple of 4 / 256, rows that are no multiple of 4, inputs 4..9 pixels wide (shifted last quad), up- and
     down-scales up to its limits (1.49 / 2.3; beyond: the per-output kernel), align_corners — against torch CPU."""
     g = gen(71)
@@ -585,11 +586,11 @@ def test_resize_bilinear_tile_kernel_shapes(align):
         # the launcher takes the tiled kernel from 16384 tile-planes on: enough planes for every shape
         tiles = -(-ow // 256) * -(-oh // 4)
         img = torch.rand(1, -(-16384 // tiles) + 3, ih, iw, generator=g)
-        ref = F.interpolate(img, size=(oh, ow), mode="bilinear", align_corners=align)
-        out = vision_amd.interpolate(img.to(DEV), size=(oh, ow), mode="bilinear", align_corners=align)
-        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=TOL, err_msg=f"{ih}x{iw}->{oh}x{ow}")
-        out16 = vision_amd.interpolate(img.to(DEV, torch.bfloat16), size=(oh, ow), mode="bilinear", align_corners=align)
-        ref16 = F.interpolate(img.to(torch.bfloat16).float(), size=(oh, ow), mode="bilinear", align_corners=align)
+        ref = F.interpolate(img, size=(oh, ow), mode=mode, align_corners=align)
+        out = vision_amd.interpolate(img.to(DEV), size=(oh, ow), mode=mode, align_corners=align)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=TOL, err_msg=f"{mode} {ih}x{iw}->{oh}x{ow}")
+        out16 = vision_amd.interpolate(img.to(DEV, torch.bfloat16), size=(oh, ow), mode=mode, align_corners=align)
+        ref16 = F.interpolate(img.to(torch.bfloat16).float(), size=(oh, ow), mode=mode, align_corners=align)
         np.testing.assert_allclose(out16.float().cpu().numpy(), ref16.numpy(), rtol=0, atol=2e-2)
 
 

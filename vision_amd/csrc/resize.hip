@@ -310,46 +310,106 @@ __global__ void aa_table_kernel(float* __restrict__ table, int out_size, int in_
 // here a patch pixel is fetched once per tile.  Both axes <= 8 taps (scale <= 3.5 bilinear, <= 1.75 bicubic).
 constexpr int kAATaps = 8, kAARows = 16;
 
-template <typename T>
-__global__ __launch_bounds__(64) void aa2d_tile_kernel(const T* __restrict__ in, T* __restrict__ out,
-                                                       const float* __restrict__ ytab, const float* __restrict__ xtab,
-                                                       int NC, int IH, int IW, int OH, int OW, int ytaps, int xtaps,
-                                                       int nc_per_block) {
+// One axis of a separable filter: output index -> first source index, number of taps, weights (zero padded to kAATaps).
+// TableAxis reads the Pillow tables of aa_table_kernel; CubicAxis evaluates torch's non-anti-aliased bicubic
+// (UpSample.h:400-435, A = -0.75; taps clamped into the image are folded onto the border pixel: the weights of a
+// repeated pixel are added first, a ~1e-7 relative change at the image border only).
+struct TableAxis {
+  const float* tab;
+  int taps;
+  __device__ __forceinline__ int first(int i) const { return __float_as_int(tab[(int64_t)i * (taps + 2)]); }
+  __device__ __forceinline__ int end(int i) const {
+    const float* r = tab + (int64_t)i * (taps + 2);
+    return __float_as_int(r[0]) + __float_as_int(r[1]);
+  }
+  __device__ __forceinline__ void weights(int i, float (&w)[kAATaps]) const {
+    const float* r = tab + (int64_t)i * (taps + 2);
+#pragma unroll
+    for (int k = 0; k < kAATaps; ++k) w[k] = k < taps ? r[2 + k] : 0.f;
+  }
+};
+struct CubicAxis {
+  float scale;
+  int in;
+  bool align;
+  __device__ __forceinline__ void place(int i, int& ix, float& t) const {
+    const float real = source_index(scale, i, align, true);
+    ix = min((int)floorf(real), in - 1);
+    t = fminf(fmaxf(real - (float)ix, 0.f), 1.f);
+  }
+  __device__ __forceinline__ int first(int i) const {
+    int ix;
+    float t;
+    place(i, ix, t);
+    return max(min(ix - 1, in - 1), 0);
+  }
+  __device__ __forceinline__ int end(int i) const {
+    int ix;
+    float t;
+    place(i, ix, t);
+    return max(min(ix + 2, in - 1), 0) + 1;
+  }
+  __device__ __forceinline__ void weights(int i, float (&w)[kAATaps]) const {
+    int ix;
+    float t;
+    place(i, ix, t);
+    const float A = -0.75f;
+    const float c[4] = {cubic2(t + 1.f, A), cubic1(t, A), cubic1(1.f - t, A), cubic2(1.f - t + 1.f, A)};
+    const int f = max(min(ix - 1, in - 1), 0);
+#pragma unroll
+    for (int k = 0; k < kAATaps; ++k) w[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = max(min(ix - 1 + k, in - 1), 0) - f;  // 0..3
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (d == q) w[q] += c[k];
+    }
+  }
+};
+
+template <typename T, typename AX, int TAPS>  // TAPS: horizontal taps evaluated per output (4 or 8)
+__global__ __launch_bounds__(64) void aa2d_tile_kernel(const T* __restrict__ in, T* __restrict__ out, AX yax, AX xax, int NC,
+                                                       int IH, int IW, int OH, int OW, int nc_per_block) {
   typedef typename Vec4<T>::raw raw4;
   __shared__ float patch[kAARows][kPatchCols];
   const int lane = threadIdx.x;
   const int ox0 = blockIdx.x * kTileW, oy0 = blockIdx.y * kTileRows;
-  // cells right of the image edge are read with weight 0 (the table rows are zero padded): make them finite once
+  // cells right of the image edge are read with weight 0 (the weight rows are zero padded): make them finite once
   for (int i = lane; i < kAARows * kPatchCols; i += 64) (&patch[0][0])[i] = 0.f;
   // the lane's four output columns: first tap and weights
   int cx[4];
-  float wx[4][kAATaps];
+  float wx[4][TAPS];
   const int nx = min(4, OW - (ox0 + 4 * lane));
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float* xr = xtab + (int64_t)min(ox0 + 4 * lane + j, OW - 1) * (xtaps + 2);
-    cx[j] = __float_as_int(xr[0]);
+    const int ox = min(ox0 + 4 * lane + j, OW - 1);
+    cx[j] = xax.first(ox);
+    float w[kAATaps];
+    xax.weights(ox, w);
 #pragma unroll
-    for (int i = 0; i < kAATaps; ++i) wx[j][i] = i < xtaps ? xr[2 + i] : 0.f;
+    for (int i = 0; i < TAPS; ++i) wx[j][i] = w[i];
   }
-  const int xin0 = __builtin_amdgcn_readfirstlane(__float_as_int(xtab[(int64_t)ox0 * (xtaps + 2)]));
-  const int xlast = __builtin_amdgcn_readfirstlane(__float_as_int(xtab[(int64_t)min(ox0 + kTileW - 1, OW - 1) * (xtaps + 2)]));
-  const int ncols = min(xlast + kAATaps, IW) - xin0;  // staged columns (every tap index below stays inside the patch)
+  const int xin0 = __builtin_amdgcn_readfirstlane(xax.first(ox0));
+  const int xlast = __builtin_amdgcn_readfirstlane(xax.first(min(ox0 + kTileW - 1, OW - 1)));
+  const int ncols = min(xlast + TAPS, IW) - xin0;  // staged columns (every tap index below stays inside the patch)
   const int nq = (ncols + 3) >> 2;
 #pragma unroll
   for (int j = 0; j < 4; ++j) cx[j] -= xin0;
   // rows: patch origin, and the 4 x 16 matrix of vertical weights: lane (ro * 16 + r) holds the weight of patch row r
   // in output row ro (0 outside its support)
-  const int ylo = min(oy0, OH - 1), yhi = min(oy0 + kTileRows - 1, OH - 1);
-  const int yin0 = __builtin_amdgcn_readfirstlane(__float_as_int(ytab[(int64_t)ylo * (ytaps + 2)]));
-  const float* ylr = ytab + (int64_t)yhi * (ytaps + 2);
-  const int nrows = __builtin_amdgcn_readfirstlane(__float_as_int(ylr[0]) + __float_as_int(ylr[1])) - yin0;
-  float wv;
+  const int yin0 = __builtin_amdgcn_readfirstlane(yax.first(min(oy0, OH - 1)));
+  const int nrows = __builtin_amdgcn_readfirstlane(yax.end(min(oy0 + kTileRows - 1, OH - 1))) - yin0;
+  float wv = 0.f;
   {
     const int ro = lane >> 4, r = lane & 15;
-    const float* yr = ytab + (int64_t)min(oy0 + ro, OH - 1) * (ytaps + 2);
-    const int t = r - (__float_as_int(yr[0]) - yin0);
-    wv = (t >= 0 && t < __float_as_int(yr[1])) ? yr[2 + t] : 0.f;
+    const int oy = min(oy0 + ro, OH - 1);
+    float wy[kAATaps];
+    yax.weights(oy, wy);
+    const int t = r - (yax.first(oy) - yin0);
+#pragma unroll
+    for (int k = 0; k < kAATaps; ++k)
+      if (t == k) wv = wy[k];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -394,7 +454,7 @@ __global__ __launch_bounds__(64) void aa2d_tile_kernel(const T* __restrict__ in,
           const float* row = &patch[r][cx[j]];
           float t = 0.f;
 #pragma unroll
-          for (int i = 0; i < kAATaps; ++i) t += row[i] * wx[j][i];
+          for (int i = 0; i < TAPS; ++i) t += row[i] * wx[j][i];
           h[j] = t;
         }
 #pragma unroll
@@ -683,6 +743,26 @@ extern "C" int tvmi_upsample_bicubic2d(const void* input, void* output, tvmi_dty
                                        double scale_w, void* stream) {
   TVMI_RESIZE_PROLOGUE("upsample_bicubic2d");
   const float sh = compute_scale(IH, OH, align_corners, scale_h), sw = compute_scale(IW, OW, align_corners, scale_w);
+  {  // LDS-tiled separable kernel (aa2d_tile_kernel with on-the-fly cubic weights) when the tile's patch fits
+    const double need_cols = std::ceil((double)(kTileW - 1) * (double)sw) + kAATaps + 3.0;
+    const double need_rows = std::ceil((double)(kTileRows - 1) * (double)sh) + 4 + 3.0;
+    const int64_t tiles = ceil_div(OW, kTileW) * ceil_div(OH, kTileRows);
+    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(8, NC * tiles / 8192));
+    const dim3 grid((unsigned)ceil_div(OW, kTileW), (unsigned)ceil_div(OH, kTileRows), (unsigned)ceil_div(NC, per));
+    if (dt != TVMI_F64 && IW >= 4 && !(IH == OH && IW == OW) && need_cols <= (double)(kPatchCols - 4) &&
+        need_rows <= (double)kAARows && grid.z <= 65535 && NC * tiles >= 16384) {
+      const CubicAxis yax{sh, (int)IH, align_corners != 0}, xax{sw, (int)IW, align_corners != 0};
+#define TVMI_CUBIC_TILE(scalar_t)                                                                                      \
+  aa2d_tile_kernel<scalar_t, CubicAxis, 4><<<grid, dim3(64), 0, s>>>((const scalar_t*)input, (scalar_t*)output, yax, xax, (int)NC, \
+                                                                 (int)IH, (int)IW, (int)OH, (int)OW, per)
+      if (dt == TVMI_F32) TVMI_CUBIC_TILE(float);
+      else if (dt == TVMI_F16) TVMI_CUBIC_TILE(__half);
+      else if (dt == TVMI_BF16) TVMI_CUBIC_TILE(__hip_bfloat16);
+      else return ::tvmi::set_error(hipErrorInvalidValue, "upsample_bicubic2d: unsupported dtype");
+#undef TVMI_CUBIC_TILE
+      TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_bicubic2d");
+    }
+  }
   TVMI_DISPATCH_FLOAT(dt, "upsample_bicubic2d",
                       bicubic2d_kernel<scalar_t><<<L.grid, dim3(kThreads), 0, s>>>(
                           (const scalar_t*)input, (scalar_t*)output, (int)NC, (int)IH, (int)IW, (int)OH, (int)OW, sh,
@@ -735,8 +815,9 @@ extern "C" int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt
     if (dt != TVMI_F64 && IW >= 4 && xt <= kAATaps && yt <= kAATaps && need_cols <= (double)(kPatchCols - 4) &&
         need_rows <= (double)kAARows && grid.z <= 65535 && NC * tiles >= 16384) {
 #define TVMI_AA_TILE(scalar_t)                                                                                          \
-  aa2d_tile_kernel<scalar_t><<<grid, dim3(64), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)NC, (int)IH, \
-                                                      (int)IW, (int)OH, (int)OW, yt, xt, per)
+  aa2d_tile_kernel<scalar_t, TableAxis, 8><<<grid, dim3(64), 0, s>>>((const scalar_t*)input, (scalar_t*)output, TableAxis{ytab, yt}, \
+                                                                 TableAxis{xtab, xt}, (int)NC, (int)IH, (int)IW, (int)OH,         \
+                                                                 (int)OW, per)
       if (dt == TVMI_F32) TVMI_AA_TILE(float);
       else if (dt == TVMI_F16) TVMI_AA_TILE(__half);
       else if (dt == TVMI_BF16) TVMI_AA_TILE(__hip_bfloat16);
