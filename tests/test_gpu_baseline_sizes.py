@@ -7,6 +7,7 @@ exact configurations the metric is quoted on:
   config 3  nms / batched_nms, 100,000 boxes, 80 classes, IoU 0.5, sparse canvas and the dense 200x200 variant,
             index lists bit-exact                                     (test/test_ops.py:916-925, 1026-1044)
   config 4  deform_conv2d 2x256x100x136, k3, groups 1 / 256, with and without mask (test/test_ops.py:1287-1319)
+  RoIPool   the shape DESIGN.md quotes its timing on (4x256x100x168, 4000 RoIs, 7x7): value and argmax bit-exact
 
 Bars: NMS index lists identical; fp32 values within 1e-4 (BASELINE.json north_star); bf16 within the reference's
 own 5e-3 (test/test_ops.py:139-140) against the fp32 result on the rounded inputs; backward sums within
@@ -163,3 +164,23 @@ def test_config2_schema_ops_match_fused_op(tv):
         idx = torch.where(levels == lvl)[0]
         result[idx] = tv.roi_align(feats[lvl].to(DEV), rois[idx], pool.scales[lvl], 7, 7, 2, False)
     assert torch.equal(result, fused)
+
+
+def test_roi_pool_measured_shape_bit_exact(tv):
+    """RoIPool 7x7 at the shape its timing is quoted on (tools/gpu_matrix.py `roipool`): 4x256x100x168 fp32, 4000 RoIs of
+    32-400 px at scale 1/8 grouped by image — pooled values and argmax identical to the reference CPU kernel
+    (cpu/roi_pool_kernel.cpp), incl. ties (values rounded to quarter steps)."""
+    from helpers import rois_for
+
+    g = gen(3)
+    x = (torch.randn(4, 256, 100, 168, generator=g) * 4).round() / 4
+    rois = rois_for(4, 4000, 1344, 800, 32, 400, g)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)]
+    y, a = tv.roi_pool(x.to(DEV), rois.to(DEV), 0.125, 7, 7)
+    if O.load_reference():
+        ry, ra = torch.ops.torchvision.roi_pool(x, rois, 0.125, 7, 7)
+        ry, ra = ry.numpy(), ra.numpy()
+    else:
+        ry, ra = O.roi_pool(x.numpy(), rois.numpy(), 0.125, 7, 7)
+    assert np.array_equal(a.cpu().numpy(), ra)
+    assert np.array_equal(y.cpu().numpy(), ry)

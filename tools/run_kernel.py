@@ -36,6 +36,13 @@ with torch.no_grad():
         rois = rois[torch.argsort(rois[:, 0], stable=True)].to(dev)
         for _ in range(reps):
             torch.ops.torchvision.roi_pool(x, rois, 0.125, 7, 7)
+    elif which.startswith("resize_"):       # resize_bilinear | resize_bilinear_aa | resize_bicubic | resize_bicubic_aa
+        import torch.nn.functional as F
+        g = torch.Generator().manual_seed(1)
+        img = torch.rand(8, 3, 1080, 1920, generator=g).to(dev)
+        mode = "bicubic" if "bicubic" in which else "bilinear"
+        for _ in range(reps):
+            vision_amd.interpolate(img, size=(800, 1422), mode=mode, align_corners=False, antialias=which.endswith("_aa"))
     elif which == "nms100k":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import random_boxes
