@@ -428,6 +428,71 @@ def test_roi_pool_column_kernel_channel_partitions(tv, C):
     assert np.array_equal(y.cpu().numpy(), ry, equal_nan=True)
 
 
+def test_roi_pool_backward_plane_owner(tv):
+    """RoIPool backward, plane-owner regime (one wave per gradient plane, LDS accumulation in program order): equals the
+    oracle, is bit-reproducible, handles > 1024 RoIs per image-list chunk, RoIs in random image order, strided grads
+    and 16-bit grads (fp32 accumulation); planes too large for the LDS take the atomic kernel and still agree."""
+    g = gen(81)
+    for (N, C, H, W, K) in ((3, 37, 40, 56, 2500), (2, 5, 200, 190, 300)):     # second: 38000 pixels > LDS plane -> atomics
+        x = (torch.randn(N, C, H, W, generator=g) * 3).round()
+        rois = rois_for(N, K, W * 4, H * 4, 4, 120, g)
+        y, a = tv.roi_pool(x.to(DEV), rois.to(DEV), 0.25, 7, 7)
+        gr = torch.randn(K, C, 7, 7, generator=g)
+        want = O.roi_pool_backward(gr.numpy(), rois.numpy(), a.cpu().numpy(), N, C, H, W)
+        got = tv._roi_pool_backward(gr.to(DEV), rois.to(DEV), a, 0.25, 7, 7, N, C, H, W)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        again = tv._roi_pool_backward(gr.to(DEV), rois.to(DEV), a, 0.25, 7, 7, N, C, H, W)
+        if H * W <= 36864:
+            assert torch.equal(got, again)                                   # fixed summation order
+        # strided grad (channels_last storage of [K, C, 7, 7]) and bf16
+        gs = gr.to(DEV).contiguous(memory_format=torch.channels_last)
+        got_s = tv._roi_pool_backward(gs, rois.to(DEV), a, 0.25, 7, 7, N, C, H, W)
+        np.testing.assert_allclose(got_s.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        g16 = gr.to(torch.bfloat16)
+        got16 = tv._roi_pool_backward(g16.to(DEV), rois.to(torch.bfloat16).to(DEV), a, 0.25, 7, 7, N, C, H, W)
+        want16 = O.roi_pool_backward(g16.float().numpy(), rois.numpy(), a.cpu().numpy(), N, C, H, W)
+        tol16 = 2e-2 * max(1.0, float(np.abs(want16).max())) if H * W <= 36864 else 0.5 * max(1.0, float(np.abs(want16).max()))
+        np.testing.assert_allclose(got16.float().cpu().numpy(), want16, rtol=0, atol=tol16)
+    # deterministic flag: the plane regime does not raise under torch.use_deterministic_algorithms
+    torch.use_deterministic_algorithms(True)
+    try:
+        x = torch.randn(1, 4, 20, 20, generator=g)
+        rois = rois_for(1, 30, 80, 80, 4, 60, g)
+        _, a = tv.roi_pool(x.to(DEV), rois.to(DEV), 0.25, 7, 7)
+        tv._roi_pool_backward(torch.randn(30, 4, 7, 7, generator=g).to(DEV), rois.to(DEV), a, 0.25, 7, 7, 1, 4, 20, 20)
+    finally:
+        torch.use_deterministic_algorithms(False)
+
+
+@pytest.mark.parametrize("align", [True, False])
+def test_ps_roi_backward_plane_owner(tv, align):
+    """PSRoIAlign / PSRoIPool backward, plane-owner regime: equals the oracle, bit-reproducible, > 64 and > 1024 RoIs per
+    image, adaptive sampling grid (sampling_ratio 0), RoIs sticking out of the map; large planes take the atomic kernels."""
+    g = gen(83 + int(align))
+    for (N, C_out, H, W, K, P, sr) in ((2, 3, 30, 44, 2300, 3, 2), (3, 2, 25, 31, 150, 7, 0), (1, 2, 200, 190, 60, 3, 2)):
+        C = C_out * P * P
+        x = torch.randn(N, C, H, W, generator=g)
+        rois = rois_for(N, K, W * 4, H * 4, 4, 100, g)
+        rois[::7, 1:3] -= 20.0
+        xd = x.to(DEV)
+        if align:
+            y, m = tv.ps_roi_align(xd, rois.to(DEV), 0.25, P, P, sr)
+        else:
+            y, m = tv.ps_roi_pool(xd, rois.to(DEV), 0.25, P, P)
+        gr = torch.randn(K, C_out, P, P, generator=g)
+        if align:
+            got = tv._ps_roi_align_backward(gr.to(DEV), rois.to(DEV), m, 0.25, P, P, sr, N, C, H, W)
+            again = tv._ps_roi_align_backward(gr.to(DEV), rois.to(DEV), m, 0.25, P, P, sr, N, C, H, W)
+            want = O.ps_roi_align_backward(gr.numpy(), rois.numpy(), m.cpu().numpy(), 0.25, P, P, sr, N, C, H, W)
+        else:
+            got = tv._ps_roi_pool_backward(gr.to(DEV), rois.to(DEV), m, 0.25, P, P, N, C, H, W)
+            again = tv._ps_roi_pool_backward(gr.to(DEV), rois.to(DEV), m, 0.25, P, P, N, C, H, W)
+            want = O.ps_roi_pool_backward(gr.numpy(), rois.numpy(), m.cpu().numpy(), 0.25, P, P, N, C, H, W)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+        if H * W <= 36864:
+            assert torch.equal(got, again)
+
+
 def test_roi_ops_autograd_on_gpu(tv):
     g = gen(12)
     x = torch.rand(1, 8, 9, 9, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)

@@ -332,6 +332,75 @@ __global__ __launch_bounds__(kThreads) void roi_pool_bwd(const T* __restrict__ g
   }
 }
 
+// ---- roi_pool backward, one wave per feature PLANE ------------------------------------------------------------
+// The reference scatters every pooled gradient to its argmax pixel with a global atomic (cuda/roi_pool_kernel.cu:
+// 80-125; 50 M atomics at 4x256x100x168 / 4000 RoIs, overlapping RoIs hammer the same 64-byte granules: 1.85 ms,
+// non-deterministic).  A gfx950 CU has 160 KB of LDS — a whole gradient plane (H*W floats, 67 KB here) fits.  So one
+// wave owns plane (image b, channel c): it lists the RoIs of image b, walks their pooled gradients as one flat stream
+// (coalesced argmax / grad reads, 16 x 64 elements in flight), accumulates into the LDS plane with ds_add_f32 in
+// PROGRAM ORDER — one wave, in-order LDS: the same summation order every run, no global atomics — and writes the
+// plane once (every pixel, zeros included: the caller's zero-fill is not needed).  16-bit gradients accumulate in
+// fp32 and are rounded once.  Planes above kPlaneMaxPixels keep the atomic kernel above.
+constexpr int kPlaneMaxPixels = 36864;  // 144 KB of LDS for the plane + 4 KB for the RoI list
+constexpr int kPlaneList = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(64) void roi_pool_bwd_plane(const T* __restrict__ grad, const T* __restrict__ rois,
+                                                         const int* __restrict__ argmax, T* __restrict__ grad_input, int K,
+                                                         int C, int HW, int bins, int PW, int64_t ns, int64_t cs,
+                                                         int64_t hs, int64_t ws) {
+  extern __shared__ float smem[];
+  float* plane = smem;
+  int* list = reinterpret_cast<int*>(smem + HW);
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  for (int i = lane; i < HW; i += 64) plane[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += kPlaneList) {
+    // RoIs of image b among [k0, k0 + kPlaneList), in index order
+    int cnt = 0;
+    for (int j = 0; j < kPlaneList && k0 + j < K; j += 64) {
+      const int kk = k0 + j + lane;
+      const bool mine = kk < K && (int)ld(rois + (int64_t)kk * 5) == b;
+      const unsigned long long m = __ballot(mine);
+      if (mine) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = kk;
+      cnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int total = cnt * bins;
+    constexpr int U = 16;
+    for (int e0 = 0; e0 < total; e0 += 64 * U) {
+      int am[U];
+      float g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 64 + lane;
+        am[u] = -1;
+        g[u] = 0.f;
+        if (e < total) {
+          const int r = e / bins, bin = e - r * bins;
+          const int64_t k = list[r];
+          am[u] = argmax[(k * C + c) * bins + bin];
+          g[u] = ld(grad + k * ns + c * cs + (bin / PW) * hs + (bin % PW) * ws);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (am[u] >= 0) atomicAdd(&plane[am[u]], g[u]);  // ds_add_f32, program order
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  T* dst = grad_input + ((int64_t)b * C + c) * HW;
+  for (int i = lane; i < HW; i += 64) st(dst + i, plane[i]);
+}
+
+inline bool roi_pool_bwd_plane_applies(tvmi_dtype dt, int64_t H, int64_t W, int64_t N, int64_t C) {
+  return dt != TVMI_F64 && H * W <= kPlaneMaxPixels && H * W > 0 && N * C < (1ll << 31);
+}
+
 // ---- bilinear helpers of the PS-RoIAlign CPU kernel (cpu/ps_roi_align_kernel.cpp:17-70,153-217)
 template <typename A>
 __device__ __forceinline__ bool bilinear_setup(int H, int W, A y, A x, int& yl, int& yh, int& xl, int& xh,
@@ -481,6 +550,152 @@ inline dim3 grid_for(int64_t total) {
   return dim3((unsigned)std::min<int64_t>(ceil_div(total, kThreads), 1 << 20));
 }
 
+// ---- ps_roi_align / ps_roi_pool backward, one wave per feature PLANE (same idea as roi_pool_bwd_plane) -----------
+// Input channel c_in receives gradient from exactly one pooled cell (c_out, ph, pw) of every RoI of its image
+// (c_in = (c_out*PH + ph)*PW + pw), so the wave that owns plane (b, c_in) walks the RoIs of image b — 64 at a time with
+// lane = RoI for the loads and the per-RoI geometry, then one RoI after the other (values broadcast with v_readlane)
+// with lane = sample / pixel of the cell — and accumulates in its LDS plane in program order: deterministic, no
+// global atomics (the reference: cuda/ps_roi_align_kernel.cu:218-330, cuda/ps_roi_pool_kernel.cu:94-140).
+// Arithmetic of the cell is the atomic kernels' above, expression for expression.
+__device__ __forceinline__ float bcast(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+
+template <typename T, bool ALIGN>
+__global__ __launch_bounds__(64) void ps_bwd_plane(const T* __restrict__ grad, const T* __restrict__ rois,
+                                                   const int* __restrict__ channel_mapping, T* __restrict__ grad_input, int K,
+                                                   int C, int H, int W, int PH, int PW, int C_out, double spatial_scale,
+                                                   int sr) {
+  extern __shared__ float smem[];
+  const int HW = H * W;
+  float* plane = smem;
+  int* list = reinterpret_cast<int*>(smem + HW);
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / C, c_in = blockIdx.x % C;
+  const int c_out = c_in / (PH * PW), ph = (c_in / PW) % PH, pw = c_in % PW;
+  const float scale = (float)spatial_scale;
+  for (int i = lane; i < HW; i += 64) plane[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += kPlaneList) {
+    int cnt = 0;
+    for (int j = 0; j < kPlaneList && k0 + j < K; j += 64) {
+      const int kk = k0 + j + lane;
+      const bool mine = kk < K && (int)ld(rois + (int64_t)kk * 5) == b;
+      const unsigned long long m = __ballot(mine);
+      if (mine) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = kk;
+      cnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int r0 = 0; r0 < cnt; r0 += 64) {
+      // lane = RoI: loads and geometry
+      const int nr = min(64, cnt - r0);
+      const bool on = lane < nr;
+      const int64_t k = on ? list[r0 + lane] : 0;
+      const int64_t idx = ((k * C_out + c_out) * PH + ph) * PW + pw;
+      const bool use = on && channel_mapping[idx] == c_in;  // the mapping tensor is the forward's formula
+      const float go = use ? ld(grad + idx) : 0.f;
+      const T* roi = rois + k * 5;
+      float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f;
+      int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+      if (ALIGN) {  // ps_roi_align_kernel above
+        const float rsw = ld(roi + 1) * scale - 0.5f, rsh = ld(roi + 2) * scale - 0.5f;
+        const float rew = ld(roi + 3) * scale - 0.5f, reh = ld(roi + 4) * scale - 0.5f;
+        const float rw = rew - rsw, rh = reh - rsh;
+        const float bin_h = rh / (float)PH, bin_w = rw / (float)PW;
+        f0 = (float)ph * bin_h + rsh;  // hstart
+        f1 = (float)pw * bin_w + rsw;  // wstart
+        f2 = bin_h;
+        f3 = bin_w;
+        f4 = go;
+        i0 = sr > 0 ? sr : (int)ceil(rh / (float)PH);  // gh
+        i1 = sr > 0 ? sr : (int)ceil(rw / (float)PW);  // gw
+        if (!use) i0 = 0;
+      } else {  // ps_roi_pool_kernel above, backward flavour (roundf, clip to H / W)
+        const int rsw = (int)roundf((float)(ld(roi + 1) * scale)), rsh = (int)roundf((float)(ld(roi + 2) * scale));
+        const int rew = (int)roundf((float)(ld(roi + 3) * scale)), reh = (int)roundf((float)(ld(roi + 4) * scale));
+        const int rw = max(rew - rsw, 1), rh = max(reh - rsh, 1);
+        const float bin_h = (float)rh / (float)PH, bin_w = (float)rw / (float)PW;
+        i0 = clampi((int)floor((float)ph * bin_h) + rsh, 0, H);        // hs
+        i1 = clampi((int)ceil((float)(ph + 1) * bin_h) + rsh, 0, H);   // he
+        i2 = clampi((int)floor((float)pw * bin_w) + rsw, 0, W);        // ws
+        i3 = clampi((int)ceil((float)(pw + 1) * bin_w) + rsw, 0, W);   // we
+        const bool empty = (i1 <= i0) || (i3 <= i2);
+        f0 = empty ? 0.f : go / (float)((i1 - i0) * (i3 - i2));       // diff
+        if (!use || empty) i1 = i0;
+      }
+      if (ALIGN) {
+        // small sampling grids (the usual sampling_ratio 2): lane = (RoI slot, sample), 64 / S RoIs per step; the taps of
+        // different RoIs may meet on a pixel inside one ds_add — the LDS serialises them in lane order
+        int smax = i0 * i1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
+        if (smax <= 16) {
+          const int S = smax <= 1 ? 1 : (smax <= 2 ? 2 : (smax <= 4 ? 4 : (smax <= 8 ? 8 : 16)));
+          const int per = 64 / S, slot = lane / S, sidx = lane % S;
+          for (int j0 = 0; j0 < nr; j0 += per) {
+            const int j = j0 + slot;
+            const int src = min(j, 63);
+            const int gh = __shfl(i0, src), gw = __shfl(i1, src);
+            const float hstart = __shfl(f0, src), wstart = __shfl(f1, src), bin_h = __shfl(f2, src), bin_w = __shfl(f3, src);
+            const float g = __shfl(f4, src);
+            if (j < nr && sidx < gh * gw) {
+              const float count = (float)(gh * gw);
+              const int iy = sidx / gw, ix = sidx - iy * gw;
+              const float y = hstart + (float)((float)iy + .5f) * bin_h / (float)gh;
+              const float x = wstart + (float)((float)ix + .5f) * bin_w / (float)gw;
+              int yl, yh, xl, xh;
+              float w1, w2, w3, w4;
+              if (bilinear_setup<float>(H, W, y, x, yl, yh, xl, xh, w1, w2, w3, w4)) {
+                atomicAdd(&plane[yl * W + xl], g * w1 / count);
+                atomicAdd(&plane[yl * W + xh], g * w2 / count);
+                atomicAdd(&plane[yh * W + xl], g * w3 / count);
+                atomicAdd(&plane[yh * W + xh], g * w4 / count);
+              }
+            }
+          }
+          continue;
+        }
+      }
+      // one RoI after the other: lane = sample (align, large adaptive grids) / pixel (pool) of its cell
+      for (int j = 0; j < nr; ++j) {
+        if (ALIGN) {
+          const int gh = bcast(i0, j), gw = bcast(i1, j);
+          if (gh <= 0 || gw <= 0) continue;
+          const float hstart = bcast(f0, j), wstart = bcast(f1, j), bin_h = bcast(f2, j), bin_w = bcast(f3, j), g = bcast(f4, j);
+          const float count = (float)(gh * gw);
+          for (int sidx = lane; sidx < gh * gw; sidx += 64) {
+            const int iy = sidx / gw, ix = sidx - iy * gw;
+            const float y = hstart + (float)((float)iy + .5f) * bin_h / (float)gh;
+            const float x = wstart + (float)((float)ix + .5f) * bin_w / (float)gw;
+            int yl, yh, xl, xh;
+            float w1, w2, w3, w4;
+            if (!bilinear_setup<float>(H, W, y, x, yl, yh, xl, xh, w1, w2, w3, w4)) continue;
+            atomicAdd(&plane[yl * W + xl], g * w1 / count);
+            atomicAdd(&plane[yl * W + xh], g * w2 / count);
+            atomicAdd(&plane[yh * W + xl], g * w3 / count);
+            atomicAdd(&plane[yh * W + xh], g * w4 / count);
+          }
+        } else {
+          const int hs_ = bcast(i0, j), he_ = bcast(i1, j);
+          if (he_ <= hs_) continue;
+          const int ws_ = bcast(i2, j), we_ = bcast(i3, j);
+          const float diff = bcast(f0, j);
+          const int bw = we_ - ws_, npx = (he_ - hs_) * bw;
+          for (int px = lane; px < npx; px += 64) {
+            const int dh = px / bw, dw = px - dh * bw;
+            plane[(hs_ + dh) * W + ws_ + dw] += diff;  // pixels of one cell are distinct: no conflict inside a step
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  T* dst = grad_input + ((int64_t)b * C + c_in) * HW;
+  for (int i = lane; i < HW; i += 64) st(dst + i, plane[i]);
+}
+
 }  // namespace
 }  // namespace tvmi
 
@@ -533,12 +748,36 @@ extern "C" int tvmi_roi_pool_backward(const void* grad, const void* rois, const 
   if (total == 0 || N * C * H * W == 0) return 0;
   TVMI_CHECK_ARG(grad && rois && argmax && grad_input, "roi_pool_backward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {
+    const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
+#define TVMI_POOL_PLANE(scalar_t)                                                                                      \
+  do {                                                                                                                 \
+    auto kern = tvmi::roi_pool_bwd_plane<scalar_t>;                                                                    \
+    if (lds > 64 * 1024)                                                                                               \
+      TVMI_CHECK_ARG(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, \
+                     "roi_pool_backward: cannot reserve the LDS plane");                                               \
+    kern<<<dim3((unsigned)(N * C)), dim3(64), lds, s>>>((const scalar_t*)grad, (const scalar_t*)rois, argmax,          \
+                                                        (scalar_t*)grad_input, (int)K, (int)C, (int)(H * W),          \
+                                                        (int)(pooled_h * pooled_w), (int)pooled_w, n_stride, c_stride, \
+                                                        h_stride, w_stride);                                           \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_POOL_PLANE(float);
+    else if (dt == TVMI_F16) TVMI_POOL_PLANE(__half);
+    else if (dt == TVMI_BF16) TVMI_POOL_PLANE(__hip_bfloat16);
+    else return ::tvmi::set_error(hipErrorInvalidValue, "roi_pool_backward: unsupported dtype");
+#undef TVMI_POOL_PLANE
+    TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_pool_backward");
+  }
   TVMI_DISPATCH_FLOAT(dt, "roi_pool_backward",
                       tvmi::roi_pool_bwd<scalar_t><<<grid_for(total), dim3(kThreads), 0, s>>>(
                           (const scalar_t*)grad, (const scalar_t*)rois, argmax, (scalar_t*)grad_input, total,
                           (int)C, (int)H, (int)W, (int)pooled_h, (int)pooled_w, n_stride, c_stride, h_stride,
                           w_stride));
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_pool_backward");
+}
+
+extern "C" int tvmi_roi_pool_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W) {
+  return tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C) ? 1 : 0;
 }
 
 extern "C" int tvmi_ps_roi_align_forward(const void* input, const void* rois, void* output,
@@ -573,6 +812,25 @@ extern "C" int tvmi_ps_roi_align_backward(const void* grad, const void* rois,
   if (total == 0 || N * C * H * W == 0) return 0;
   TVMI_CHECK_ARG(grad && rois && channel_mapping && grad_input, "ps_roi_align_backward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {  // plane-owner regime: see ps_bwd_plane
+    const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
+#define TVMI_PS_PLANE(scalar_t)                                                                                       \
+  do {                                                                                                                \
+    auto kern = tvmi::ps_bwd_plane<scalar_t, true>;                                                                  \
+    if (lds > 64 * 1024)                                                                                              \
+      TVMI_CHECK_ARG(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, \
+                     "ps_roi_align_backward: cannot reserve the LDS plane");                                           \
+    kern<<<dim3((unsigned)(N * C)), dim3(64), lds, s>>>((const scalar_t*)grad, (const scalar_t*)rois, channel_mapping, \
+                                                        (scalar_t*)grad_input, (int)K, (int)C, (int)H, (int)W,        \
+                                                        (int)pooled_h, (int)pooled_w, (int)C_out, spatial_scale, (int)sampling_ratio); \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_PS_PLANE(float);
+    else if (dt == TVMI_F16) TVMI_PS_PLANE(__half);
+    else if (dt == TVMI_BF16) TVMI_PS_PLANE(__hip_bfloat16);
+    else return ::tvmi::set_error(hipErrorInvalidValue, "ps_roi_align_backward: unsupported dtype");
+#undef TVMI_PS_PLANE
+    TVMI_RETURN_LAUNCH_STATUS("tvmi_ps_roi_align_backward");
+  }
   TVMI_DISPATCH_FLOAT(dt, "ps_roi_align_backward",
                       (tvmi::ps_roi_align_kernel<scalar_t, true><<<grid_for(total), dim3(kThreads), 0, s>>>(
                           (const scalar_t*)grad, (const scalar_t*)rois, (scalar_t*)grad_input,
@@ -611,6 +869,25 @@ extern "C" int tvmi_ps_roi_pool_backward(const void* grad, const void* rois, con
   if (total == 0 || N * C * H * W == 0) return 0;
   TVMI_CHECK_ARG(grad && rois && channel_mapping && grad_input, "ps_roi_pool_backward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {  // plane-owner regime: see ps_bwd_plane
+    const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
+#define TVMI_PS_PLANE(scalar_t)                                                                                       \
+  do {                                                                                                                \
+    auto kern = tvmi::ps_bwd_plane<scalar_t, false>;                                                                  \
+    if (lds > 64 * 1024)                                                                                              \
+      TVMI_CHECK_ARG(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, \
+                     "ps_roi_pool_backward: cannot reserve the LDS plane");                                           \
+    kern<<<dim3((unsigned)(N * C)), dim3(64), lds, s>>>((const scalar_t*)grad, (const scalar_t*)rois, channel_mapping, \
+                                                        (scalar_t*)grad_input, (int)K, (int)C, (int)H, (int)W,        \
+                                                        (int)pooled_h, (int)pooled_w, (int)C_out, spatial_scale, 0); \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_PS_PLANE(float);
+    else if (dt == TVMI_F16) TVMI_PS_PLANE(__half);
+    else if (dt == TVMI_BF16) TVMI_PS_PLANE(__hip_bfloat16);
+    else return ::tvmi::set_error(hipErrorInvalidValue, "ps_roi_pool_backward: unsupported dtype");
+#undef TVMI_PS_PLANE
+    TVMI_RETURN_LAUNCH_STATUS("tvmi_ps_roi_pool_backward");
+  }
   TVMI_DISPATCH_FLOAT(dt, "ps_roi_pool_backward",
                       (tvmi::ps_roi_pool_kernel<scalar_t, true><<<grid_for(total), dim3(kThreads), 0, s>>>(
                           (const scalar_t*)grad, (const scalar_t*)rois, (scalar_t*)grad_input,

@@ -279,9 +279,12 @@ at::Tensor roi_pool_backward(const at::Tensor& grad, const at::Tensor& rois, con
   TORCH_CHECK(argmax.is_cuda(), "argmax must be a CUDA tensor");
   TORCH_CHECK(grad.scalar_type() == rois.scalar_type(), "roi_pool_backward_kernel: grad and rois must have the same type");
   c10::DeviceGuard guard(grad.device());
-  at::Tensor grad_input = at::zeros({batch_size, channels, height, width}, grad.options());
-  if (grad.numel() == 0) return grad_input;
-  at::globalContext().alertNotDeterministic("roi_pool_backward_kernel");
+  if (grad.numel() == 0) return at::zeros({batch_size, channels, height, width}, grad.options());
+  // plane-owner regime (a gradient plane fits a CU's LDS): every pixel is written, fixed summation order
+  const bool overwrites = tvmi_roi_pool_backward_overwrites(dtype_of(grad, "_roi_pool_backward"), batch_size, channels, height, width) != 0;
+  at::Tensor grad_input = overwrites ? at::empty({batch_size, channels, height, width}, grad.options())
+                                     : at::zeros({batch_size, channels, height, width}, grad.options());
+  if (!overwrites) at::globalContext().alertNotDeterministic("roi_pool_backward_kernel");
   at::Tensor argmax_ = argmax.to(at::kInt).contiguous(), rois_ = rois.contiguous();
   check_status(tvmi_roi_pool_backward(grad.const_data_ptr(), rois_.const_data_ptr(), argmax_.const_data_ptr<int32_t>(),
                                       grad_input.mutable_data_ptr(), dtype_of(grad, "_roi_pool_backward"), batch_size,
@@ -333,9 +336,13 @@ at::Tensor ps_roi_common_backward(const char* name, bool align, const at::Tensor
   TORCH_CHECK(channel_mapping.is_cuda(), "channel_mapping must be a CUDA tensor");
   TORCH_CHECK(grad.scalar_type() == rois.scalar_type(), name, ": grad and rois must have the same type");
   c10::DeviceGuard guard(grad.device());
-  at::Tensor grad_input = at::zeros({batch_size, channels, height, width}, grad.options());
-  if (grad.numel() == 0) return grad_input;
-  at::globalContext().alertNotDeterministic(name);
+  if (grad.numel() == 0) return at::zeros({batch_size, channels, height, width}, grad.options());
+  // plane-owner regime (a gradient plane fits a CU's LDS): every pixel is written, fixed summation order — the same
+  // predicate as roi_pool's
+  const bool overwrites = tvmi_roi_pool_backward_overwrites(dtype_of(grad, name), batch_size, channels, height, width) != 0;
+  at::Tensor grad_input = overwrites ? at::empty({batch_size, channels, height, width}, grad.options())
+                                     : at::zeros({batch_size, channels, height, width}, grad.options());
+  if (!overwrites) at::globalContext().alertNotDeterministic(name);
   at::Tensor grad_ = grad.contiguous(), rois_ = rois.contiguous(), map_ = channel_mapping.to(at::kInt).contiguous();
   int st = align ? tvmi_ps_roi_align_backward(grad_.const_data_ptr(), rois_.const_data_ptr(),
                                               map_.const_data_ptr<int32_t>(), grad_input.mutable_data_ptr(),
