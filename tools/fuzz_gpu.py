@@ -62,5 +62,26 @@ while time.time() - t0 < 40:
     yp, ap = tv.roi_pool(xp.to(dt).to(dev), rois_p.to(dt).to(dev), scale, 7, 7)
     ryp, rap = O.roi_pool(xp.to(dt).float().numpy(), rois_p.to(dt).float().numpy(), scale, 7, 7)
     assert np.array_equal(ap.cpu().numpy(), rap) and np.array_equal(yp.float().cpu().numpy(), ryp), ("roi_pool", N, C2, H, W, dt)
+    if dt == torch.float32:                               # RoIPool backward, plane-owner regime (or atomics for big planes)
+        gp = torch.randn(k, C2, 7, 7, generator=g)
+        gip = tv._roi_pool_backward(gp.to(dev), rois_p.to(dev), ap, scale, 7, 7, N, C2, H, W)
+        rgp = O.roi_pool_backward(gp.numpy(), rois_p.numpy(), rap, N, C2, H, W)
+        assert np.abs(gip.cpu().numpy() - rgp).max() < 1e-4 * max(1.0, float(np.abs(rgp).max())), ("roi_pool bwd", N, C2, H, W)
+    # ---- PSRoIAlign / PSRoIPool forward + plane-owner backward
+    P = ri(1, 4); Co = ri(1, 4); Cps = Co * P * P; srp = ri(0, 3)
+    xs = torch.randn(N, Cps, H, W, generator=g)
+    ya, ma = tv.ps_roi_align(xs.to(dev), rois.to(dev), scale, P, P, srp)
+    rya, rma = O.ps_roi_align(xs.numpy(), rois.numpy(), scale, P, P, srp)
+    assert np.abs(ya.cpu().numpy() - rya).max() < 1e-4 and np.array_equal(ma.cpu().numpy(), rma), ("ps_align", N, Cps, H, W, P, srp)
+    gs = torch.randn(k, Co, P, P, generator=g)
+    ga = tv._ps_roi_align_backward(gs.to(dev), rois.to(dev), ma, scale, P, P, srp, N, Cps, H, W)
+    rga = O.ps_roi_align_backward(gs.numpy(), rois.numpy(), rma, scale, P, P, srp, N, Cps, H, W)
+    assert np.abs(ga.cpu().numpy() - rga).max() < 1e-4 * max(1.0, float(np.abs(rga).max())), ("ps_align bwd", N, Cps, H, W, P, srp)
+    yq, mq = tv.ps_roi_pool(xs.to(dev), rois.to(dev), scale, P, P)
+    ryq, rmq = O.ps_roi_pool(xs.numpy(), rois.numpy(), scale, P, P)
+    assert np.abs(yq.cpu().numpy() - ryq).max() < 1e-4 and np.array_equal(mq.cpu().numpy(), rmq), ("ps_pool", N, Cps, H, W, P)
+    gq = tv._ps_roi_pool_backward(gs.to(dev), rois.to(dev), mq, scale, P, P, N, Cps, H, W)
+    rgq = O.ps_roi_pool_backward(gs.numpy(), rois.numpy(), rmq, scale, P, P, N, Cps, H, W)
+    assert np.abs(gq.cpu().numpy() - rgq).max() < 1e-4 * max(1.0, float(np.abs(rgq).max())), ("ps_pool bwd", N, Cps, H, W, P)
     cases += 1
-print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, roi_align NCHW + channels_last + backward, roi_pool)")
+print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, roi_align NCHW + channels_last + backward, roi_pool fwd + bwd, ps_roi_align / ps_roi_pool fwd + bwd)")
