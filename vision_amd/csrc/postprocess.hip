@@ -81,7 +81,11 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
       }
       s_cnt[i] += add;
     }
-    __syncthreads();
+    // the keep list is in score order: once every image holds max_dets detections nothing later can enter the payload
+    // (a detector step keeps tens of thousands of candidates for a payload of 100 per image)
+    bool full = true;
+    for (int i = tid; i < num_images; i += kPackThreads) full = full && s_cnt[i] >= max_dets;
+    if (__syncthreads_and(full)) break;
   }
   for (int i = tid; i < num_images; i += kPackThreads) counts[i] = poisoned ? -1 : min(s_cnt[i], max_dets);
 }
