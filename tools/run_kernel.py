@@ -43,11 +43,12 @@ with torch.no_grad():
         mode = "bicubic" if "bicubic" in which else "bilinear"
         for _ in range(reps):
             vision_amd.interpolate(img, size=(800, 1422), mode=mode, align_corners=False, antialias=which.endswith("_aa"))
-    elif which == "nms100k":
+    elif which in ("nms100k", "nms100k_dense"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from helpers import random_boxes
         g = torch.Generator().manual_seed(7)
-        b = random_boxes(100_000, 1000, 1000, 1, 101, g).to(dev); s = torch.rand(100_000, generator=g).to(dev)
+        canvas = 200 if which.endswith("dense") else 1000
+        b = random_boxes(100_000, canvas, canvas, 1, 101, g).to(dev); s = torch.rand(100_000, generator=g).to(dev)
         for _ in range(reps):
             torch.ops.torchvision.nms(b, s, 0.5)
     elif which == "nms":

@@ -132,10 +132,11 @@ constexpr float kAreaMin = 0x1p-60f, kAreaMax = 0x1p60f;  // fast-path range of 
 template <typename T, int RS>
 __device__ __forceinline__ u64 suppression_tile_exact(const T* __restrict__ rows, const long long* __restrict__ row_keys,
                                                       T jx1, T jy1, T jx2, T jy2, T jarea, long long jkey, u64 valid_cols,
-                                                      bool diag, double thr) {
+                                                      bool diag, double thr, u64 skip_rows) {
   const int lane = threadIdx.x & 63;
   u64 mine = 0ull;
   for (int i = 0; i < 64; ++i) {
+    if ((skip_rows >> i) & 1ull) continue;  // wave-uniform: a row nobody will read (see nms_mask_tiles)
     const T ix1 = rows[0 * RS + i], iy1 = rows[1 * RS + i], ix2 = rows[2 * RS + i], iy2 = rows[3 * RS + i];
     const T iarea = rows[4 * RS + i];
     const T xx1 = ix1 > jx1 ? ix1 : jx1;  // std::max(ix1, x1[j])
@@ -217,20 +218,31 @@ __device__ __forceinline__ void suppression_row_pair(const float* __restrict__ r
                : "s"((int)(unsigned)word1), "n"(I + 1), "s"((int)(unsigned)(word1 >> 32)));
 }
 
+template <int I, bool DIAG, bool KEYS, int RS>
+__device__ __forceinline__ void suppression_row_pair_unless_skipped(const float* __restrict__ rows,
+                                                                    const long long* __restrict__ row_keys, float jx1, float jy1,
+                                                                    float jx2, float jy2, v2f jarea2, long long jkey, v2f negc,
+                                                                    v2f r2, int& mine_lo, int& mine_hi, float& margin,
+                                                                    u64 skip_rows) {
+  // wave-uniform: both rows of the pair are already known to be suppressed — nobody reads their words
+  if (((skip_rows >> I) & 3ull) != 3ull)
+    suppression_row_pair<I, DIAG, KEYS, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+}
+
 template <bool DIAG, bool KEYS, int RS, int... Is>
 __device__ __forceinline__ void suppression_rows(std::integer_sequence<int, Is...>, const float* __restrict__ rows,
                                                  const long long* __restrict__ row_keys, float jx1, float jy1, float jx2,
                                                  float jy2, v2f jarea2, long long jkey, v2f negc, v2f r2, int& mine_lo,
-                                                 int& mine_hi, float& margin) {
-  (suppression_row_pair<2 * Is, DIAG, KEYS, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi,
-                                                margin),
+                                                 int& mine_hi, float& margin, u64 skip_rows) {
+  (suppression_row_pair_unless_skipped<2 * Is, DIAG, KEYS, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2,
+                                                               mine_lo, mine_hi, margin, skip_rows),
    ...);
 }
 
 template <typename T, int RS>
 __device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, const long long* __restrict__ row_keys, int nrows,
                                                 T jx1, T jy1, T jx2, T jy2, T jarea, long long jkey, bool jvalid, bool diag,
-                                                double thr, ThrBand band) {
+                                                double thr, ThrBand band, u64 skip_rows = 0ull) {
   const u64 valid_cols = __ballot(jvalid);
   if constexpr (std::is_same<T, float>::value) {
     const int lane = threadIdx.x & 63;
@@ -244,11 +256,11 @@ __device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, cons
       const auto seq = std::make_integer_sequence<int, 32>{};
       asm volatile("s_mov_b32 %0, m0" : "=s"(m0_save));
       if (row_keys) {
-        if (diag) suppression_rows<true, true, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
-        else suppression_rows<false, true, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+        if (diag) suppression_rows<true, true, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin, skip_rows);
+        else suppression_rows<false, true, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin, skip_rows);
       } else {
-        if (diag) suppression_rows<true, false, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
-        else suppression_rows<false, false, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin);
+        if (diag) suppression_rows<true, false, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin, skip_rows);
+        else suppression_rows<false, false, RS>(seq, rows, row_keys, jx1, jy1, jx2, jy2, jarea2, jkey, negc, r2, mine_lo, mine_hi, margin, skip_rows);
       }
       asm volatile("s_mov_b32 m0, %0" : : "s"(m0_save));
       // rows that do not exist hold zeros in the mask kernels (decided: inter = 0) or leftovers in the small-segment
@@ -257,14 +269,14 @@ __device__ __forceinline__ u64 suppression_tile(const T* __restrict__ rows, cons
         return (((u64)(unsigned)mine_hi << 32) | (u64)(unsigned)mine_lo) & valid_cols;
     }
   }
-  return suppression_tile_exact<T, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, valid_cols, diag, thr);
+  return suppression_tile_exact<T, RS>(rows, row_keys, jx1, jy1, jx2, jy2, jarea, jkey, valid_cols, diag, thr, skip_rows);
 }
 
 // mask layout: tile (rb, cb) = 64 words at mask + (rb*CB + cb)*64; word r = row rb*64+r.
 template <typename T>
 __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     const T* __restrict__ dets, const int64_t* __restrict__ order, const int64_t* __restrict__ seg, int n, int CB,
-    double thr, ThrBand band, u64* __restrict__ mask, int rb0) {
+    double thr, ThrBand band, u64* __restrict__ mask, int rb0, const u64* removed) {
   __shared__ __attribute__((aligned(16))) T s_row[5][64];  // x1,y1,x2,y2,area of the row block, component-major
   __shared__ long long s_seg[64];
   const int lane = threadIdx.x & 63;
@@ -309,25 +321,35 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     if (seg) jseg = seg[oj];
   }
   const T jarea = (jx2 - jx1) * (jy2 - jy1);
+  // rows already known to be suppressed (by kept boxes of chunks the sweep has finished) are never read by anybody: a
+  // kept row is by definition not removed, and both the column reduction and the resolve step only use kept rows.  The
+  // word may be stale (the sweep runs concurrently on other streams and only ever ADDS bits): stale = fewer rows skipped.
+  u64 skip_rows = 0ull;
+  if (removed) {
+    const u64 r = __hip_atomic_load(&removed[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    skip_rows = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
+                (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r);
+  }
   const u64 mine = suppression_tile<T, 64>(&s_row[0][0], seg ? s_seg : nullptr, min(64, n - row0), jx1, jy1, jx2, jy2, jarea,
-                                           jseg, jvalid, cb == rb, thr, band);
+                                           jseg, jvalid, cb == rb, thr, band, skip_rows);
   mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
 }
 
-// K2: fold the rows kept in super-blocks before `b0` into removed[cb] for cb in [b0, b1).
+// K2: fold the rows kept in a range of row blocks into removed[cb] for a range of column blocks (see launch()).
 __global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mask, const u64* __restrict__ keepbits,
-                                                     u64* __restrict__ removed, int CB, int b0, int b1) {
+                                                     u64* __restrict__ removed, int CB, int rlo, int rhi, int c0, int c1) {
+  // removed[cb] |= OR over the rows kept in row blocks [rlo, rhi) of tile(rb, cb)[row], for cb in [c0, c1)
   __builtin_amdgcn_s_setprio(2);  // on the sweep's critical path, under the mask kernels of later chunks
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int cb = b0 + blockIdx.x;
-  if (cb >= b1) return;
-  const int rb_begin = (blockIdx.y * 4 + wave) * kReduceRows;
+  const int cb = c0 + blockIdx.x;
+  if (cb >= c1) return;
+  const int rb_begin = rlo + (blockIdx.y * 4 + wave) * kReduceRows;
   u64 acc = 0ull;
 #pragma unroll
   for (int q = 0; q < kReduceRows; ++q) {
     const int rb = rb_begin + q;
-    if (rb < b0) {
+    if (rb < rhi) {
       const u64 w = mask[((size_t)rb * CB + cb) * 64 + lane];
       const u64 kb = keepbits[rb];
       if ((kb >> lane) & 1ull) acc |= w;
@@ -560,9 +582,9 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __r
 // capturable).  Streams / events are cached per host thread and device.
 struct SweepStreams {
   int device = -1;
-  hipStream_t mask_stream = nullptr, sweep_stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  std::vector<hipEvent_t> chunk_done;
+  hipStream_t mask_stream = nullptr, sweep_stream = nullptr, far_stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, join_far = nullptr;
+  std::vector<hipEvent_t> chunk_done, resolved, far_done;
   bool ensure(int nchunks) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
@@ -571,16 +593,21 @@ struct SweepStreams {
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       if (hipStreamCreateWithPriority(&mask_stream, hipStreamNonBlocking, lo) != hipSuccess) return false;
       if (hipStreamCreateWithPriority(&sweep_stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
+      if (hipStreamCreateWithPriority(&far_stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
       if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
       if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&join_far, hipEventDisableTiming) != hipSuccess) return false;
       chunk_done.clear();
+      resolved.clear();
+      far_done.clear();
       device = dev;
     }
-    while ((int)chunk_done.size() < nchunks) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-      chunk_done.push_back(e);
-    }
+    for (std::vector<hipEvent_t>* v : {&chunk_done, &resolved, &far_done})
+      while ((int)v->size() < nchunks) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        v->push_back(e);
+      }
     return true;
   }
 };
@@ -597,7 +624,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   const ThrBand band = thr_band(thr);
   if (CB <= kSmallCB) {  // latency-bound sizes: one mask launch, the whole sweep is one more
     const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
-    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(d, order, seg, (int)n, CB, thr, band, mask, 0);
+    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(d, order, seg, (int)n, CB, thr, band, mask, 0, nullptr);
     nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, (int)n, CB, keep_out, num_keep);
     TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
   }
@@ -608,35 +635,57 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   SweepStreams& ss = g_sweep_streams;
   const bool forked = ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
                       hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
-                      hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess;
-  hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream;
-  auto mask_chunk = [&](int c) {
+                      hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess &&
+                      hipStreamWaitEvent(ss.far_stream, ss.fork, 0) == hipSuccess;
+  hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream, fs = forked ? ss.far_stream : stream;
+  auto mask_chunk = [&](int c, bool skip_known) {
     const int r0 = c * kWide, r1 = std::min(CB, r0 + kWide);
     // row block r only has tiles for column blocks >= r: workgroups left of the chunk's first row block exit at once
     const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)(r1 - r0));
-    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, ms>>>(d, order, seg, (int)n, CB, thr, band, mask, r0);
+    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, ms>>>(d, order, seg, (int)n, CB, thr, band, mask, r0,
+                                                                 skip_known ? removed : nullptr);
   };
-  auto sweep_chunk = [&](int c) {
+  auto push = [&](hipStream_t st, int rlo, int rhi, int c0, int c1) {  // rows kept in [rlo, rhi) -> removed[c0..c1)
+    if (c1 <= c0 || rhi <= rlo) return;
+    const dim3 rgrid((unsigned)(c1 - c0), (unsigned)ceil_div(rhi - rlo, 4 * kReduceRows));
+    nms_colreduce<<<rgrid, dim3(256), 0, st>>>(mask, keepbits, removed, CB, rlo, rhi, c0, c1);
+  };
+  auto resolve = [&](int c) {
     const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
-    if (b0 > 0) {
-      const dim3 rgrid((unsigned)(b1 - b0), (unsigned)ceil_div(b0, 4 * kReduceRows));
-      nms_colreduce<<<rgrid, dim3(256), 0, sw>>>(mask, keepbits, removed, CB, b0, b1);
-    }
     nms_resolve_wide<<<dim3(1), dim3(kSuper * kWave), 0, sw>>>(mask, order, removed, keepbits, (int)n, CB, b0, b1, keep_out,
                                                                num_keep);
   };
   bool ok = true;
   if (forked) {
+    // PUSH pipeline on three streams.  Chunk c: its mask tiles (mask stream), then — sweep stream, the serial link —
+    // resolve(c) and the NEAR push (rows kept in chunk c -> removed[] of chunk c + 1, all resolve(c + 1) still lacks),
+    // then — far stream, off the critical path — the FAR push to every later column block, which has the whole of
+    // resolve(c + 1) to finish before resolve(c + 2) needs it.  Because removed[] of a chunk is now filled as the
+    // sweep advances (not just before its own resolve), the mask kernel of chunk c can SKIP the rows that are already
+    // known to be suppressed; it is held back until the far push of chunk c - 3 is done, so that it sees (at least)
+    // every removal caused by chunks <= c - 3 — in a sorted list that is nearly all of them.
     for (int c = 0; c < nchunks; ++c) {
-      mask_chunk(c);
+      const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide), b2 = std::min(CB, b1 + kWide);
+      if (c >= 3) ok = ok && hipStreamWaitEvent(ms, ss.far_done[c - 3], 0) == hipSuccess;
+      mask_chunk(c, true);
       ok = ok && hipEventRecord(ss.chunk_done[c], ms) == hipSuccess && hipStreamWaitEvent(sw, ss.chunk_done[c], 0) == hipSuccess;
-      sweep_chunk(c);
+      if (c >= 2) ok = ok && hipStreamWaitEvent(sw, ss.far_done[c - 2], 0) == hipSuccess;
+      resolve(c);
+      push(sw, b0, b1, b1, b2);
+      ok = ok && hipEventRecord(ss.resolved[c], sw) == hipSuccess && hipStreamWaitEvent(fs, ss.resolved[c], 0) == hipSuccess;
+      push(fs, b0, b1, b2, CB);
+      ok = ok && hipEventRecord(ss.far_done[c], fs) == hipSuccess;
     }
-    // the sweep stream has waited for every mask chunk: joining it joins both
+    // the sweep stream has waited for every mask chunk: joining it and the far stream joins all three
     ok = ok && hipEventRecord(ss.join, sw) == hipSuccess && hipStreamWaitEvent(stream, ss.join, 0) == hipSuccess;
+    ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
   } else {  // no side streams (creation failed): same kernels, serially on the caller's stream
-    for (int c = 0; c < nchunks; ++c) mask_chunk(c);
-    for (int c = 0; c < nchunks; ++c) sweep_chunk(c);
+    for (int c = 0; c < nchunks; ++c) mask_chunk(c, false);
+    for (int c = 0; c < nchunks; ++c) {
+      const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
+      resolve(c);
+      push(stream, b0, b1, b1, CB);
+    }
   }
   if (!ok) return set_error((int)hipErrorUnknown, "tvmi_nms: stream fork / join failed");
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
