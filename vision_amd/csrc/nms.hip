@@ -18,16 +18,19 @@
 //      an SGPR pair) and is parked in lane `row`.  The mask is stored TILE-major: tile
 //      (rb, cb) is 64 consecutive words, so both this store and every later read of a tile
 //      is one coalesced 512-byte access.  Boxes are gathered through `order` in-kernel.
-//   The greedy sweep is blocked in super-blocks of 16 x 64 boxes and formulated as a PULL:
-//   K2 nms_colreduce   : (super-blocks > 0) removed[cb] |= OR over rows kept in EARLIER
-//      super-blocks of tile(rb, cb)[row] — thousands of independent waves, each a masked
-//      512-byte load + a DPP OR-reduction + one atomic.
-//   K3 nms_resolve     : one 16-wave workgroup per super-block.  Wave c owns column block c:
-//      it prefetches its diagonal tile and the <=15 tiles above it into registers (no memory
-//      access inside the serial chain), folds in the keep bits of the blocks before it as
-//      they are published through LDS, then resolves its own 64 boxes with a scalar loop over
-//      the not-yet-removed bits (s_ff1 + v_readlane).  Kept original indices are written in
-//      score order and the running count stays on the device — no masked_select pass.
+//      Two rows per step with packed fp32 and a division-free band test (see thr_band below); above 4096 boxes the
+//      kernel runs in chunks of 64 row blocks and skips the rows the sweep already knows to be suppressed.
+//   The greedy sweep is blocked and runs UNDER the mask kernels on side streams (see launch()):
+//   K2 nms_colreduce   : removed[cb] |= OR over the rows kept in a range of row blocks of tile(rb, cb)[row] —
+//      thousands of independent waves, each a masked 512-byte load + a DPP OR-reduction + one atomic.  Used as the
+//      PUSH of a resolved chunk's suppression to the later column blocks (near part on the sweep stream, far part on
+//      its own stream).
+//   K3 nms_resolve_wide: one 16-wave workgroup per chunk of 64 blocks, walked in mini super-blocks of 16.  Wave c owns
+//      column block c: it pulls the tiles of the earlier mini super-blocks (keep bits final, in LDS), then the 16
+//      diagonal blocks are resolved by parallel fixed-point rounds (exact when two rounds agree) with the serial walk
+//      over the not-yet-removed bits (s_ff1 + v_readlane) as fallback.  Kept original indices are written in score
+//      order and the running count stays on the device — no masked_select pass.
+//   Up to 4096 boxes one mask launch + nms_sweep_small; batched NMS: segment-major kernels further down.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -359,11 +362,10 @@ __global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mas
   if (lane == 0 && red) atomicOr(&removed[cb], red);
 }
 
-// K3 for large problems: ONE workgroup resolves a WIDE super-block of up to kWide 64-box blocks [b0, b1): it walks it
-// in mini super-blocks of kSuper blocks; removed[] (filled by nms_colreduce) carries what every earlier wide super-block
-// suppresses, the rows of earlier mini super-blocks of THIS wide block are pulled here by the wave that owns the
-// column (keep bits in LDS), then the same register-resident resolve chain as nms_resolve.  4x fewer launch pairs on the
-// serial chain than with 16-block super-blocks.
+// K3 for large problems: ONE workgroup resolves a WIDE super-block (chunk) of up to kWide 64-box blocks [b0, b1): it
+// walks it in mini super-blocks of kSuper blocks; removed[] (filled by the pushes of the earlier chunks, nms_colreduce)
+// carries what every earlier chunk suppresses, the rows of earlier mini super-blocks of THIS chunk are pulled here by
+// the wave that owns the column (keep bits in LDS), then the diagonal blocks are resolved in registers.
 constexpr int kWide = 64;
 constexpr int kJacobiRounds = 24;  // parallel fixed-point rounds tried per mini super-block before the serial walk
 __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __restrict__ mask,
@@ -576,10 +578,10 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __r
 
 // Fork / join helpers of the large-problem path.  The mask kernel (throughput-bound, fills the chip) is launched in
 // chunks of kWide row blocks on one internal stream; the sweep of chunk c (latency-bound: one resolve workgroup plus
-// a modest column reduction) runs on a second, higher-priority stream as soon as chunk c of the mask is complete —
-// i.e. UNDER the mask kernels of the later chunks instead of after them.  Both streams are forked from and joined back
-// into the caller's stream with events, so the caller sees ordinary stream-ordered behaviour (and the pattern is
-// capturable).  Streams / events are cached per host thread and device.
+// the near push) runs on a second, higher-priority stream as soon as chunk c of the mask is complete — i.e. UNDER the
+// mask kernels of the later chunks instead of after them; the far pushes run on a third stream (see launch()).  All
+// three are forked from and joined back into the caller's stream with events, so the caller sees ordinary
+// stream-ordered behaviour (and the pattern is capturable).  Streams / events are cached per host thread and device.
 struct SweepStreams {
   int device = -1;
   hipStream_t mask_stream = nullptr, sweep_stream = nullptr, far_stream = nullptr;
