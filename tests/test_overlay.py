@@ -61,6 +61,12 @@ def test_reference_python_package_binds_to_our_library(tmp_path):
         assert x.grad is not None and keep.dtype == torch.int64
         m = ops.MultiScaleRoIAlign(["0"], 3, 2)
         assert torch._C._dispatch_has_kernel_for_dispatch_key("torchvision::roi_align", "CUDA")
+        # our DeformConv2d mirror (a torch _ConvNd) presents the reference module's interface: repr, parameters, state_dict
+        import vision_amd
+        for kw in (dict(kernel_size=3), dict(kernel_size=(3, 5), stride=2, padding=1, dilation=2, groups=2, bias=False)):
+            a, bm = ops.DeformConv2d(4, 6, **kw), vision_amd.DeformConv2d(4, 6, **kw)
+            assert repr(a) == repr(bm), (repr(a), repr(bm))
+            assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in bm.state_dict().items()}
         print("OVERLAY_OK", torchvision.__file__)
         """
     )
