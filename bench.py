@@ -28,9 +28,16 @@ Besides the contract line it reports
                  torchvision::roi_align + torchvision::nms), the channels_last kernel, the dense NMS variant
                  — reported beside `value`, never part of it.  Inputs rotate over N_SETS sets so the 256 MiB
                  Infinity Cache cannot carry one step's feature maps into the next.
---e2e prints a SECOND JSON line: BASELINE config 5 (Mask R-CNN R50-FPN inference img/s through the unchanged
-reference python laid over this library, and with the fused vision_amd pieces swapped in) — tools/e2e_maskrcnn.py,
-run in fresh processes; needs the staged reference python package (tools/stage_reference_python.py).
+  config5      : BASELINE config 5 inside the SAME line — Mask R-CNN R50-FPN inference img/s (random init, synthetic
+                 3x800x1333 images, box_score_thresh 0.0 so that the post-processing is busy) through the unchanged
+                 reference python laid over this library and with the fused vision_amd pieces swapped in, plus the
+                 check that both give the same detections; tools/e2e_maskrcnn.py --variant both, ONE fresh process per
+                 rank (under N > 1 the ranks form their own RCCL group and all-gather the detections).  --no-e2e skips it.
+`--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N ranks; a
+rank count that differs from --gpus, or fewer visible GPUs than ranks, is an error (never a silent 1-GPU run).
+--e2e prints a SECOND JSON line with all four (variant x score threshold) runs of config 5 in fresh processes.
+--dry-run (CPU, gloo) exercises only the launcher / rank plumbing / all-gather and prints a line with "dry_run": true —
+used by tests/test_dist.py; it measures nothing.
 """
 import argparse
 import json
@@ -86,18 +93,31 @@ def main():
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the config-5 block (Mask R-CNN img/s) of the contract line")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, rank plumbing and the all-gather only; measures nothing")
     ap.add_argument("--graph", action="store_true", help="replay the per-rank chain from a captured hipGraph (measured: no gain "
                     "over eager sync-free launches on this stack, so off by default)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))      # one process per GPU: re-execute under torch.distributed.run
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report a "
+                 f"{world}-GPU number as a {args.gpus}-GPU one")
+    if args.dry_run:
+        return dry_run(rank, world, args)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one process per GPU)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
@@ -302,14 +322,80 @@ def main():
         parity_ok = err <= 1e-4 and same
         result["parity"] = {"roi_align_max_abs_err": err, "roi_align_tolerance": 1e-4, "nms_index_sets_equal": bool(same),
                             "checked_against": base["kind"], "ok": bool(parity_ok)}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()          # the config-5 processes form their own group
+    if not args.no_e2e:
+        c5 = config5_block(rank, local_rank, world)
+        if rank == 0:
+            result["config5"] = c5
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     if not parity_ok:
         sys.exit("bench.py: outputs differ from the CPU reference (see the parity block)")
     if args.e2e and rank == 0 and world == 1:
         print(json.dumps(e2e_config5()), flush=True)
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) of this very command line."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n}: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def dry_run(rank, world, args):
+    """CPU / gloo: what the launcher, the rank plumbing and the one collective do — no kernel, no measurement."""
+    from vision_amd import sharding
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dets = torch.full((BATCH, MAX_DETS, sharding.DET_FIELDS), float(rank))
+    counts = torch.full((BATCH,), rank + 1, dtype=torch.int32)
+    gd, gc = sharding.all_gather_detections(dets, counts)
+    ok = gd.shape[0] == BATCH * world and gc.tolist() == [r + 1 for r in range(world) for _ in range(BATCH)]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "boxes/sec RoIAlign+NMS (1000 prop, 256ch FPN)", "value": None, "dry_run": True, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "gathered_images": int(gd.shape[0]), "gather_ok": bool(ok)}), flush=True)
+    if not ok:
+        sys.exit("bench.py --dry-run: all-gather payload mismatch")
+
+
+def config5_block(rank, local_rank, world):
+    """BASELINE config 5 for the contract line: ONE fresh process per rank runs tools/e2e_maskrcnn.py --variant both (the
+    overlay of the reference python needs its own interpreter state).  Under N > 1 the child processes form their own
+    RCCL group on a port next to the launcher's.  Never raises: a failure is reported inside the block."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_maskrcnn.py"), "--variant", "both", "--score-thresh", "0.0",
+           "--steps", "6", "--warmup", "2"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        out = json.loads(line[-1]) if line else {"error": (p.stderr or p.stdout)[-600:]}
+    except Exception as exc:  # pragma: no cover - depends on the box
+        out = {"error": f"{type(exc).__name__}: {exc}"}
+    out["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 def e2e_config5():

@@ -72,3 +72,30 @@ def test_single_process_gather_is_identity():
     d, c = torch.rand(2, 3, 6), torch.tensor([3, 1], dtype=torch.int32)
     gd, gc = sharding.all_gather_detections(d, c)
     assert gd is d and gc is c
+
+
+def _bench(*argv, env=None, timeout=300):
+    import subprocess
+    import sys
+
+    from helpers import ROOT
+
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` outside torchrun must start two ranks, here on CPU through --dry-run / gloo:
+    launcher, RANK / WORLD_SIZE plumbing and the one all-gather; the line reports n_gpus = 2."""
+    import json
+
+    p = _bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["gather_ok"] is True and line["gathered_images"] == 8
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    p = _bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "refusing" in p.stderr

@@ -153,3 +153,58 @@ def test_reference_python_on_the_gpu_lands_in_our_kernels(tmp_path):
         """
     )
     _run(code, tmp_path)
+
+
+@pytest.mark.gpu
+def test_reference_retinanet_and_maskrcnn_run_on_our_kernels(tmp_path):
+    """north_star names FasterRCNN / MaskRCNN / RetinaNet "unchanged": RetinaNet's post-processing
+    (models/detection/retinanet.py:509-571: per-level top-k, decode, clip, batched_nms) and Mask R-CNN's
+    (roi_heads.py:680-737 + MultiScaleRoIAlign 7x7 / 14x14 + paste_masks) of the UNCHANGED reference python run with
+    CUDA tensors; a dispatch-mode counter proves the torchvision:: ops of this library were the ones called, and the
+    RetinaNet detections equal what the same post-processing gives with the per-class NMS done by the oracle."""
+    code = _prelude(tmp_path) + textwrap.dedent(
+        """
+        import numpy as np
+        import vision_amd
+        from oracle import oracle as O
+        from torch.utils._python_dispatch import TorchDispatchMode
+        from torchvision.models import detection as D
+
+        class Count(TorchDispatchMode):
+            def __init__(self):
+                super().__init__(); self.n = {}; self.nms_io = []
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                out = func(*args, **(kwargs or {}))
+                name = str(func)
+                if name.startswith("torchvision."):
+                    self.n[name] = self.n.get(name, 0) + 1
+                    assert all(a.is_cuda for a in args if isinstance(a, torch.Tensor)), name
+                    if name.startswith("torchvision.nms"):
+                        self.nms_io.append((args[0].cpu(), args[1].cpu(), float(args[2]), out.cpu()))
+                return out
+
+        dev = "cuda"
+        g = torch.Generator().manual_seed(0)
+        imgs = [torch.rand(3, 256, 320, generator=g).to(dev), torch.rand(3, 224, 288, generator=g).to(dev)]
+        torch.manual_seed(0)
+        model = D.retinanet_resnet50_fpn(weights=None, weights_backbone=None, score_thresh=0.0, min_size=256, max_size=320).eval().to(dev)
+        with torch.no_grad(), Count() as c:
+            out = model(imgs)
+        assert len(out) == 2 and all(o["boxes"].is_cuda and o["boxes"].shape[1] == 4 for o in out)
+        assert c.n.get("torchvision.nms.default", 0) >= 2, c.n          # batched_nms -> coordinate trick -> torchvision::nms (ours)
+        assert sum(o["boxes"].shape[0] for o in out) > 0
+        for b, s, thr, keep in c.nms_io:                                # every NMS call of the model: index list == reference CPU algorithm
+            assert np.array_equal(keep.numpy(), O.nms(b.numpy(), s.numpy(), thr)), "retinanet nms differs from the oracle"
+        torch.manual_seed(0)
+        model = D.maskrcnn_resnet50_fpn(weights=None, weights_backbone=None, box_score_thresh=0.0, min_size=256, max_size=320,
+                                        rpn_post_nms_top_n_test=200, box_detections_per_img=20).eval().to(dev)
+        with torch.no_grad(), Count() as c:
+            out = model(imgs)
+        assert c.n.get("torchvision.roi_align.default", 0) >= 8 and c.n.get("torchvision.nms.default", 0) >= 4, c.n
+        assert out[0]["masks"].shape[1:] == (1, 256, 320) and out[0]["masks"].is_cuda
+        for b, s, thr, keep in c.nms_io:
+            assert np.array_equal(keep.numpy(), O.nms(b.numpy(), s.numpy(), thr))
+        print("OVERLAY_OK", torchvision.__file__)
+        """
+    )
+    _run(code, tmp_path)

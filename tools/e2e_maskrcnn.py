@@ -5,13 +5,16 @@ padded detections per step (vision_amd.sharding).  Runs the UNCHANGED reference 
 (models/detection/generalized_rcnn.py:53-133, mask_rcnn.py) laid over our operator library
 (vision_amd.integration.make_overlay); the backbone / heads are MIOpen + hipBLASLt through torch, outside our kernels.
 
-    python tools/e2e_maskrcnn.py --variant reference|fused [--batch 2] [--steps 8] [--warmup 3] [--score-thresh 0.0]
+    python tools/e2e_maskrcnn.py --variant reference|fused|both|check [--model maskrcnn|fasterrcnn|retinanet] [--batch 2]
+                                 [--steps 8] [--warmup 3] [--score-thresh 0.0]
 
 variant reference : nothing swapped — every torchvision.ops call of the reference python lands in the
                     `torchvision::` schema kernels of this library (and, with the opt-in aten override, every
                     F.interpolate in resize.hip)
 variant fused     : vision_amd.{MultiScaleRoIAlign, postprocess_detections, filter_proposals, paste_masks_in_image,
                     transform_images} swapped in
+variant both      : ONE process, one model: the reference variant is timed, then the fused pieces are swapped in and timed,
+                    and the detections of both on the same images are compared (what bench.py puts into its `config5` block)
 Prints one JSON object.  Launched by `bench.py --e2e` in a fresh process (the overlay needs TVMI_NO_PY_REGISTRATIONS=1
 before vision_amd is imported: the reference package brings its own fake / autograd registrations)."""
 import argparse
@@ -31,8 +34,13 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="reference", choices=["reference", "fused", "check"],
-                    help="check: run the SAME model both ways on the same images and compare the detections")
+    ap.add_argument("--variant", default="reference", choices=["reference", "fused", "both", "check"],
+                    help="check: run the SAME model both ways on the same images and compare the detections; both: time both "
+                         "ways in one process and compare")
+    ap.add_argument("--model", default="maskrcnn", choices=["maskrcnn", "fasterrcnn", "retinanet"],
+                    help="detection model of the reference (all ResNet50-FPN, random init); the fused variant swaps what the "
+                         "model has: RetinaNet keeps its own post-processing (retinanet.py:509-571: per-level top-k + batched_nms, "
+                         "which lands in our NMS kernels unchanged) and only gets the fused image transform")
     ap.add_argument("--batch", type=int, default=2, help="images per GPU and step")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
@@ -63,29 +71,39 @@ def main():
     sys.path.insert(0, integration.make_overlay(os.path.join(scratch, "overlay"), pkg))
     import torchvision  # the reference package, unmodified
     from torchvision import extension
-    from torchvision.models.detection import maskrcnn_resnet50_fpn
+    from torchvision.models import detection as D
 
     assert extension._has_ops(), "the reference loader did not find our library as _C / _C_stable"
     if not args.no_aten_override:
         vision_amd.override_aten_upsample(True)
 
     torch.manual_seed(0)
-    model = maskrcnn_resnet50_fpn(weights=None, weights_backbone=None, box_score_thresh=args.score_thresh).eval().to(device)
+    if args.model == "retinanet":
+        model = D.retinanet_resnet50_fpn(weights=None, weights_backbone=None, score_thresh=args.score_thresh)
+    else:
+        ctor = D.maskrcnn_resnet50_fpn if args.model == "maskrcnn" else D.fasterrcnn_resnet50_fpn
+        model = ctor(weights=None, weights_backbone=None, box_score_thresh=args.score_thresh)
+    model = model.eval().to(device)
+    has_masks = args.model == "maskrcnn"
+
     def apply_fused():
         import torchvision.models.detection.transform as T
         from torchvision.models.detection.image_list import ImageList
 
         names = ["0", "1", "2", "3"]
-        model.roi_heads.box_roi_pool = vision_amd.MultiScaleRoIAlign(names, 7, 2)
-        model.roi_heads.mask_roi_pool = vision_amd.MultiScaleRoIAlign(names, 14, 2)
-        rh, rpn, tr = model.roi_heads, model.rpn, model.transform
-        rh.postprocess_detections = lambda logits, reg, props, shapes: vision_amd.postprocess_detections(
-            logits, reg, props, shapes, bbox_reg_weights=rh.box_coder.weights, score_thresh=rh.score_thresh,
-            nms_thresh=rh.nms_thresh, detections_per_img=rh.detections_per_img)
-        rpn.filter_proposals = lambda props, obj, shapes, per_level: vision_amd.filter_proposals(
-            props, obj, shapes, per_level, pre_nms_top_n=rpn.pre_nms_top_n(), post_nms_top_n=rpn.post_nms_top_n(),
-            nms_thresh=rpn.nms_thresh, score_thresh=rpn.score_thresh, min_size=rpn.min_size)
-        T.paste_masks_in_image = vision_amd.paste_masks_in_image
+        tr = model.transform
+        if args.model != "retinanet":
+            model.roi_heads.box_roi_pool = vision_amd.MultiScaleRoIAlign(names, 7, 2)
+            if has_masks:
+                model.roi_heads.mask_roi_pool = vision_amd.MultiScaleRoIAlign(names, 14, 2)
+            rh, rpn = model.roi_heads, model.rpn
+            rh.postprocess_detections = lambda logits, reg, props, shapes: vision_amd.postprocess_detections(
+                logits, reg, props, shapes, bbox_reg_weights=rh.box_coder.weights, score_thresh=rh.score_thresh,
+                nms_thresh=rh.nms_thresh, detections_per_img=rh.detections_per_img)
+            rpn.filter_proposals = lambda props, obj, shapes, per_level: vision_amd.filter_proposals(
+                props, obj, shapes, per_level, pre_nms_top_n=rpn.pre_nms_top_n(), post_nms_top_n=rpn.post_nms_top_n(),
+                nms_thresh=rpn.nms_thresh, score_thresh=rpn.score_thresh, min_size=rpn.min_size)
+            T.paste_masks_in_image = vision_amd.paste_masks_in_image
 
         def fused_transform(images, targets=None):
             tensors, sizes = vision_amd.transform_images(images, tr.min_size, tr.max_size, tr.image_mean, tr.image_std,
@@ -99,77 +117,96 @@ def main():
     g = torch.Generator().manual_seed(100 + rank)
     batches = [[torch.rand(3, 800, 1333, generator=g).to(device) for _ in range(args.batch)] for _ in range(2)]
 
-    if args.variant == "check":
-        # same weights, same images: unchanged reference python vs the fused pieces
-        with torch.no_grad():
-            ref = model(batches[0])
-            apply_fused()
-            fus = model(batches[0])
-        rep = {"e2e_check": "reference python vs fused vision_amd pieces, same model and images", "images": []}
-        ok = True
+    def compare(ref, fus):
+        """same detections in the same order; values differ by fp32 rounding carried through a random-init network"""
+        rep, ok = [], True
         for a, b in zip(ref, fus):
             n = min(len(a["scores"]), len(b["scores"]))
             same_n = len(a["scores"]) == len(b["scores"])
             lab = bool(torch.equal(a["labels"][:n], b["labels"][:n]))
             ds = float((a["scores"][:n] - b["scores"][:n]).abs().max()) if n else 0.0
             db = float((a["boxes"][:n] - b["boxes"][:n]).abs().max()) if n else 0.0
-            dm = float((a["masks"][:n] - b["masks"][:n]).abs().max()) if n else 0.0
-            rep["images"].append({"detections": [len(a["scores"]), len(b["scores"])], "labels_equal": lab, "max_score_diff": ds,
-                                  "max_box_diff_px": db, "max_mask_diff": dm})
-            # same detections in the same order; values differ by fp32 rounding carried through a random-init network
+            dm = float((a["masks"][:n] - b["masks"][:n]).abs().max()) if (n and has_masks) else 0.0
+            rep.append({"detections": [len(a["scores"]), len(b["scores"])], "labels_equal": lab, "max_score_diff": ds,
+                        "max_box_diff_px": db, "max_mask_diff": dm})
             ok = ok and same_n and lab and ds < 1e-4 and db < 5e-2 and dm < 5e-3
-        rep["ok"] = ok
-        print(json.dumps(rep), flush=True)
+        return rep, ok
+
+    if args.variant == "check":
+        # same weights, same images: unchanged reference python vs the fused pieces
+        with torch.no_grad():
+            ref = model(batches[0])
+            apply_fused()
+            fus = model(batches[0])
+        images, ok = compare(ref, fus)
+        print(json.dumps({"e2e_check": "reference python vs fused vision_amd pieces, same model and images", "images": images,
+                          "ok": ok}), flush=True)
         sys.exit(0 if ok else 1)
 
     def step(i):
         with torch.no_grad():
             out = model(batches[i % 2])
-        # fixed-shape detection payload of this rank's images and its one all-gather
-        B = len(out)
-        n = torch.tensor([o["boxes"].shape[0] for o in out])
-        dets = torch.zeros(B, 100, 6, device=device)
-        for j, o in enumerate(out):
-            k = min(int(n[j]), 100)
-            dets[j, :k, :4], dets[j, :k, 4], dets[j, :k, 5] = o["boxes"][:k], o["scores"][:k], o["labels"][:k].float()
-        sharding.all_gather_detections(dets, n.to(device=device, dtype=torch.int32).clamp(max=100))
+        # fixed-shape detection payload of this rank's images (shapes are host-known: no device read) and its one all-gather
+        dets, counts = sharding.pack_detection_dicts(out, 100)
+        sharding.all_gather_detections(dets, counts)
         return out
 
-    for i in range(args.warmup):
-        out = step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    calls0 = int(torch.ops.tvmi.aten_upsample_calls())
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
-    res = {
-        "e2e": "maskrcnn_resnet50_fpn inference (BASELINE config 5)",
-        "variant": args.variant,
-        "value": round(args.batch * world * args.steps / dt, 3),
-        "unit": "img/s",
-        "n_gpus": world,
-        "images_per_gpu_per_step": args.batch,
-        "ms_per_step": round(dt / args.steps * 1e3, 2),
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "box_score_thresh": args.score_thresh,
-        "detections_per_image": [int(o["boxes"].shape[0]) for o in out],
-        "mask_shape": list(out[0]["masks"].shape),
-        "aten_upsample_override": not args.no_aten_override,
-        "aten_upsample_calls_per_step": (int(torch.ops.tvmi.aten_upsample_calls()) - calls0) / max(args.steps, 1),
-        "reference_python": torchvision.__file__,
-        "data": "synthetic", "weights": "random init (seed 0)", "dtype": "f32",
-    }
+    def timed_run(variant):
+        for i in range(args.warmup):
+            out = step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        calls0 = int(torch.ops.tvmi.aten_upsample_calls())
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = tmax.item()
+        return {
+            "e2e": f"{args.model}_resnet50_fpn inference" + (" (BASELINE config 5)" if has_masks else ""),
+            "variant": variant,
+            "value": round(args.batch * world * args.steps / dt, 3),
+            "unit": "img/s",
+            "n_gpus": world,
+            "images_per_gpu_per_step": args.batch,
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "box_score_thresh": args.score_thresh,
+            "detections_per_image": [int(o["boxes"].shape[0]) for o in out],
+            "mask_shape": list(out[0]["masks"].shape) if has_masks else None,
+            "aten_upsample_override": not args.no_aten_override,
+            "aten_upsample_calls_per_step": (int(torch.ops.tvmi.aten_upsample_calls()) - calls0) / max(args.steps, 1),
+            "reference_python": torchvision.__file__,
+            "data": "synthetic", "weights": "random init (seed 0)", "dtype": "f32",
+        }
+
+    if args.variant == "both":
+        ref_run = timed_run("reference")
+        with torch.no_grad():
+            ref_out = model(batches[0])
+        apply_fused()
+        fus_run = timed_run("fused")
+        with torch.no_grad():
+            fus_out = model(batches[0])
+        images, ok = compare(ref_out, fus_out)
+        res = {"e2e": ref_run["e2e"], "unit": "img/s", "n_gpus": world, "images_per_gpu_per_step": args.batch,
+               "box_score_thresh": args.score_thresh, "steps": args.steps, "warmup": args.warmup,
+               "reference_python_img_s": ref_run["value"], "reference_python_ms_per_step": ref_run["ms_per_step"],
+               "fused_img_s": fus_run["value"], "fused_ms_per_step": fus_run["ms_per_step"],
+               "detections_per_image": fus_run["detections_per_image"],
+               "aten_upsample_calls_per_step": [ref_run["aten_upsample_calls_per_step"], fus_run["aten_upsample_calls_per_step"]],
+               "same_detections_both_ways": ok, "check": images, "data": "synthetic", "weights": "random init (seed 0)",
+               "dtype": "f32"}
+    else:
+        res = timed_run(args.variant)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

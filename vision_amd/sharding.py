@@ -46,6 +46,25 @@ def pack_detections(boxes: Sequence[Tensor], scores: Sequence[Tensor], labels: S
     return dets, counts
 
 
+def pack_detection_dicts(outputs: Sequence[dict], max_dets: int) -> Tuple[Tensor, Tensor]:
+    """The per-image result dicts of a detection model (`boxes` [n,4], `scores` [n], `labels` [n], already sorted by
+    score) -> the fixed-shape all-gather payload.  Uses tensor SHAPES only (host-known): no device value is read, so
+    nothing synchronises between the model and the collective."""
+    import torch.nn.functional as F
+
+    B = len(outputs)
+    device = outputs[0]["boxes"].device if B else torch.device("cpu")
+    rows, ns = [], []
+    for o in outputs:
+        n = min(int(o["boxes"].shape[0]), max_dets)
+        r = torch.cat([o["boxes"][:n].to(torch.float32), o["scores"][:n, None].to(torch.float32),
+                       o["labels"][:n, None].to(torch.float32)], 1)
+        rows.append(F.pad(r, (0, 0, 0, max_dets - n)))
+        ns.append(n)
+    dets = torch.stack(rows) if B else torch.zeros((0, max_dets, DET_FIELDS), device=device)
+    return dets, torch.tensor(ns, dtype=torch.int32).to(device, non_blocking=True)
+
+
 def pack_kept_detections(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep: Tensor, num_images: int,
                           max_dets: int, labels: Tensor = None, num_keep: Tensor = None) -> Tuple[Tensor, Tensor]:
     """Batched form used on the hot path: `keep` is the score-ordered output of a batched NMS over
@@ -70,11 +89,15 @@ def pack_kept_detections(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep:
     return pack_detections(per_b, per_s, per_l, max_dets)
 
 
-def all_gather_detections(dets: Tensor, counts: Tensor, group=None) -> Tuple[Tensor, Tensor]:
+def all_gather_detections(dets: Tensor, counts: Tensor, group=None, always_collective: bool = False) -> Tuple[Tensor, Tensor]:
     """All-gather equally shaped per-rank (`dets` [B_local, D, 6], `counts` [B_local]) into
     ([world*B_local, D, 6], [world*B_local]) in rank order.  Counts ride in the same buffer as
-    the detections (one collective, not two)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    the detections (one collective, not two).  A world of one returns its inputs untouched unless
+    `always_collective` asks for the real collective (a 1-rank RCCL group still goes through
+    `all_gather_into_tensor` on device buffers — what tests/test_gpu_dist.py exercises on a 1-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return dets, counts
+    if dist.get_world_size(group) == 1 and not always_collective:
         return dets, counts
     world = dist.get_world_size(group)
     B, D, Fd = dets.shape
