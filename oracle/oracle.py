@@ -84,6 +84,22 @@ def nms(dets, scores, iou_threshold, idxs=None):
     return keep[:k].copy()
 
 
+def batched_nms(boxes, scores, idxs, iou_threshold, device_type="cuda"):
+    """torchvision/ops/boxes.py:57-126 for torch tensors: the reference's switch between the coordinate trick
+    (:93-109: one nms() on `boxes + idxs * (boxes.max() + 1)`, taken up to 4000 elements on CPU / 100,000 on other
+    devices, :83) and the per-category loop (:113-126).  The shift is done with torch arithmetic in the boxes' own dtype,
+    exactly as the reference does it, so the shifted coordinates round the same way."""
+    import torch
+
+    if boxes.numel() == 0:
+        return np.empty((0,), dtype=np.int64)
+    if boxes.numel() > (4000 if device_type == "cpu" else 100_000):
+        return nms(boxes.numpy(), scores.numpy(), iou_threshold, idxs.numpy())
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return nms((boxes + offsets[:, None]).numpy(), scores.numpy(), iou_threshold)
+
+
 def roi_align(x, rois, spatial_scale, ph, pw, sampling_ratio, aligned):
     x, rois = _c(x), _c(rois)
     sfx, _ = _sfx(x)

@@ -184,3 +184,113 @@ def test_roi_pool_measured_shape_bit_exact(tv):
         ry, ra = O.roi_pool(x.numpy(), rois.numpy(), 0.125, 7, 7)
     assert np.array_equal(a.cpu().numpy(), ra)
     assert np.array_equal(y.cpu().numpy(), ry)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_config2_roi_align_backward_16bit_values(tv, dtype):
+    """Config 2 says "fwd/bwd ... fp32 vs bf16": the VALUES of the 16-bit backward, fused (one multi-scale launch) and per
+    level (`torchvision::_roi_align_backward`), against the reference CPU kernel run in fp32 on the same rounded
+    gradients.  Ours accumulates in fp32 and rounds each pixel once (the reference's CUDA kernel adds 16-bit atomics,
+    cuda/roi_align_kernel.cu:304-327); bar = the reference's own 16-bit tolerance 5e-3 (test/test_ops.py:139-140)."""
+    P = 7
+    feats, boxes = _config2(seed=1002)
+    names = [str(i) for i in range(4)]
+    pool = vision_amd.MultiScaleRoIAlign(names, P, 2)
+    dfeats = {n: f.to(dtype).to(DEV).requires_grad_(True) for n, f in zip(names, feats)}
+    dboxes = [b.to(DEV) for b in boxes]
+    out = pool(dfeats, dboxes, [(IMG_H, IMG_W)] * BATCH)
+    assert out.dtype == dtype
+    grad = torch.randn(out.shape, generator=gen(8)).to(dtype)
+    out.backward(grad.to(DEV))
+    levels = pool.map_levels(boxes)
+    rois = torch.cat([torch.cat([torch.full((PROPS, 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+    for lvl in range(4):
+        sel = torch.nonzero(levels == lvl)[:, 0]
+        shape = tuple(feats[lvl].shape)
+        refb = _cpu_roi_align_backward(grad[sel].float().contiguous(), rois[sel], pool.scales[lvl], P, shape)
+        bar = 5e-3 * max(1.0, float(np.abs(refb).max()))
+        gb = dfeats[names[lvl]].grad
+        assert gb.dtype == dtype
+        np.testing.assert_allclose(gb.float().cpu().numpy(), refb, rtol=5e-3, atol=bar, err_msg=f"fused backward level {lvl}")
+        # the schema op the reference's autograd formula calls (_autograd_registrations.py:30-60), 16-bit rois like the reference passes
+        r16 = rois[sel].to(dtype)
+        got = tv._roi_align_backward(grad[sel].to(DEV), r16.to(DEV), pool.scales[lvl], P, P, *shape, 2, False)
+        assert got.dtype == dtype
+        ref16 = _cpu_roi_align_backward(grad[sel].float().contiguous(), r16.float(), pool.scales[lvl], P, shape)
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref16, rtol=5e-3, atol=5e-3 * max(1.0, float(np.abs(ref16).max())),
+                                   err_msg=f"per-level backward level {lvl}")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("groups", [1, 256])
+def test_config4_deform_conv2d_16bit(dtype, tol, groups):
+    """16-bit deform_conv2d at config 4 (timed in profiles/*matrix.json) against the reference CPU kernel in fp32 on the
+    rounded tensors.  The reference keeps `columns` and the addmm_ accumulation in the 16-bit type
+    (cuda/deform_conv2d_kernel.cu:1234-1239); ours accumulates in fp32 (exact 16-bit products on the MFMA path) and rounds
+    the output once, so it sits inside the reference's own 16-bit error: bar 2e-3 for fp16 / 1e-2 for bf16 (output std ~0.3)."""
+    g = gen(510 + groups)
+    B, C, H, W, OC = 2, 256, 100, 136, 256
+    x = torch.randn(B, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(OC, C // groups, 3, 3, generator=g) * (0.01 if groups == 1 else 0.2)).to(dtype)
+    off = torch.randn(B, 18, H, W, generator=g).to(dtype)
+    m = torch.rand(B, 9, H, W, generator=g).to(dtype)
+    b = torch.randn(OC, generator=g).to(dtype)
+    for use_mask in (False, True):
+        y = vision_amd.deform_conv2d(x.to(DEV), off.to(DEV), w.to(DEV), b.to(DEV), (1, 1), (1, 1), (1, 1), m.to(DEV) if use_mask else None)
+        assert y.dtype == dtype
+        if O.load_reference():
+            ref = torch.ops.torchvision.deform_conv2d(x.float(), w.float(), off.float(), m.float() if use_mask else torch.zeros(B, 1),
+                                                      b.float(), 1, 1, 1, 1, 1, 1, groups, 1, use_mask).numpy()
+        else:
+            ref = O.deform_conv2d(x.float().numpy(), w.float().numpy(), off.float().numpy(), m.float().numpy(), b.float().numpy(),
+                                  (1, 1), (1, 1), (1, 1), groups, 1, use_mask)
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=tol, atol=tol, err_msg=f"mask={use_mask}")
+
+
+@pytest.mark.parametrize("mode,aa", [("nearest", False), ("bilinear", False), ("bicubic", False), ("bilinear", True), ("bicubic", True)])
+def test_resize_at_the_measured_shape(mode, aa):
+    """8x3x1080x1920 -> 800x1422, the shape the resize kernels are timed on (tools/gpu_matrix.py): all five
+    modes, the LDS-tiled kernels included, against installed-torch CPU F.interpolate (the arithmetic the reference's
+    wrappers call, _geometry.py:344) at the 1e-4 bar."""
+    import torch.nn.functional as F
+
+    x = torch.rand(8, 3, 1080, 1920, generator=gen(21))
+    kw = {} if mode == "nearest" else dict(align_corners=False, antialias=aa)
+    want = F.interpolate(x, size=(800, 1422), mode=mode, **kw)
+    with torch.no_grad():
+        got = vision_amd.interpolate(x.to(DEV), size=(800, 1422), mode=mode, **kw).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= TOL, (mode, aa)
+
+
+def test_resize_config5_image_through_the_aten_override():
+    """The resize of config 5: a 3x800x1333 image through torch.nn.functional.interpolate with the aten override on — the
+    identity-size call GeneralizedRCNNTransform makes (models/detection/transform.py:65-72: scale_factor with
+    recompute_scale_factor=True), an up- and a down-scale of the same image, bilinear like the transform and the FPN's nearest
+    (ops/feature_pyramid_network.py:194) — against torch CPU; the call counter proves our kernel ran."""
+    import torch.nn.functional as F
+
+    img = torch.rand(1, 3, 800, 1333, generator=gen(22))
+    d = img.to(DEV)
+    was = vision_amd.override_aten_upsample(True)
+    try:
+        c0 = int(torch.ops.tvmi.aten_upsample_calls())
+        cases = [dict(scale_factor=1.0, mode="bilinear", recompute_scale_factor=True, align_corners=False),
+                 dict(size=(800, 1333), mode="bilinear", align_corners=False),
+                 dict(scale_factor=0.6, mode="bilinear", recompute_scale_factor=True, align_corners=False),
+                 dict(size=(1000, 1666), mode="bilinear", align_corners=False),
+                 dict(size=(400, 667), mode="bicubic", align_corners=False, antialias=True),
+                 dict(size=(1600, 2666), mode="nearest")]
+        for kw in cases:
+            want = F.interpolate(img, **kw)
+            got = F.interpolate(d, **kw).cpu()
+            assert got.shape == want.shape and float((got - want).abs().max()) <= TOL, kw
+        assert int(torch.ops.tvmi.aten_upsample_calls()) - c0 == len(cases)
+        # float64 is NOT taken over (ADVICE r02: resize.hip sums in float; a process-wide override must keep fp64 exact)
+        c1 = int(torch.ops.tvmi.aten_upsample_calls())
+        x64 = img[..., :96, :128].double()
+        got = F.interpolate(x64.to(DEV), size=(150, 201), mode="bicubic", align_corners=False).cpu()
+        assert int(torch.ops.tvmi.aten_upsample_calls()) == c1
+        assert float((got - F.interpolate(x64, size=(150, 201), mode="bicubic", align_corners=False)).abs().max()) < 1e-12
+    finally:
+        vision_amd.override_aten_upsample(was)

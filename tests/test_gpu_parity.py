@@ -105,13 +105,13 @@ def test_nms_threshold_edge_is_exact_without_the_division(tv):
         want = O.nms(boxes.numpy(), scores.numpy(), thr)
         assert np.array_equal(tv.nms(bd, sd, thr).cpu().numpy(), want), thr
         wseg = O.nms(boxes.numpy(), scores.numpy(), thr, idxs.numpy())
-        assert np.array_equal(vision_amd.batched_nms(bd, sd, idd, thr, num_segments=3).cpu().numpy(), wseg), thr
+        assert np.array_equal(torch.ops.tvmi.nms_segmented(bd, sd, idd, thr, 3).cpu().numpy(), wseg), thr
     big = torch.cat([boxes] * 4) + torch.arange(4 * n)[:, None].float() * 0   # n > 4096: segment-major kernel
     sbig = torch.rand(4 * n, generator=g)
     ibig = torch.randint(0, 5, (4 * n,), generator=g)
     for thr in thrs[:12]:
         want = O.nms(big.numpy(), sbig.numpy(), thr, ibig.numpy())
-        assert np.array_equal(vision_amd.batched_nms(big.to(DEV), sbig.to(DEV), ibig.to(DEV), thr).cpu().numpy(), want), thr
+        assert np.array_equal(torch.ops.tvmi.nms_segmented(big.to(DEV), sbig.to(DEV), ibig.to(DEV), thr, -1).cpu().numpy(), want), thr
 
 
 def test_nms_area_range_of_the_fast_path(tv):
@@ -139,14 +139,33 @@ def test_nms_area_range_of_the_fast_path(tv):
             want = O.nms(b.numpy(), scores.numpy(), thr)
             assert np.array_equal(tv.nms(b.to(DEV), scores.to(DEV), thr).cpu().numpy(), want), (name, thr)
             wseg = O.nms(b.numpy(), scores.numpy(), thr, idxs.numpy())
-            got = vision_amd.batched_nms(b.to(DEV), scores.to(DEV), idxs.to(DEV), thr, num_segments=4).cpu().numpy()
+            got = torch.ops.tvmi.nms_segmented(b.to(DEV), scores.to(DEV), idxs.to(DEV), thr, 4).cpu().numpy()
             assert np.array_equal(got, wseg), (name, thr)
     big = torch.cat([mixed, base, mixed * 0.5])  # n > 4096: chunked mask kernels / segment-major kernel
     sbig = torch.rand(big.shape[0], generator=g)
     ibig = torch.randint(0, 6, (big.shape[0],), generator=g)
     assert np.array_equal(tv.nms(big.to(DEV), sbig.to(DEV), 0.5).cpu().numpy(), O.nms(big.numpy(), sbig.numpy(), 0.5))
-    assert np.array_equal(vision_amd.batched_nms(big.to(DEV), sbig.to(DEV), ibig.to(DEV), 0.5).cpu().numpy(),
+    assert np.array_equal(torch.ops.tvmi.nms_segmented(big.to(DEV), sbig.to(DEV), ibig.to(DEV), 0.5, -1).cpu().numpy(),
                           O.nms(big.numpy(), sbig.numpy(), 0.5, ibig.numpy()))
+
+
+def test_batched_nms_follows_the_reference_switch_of_arithmetic():
+    """ops/boxes.py:83-109: up to 100,000 elements the reference evaluates the IoUs on boxes shifted by
+    idxs * (max + 1); fp32 rounding of the shifted coordinates flips pairs at the threshold edge.  Seed 9 is such a
+    case (the shifted and the per-category results differ by one box on the CPU): the mirror must give the
+    reference's answer in both regimes."""
+    g = gen(9)
+    n = 20000
+    boxes = random_boxes(n, 1000, 1000, 1, 101, g)
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, 80, (n,), generator=g)
+    want_trick = O.batched_nms(boxes, scores, idxs, 0.5)
+    want_loop = O.nms(boxes.numpy(), scores.numpy(), 0.5, idxs.numpy())
+    assert not np.array_equal(want_trick, want_loop)           # the case discriminates
+    keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), 0.5).cpu().numpy()
+    assert np.array_equal(keep, want_trick)
+    keep = torch.ops.tvmi.nms_segmented(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), 0.5, -1).cpu().numpy()
+    assert np.array_equal(keep, want_loop)                     # the schema-free op keeps the per-category arithmetic
 
 
 def test_batched_nms_native_segmented_path():
@@ -199,17 +218,17 @@ def test_batched_nms_single_launch_small_path():
         idxs = torch.randint(0, S, (n,), generator=g)
         idxs[idxs == 1] = 0                                              # id 1 stays empty
         keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), idxs.to(DEV), thr, num_segments=S).cpu().numpy()
-        assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), thr, idxs.numpy())), (n, S)
+        assert np.array_equal(keep, O.batched_nms(boxes, scores, idxs, thr)), (n, S)
     keep = vision_amd.batched_nms(boxes.double().to(DEV), scores.double().to(DEV), idxs.to(DEV), 0.5, num_segments=1).cpu().numpy()
-    assert np.array_equal(keep, O.nms(boxes.double().numpy(), scores.double().numpy(), 0.5, idxs.numpy()))
+    assert np.array_equal(keep, O.batched_nms(boxes.double(), scores.double(), idxs, 0.5))
     n = 3000
     boxes = random_boxes(n, 500, 400, 4, 150, g)
     scores = torch.rand(n, generator=g)
     big = torch.where(torch.arange(n) < 1500, torch.zeros(n, dtype=torch.int64), torch.randint(1, 5, (n,), generator=g))
     keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), big.to(DEV), 0.5, num_segments=5).cpu().numpy()
-    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.5, big.numpy()))            # 1500-box segment
+    assert np.array_equal(keep, O.batched_nms(boxes, scores, big, 0.5))                             # 1500-box segment
     keep = vision_amd.batched_nms(boxes.to(DEV), scores.to(DEV), (big + 7).to(DEV), 0.5, num_segments=5).cpu().numpy()
-    assert np.array_equal(keep, O.nms(boxes.numpy(), scores.numpy(), 0.5, big.numpy()))            # ids outside [0, 5)
+    assert np.array_equal(keep, O.batched_nms(boxes, scores, big + 7, 0.5))                         # ids outside [0, 5)
     _, num = vision_amd.boxes.batched_nms_padded(boxes.to(DEV), scores.to(DEV), big.to(DEV), 0.5, num_segments=5)
     assert int(num) == -1                                                                           # sync-free form reports it
 
@@ -858,7 +877,7 @@ def test_sync_free_nms_pack_chain_and_graph_replay():
     boxes = random_boxes(n, 800, 600, 4, 200, g).to(DEV)
     scores = torch.rand(n, generator=g).to(DEV)
     img = torch.randint(0, B, (n,), generator=g).to(DEV)
-    keep = vision_amd.batched_nms(boxes, scores, img, 0.5)
+    keep = torch.ops.tvmi.nms_segmented(boxes, scores, img, 0.5, -1)    # the synchronising form of the same per-segment arithmetic
     want_d, want_c = sharding.pack_kept_detections(boxes, scores, img, keep, B, 50)
     kp, num = vision_amd.boxes.batched_nms_padded(boxes, scores, img, 0.5, B)
     assert int(num) == keep.numel() and torch.equal(kp[: keep.numel()], keep)
@@ -884,7 +903,7 @@ def test_sync_free_nms_pack_chain_and_graph_replay():
     ss.copy_(ns)
     graph.replay()
     torch.cuda.synchronize()
-    keep = vision_amd.batched_nms(nb, ns, img, 0.5)
+    keep = torch.ops.tvmi.nms_segmented(nb, ns, img, 0.5, -1)
     want_d, want_c = sharding.pack_kept_detections(nb, ns, img, keep, B, 50)
     assert int(n2) == keep.numel() and torch.equal(d2, want_d) and torch.equal(c2, want_c)
 

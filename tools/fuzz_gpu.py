@@ -28,8 +28,10 @@ while time.time() - t0 < 40:
     assert np.array_equal(got, want), ("nms", n, canvas, thr)
     wants = O.nms(b.numpy(), s.numpy(), thr, idx.numpy())
     for hint in (-1, S):
-        gots = vision_amd.batched_nms(b.to(dev), s.to(dev), idx.to(dev), thr, num_segments=hint).cpu().numpy()
-        assert np.array_equal(gots, wants), ("batched", n, S, hint, thr)
+        gots = torch.ops.tvmi.nms_segmented(b.to(dev), s.to(dev), idx.to(dev), thr, hint).cpu().numpy()
+        assert np.array_equal(gots, wants), ("segmented", n, S, hint, thr)
+        gotb = vision_amd.batched_nms(b.to(dev), s.to(dev), idx.to(dev), thr, num_segments=hint).cpu().numpy()   # the reference's switch of arithmetic
+        assert np.array_equal(gotb, O.batched_nms(b, s, idx, thr)), ("batched", n, S, hint, thr)
     # ---- RoIAlign forward NCHW vs channels_last vs oracle, backward vs oracle
     N, C, H, W = ri(1, 3), ri(1, 70), ri(2, 60), ri(4, 70)
     x = torch.rand(N, C, H, W, generator=g)

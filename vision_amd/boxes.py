@@ -22,17 +22,26 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
     """NMS that never suppresses across categories (ops/boxes.py:57-91).
 
     The reference switches between shifting the boxes per category and running one nms()
-    ("coordinate trick", :93-109) and a python loop over categories (:113-126).  On device
-    tensors both are replaced by ONE segment-major launch chain (`tvmi::nms_segmented`): IoU is
-    evaluated on the unshifted boxes (the loop's arithmetic, exactly), category-mismatched pairs
-    are never even tested, every category is swept by its own workgroup, and there is no
-    torch.unique / torch.where host round trip per category.  `num_segments` (extension, optional): a
-    promise that 0 <= idxs < num_segments, which lets N <= 4096 run as a single launch.  CPU tensors
-    (tests only) follow the reference's switch."""
+    ("coordinate trick", :93-109; device tensors up to 100,000 elements) and a python loop over
+    categories (:113-126).  On device tensors both run as ONE segment-major launch chain
+    (`tvmi::nms_segmented`): category-mismatched pairs are never even tested, every category is swept
+    by its own workgroup, and there is no torch.unique / torch.where host round trip per category.
+    The ARITHMETIC follows the reference's switch: in the coordinate-trick regime the IoUs are
+    evaluated on the shifted boxes `boxes + idxs * (boxes.max() + 1)` (fp32 rounding of the shifted
+    coordinates moves IoUs at the threshold edge, so the kept set can differ from the per-category
+    loop's — tests/test_gpu_parity.py pins a case), above it on the unshifted boxes (the loop's
+    arithmetic).  The one thing not reproduced is the trick's cross-category suppression when boxes
+    have coordinates below -1 (shifted categories then overlap in the reference).
+    `num_segments` (extension, optional): a promise that 0 <= idxs < num_segments, which lets
+    N <= 4096 run as a single launch.  CPU tensors (tests only) follow the reference's switch."""
     if boxes.is_cuda:
         assert_has_ops()
         if boxes.numel() == 0:
             return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+        if boxes.numel() <= 100_000:   # ops/boxes.py:83: the reference's coordinate-trick regime on device tensors
+            max_coordinate = boxes.max()
+            offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+            boxes = boxes + offsets[:, None]
         return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold, int(num_segments))
     if boxes.numel() > 4000:
         return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)

@@ -36,6 +36,7 @@
 #include <type_traits>
 #include <utility>
 
+#include <memory>
 #include <vector>
 
 #include "tvmi_common.h"
@@ -583,14 +584,12 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __r
 // three are forked from and joined back into the caller's stream with events, so the caller sees ordinary
 // stream-ordered behaviour (and the pattern is capturable).  Streams / events are cached per host thread and device.
 struct SweepStreams {
-  int device = -1;
   hipStream_t mask_stream = nullptr, sweep_stream = nullptr, far_stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr, join_far = nullptr;
   std::vector<hipEvent_t> chunk_done, resolved, far_done;
+  bool ready = false;
   bool ensure(int nchunks) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (dev != device) {  // first use on this thread / device (handles of another device are simply abandoned)
+    if (!ready) {  // first use on this thread for this device (the caller has made it current)
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       if (hipStreamCreateWithPriority(&mask_stream, hipStreamNonBlocking, lo) != hipSuccess) return false;
@@ -599,10 +598,7 @@ struct SweepStreams {
       if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
       if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
       if (hipEventCreateWithFlags(&join_far, hipEventDisableTiming) != hipSuccess) return false;
-      chunk_done.clear();
-      resolved.clear();
-      far_done.clear();
-      device = dev;
+      ready = true;
     }
     for (std::vector<hipEvent_t>* v : {&chunk_done, &resolved, &far_done})
       while ((int)v->size() < nchunks) {
@@ -612,8 +608,31 @@ struct SweepStreams {
       }
     return true;
   }
+  // Handles are destroyed when the owning host thread exits.  Errors are ignored on purpose: at process teardown the
+  // HIP runtime may already be gone (hipErrorDeinitialized), and a handle whose work is still queued is released by
+  // the runtime once that work has drained.
+  ~SweepStreams() {
+    for (std::vector<hipEvent_t>* v : {&chunk_done, &resolved, &far_done})
+      for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {fork, join, join_far})
+      if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {mask_stream, sweep_stream, far_stream})
+      if (st) (void)hipStreamDestroy(st);
+  }
 };
-thread_local SweepStreams g_sweep_streams;
+// one set per (host thread, device): a thread that alternates between GPUs keeps both sets instead of re-creating
+// (and leaking) streams on every switch
+struct SweepStreamsByDevice {
+  std::vector<std::unique_ptr<SweepStreams>> per_device;
+  SweepStreams* current() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    if ((int)per_device.size() <= dev) per_device.resize(dev + 1);
+    if (!per_device[dev]) per_device[dev] = std::make_unique<SweepStreams>();
+    return per_device[dev].get();
+  }
+};
+thread_local SweepStreamsByDevice g_sweep_streams;
 
 template <typename T>
 int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr, void* workspace,
@@ -634,8 +653,10 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   if (e == hipSuccess) e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
   const int nchunks = (int)ceil_div(CB, kWide);
-  SweepStreams& ss = g_sweep_streams;
-  const bool forked = ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
+  static SweepStreams no_streams;  // never ensure()d: only names the members below when the device query failed
+  SweepStreams* ssp = g_sweep_streams.current();
+  SweepStreams& ss = ssp ? *ssp : no_streams;
+  const bool forked = ssp && ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
                       hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
                       hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess &&
                       hipStreamWaitEvent(ss.far_stream, ss.fork, 0) == hipSuccess;

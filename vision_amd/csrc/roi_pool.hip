@@ -739,15 +739,32 @@ extern "C" int tvmi_roi_pool_forward(const void* input, const void* rois, void* 
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_pool_forward");
 }
 
+
+namespace tvmi {
+namespace {
+// K == 0 in the plane-owner regime: the `*_backward_overwrites` queries still answer 1 (they do not know K), so a C-ABI
+// caller may have handed over an uninitialised buffer — honour the contract and write the zeros.
+inline int zero_planes_if_owner(tvmi_dtype dt, void* grad_input, int64_t N, int64_t C, int64_t H, int64_t W, hipStream_t s,
+                                const char* what) {
+  if (N * C * H * W == 0 || !roi_pool_bwd_plane_applies(dt, H, W, N, C)) return 0;
+  if (!grad_input) return set_error((int)hipErrorInvalidValue, what);
+  const size_t esz = dt == TVMI_F32 ? 4 : dt == TVMI_F64 ? 8 : 2;
+  const hipError_t e = hipMemsetAsync(grad_input, 0, (size_t)(N * C * H * W) * esz, s);
+  return e == hipSuccess ? 0 : set_error((int)e, what);
+}
+}  // namespace
+}  // namespace tvmi
+
 extern "C" int tvmi_roi_pool_backward(const void* grad, const void* rois, const int32_t* argmax,
                                       void* grad_input, tvmi_dtype dt, int64_t N, int64_t C, int64_t H,
                                       int64_t W, int64_t K, int64_t pooled_h, int64_t pooled_w,
                                       int64_t n_stride, int64_t c_stride, int64_t h_stride,
                                       int64_t w_stride, void* stream) {
   const int64_t total = K * C * pooled_h * pooled_w;
-  if (total == 0 || N * C * H * W == 0) return 0;
-  TVMI_CHECK_ARG(grad && rois && argmax && grad_input, "roi_pool_backward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (total == 0) return tvmi::zero_planes_if_owner(dt, grad_input, N, C, H, W, s, "roi_pool_backward: zero fill");
+  if (N * C * H * W == 0) return 0;
+  TVMI_CHECK_ARG(grad && rois && argmax && grad_input, "roi_pool_backward: null pointer");
   if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {
     const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
 #define TVMI_POOL_PLANE(scalar_t)                                                                                      \
@@ -809,9 +826,10 @@ extern "C" int tvmi_ps_roi_align_backward(const void* grad, const void* rois,
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "ps_roi_align_backward: pooled size must be positive");
   const int64_t C_out = C / (pooled_h * pooled_w);
   const int64_t total = K * C_out * pooled_h * pooled_w;
-  if (total == 0 || N * C * H * W == 0) return 0;
-  TVMI_CHECK_ARG(grad && rois && channel_mapping && grad_input, "ps_roi_align_backward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (total == 0) return tvmi::zero_planes_if_owner(dt, grad_input, N, C, H, W, s, "ps_roi_align_backward: zero fill");
+  if (N * C * H * W == 0) return 0;
+  TVMI_CHECK_ARG(grad && rois && channel_mapping && grad_input, "ps_roi_align_backward: null pointer");
   if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {  // plane-owner regime: see ps_bwd_plane
     const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
 #define TVMI_PS_PLANE(scalar_t)                                                                                       \
@@ -866,9 +884,10 @@ extern "C" int tvmi_ps_roi_pool_backward(const void* grad, const void* rois, con
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "ps_roi_pool_backward: pooled size must be positive");
   const int64_t C_out = C / (pooled_h * pooled_w);
   const int64_t total = K * C_out * pooled_h * pooled_w;
-  if (total == 0 || N * C * H * W == 0) return 0;
-  TVMI_CHECK_ARG(grad && rois && channel_mapping && grad_input, "ps_roi_pool_backward: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (total == 0) return tvmi::zero_planes_if_owner(dt, grad_input, N, C, H, W, s, "ps_roi_pool_backward: zero fill");
+  if (N * C * H * W == 0) return 0;
+  TVMI_CHECK_ARG(grad && rois && channel_mapping && grad_input, "ps_roi_pool_backward: null pointer");
   if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {  // plane-owner regime: see ps_bwd_plane
     const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
 #define TVMI_PS_PLANE(scalar_t)                                                                                       \

@@ -578,10 +578,18 @@ std::unique_ptr<torch::Library> g_lib;
 std::mutex g_mutex;
 std::atomic<int64_t> g_calls{0};  // how many aten::upsample_* calls were served by tvmi kernels (tests read it)
 
+// What the override serves itself.  Everything else falls through to ATen's own kernel: float64 (resize.hip computes scales,
+// weights and sums in float — fine for the 16/32-bit types, but a process-wide override must not cost fp64 callers their
+// precision, e.g. gradcheck), channels_last / strided inputs, integer types, empty tensors, and shapes beyond the limits
+// of the resize launchers (TVMI_RESIZE_PROLOGUE in resize.hip: OH <= 65535, IH*IW and OH*OW below 2^31) — those must reach
+// ATen, not raise "size too large".
 bool ours(const at::Tensor& self, at::IntArrayRef size) {
   const auto t = self.scalar_type();
-  return self.is_cuda() && self.dim() == 4 && size.size() == 2 && self.numel() > 0 && size[0] > 0 && size[1] > 0 &&
-         (t == at::kFloat || t == at::kHalf || t == at::kBFloat16 || t == at::kDouble) && self.is_contiguous();
+  if (!(self.is_cuda() && self.dim() == 4 && size.size() == 2 && self.numel() > 0 && size[0] > 0 && size[1] > 0 &&
+        (t == at::kFloat || t == at::kHalf || t == at::kBFloat16) && self.is_contiguous()))
+    return false;
+  const int64_t IH = self.size(2), IW = self.size(3), OH = size[0], OW = size[1];
+  return OH <= 65535 && IH * IW < (1ll << 31) && OH * OW < (1ll << 31);
 }
 
 double sc(const std::optional<double>& v) { return v.has_value() ? *v : -1.0; }
