@@ -31,8 +31,20 @@ typedef enum tvmi_dtype {
   TVMI_BF16 = 3
 } tvmi_dtype;
 
-/* Library / ABI version (major*10000 + minor*100 + patch). */
+/* Library / ABI version (major*10000 + minor*100 + patch).  300 = round 3: the RoI backward entries OVERWRITE grad_input
+ * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
+ * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
+ * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
+#define TVMI_ABI_VERSION 300
 int tvmi_version(void);
+/* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
+ * error for an unknown name.
+ *   "roi_align.shared_staging"   1 (default) / 0: serve FPN levels by staging the map (roi_align_plane.hip)
+ *   "roi_align.min_band_rows"    maps that do not fit the LDS are cut into row bands only if a band holds this many rows
+ *                                (default 32; 0 = never cut, only whole planes are staged)
+ *   "roi_align.staging_gain_x16" weight (x/16, default 32 = 2.0) of the RoIs' window pixels against the map pixels in
+ *                                the device-side decision which levels are staged */
+int tvmi_set_option(const char* name, int64_t value);
 /* Static string of the gfx arch the kernels were compiled for ("gfx950"). */
 const char* tvmi_arch(void);
 /* Human-readable text for the last non-zero status returned on this thread. */
@@ -98,8 +110,11 @@ int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_
  * torchvision/csrc/ops/cpu/roi_align_kernel.cpp:18-115,183-289 and
  * cpu/roi_align_common.h:32-124.
  *   input  [N,C,H,W]  output [K,C,PH,PW] (fully overwritten, no pre-zero needed)
- *   workspace (optional, may be NULL): K*4 bytes of device scratch (per-RoI "declined by the LDS-DMA
- *   kernel" flags).  Without it the fast path that needs the flags is not used; results do not depend on it.
+ *   workspace (optional, may be NULL): tvmi_roi_align_forward_workspace_bytes(K, PH, PW, sampling_ratio) bytes of
+ *   device scratch: per-RoI "declined by the LDS-DMA kernel" flags (the first K*4 bytes; a workspace of only that
+ *   size selects the per-RoI kernels alone) and, for 7x7 / 14x14 bins with sampling_ratio 2, the tables of the
+ *   shared-staging kernel (roi_align_plane.hip: per-RoI level / band key + axis-sample table, per-level window
+ *   pixel sums).  Results do not depend on it, only which kernels run.
  * backward: grad [K,C,PH,PW] read with the given element strides.  Two regimes:
  *   - TILE-OWNER path (deterministic; what torchvision/ops/roi_align.py:276-281 reroutes to python for):
  *     float32, 7x7 or 14x14 bins (any sampling_ratio), the [C,PH,PW] block of a RoI contiguous (w_stride 1,
@@ -110,6 +125,7 @@ int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_
  *   - otherwise (fp64, 16-bit, other bin shapes, no workspace): accumulates with hardware atomics into a
  *     grad_input the CALLER zero-filled, like cuda/roi_align_kernel.cu:304-327,440.
  */
+size_t tvmi_roi_align_forward_workspace_bytes(int64_t K, int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio);
 int tvmi_roi_align_forward(const void* input, const void* rois, void* output, tvmi_dtype dt,
                            int64_t N, int64_t C, int64_t H, int64_t W, int64_t K,
                            int64_t pooled_h, int64_t pooled_w, double spatial_scale,

@@ -477,24 +477,6 @@ struct DmaWindow {
   int sparse;  // 1: the LDS image holds only the SAMPLED rows — slot 2s / 2s+1 = low / high tap row of y-sample s
 };
 
-// lo/l/h of one axis sample in the "shifted" form described above (dim >= 2)
-__device__ __forceinline__ bool axis_sample_shifted(int dim, float start, float bin, int grid, int p, int i, int& lo,
-                                                    float& l, float& h) {
-  int hi;
-  const bool v = axis_sample<float>(dim, start, bin, grid, p, i, lo, hi, l, h);
-  if (!v) {
-    lo = 0;
-    l = h = 0.f;
-    return false;
-  }
-  if (lo > dim - 2) {  // lo == dim-1: value is in[dim-1]
-    lo = dim - 2;
-    l = 1.f;
-    h = 0.f;
-  }
-  return true;
-}
-
 // EPP = elements per 16-byte DMA piece (4 for fp32, 8 for fp16/bf16); nq then counts pieces.
 template <int PHT, int PWT, int SRT, int EPP = 4>
 __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, int W) {
@@ -648,6 +630,26 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   }
 }
 
+// A RoI the shared-staging kernel (roi_align_plane.hip) serves is not this kernel's: key >= 0 names its level, and the
+// level is active iff the pre-pass's window-pixel sums say so — the very rule and integers the other kernel uses.
+struct PlaneSkip {
+  const int* key;        // nullptr: no shared-staging launch ran
+  const int* blocksum;
+  PlanePlan plan;
+};
+
+__device__ __forceinline__ bool served_by_plane_kernel(const PlaneSkip& ps, const MsLevels& lv, int k) {
+  if (ps.key == nullptr) return false;
+  const int kv = __builtin_amdgcn_readfirstlane(ps.key[k]);
+  if (kv < 0) return false;
+  const int l = (kv >> 12) & 15;
+  const int lane = threadIdx.x & 63;
+  int v = lane < kPlanePreBlocks ? ps.blocksum[lane * kMaxLevels + l] : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return plane_level_active(v, ps.plan.lv[l], ps.plan.gain_x16, ps.plan.N, lv.H[l], lv.W[l]);
+}
+
 template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
@@ -773,11 +775,23 @@ template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restrict__ input,
                                                               const T* __restrict__ rois, T* __restrict__ output,
                                                               int C, int H, int W, float spatial_scale, int aligned,
-                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ declined) {
+                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
+                                                              const int* __restrict__ plane_key, const int* __restrict__ plane_blocksum,
+                                                              PlaneLevel plane_level, int plane_gain_x16, int plane_N) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
+  if (plane_key != nullptr && __builtin_amdgcn_readfirstlane(plane_key[k]) >= 0) {  // single level: level 0 of the plan
+    const int lane = threadIdx.x & 63;
+    int v = lane < kPlanePreBlocks ? plane_blocksum[lane * kMaxLevels] : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (plane_level_active(v, plane_level, plane_gain_x16, plane_N, H, W)) {
+      if (ci == 0 && lane == 0) declined[k] = 0;
+      return;
+    }
+  }
   roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
                                               chunk, declined);
 }
@@ -786,11 +800,16 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restric
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const float* __restrict__ rois,
                                                                  T* __restrict__ output, int C, int aligned,
-                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ declined) {
+                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
+                                                                 PlaneSkip ps) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
+  if (served_by_plane_kernel(ps, lv, k)) {
+    if (ci == 0 && (threadIdx.x & 63) == 0) declined[k] = 0;
+    return;
+  }
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
   roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
                                                   lv.scale[l], aligned, k, ci * chunk, chunk, declined);
@@ -811,13 +830,41 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, c
                                                    lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, c0, chunk, declined);
 }
 
+// Workspace of the forward entries: [declined: K ints, padded to 16 bytes][shared-staging part: plane_workspace_bytes()].
+// A caller that passes only the first part gets the per-RoI kernels alone (the pre-round-3 behaviour).
+inline size_t fwd_declined_bytes(int64_t K) { return ((size_t)K * sizeof(int) + 15) & ~(size_t)15; }
+inline void* plane_part(void* ws, size_t ws_bytes, int64_t K, int64_t PH, int64_t PW, int64_t sr) {
+  const size_t need = plane_workspace_bytes(K, PH, PW, sr);
+  if (!ws || need == 0 || K >= (1 << 30) || ws_bytes < fwd_declined_bytes(K) + need) return nullptr;
+  return static_cast<char*>(ws) + fwd_declined_bytes(K);
+}
+
+int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, const int64_t* widths, const double* scales,
+                int64_t n_levels, int64_t k_min, int64_t k_max, double s0, double lvl0, double eps) {
+  for (int i = 0; i < kMaxLevels; ++i) {
+    const int j = i < n_levels ? i : 0;
+    lv.ptr[i] = ptrs[j];
+    lv.H[i] = (int)heights[j];
+    lv.W[i] = (int)widths[j];
+    lv.scale[i] = (float)scales[j];
+  }
+  lv.n_levels = (int)n_levels;
+  lv.k_min = (int)k_min;
+  lv.k_max = (int)k_max;
+  lv.s0 = (float)s0;
+  lv.lvl0 = (float)lvl0;
+  lv.eps = (float)eps;
+  return 0;
+}
+
+
 constexpr int kUnitChunk = 32;  // channels per wave unit
 constexpr int kMopChunk = 64;   // channels per unit of the launch that mops up what the DMA kernel declined (almost always empty)
 
 template <typename T>
 int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int* declined, hipStream_t stream) {
+               int* declined, void* plane_ws, hipStream_t stream) {
   const T* in = static_cast<const T*>(input);
   const T* r = static_cast<const T*>(rois);
   T* out = static_cast<T*>(output);
@@ -831,10 +878,33 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
     const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
     const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
     const dim3 grid(wave_unit_grid(K, nchunks)), mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
+    // shared staging of the map (roi_align_plane.hip) for the RoIs / shapes it serves; this launcher keeps the rest
+    const int* pkey = nullptr;
+    const int* pblocksum = nullptr;
+    PlanePlan plan;
+    plan.lv[0] = PlaneLevel{0, 1, 1, 1, 1, 1, 0, 0};
+    plan.gain_x16 = 0;
+    plan.N = (int)N;
+    if (declined && plane_ws) {
+      MsLevels one;
+      const void* ptrs[1] = {input};
+      const int64_t hs[1] = {H}, ws_[1] = {W};
+      const double sc[1] = {scale};
+      fill_levels(one, ptrs, hs, ws_, sc, 1, 0, 0, 1.0, 0.0, 0.0);
+      plan = make_plane_plan(one, N, C, K, (int)sizeof(T), PH, PW, sr);
+      if (plan.total_blocks > 0) {
+        const PlaneBuffers pb = plane_buffers(plane_ws, K);
+        const int st = launch_plane<T, T>(one, plan, rois, output, C, K, PH, aligned, /*multiscale=*/0, pb, stream);
+        if (st != 0) return st;
+        pkey = pb.key;
+        pblocksum = pb.blocksum;
+      }
+    }
 #define TVMI_FWD(PHT, PWT, SRT)                                                                                   \
   if (declined) {                                                                                                 \
     roi_align_fwd_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, aligned, \
-                                                                    nchunks, kUnitChunk, nunits, declined);       \
+                                                                    nchunks, kUnitChunk, nunits, declined, pkey,  \
+                                                                    pblocksum, plan.lv[0], plan.gain_x16, plan.N); \
     roi_align_fwd_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH, \
                                                                          (int)PW, fs, (int)sr, aligned, mop_nchunks, \
                                                                          kMopChunk, mop_nunits, declined);        \
@@ -1006,17 +1076,31 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
 }
 
 template <typename T>
-int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
-                  int64_t PW, int64_t sr, int aligned, int* declined, hipStream_t stream) {
+int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH,
+                  int64_t PW, int64_t sr, int aligned, int* declined, void* plane_ws, hipStream_t stream) {
   const float* r = static_cast<const float*>(rois);
   T* out = static_cast<T*>(output);
   const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
   const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
   const dim3 grid(wave_unit_grid(K, nchunks)), mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
+  // shared staging of the maps (roi_align_plane.hip) first; the wave kernel below keeps what that one does not serve
+  PlaneSkip ps;
+  ps.key = nullptr;
+  ps.blocksum = nullptr;
+  if (declined && plane_ws) {
+    ps.plan = make_plane_plan(lv, N, C, K, (int)sizeof(T), PH, PW, sr);
+    if (ps.plan.total_blocks > 0) {
+      const PlaneBuffers pb = plane_buffers(plane_ws, K);
+      const int st = launch_plane<T, float>(lv, ps.plan, rois, output, C, K, PH, aligned, /*multiscale=*/1, pb, stream);
+      if (st != 0) return st;
+      ps.key = pb.key;
+      ps.blocksum = pb.blocksum;
+    }
+  }
 #define TVMI_MS(PHT, PWT, SRT)                                                                                      \
   if (declined) {                                                                                                   \
     roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
-                                                                       nunits, declined);                           \
+                                                                       nunits, declined, ps);                       \
     roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
                                                                             aligned, mop_nchunks, kMopChunk, mop_nunits, \
                                                                             declined);                              \
@@ -1035,26 +1119,18 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward");
 }
 
-int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, const int64_t* widths, const double* scales,
-                int64_t n_levels, int64_t k_min, int64_t k_max, double s0, double lvl0, double eps) {
-  for (int i = 0; i < kMaxLevels; ++i) {
-    const int j = i < n_levels ? i : 0;
-    lv.ptr[i] = ptrs[j];
-    lv.H[i] = (int)heights[j];
-    lv.W[i] = (int)widths[j];
-    lv.scale[i] = (float)scales[j];
-  }
-  lv.n_levels = (int)n_levels;
-  lv.k_min = (int)k_min;
-  lv.k_max = (int)k_max;
-  lv.s0 = (float)s0;
-  lv.lvl0 = (float)lvl0;
-  lv.eps = (float)eps;
-  return 0;
-}
-
 }  // namespace
 }  // namespace tvmi
+
+extern "C" size_t tvmi_roi_align_forward_workspace_bytes(int64_t K, int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio) {
+  if (K <= 0) return 0;
+  return tvmi::fwd_declined_bytes(K) + tvmi::plane_workspace_bytes(K, pooled_h, pooled_w, sampling_ratio);
+}
+
+extern "C" int tvmi_set_option(const char* name, int64_t value) {
+  if (tvmi::set_plane_option(name, value) == 0) return 0;
+  return tvmi::set_error((int)hipErrorInvalidValue, "tvmi_set_option: unknown option");
+}
 
 extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void* output,
                                       tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W,
@@ -1063,6 +1139,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
                                       void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
   int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
+  void* plane_ws = tvmi::plane_part(workspace, workspace_bytes, K, pooled_h, pooled_w, sampling_ratio);
   TVMI_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0, "roi_align: negative size");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(input && rois && output, "roi_align: null pointer");
@@ -1072,7 +1149,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
   TVMI_DISPATCH_FLOAT(dt, "roi_align_forward",
                       return tvmi::launch_fwd<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h,
                                                         pooled_w, spatial_scale, sampling_ratio,
-                                                        aligned, declined, s));
+                                                        aligned, declined, plane_ws, s));
   return 0;
 }
 
@@ -1097,13 +1174,15 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
   tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
+  void* plane_ws = tvmi::plane_part(workspace, workspace_bytes, K, pooled_h, pooled_w, sampling_ratio);
   switch (dt) {
     case TVMI_F32:
-      return tvmi::launch_ms_fwd<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, s);
+      return tvmi::launch_ms_fwd<float>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, plane_ws, s);
     case TVMI_F16:
-      return tvmi::launch_ms_fwd<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, s);
+      return tvmi::launch_ms_fwd<__half>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, plane_ws, s);
     default:
-      return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, s);
+      return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined,
+                                                 plane_ws, s);
   }
 }
 

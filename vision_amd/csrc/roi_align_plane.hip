@@ -1,0 +1,409 @@
+// roi_align_plane.hip — RoIAlign forward, SHARED-STAGING kernels for gfx950 (7x7 / 14x14 bins, sampling_ratio 2).
+//
+// Semantics: torchvision/csrc/ops/cpu/roi_align_kernel.cpp:18-115 + cpu/roi_align_common.h:32-124, like roi_align.hip.
+// Reference structure being replaced: cuda/roi_align_kernel.cu:68-143 (one thread per output element, 16 dependent
+// scattered loads each).  roi_align.hip's wave kernel stages ONE RoI's window per (RoI, 32 channels) wave: at the FPN
+// workload every pixel of the coarse levels is wanted by 6-30 RoIs and is re-staged every time, out of 60-160-byte row
+// fragments that cost the texture addresser ~2.4 accesses per useful 64 bytes (profiles/r01_pmc_roi_align_dma_summary.txt).
+//
+// Here the MAP is staged, not the RoI:
+//   * a 512-thread workgroup owns (level, image, row band, channel group): it copies the band — full-width rows, one
+//     contiguous run per channel — HBM -> LDS with 16-byte LDS-DMA pieces (global_load_lds_dwordx4; every piece a useful,
+//     aligned 16 bytes), then its 8 waves serve EVERY RoI of that image and level whose sampled rows lie in the band;
+//   * a level whose whole plane fits the LDS budget is one band (P3: 1 channel, P4: 4, P5: 18 channels per workgroup at
+//     the 800x1344 FPN shapes); a larger map (P2) is cut into half-overlapping bands of full-width rows;
+//   * lane = output bin (as in the wave kernel): 8 ds_read2_b32 + the separable FMAs per channel, one coalesced
+//     non-temporal store of the 49 outputs;
+//   * a pre-pass (one 32/64-lane group per RoI) computes, once per RoI instead of once per (RoI, channel group): the FPN
+//     level, the band the RoI belongs to (or "not eligible": the wave kernel of roi_align.hip keeps those), and the table
+//     of its 28 (56) axis samples {low index, fraction} that the lanes of the serving wave then simply load;
+//   * whether a level is served here at all is decided ON THE DEVICE from the pre-pass's per-level sum of window pixels
+//     (staging a map pays when the RoIs would otherwise stage more than the map): no host synchronisation, and both
+//     kernels read the same integers, so they always agree on who owns a RoI.
+// Zero-weight taps (roi_align_common.h:60-73 `continue`, and the x_high = x_low edge): a skipped sample reads a
+// zeroed 16-byte cell, the y edge uses the reference's own y_high = y_low row, and the x edge — re-expressed on the pair
+// (W-2, W-1) with factors (0, 1) so the pair stays one LDS read — multiplies its untouched pixel with v_mul_legacy_f32
+// (0 * anything = 0): a NaN / Inf pixel the reference never reads cannot leak into the result.
+#include <algorithm>
+#include <string>
+#include <type_traits>
+
+#include "roi_common.h"
+
+namespace tvmi {
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ int level_window_px(const int* __restrict__ blocksum, int l) {
+  // every consumer sums the same integers: the result does not depend on the order
+  const int lane = threadIdx.x & 63;
+  int v = lane < kPlanePreBlocks ? blocksum[lane * kMaxLevels + l] : 0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Pre-pass: LP lanes per RoI (32 for 7x7, 64 for 14x14), one axis sample per lane.
+template <typename R, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kPlanePreThreads) void roi_fwd_prepass(MsLevels lv, PlanePlan plan, const R* __restrict__ rois,
+                                                                    int K, int aligned, int multiscale,
+                                                                    int* __restrict__ key, float2* __restrict__ axis,
+                                                                    int* __restrict__ blocksum) {
+  constexpr int NY = PHT * SRT, NX = PWT * SRT, LP = plane_lanes_per_roi(PHT, PWT, SRT);
+  constexpr int RPB = kPlanePreThreads / LP;  // RoIs per block and iteration
+  __shared__ int s_px[kMaxLevels];
+  if (threadIdx.x < kMaxLevels) s_px[threadIdx.x] = 0;
+  __syncthreads();
+  const int sl = threadIdx.x % LP;
+  for (int k0 = blockIdx.x * RPB; k0 < K; k0 += gridDim.x * RPB) {
+    const int k = k0 + threadIdx.x / LP;
+    const bool live = k < K;
+    const R* roi = rois + (int64_t)(live ? k : K - 1) * 5;
+    const int l = multiscale ? fpn_level<R>(roi, lv) : 0;
+    int H = 0, W = 0;
+    float scale = 0.f;
+    PlaneLevel pl = plan.lv[0];
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; ++i)
+      if (i == l) {
+        H = lv.H[i];
+        W = lv.W[i];
+        scale = lv.scale[i];
+        pl = plan.lv[i];
+      }
+    const RoiGeom<float> g = roi_geom<R, float>(roi, scale, PHT, PWT, SRT, aligned != 0);
+    int lo = -1, hi = -1;
+    float fr = 0.f;
+    if (sl < NY) {
+      int a, b;
+      float l_, h_;
+      if (axis_sample<float>(H, g.start_h, g.bin_h, SRT, sl / SRT, sl % SRT, a, b, l_, h_)) {
+        lo = a;
+        hi = b;
+        fr = l_;
+      }
+    } else if (sl < NY + NX) {
+      const int s = sl - NY;
+      int a;
+      float l_, h_;
+      if (W >= 2 && axis_sample_shifted(W, g.start_w, g.bin_w, SRT, s / SRT, s % SRT, a, l_, h_)) {
+        lo = a;
+        hi = a + 1;
+        fr = l_;
+      }
+    }
+    const bool isy = sl < NY, isx = !isy && sl < NY + NX;
+    int ymin = (isy && lo >= 0) ? lo : 0x7fffffff, ymax = (isy && lo >= 0) ? hi : -1;
+    int xmin = (isx && lo >= 0) ? lo : 0x7fffffff, xmax = (isx && lo >= 0) ? hi : -1;
+#pragma unroll
+    for (int m = LP / 2; m >= 1; m >>= 1) {
+      ymin = min(ymin, __shfl_xor(ymin, m));
+      ymax = max(ymax, __shfl_xor(ymax, m));
+      xmin = min(xmin, __shfl_xor(xmin, m));
+      xmax = max(xmax, __shfl_xor(xmax, m));
+    }
+    bool ok = pl.enabled != 0 && g.batch >= 0 && g.batch < plan.N && g.batch < 32768 && W >= 2 && H >= 1;
+    int band = 0, px = 0;
+    if (ok && ymax >= 0 && xmax >= 0) {
+      band = min(ymin / pl.S, pl.nbands - 1);
+      const int r0 = min(band * pl.S, H - pl.B);
+      ok = ymin >= r0 && ymax < r0 + pl.B;
+      // what the per-RoI stager would move for this RoI and one channel (only the sampled rows of a tall window)
+      px = min(ymax - ymin + 1, 2 * NY) * (xmax - xmin + 1);
+    }
+    if (live && sl == 0) {
+      key[k] = ok ? ((g.batch << 16) | (l << 12) | band) : -1;
+      if (ok && px > 0) atomicAdd(&s_px[l], min(px, 1 << 14));
+    }
+    if (live && sl < NY + NX) axis[(int64_t)k * LP + sl] = make_float2(__int_as_float(lo), fr);
+  }
+  __syncthreads();
+  if (threadIdx.x < kMaxLevels) blocksum[blockIdx.x * kMaxLevels + threadIdx.x] = min(s_px[threadIdx.x], 1 << 24);
+}
+
+// ---------------------------------------------------------------------------------------
+// The serving kernel.
+// v_mul_legacy_f32 (0 * x = 0 for every x, NaN and Inf included) as the LLVM intrinsic itself — clang 22 has no builtin
+// for it; an inline-asm form would pin the surrounding LDS reads in place
+extern "C" __device__ float tvmi_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+__device__ __forceinline__ float mul_legacy(float a, float b) { return tvmi_fmul_legacy(a, b); }
+
+template <typename T>
+__device__ __forceinline__ float tap_pair(const char* __restrict__ p, float l, float h) {
+  // h * p[0] + l * p[1]; the h product is the one that may carry an exact-zero weight onto a pixel the reference does
+  // not read (shifted x edge): v_mul_legacy_f32 makes 0 * NaN = 0
+  const T* q = reinterpret_cast<const T*>(p);
+  return __builtin_fmaf(l, ld(q + 1), mul_legacy(h, ld(q)));
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv, PlanePlan plan, const int* __restrict__ key,
+                                                                     const float2* __restrict__ axis,
+                                                                     const int* __restrict__ blocksum, T* __restrict__ output,
+                                                                     int C, int K) {
+  constexpr int PHW = PHT * PWT, NB = (PHW + 63) / 64, NS = SRT * SRT, NY = PHT * SRT;
+  constexpr int LP = plane_lanes_per_roi(PHT, PWT, SRT);
+  constexpr int EPP = 16 / (int)sizeof(T);
+  static_assert(SRT == 2, "separable 2x2 sampling");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_next;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- which (level, image, band, channel group) is this workgroup?  Blocks of one level are numbered so that block b
+  // (observed on XCD b % 8 — speed only) gets every band of the channel groups gid = x (mod 8): neighbouring bands, which
+  // share half their rows, meet in one L2.
+  int l = -1;
+#pragma unroll
+  for (int i = 0; i < kMaxLevels; ++i)
+    if (plan.lv[i].enabled && (int)blockIdx.x >= plan.lv[i].block_base && (int)blockIdx.x < plan.lv[i].block_base + plan.lv[i].nblocks) l = i;
+  if (l < 0) return;
+  PlaneLevel pl = plan.lv[0];
+  int H = 0, W = 0;
+  const T* src = nullptr;
+#pragma unroll
+  for (int i = 0; i < kMaxLevels; ++i)
+    if (i == l) {
+      pl = plan.lv[i];
+      H = lv.H[i];
+      W = lv.W[i];
+      src = static_cast<const T*>(lv.ptr[i]);
+    }
+  const int q = (int)blockIdx.x - pl.block_base;
+  const int r = q >> 3;
+  const int gid = (r / pl.nbands) * 8 + (q & 7), band = r % pl.nbands;
+  if (gid >= plan.N * pl.ngroups) return;
+  // the device-side decision "is this level served here": same integers, same rule as the wave kernel (roi_align.hip)
+  if (!plane_level_active(level_window_px(blocksum, l), pl, plan.gain_x16, plan.N, H, W)) return;
+  const int img = gid / pl.ngroups, cgi = gid - img * pl.ngroups;
+  const int c0 = cgi * pl.cg, cc = min(pl.cg, C - c0);
+  const int r0 = min(band * pl.S, H - pl.B);
+  const int n = pl.B * W;                                   // elements of one channel's band
+  const int chs = 16 + ((n * (int)sizeof(T) + 15) & ~15);  // bytes per channel region: [16-byte zero cell][band]
+  const int want = (img << 16) | (l << 12) | band;
+
+  // ---- stage the band: per channel one contiguous run of n elements, 16-byte LDS-DMA pieces, instruction f = (c, i)
+  // issued by wave f % 8; lanes past the run are masked off (they must not write the next channel's region)
+  {
+    const int npf = n / EPP, ipc = (npf + 63) >> 6;
+    const T* band0 = src + (((int64_t)img * C + c0) * H + r0) * W;
+    for (int f = wave; f < cc * ipc; f += kPlaneThreads / 64) {
+      const int c = f / ipc, i = f - c * ipc;
+      const int piece = i * 64 + lane;
+      if (piece < npf)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(band0 + (int64_t)c * H * W + (int64_t)piece * EPP),
+                                         (lds_ptr_t)(smem + c * chs + 16 + i * 1024), 16, 0, 0);
+    }
+    const int tail = n - npf * EPP;  // run length not a multiple of a piece: the last 1..EPP-1 elements by hand
+    if (tid < cc * tail) {
+      const int c = tid / tail, e = npf * EPP + tid % tail;
+      reinterpret_cast<T*>(smem + c * chs + 16)[e] = band0[(int64_t)c * H * W + e];
+    }
+    if (tid < cc * 4) reinterpret_cast<int*>(smem + (tid >> 2) * chs)[tid & 3] = 0;  // the zero cells
+    if (tid == 0) s_next = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- serve: waves pull 64-key chunks; every matching RoI is one unit of work for the wave
+  const int nchunk = (K + 63) >> 6;
+  const int rowb = W * (int)sizeof(T);
+  for (;;) {
+    int chunk = 0;
+    if (lane == 0) chunk = atomicAdd(&s_next, 1);
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    if (chunk >= nchunk) break;
+    const int kk = chunk * 64 + lane;
+    unsigned long long bal = __ballot(kk < K && key[kk] == want);
+    while (bal) {
+      const int k = chunk * 64 + __builtin_ctzll(bal);
+      bal &= bal - 1;
+      // per-lane sample set-up from the RoI's axis table
+      int off[NB][NS][2];
+      float fy[NB][SRT][2], fx[NB][SRT][2];
+      const float2* ax = axis + (int64_t)k * LP;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int bin = min(lane + 64 * b, PHW - 1);
+        const int ph = bin / PWT, pw = bin - ph * PWT;
+        int row0[SRT], row1[SRT], col[SRT];
+        bool vy[SRT], vx[SRT];
+#pragma unroll
+        for (int i = 0; i < SRT; ++i) {
+          const float2 ey = ax[ph * SRT + i], ex = ax[NY + pw * SRT + i];
+          const int ylo = __float_as_int(ey.x), xlo = __float_as_int(ex.x);
+          vy[i] = ylo >= 0;
+          vx[i] = xlo >= 0;
+          row0[i] = 16 + (ylo - r0) * rowb;
+          row1[i] = row0[i] + (ylo < H - 1 ? rowb : 0);  // y edge: y_high = y_low, like the reference
+          col[i] = xlo * (int)sizeof(T);
+          fy[b][i][0] = ey.y;
+          fy[b][i][1] = 1.f - ey.y;
+          fx[b][i][0] = ex.y;
+          fx[b][i][1] = 1.f - ex.y;
+        }
+#pragma unroll
+        for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+          for (int ix = 0; ix < SRT; ++ix) {
+            const bool v = vy[iy] && vx[ix];
+            off[b][iy * SRT + ix][0] = v ? row0[iy] + col[ix] : 0;  // skipped sample: the zero cell
+            off[b][iy * SRT + ix][1] = v ? row1[iy] + col[ix] : 0;
+          }
+      }
+      T* out = output + ((int64_t)k * C + c0) * PHW;
+      for (int c = 0; c < cc; ++c) {
+        const char* cb = smem + c * chs;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int bin = lane + 64 * b;
+          if (bin < PHW) {  // the whole bin under the mask: idle lanes issue no LDS reads, and the tap pairs stay in one block
+            float acc = 0.f;
+#pragma unroll
+            for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+              for (int ix = 0; ix < SRT; ++ix) {
+                const float t0 = tap_pair<T>(cb + off[b][iy * SRT + ix][0], fx[b][ix][0], fx[b][ix][1]);
+                const float t1 = tap_pair<T>(cb + off[b][iy * SRT + ix][1], fx[b][ix][0], fx[b][ix][1]);
+                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+              }
+            const float res = acc * (1.f / (float)NS);
+            if constexpr (std::is_same<T, float>::value)
+              __builtin_nontemporal_store(res, out + c * PHW + bin);
+            else
+              st(out + c * PHW + bin, res);
+          }
+        }
+      }
+    }
+  }
+}
+
+struct PlaneOptions {
+  int enabled = 1;
+  int min_band_rows = 32;   // a map that does not fit is cut into bands only if a band holds at least this many rows
+  int gain_x16 = 32;        // a level is served by staging the map when 16 * (window pixels the RoIs would stage) * gain/16 >= map pixels * overlap
+};
+PlaneOptions g_opt;
+
+}  // namespace
+
+PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, int esize, int64_t PH, int64_t PW, int64_t sr) {
+  PlanePlan plan;
+  plan.N = (int)N;
+  plan.total_blocks = 0;
+  plan.gain_x16 = g_opt.gain_x16;
+  for (int i = 0; i < kMaxLevels; ++i) plan.lv[i] = PlaneLevel{0, 1, 1, 1, 1, 1, 0, 0};
+  const bool shape_ok = sr == 2 && ((PH == 7 && PW == 7) || (PH == 14 && PW == 14));
+  if (!g_opt.enabled || !shape_ok || (esize != 4 && esize != 2) || N <= 0 || N >= 32768 || C <= 0 || K <= 0) return plan;
+  int64_t blocks = 0;
+  for (int i = 0; i < lv.n_levels; ++i) {
+    const int64_t H = lv.H[i], W = lv.W[i];
+    if (H < 1 || W < 2 || H > 32767 || W > 32767) continue;
+    PlaneLevel& pl = plan.lv[i];
+    const int64_t whole = 16 + ((H * W * esize + 15) & ~(int64_t)15);
+    if (whole <= kPlaneImageBytes) {
+      pl.B = pl.S = (int)H;
+      pl.nbands = 1;
+      pl.cg = (int)std::min<int64_t>(std::min<int64_t>(kPlaneImageBytes / whole, C), 32);
+    } else {
+      const int64_t rows = (kPlaneImageBytes - 32) / (W * esize);
+      if (rows < g_opt.min_band_rows || rows < 4 || g_opt.min_band_rows <= 0) continue;
+      pl.B = (int)(rows & ~(int64_t)1);
+      pl.S = pl.B / 2;
+      pl.nbands = (int)ceil_div(H - pl.B, pl.S) + 1;
+      pl.cg = 1;
+      if (pl.nbands > 4095) continue;
+    }
+    pl.ngroups = (int)ceil_div(C, pl.cg);
+    const int64_t nb = 8 * ceil_div(N * pl.ngroups, 8) * pl.nbands;
+    if (blocks + nb > (1ll << 30)) continue;
+    pl.enabled = 1;
+    pl.block_base = (int)blocks;
+    pl.nblocks = (int)nb;
+    blocks += nb;
+  }
+  plan.total_blocks = (int)blocks;
+  return plan;
+}
+
+size_t plane_workspace_bytes(int64_t K, int64_t PH, int64_t PW, int64_t sr) {
+  if (!(sr == 2 && ((PH == 7 && PW == 7) || (PH == 14 && PW == 14))) || K <= 0) return 0;
+  const int LP = plane_lanes_per_roi((int)PH, (int)PW, (int)sr);
+  // [key: K ints][blocksum: kPlanePreBlocks * kMaxLevels ints][pad to 16][axis: K * LP float2]
+  size_t b = (size_t)K * 4 + (size_t)kPlanePreBlocks * kMaxLevels * 4;
+  b = (b + 15) & ~(size_t)15;
+  return b + (size_t)K * LP * 8;
+}
+
+PlaneBuffers plane_buffers(void* ws, int64_t K) {
+  PlaneBuffers pb;
+  char* p = static_cast<char*>(ws);
+  pb.key = reinterpret_cast<int*>(p);
+  pb.blocksum = pb.key + K;
+  size_t b = (size_t)K * 4 + (size_t)kPlanePreBlocks * kMaxLevels * 4;
+  b = (b + 15) & ~(size_t)15;
+  pb.axis = reinterpret_cast<float2*>(p + b);
+  return pb;
+}
+
+namespace {
+template <typename T, typename R, int PHT, int PWT, int SRT>
+int launch_plane_t(const MsLevels& lv, const PlanePlan& plan, const void* rois, void* output, int64_t C, int64_t K, int aligned,
+                   int multiscale, const PlaneBuffers& pb, hipStream_t s) {
+  constexpr int LP = plane_lanes_per_roi(PHT, PWT, SRT);
+  const int pre_blocks = (int)std::min<int64_t>(kPlanePreBlocks, ceil_div(K * LP, kPlanePreThreads));
+  if (pre_blocks < kPlanePreBlocks) {  // unused block sums must read as zero
+    const hipError_t e = hipMemsetAsync(pb.blocksum, 0, sizeof(int) * kPlanePreBlocks * kMaxLevels, s);
+    if (e != hipSuccess) return set_error((int)e, "roi_align: plane pre-pass memset");
+  }
+  roi_fwd_prepass<R, PHT, PWT, SRT><<<dim3((unsigned)pre_blocks), dim3(kPlanePreThreads), 0, s>>>(
+      lv, plan, static_cast<const R*>(rois), (int)K, aligned, multiscale, pb.key, pb.axis, pb.blocksum);
+  auto kern = roi_align_fwd_plane<T, PHT, PWT, SRT>;
+  static bool attr_set[64] = {};  // per instantiation and device (the attribute belongs to the device's code object);
+  int dev = 0;                    // racing threads set the same value
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPlaneImageBytes) != hipSuccess)
+      return set_error((int)hipErrorInvalidValue, "roi_align: cannot reserve the LDS band");
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  kern<<<dim3((unsigned)plan.total_blocks), dim3(kPlaneThreads), kPlaneImageBytes, s>>>(
+      lv, plan, pb.key, pb.axis, pb.blocksum, static_cast<T*>(output), (int)C, (int)K);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_forward (shared staging)");
+}
+}  // namespace
+
+template <typename T, typename R>
+int launch_plane(const MsLevels& lv, const PlanePlan& plan, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
+                 int aligned, int multiscale, const PlaneBuffers& pb, hipStream_t s) {
+  if (PH == 7) return launch_plane_t<T, R, 7, 7, 2>(lv, plan, rois, output, C, K, aligned, multiscale, pb, s);
+  return launch_plane_t<T, R, 14, 14, 2>(lv, plan, rois, output, C, K, aligned, multiscale, pb, s);
+}
+
+template int launch_plane<float, float>(const MsLevels&, const PlanePlan&, const void*, void*, int64_t, int64_t, int64_t, int, int,
+                                        const PlaneBuffers&, hipStream_t);
+template int launch_plane<__half, float>(const MsLevels&, const PlanePlan&, const void*, void*, int64_t, int64_t, int64_t, int, int,
+                                         const PlaneBuffers&, hipStream_t);
+template int launch_plane<__hip_bfloat16, float>(const MsLevels&, const PlanePlan&, const void*, void*, int64_t, int64_t, int64_t, int,
+                                                 int, const PlaneBuffers&, hipStream_t);
+template int launch_plane<__half, __half>(const MsLevels&, const PlanePlan&, const void*, void*, int64_t, int64_t, int64_t, int, int,
+                                          const PlaneBuffers&, hipStream_t);
+template int launch_plane<__hip_bfloat16, __hip_bfloat16>(const MsLevels&, const PlanePlan&, const void*, void*, int64_t, int64_t,
+                                                          int64_t, int, int, const PlaneBuffers&, hipStream_t);
+
+int set_plane_option(const char* name, int64_t value) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "roi_align.shared_staging") g_opt.enabled = value != 0;
+  else if (n == "roi_align.min_band_rows") g_opt.min_band_rows = (int)value;
+  else if (n == "roi_align.staging_gain_x16") g_opt.gain_x16 = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
+  else return -1;
+  return 0;
+}
+
+}  // namespace tvmi

@@ -112,4 +112,50 @@ __device__ __forceinline__ int fpn_level(const R* roi, const MsLevels& lv) {
   return min(max(l, 0), lv.n_levels - 1);
 }
 
+// ---------------------------------------------------------------------------------------
+// Shared-staging forward (roi_align_plane.hip): plan of which levels are served by staging the MAP (whole planes or
+// half-overlapping row bands) instead of every RoI's window, computed on the host from the level shapes alone.
+constexpr int kPlaneThreads = 512;              // 8 waves per workgroup, two workgroups per CU
+constexpr int kPlaneImageBytes = 78 * 1024;     // LDS of one workgroup: [16-byte zero cell][band] per channel
+constexpr int kPlanePreThreads = 1024;          // pre-pass block
+constexpr int kPlanePreBlocks = 64;             // pre-pass grid cap = number of per-block window-pixel sums
+
+constexpr int plane_lanes_per_roi(int PH, int PW, int SR) { return (PH + PW) * SR <= 32 ? 32 : 64; }
+
+struct PlaneLevel {
+  int enabled;
+  int B, S, nbands;       // band rows, band stride (rows), bands per plane (1: the whole plane)
+  int cg, ngroups;        // channels per workgroup, channel groups
+  int block_base, nblocks;
+};
+
+struct PlanePlan {
+  PlaneLevel lv[kMaxLevels];
+  int total_blocks;
+  int N;
+  int gain_x16;
+};
+
+struct PlaneBuffers {
+  int* key;        // [K]  (image << 16 | level << 12 | band) of a RoI the shared-staging kernel may serve, else -1
+  int* blocksum;   // [kPlanePreBlocks][kMaxLevels] window pixels the eligible RoIs of a level would stage one by one
+  float2* axis;    // [K][LP] {low index or -1, fraction} of every axis sample
+};
+
+// The device-side rule both forward kernels apply to the same integers: a level is served by staging the map when the
+// RoIs' own windows add up to more than the map (x overlap of the bands), weighted by `gain` — short row fragments cost
+// the texture path ~2.4 accesses per useful 64 bytes, full rows one.
+__host__ __device__ inline bool plane_level_active(int window_px, const PlaneLevel& pl, int gain_x16, int N, int H, int W) {
+  const long long map_px = (long long)N * H * W * (pl.nbands > 1 ? 2 : 1);
+  return pl.enabled != 0 && (long long)window_px * gain_x16 >= map_px * 16;
+}
+
+PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, int esize, int64_t PH, int64_t PW, int64_t sr);
+size_t plane_workspace_bytes(int64_t K, int64_t PH, int64_t PW, int64_t sr);
+PlaneBuffers plane_buffers(void* ws, int64_t K);
+template <typename T, typename R>
+int launch_plane(const MsLevels& lv, const PlanePlan& plan, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
+                 int aligned, int multiscale, const PlaneBuffers& pb, hipStream_t s);
+int set_plane_option(const char* name, int64_t value);
+
 }  // namespace tvmi

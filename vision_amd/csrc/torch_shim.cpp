@@ -194,11 +194,13 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
     return output;
   }
   at::Tensor input_ = input.contiguous(), rois_ = rois.contiguous();
-  at::Tensor ws = at::empty({K}, input.options().dtype(at::kInt));  // "declined by the LDS-DMA kernel" flags
+  // "declined by the LDS-DMA kernel" flags + the tables of the shared-staging kernel
+  const size_t ws_bytes = tvmi_roi_align_forward_workspace_bytes(K, pooled_height, pooled_width, sampling_ratio);
+  at::Tensor ws = at::empty({(int64_t)ws_bytes}, input.options().dtype(at::kByte));
   check_status(tvmi_roi_align_forward(input_.const_data_ptr(), rois_.const_data_ptr(), output.mutable_data_ptr(),
                                       dtype_of(input, "roi_align"), input.size(0), C, H, W, K, pooled_height,
                                       pooled_width, spatial_scale, sampling_ratio, aligned ? 1 : 0,
-                                      ws.mutable_data_ptr(), (size_t)K * sizeof(int32_t), current_stream(input)),
+                                      ws.mutable_data_ptr(), ws_bytes, current_stream(input)),
                "roi_align");
   return output;
 }
@@ -720,14 +722,15 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
   const int64_t K = rois.size(0), C = f0.size(1);
   at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, f0.options());
   if (output.numel() == 0) return output;
-  at::Tensor order_ws = at::empty({K}, f0.options().dtype(at::kInt));  // "declined by the LDS-DMA kernel" flags
+  // "declined by the LDS-DMA kernel" flags + the tables of the shared-staging kernel
+  const size_t fwd_ws_bytes = tvmi_roi_align_forward_workspace_bytes(K, pooled_height, pooled_width, sampling_ratio);
+  at::Tensor order_ws = at::empty({(int64_t)fwd_ws_bytes}, f0.options().dtype(at::kByte));
   check_status(tvmi_multiscale_roi_align_forward(ptrs.data(), hs.data(), ws.data(), scales.data(),
                                                  (int64_t)features.size(), rois_.const_data_ptr(),
                                                  output.mutable_data_ptr(), dtype_of(f0, "multiscale_roi_align"),
                                                  f0.size(0), C, K, pooled_height, pooled_width, sampling_ratio,
                                                  aligned ? 1 : 0, k_min, k_max, canonical_scale, canonical_level, eps,
-                                                 order_ws.mutable_data_ptr(), (size_t)K * sizeof(int32_t),
-                                                 current_stream(f0)),
+                                                 order_ws.mutable_data_ptr(), fwd_ws_bytes, current_stream(f0)),
                "multiscale_roi_align");
   return output;
 }
@@ -1025,7 +1028,15 @@ at::Tensor sort_scores_desc(const at::Tensor& scores) {
 }
 
 int64_t cuda_version() { return -1; }  // vision.cpp:21-28 without WITH_CUDA; ROCm never checks it
-int64_t tvmi_abi_version() { return tvmi_version(); }
+int64_t tvmi_abi_version() {
+  // the glue was compiled against this header: refuse to run on a kernels library of another ABI generation
+  TORCH_CHECK(tvmi_version() == TVMI_ABI_VERSION, "libtvmi_kernels.so has ABI ", tvmi_version(), ", the glue was built for ", TVMI_ABI_VERSION);
+  return tvmi_version();
+}
+bool tvmi_set_option_op(const std::string& name, int64_t value) {
+  check_status(tvmi_set_option(name.c_str(), value), "set_option");
+  return true;
+}
 
 }  // namespace
 
@@ -1064,6 +1075,7 @@ TORCH_LIBRARY_FRAGMENT(torchvision, m) {
 // loops in the reference); they live in their own namespace.
 TORCH_LIBRARY(tvmi, m) {
   m.def("abi_version", &tvmi_abi_version);
+  m.def("set_option", &tvmi_set_option_op);   // process-wide kernel switches (include/tvmi.h: tvmi_set_option)
   // opt-in: our resize kernels on the CUDA key of aten::upsample_* (returns the previous state)
   m.def("override_aten_upsample", &upsample_override::set);
   m.def("aten_upsample_calls", &upsample_override::calls);

@@ -16,6 +16,6 @@ int set_error(int code, const char* what) {
 }
 }  // namespace tvmi
 
-extern "C" int tvmi_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int tvmi_version(void) { return TVMI_ABI_VERSION; }
 extern "C" const char* tvmi_arch(void) { return "gfx950"; }
 extern "C" const char* tvmi_last_error(void) { return tvmi::g_last_error; }
