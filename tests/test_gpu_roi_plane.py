@@ -80,7 +80,6 @@ def test_multiscale_all_routes_agree_with_the_reference(P, aligned):
         b[:40, 2].clamp_(max=1344.0)
         b[:40, 3].clamp_(max=800.0)
         boxes.append(b)
-    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], P, 2)
     dfeats = {k: v.to(DEV) for k, v in feats.items()}
     dboxes = [b.to(DEV) for b in boxes]
     rois = torch.cat([torch.cat([torch.full((b.shape[0], 1), float(i)), b], 1) for i, b in enumerate(boxes)]).to(DEV)
@@ -91,7 +90,8 @@ def test_multiscale_all_routes_agree_with_the_reference(P, aligned):
         with route(name), torch.no_grad():
             outs[name] = torch.ops.tvmi.multiscale_roi_align(flist, rois, scales, P, P, 2, aligned, 2, 5, 224.0, 4.0, 1e-6).cpu()
     assert torch.equal(outs["staged"], outs["per-roi"]) and torch.equal(outs["default"], outs["per-roi"])
-    levels = pool.map_levels(boxes)
+    from vision_amd.poolers import LevelMapper
+    levels = LevelMapper(2, 5)(boxes)
     r5 = rois.cpu()
     for lvl in range(4):
         sel = torch.nonzero(levels == lvl)[:, 0]

@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU-box visit of round 3: usage  gpurun -- 'bash tools/r03_visit.sh <tag> <steps...>'
+# steps: plane | variants | sizes | overlay | bench | full | prof
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROOTDIR=$(pwd)
+for STEP in "$@"; do
+  case $STEP in
+    plane)    timeout 900 python -m pytest tests/test_gpu_roi_plane.py tests/test_gpu_dist.py -x -q > $OUT/t_plane.log 2>&1; tail -25 $OUT/t_plane.log ;;
+    variants) timeout 600 python tools/roi_variants.py $OUT/variants.json > $OUT/variants.log 2>&1; tail -20 $OUT/variants.log ;;
+    sizes)    timeout 1500 python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/t_sizes.log 2>&1; tail -25 $OUT/t_sizes.log ;;
+    overlay)  timeout 1200 python -m pytest tests/test_overlay.py -q -m gpu > $OUT/t_overlay.log 2>&1; tail -25 $OUT/t_overlay.log ;;
+    bench)    timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-1500 $OUT/bench.json; tail -5 $OUT/bench.err ;;
+    benchq)   timeout 600 python bench.py --no-e2e > $OUT/bench.json 2> $OUT/bench.err; cut -c1-1500 $OUT/bench.json; tail -5 $OUT/bench.err ;;
+    full)     timeout 2400 python -m pytest tests -q -m gpu -x > $OUT/t_full.log 2>&1; tail -25 $OUT/t_full.log ;;
+    prof)     cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/prof -o bench -- python $ROOTDIR/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $ROOTDIR/$OUT/prof.log 2>&1; cd $ROOTDIR; python tools/kernel_share.py $OUT/prof 2>/dev/null | head -40 ;;
+    *)        bash -c "$STEP" ;;
+  esac
+done

@@ -139,17 +139,80 @@ __device__ __forceinline__ float tap_pair(const char* __restrict__ p, float l, f
   return __builtin_fmaf(l, ld(q + 1), mul_legacy(h, ld(q)));
 }
 
+// per-lane sample set-up of one RoI from its axis table
+template <typename T, int PHT, int PWT, int SRT>
+struct LaneSetup {
+  static constexpr int PHW = PHT * PWT, NB = (PHW + 63) / 64, NS = SRT * SRT;
+  int off[NB][NS][2];
+  float fy[NB][SRT][2], fx[NB][SRT][2];
+};
+
+template <int PHT, int PWT, int SRT>
+struct AxisEntries {  // the raw table entries a lane needs (loaded one RoI ahead)
+  static constexpr int NB = (PHT * PWT + 63) / 64;
+  float2 ey[NB][SRT], ex[NB][SRT];
+};
+
+template <int PHT, int PWT, int SRT>
+__device__ __forceinline__ void load_axis(AxisEntries<PHT, PWT, SRT>& a, const float2* __restrict__ ax, int lane) {
+  constexpr int PHW = PHT * PWT, NB = (PHW + 63) / 64, NY = PHT * SRT;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int bin = min(lane + 64 * b, PHW - 1);
+    const int ph = bin / PWT, pw = bin - ph * PWT;
+#pragma unroll
+    for (int i = 0; i < SRT; ++i) {
+      a.ey[b][i] = ax[ph * SRT + i];
+      a.ex[b][i] = ax[NY + pw * SRT + i];
+    }
+  }
+}
+
+template <typename T, int PHT, int PWT, int SRT>
+__device__ __forceinline__ void make_setup(LaneSetup<T, PHT, PWT, SRT>& s, const AxisEntries<PHT, PWT, SRT>& a, int r0, int H, int rowb) {
+  constexpr int NB = (PHT * PWT + 63) / 64;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    int row0[SRT], row1[SRT], col[SRT];
+    bool vy[SRT], vx[SRT];
+#pragma unroll
+    for (int i = 0; i < SRT; ++i) {
+      const int ylo = __float_as_int(a.ey[b][i].x), xlo = __float_as_int(a.ex[b][i].x);
+      vy[i] = ylo >= 0;
+      vx[i] = xlo >= 0;
+      row0[i] = 16 + (ylo - r0) * rowb;
+      row1[i] = row0[i] + (ylo < H - 1 ? rowb : 0);  // y edge: y_high = y_low, like the reference
+      col[i] = xlo * (int)sizeof(T);
+      s.fy[b][i][0] = a.ey[b][i].y;
+      s.fy[b][i][1] = 1.f - a.ey[b][i].y;
+      s.fx[b][i][0] = a.ex[b][i].y;
+      s.fx[b][i][1] = 1.f - a.ex[b][i].y;
+    }
+#pragma unroll
+    for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < SRT; ++ix) {
+        const bool v = vy[iy] && vx[ix];
+        s.off[b][iy * SRT + ix][0] = v ? row0[iy] + col[ix] : 0;  // skipped sample: the zero cell
+        s.off[b][iy * SRT + ix][1] = v ? row1[iy] + col[ix] : 0;
+      }
+  }
+}
+
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv, PlanePlan plan, const int* __restrict__ key,
                                                                      const float2* __restrict__ axis,
                                                                      const int* __restrict__ blocksum, T* __restrict__ output,
                                                                      int C, int K) {
-  constexpr int PHW = PHT * PWT, NB = (PHW + 63) / 64, NS = SRT * SRT, NY = PHT * SRT;
+  constexpr int PHW = PHT * PWT, NB = (PHW + 63) / 64, NS = SRT * SRT;
   constexpr int LP = plane_lanes_per_roi(PHT, PWT, SRT);
   constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int KPT = 8;  // keys per thread and scan batch
   static_assert(SRT == 2, "separable 2x2 sampling");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_next;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  int* const s_list = reinterpret_cast<int*>(smem_all);  // [kPlaneListCap] RoIs this workgroup serves
+  char* const smem = smem_all + kPlaneListCap * 4;        // the staged band
+  __shared__ int s_n;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -184,7 +247,16 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
   const int n = pl.B * W;                                   // elements of one channel's band
   const int chs = 16 + ((n * (int)sizeof(T) + 15) & ~15);  // bytes per channel region: [16-byte zero cell][band]
   const int want = (img << 16) | (l << 12) | band;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
 
+  // ---- the first batch of keys is requested before the band, so that the list is being built while the band lands
+  int kv[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int k = j * kPlaneThreads + tid;
+    kv[j] = k < K ? key[k] : -1;
+  }
   // ---- stage the band: per channel one contiguous run of n elements, 16-byte LDS-DMA pieces, instruction f = (c, i)
   // issued by wave f % 8; lanes past the run are masked off (they must not write the next channel's region)
   {
@@ -203,80 +275,107 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
       reinterpret_cast<T*>(smem + c * chs + 16)[e] = band0[(int64_t)c * H * W + e];
     }
     if (tid < cc * 4) reinterpret_cast<int*>(smem + (tid >> 2) * chs)[tid & 3] = 0;  // the zero cells
-    if (tid == 0) s_next = 0;
+  }
+  // ---- the RoIs of this (image, level, band): compacted into the LDS list (order irrelevant: every RoI writes its own
+  // outputs); beyond kPlaneListCap entries a thread remembers what it could not list and serves it itself afterwards
+  unsigned unlisted = 0;
+  for (int kb = 0; kb < K; kb += KPT * kPlaneThreads) {
+    if (kb > 0) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int k = kb + j * kPlaneThreads + tid;
+        kv[j] = k < K ? key[k] : -1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const bool m = kv[j] == want;
+      const unsigned long long bal = __ballot(m);
+      if (bal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (m) {
+          if (pos < kPlaneListCap) s_list[pos] = kb + j * kPlaneThreads + tid;
+          else if (kb == 0) unlisted |= 1u << j;   // only the first batch is remembered; later batches are re-derived below
+        }
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  const int n_all = s_n, n_list = min(n_all, kPlaneListCap);
 
-  // ---- serve: waves pull 64-key chunks; every matching RoI is one unit of work for the wave
-  const int nchunk = (K + 63) >> 6;
   const int rowb = W * (int)sizeof(T);
-  for (;;) {
-    int chunk = 0;
-    if (lane == 0) chunk = atomicAdd(&s_next, 1);
-    chunk = __builtin_amdgcn_readfirstlane(chunk);
-    if (chunk >= nchunk) break;
-    const int kk = chunk * 64 + lane;
-    unsigned long long bal = __ballot(kk < K && key[kk] == want);
-    while (bal) {
-      const int k = chunk * 64 + __builtin_ctzll(bal);
-      bal &= bal - 1;
-      // per-lane sample set-up from the RoI's axis table
-      int off[NB][NS][2];
-      float fy[NB][SRT][2], fx[NB][SRT][2];
-      const float2* ax = axis + (int64_t)k * LP;
+  auto serve = [&](const LaneSetup<T, PHT, PWT, SRT>& su, int k) {
+    T* out = output + ((int64_t)k * C + c0) * PHW;
+    for (int c = 0; c < cc; ++c) {
+      const char* cb = smem + c * chs;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int bin = min(lane + 64 * b, PHW - 1);
-        const int ph = bin / PWT, pw = bin - ph * PWT;
-        int row0[SRT], row1[SRT], col[SRT];
-        bool vy[SRT], vx[SRT];
+        const int bin = lane + 64 * b;
+        if (bin < PHW) {  // the whole bin under the mask: idle lanes issue no LDS reads, and the tap pairs stay in one block
+          float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < SRT; ++i) {
-          const float2 ey = ax[ph * SRT + i], ex = ax[NY + pw * SRT + i];
-          const int ylo = __float_as_int(ey.x), xlo = __float_as_int(ex.x);
-          vy[i] = ylo >= 0;
-          vx[i] = xlo >= 0;
-          row0[i] = 16 + (ylo - r0) * rowb;
-          row1[i] = row0[i] + (ylo < H - 1 ? rowb : 0);  // y edge: y_high = y_low, like the reference
-          col[i] = xlo * (int)sizeof(T);
-          fy[b][i][0] = ey.y;
-          fy[b][i][1] = 1.f - ey.y;
-          fx[b][i][0] = ex.y;
-          fx[b][i][1] = 1.f - ex.y;
+          for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < SRT; ++ix) {
+              const float t0 = tap_pair<T>(cb + su.off[b][iy * SRT + ix][0], su.fx[b][ix][0], su.fx[b][ix][1]);
+              const float t1 = tap_pair<T>(cb + su.off[b][iy * SRT + ix][1], su.fx[b][ix][0], su.fx[b][ix][1]);
+              acc = __builtin_fmaf(su.fy[b][iy][1], t0, acc);
+              acc = __builtin_fmaf(su.fy[b][iy][0], t1, acc);
+            }
+          const float res = acc * (1.f / (float)NS);
+          if constexpr (std::is_same<T, float>::value)
+            __builtin_nontemporal_store(res, out + c * PHW + bin);
+          else
+            st(out + c * PHW + bin, res);
         }
-#pragma unroll
-        for (int iy = 0; iy < SRT; ++iy)
-#pragma unroll
-          for (int ix = 0; ix < SRT; ++ix) {
-            const bool v = vy[iy] && vx[ix];
-            off[b][iy * SRT + ix][0] = v ? row0[iy] + col[ix] : 0;  // skipped sample: the zero cell
-            off[b][iy * SRT + ix][1] = v ? row1[iy] + col[ix] : 0;
-          }
       }
-      T* out = output + ((int64_t)k * C + c0) * PHW;
-      for (int c = 0; c < cc; ++c) {
-        const char* cb = smem + c * chs;
+    }
+  };
+
+  // ---- serve the list: entry e goes to wave e % 8 (equal cost per RoI); the axis-table entries of the next RoI are
+  // requested before the current one is served (one RoI = ~50 instructions per channel: a dependent L2 round trip per
+  // RoI would show)
+  {
+    AxisEntries<PHT, PWT, SRT> cur, nxt;
+    int e = wave;
+    if (e < n_list) load_axis<PHT, PWT, SRT>(cur, axis + (int64_t)s_list[e] * LP, lane);
+    for (; e < n_list; e += kPlaneThreads / 64) {
+      const int k = s_list[e];
+      const int en = e + kPlaneThreads / 64;
+      if (en < n_list) load_axis<PHT, PWT, SRT>(nxt, axis + (int64_t)s_list[en] * LP, lane);
+      LaneSetup<T, PHT, PWT, SRT> su;
+      make_setup<T, PHT, PWT, SRT>(su, cur, r0, H, rowb);
+      serve(su, k);
+      cur = nxt;
+    }
+  }
+  // ---- overflow of the list (more than kPlaneListCap RoIs on one band of one image): every thread re-derives its own
+  // matches in the same order and serves those that did not get a slot — wave by wave, correct and unhurried
+  if (n_all > kPlaneListCap) {
+    for (int kb = 0; kb < K; kb += KPT * kPlaneThreads) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int bin = lane + 64 * b;
-          if (bin < PHW) {  // the whole bin under the mask: idle lanes issue no LDS reads, and the tap pairs stay in one block
-            float acc = 0.f;
-#pragma unroll
-            for (int iy = 0; iy < SRT; ++iy)
-#pragma unroll
-              for (int ix = 0; ix < SRT; ++ix) {
-                const float t0 = tap_pair<T>(cb + off[b][iy * SRT + ix][0], fx[b][ix][0], fx[b][ix][1]);
-                const float t1 = tap_pair<T>(cb + off[b][iy * SRT + ix][1], fx[b][ix][0], fx[b][ix][1]);
-                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
-              }
-            const float res = acc * (1.f / (float)NS);
-            if constexpr (std::is_same<T, float>::value)
-              __builtin_nontemporal_store(res, out + c * PHW + bin);
-            else
-              st(out + c * PHW + bin, res);
-          }
+      for (int j = 0; j < KPT; ++j) {
+        const int k = kb + j * kPlaneThreads + tid;
+        bool mine = false;
+        if (kb == 0) mine = (unlisted >> j) & 1u;
+        else if (k < K && key[k] == want) {   // later batches: listed iff its index is in the list
+          mine = true;
+          for (int t = 0; t < kPlaneListCap; ++t) mine = mine && s_list[t] != k;
+        }
+        unsigned long long bal = __ballot(mine);
+        while (bal) {
+          const int src_lane = __builtin_ctzll(bal);
+          bal &= bal - 1;
+          const int kk = __builtin_amdgcn_readlane(k, src_lane);
+          AxisEntries<PHT, PWT, SRT> a;
+          load_axis<PHT, PWT, SRT>(a, axis + (int64_t)kk * LP, lane);
+          LaneSetup<T, PHT, PWT, SRT> su;
+          make_setup<T, PHT, PWT, SRT>(su, a, r0, H, rowb);
+          serve(su, kk);
         }
       }
     }
@@ -301,7 +400,9 @@ PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, i
   const bool shape_ok = sr == 2 && ((PH == 7 && PW == 7) || (PH == 14 && PW == 14));
   if (!g_opt.enabled || !shape_ok || (esize != 4 && esize != 2) || N <= 0 || N >= 32768 || C <= 0 || K <= 0) return plan;
   int64_t blocks = 0;
-  for (int i = 0; i < lv.n_levels; ++i) {
+  // coarse levels first: their workgroups (whole planes, several channels) are the long ones, the bands of a fine level the
+  // short ones — the launch should end on short workgroups
+  for (int i = lv.n_levels - 1; i >= 0; --i) {
     const int64_t H = lv.H[i], W = lv.W[i];
     if (H < 1 || W < 2 || H > 32767 || W > 32767) continue;
     PlaneLevel& pl = plan.lv[i];
@@ -309,7 +410,12 @@ PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, i
     if (whole <= kPlaneImageBytes) {
       pl.B = pl.S = (int)H;
       pl.nbands = 1;
-      pl.cg = (int)std::min<int64_t>(std::min<int64_t>(kPlaneImageBytes / whole, C), 32);
+      // channels per workgroup: as many as fit, but not more work per workgroup than ~512 (RoI, channel, bin-group)
+      // units at an even spread of the RoIs over images and levels — a workgroup is LDS-bound on ONE CU, so coarse
+      // levels with many channels per workgroup would become the tail of the launch
+      const int64_t nb = (PH * PW + 63) / 64;
+      const int64_t by_work = std::max<int64_t>(1, 512 * N * lv.n_levels / std::max<int64_t>(K * nb, 1));
+      pl.cg = (int)std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(kPlaneImageBytes / whole, C), 32), by_work);
     } else {
       const int64_t rows = (kPlaneImageBytes - 32) / (W * esize);
       if (rows < g_opt.min_band_rows || rows < 4 || g_opt.min_band_rows <= 0) continue;
@@ -368,11 +474,11 @@ int launch_plane_t(const MsLevels& lv, const PlanePlan& plan, const void* rois, 
   int dev = 0;                    // racing threads set the same value
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPlaneImageBytes) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kPlaneImageBytes + kPlaneListCap * 4) != hipSuccess)
       return set_error((int)hipErrorInvalidValue, "roi_align: cannot reserve the LDS band");
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  kern<<<dim3((unsigned)plan.total_blocks), dim3(kPlaneThreads), kPlaneImageBytes, s>>>(
+  kern<<<dim3((unsigned)plan.total_blocks), dim3(kPlaneThreads), kPlaneImageBytes + kPlaneListCap * 4, s>>>(
       lv, plan, pb.key, pb.axis, pb.blocksum, static_cast<T*>(output), (int)C, (int)K);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_forward (shared staging)");
 }

@@ -116,7 +116,8 @@ __device__ __forceinline__ int fpn_level(const R* roi, const MsLevels& lv) {
 // Shared-staging forward (roi_align_plane.hip): plan of which levels are served by staging the MAP (whole planes or
 // half-overlapping row bands) instead of every RoI's window, computed on the host from the level shapes alone.
 constexpr int kPlaneThreads = 512;              // 8 waves per workgroup, two workgroups per CU
-constexpr int kPlaneImageBytes = 78 * 1024;     // LDS of one workgroup: [16-byte zero cell][band] per channel
+constexpr int kPlaneImageBytes = 74 * 1024;     // staged band of one workgroup: [16-byte zero cell][band] per channel
+constexpr int kPlaneListCap = 1024;             // RoIs of one (image, level, band) listed in LDS (4 KB next to the band)
 constexpr int kPlanePreThreads = 1024;          // pre-pass block
 constexpr int kPlanePreBlocks = 64;             // pre-pass grid cap = number of per-block window-pixel sums
 
