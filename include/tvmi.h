@@ -39,11 +39,14 @@ typedef enum tvmi_dtype {
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
- *   "roi_align.shared_staging"   1 (default) / 0: serve FPN levels by staging the map (roi_align_plane.hip)
+ *   "roi_align.shared_staging"   0 (default) / 1: serve FPN levels by staging the map (roi_align_plane.hip); measured
+ *                                slower than the per-RoI kernel at the FPN workload (LDS-gather bound), kept as an option
  *   "roi_align.min_band_rows"    maps that do not fit the LDS are cut into row bands only if a band holds this many rows
  *                                (default 32; 0 = never cut, only whole planes are staged)
  *   "roi_align.staging_gain_x16" weight (x/16, default 32 = 2.0) of the RoIs' window pixels against the map pixels in
- *                                the device-side decision which levels are staged */
+ *                                the device-side decision which levels are staged
+ *   "roi_align.stage_whole_planes" 1 / 0: stage levels whose plane fits the LDS budget twice
+ *   "roi_align.band_channels"    channels per workgroup of a banded level (default 2) */
 int tvmi_set_option(const char* name, int64_t value);
 /* Static string of the gfx arch the kernels were compiled for ("gfx950"). */
 const char* tvmi_arch(void);

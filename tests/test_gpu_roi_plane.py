@@ -4,11 +4,10 @@
 
   staged   staging_gain huge   -> every eligible RoI is served by the map-staging kernel (whole planes; row bands where
                                   the plane does not fit; min_band_rows lowered so that small test maps are cut too)
-  per-roi  shared_staging 0    -> the per-RoI LDS-DMA wave kernel + mop-up only (round-2 path)
-  default                      -> the device-side decision picks per level
+  per-roi  shared_staging 0    -> the per-RoI LDS-DMA wave kernel + mop-up only (the shipped default: it measured faster)
+  auto     shared_staging 1    -> the device-side decision picks per level
 
-All three must agree with the oracle at 1e-4 (fp32) and with EACH OTHER bit for bit on finite inputs (same separable
-arithmetic).  Also pinned here: what a NaN / Inf pixel does next to a zero-weight tap."""
+All three must agree with the oracle at 1e-4 (fp32) and with EACH OTHER up to fp32 summation order (4e-6).  Also pinned here: what a NaN / Inf pixel does next to a zero-weight tap."""
 import math
 
 import numpy as np
@@ -26,16 +25,18 @@ TOL = 1e-4
 
 class route:
     """context manager: force one forward route, restore the defaults afterwards"""
-    DEFAULTS = {"roi_align.shared_staging": 1, "roi_align.min_band_rows": 32, "roi_align.staging_gain_x16": 32}
+    DEFAULTS = {"roi_align.shared_staging": 0, "roi_align.min_band_rows": 32, "roi_align.staging_gain_x16": 32,
+                "roi_align.stage_whole_planes": 1, "roi_align.band_channels": 2}
 
     def __init__(self, name, min_band_rows=None):
         self.opts = dict(self.DEFAULTS)
         if name == "staged":
+            self.opts["roi_align.shared_staging"] = 1
             self.opts["roi_align.staging_gain_x16"] = 1 << 20
-        elif name == "per-roi":
-            self.opts["roi_align.shared_staging"] = 0
+        elif name == "auto":      # staging on, the device-side rule decides per level
+            self.opts["roi_align.shared_staging"] = 1
         else:
-            assert name == "default"
+            assert name == "per-roi"   # the shipped default
         if min_band_rows is not None:
             self.opts["roi_align.min_band_rows"] = min_band_rows
 
@@ -86,10 +87,12 @@ def test_multiscale_all_routes_agree_with_the_reference(P, aligned):
     flist = [dfeats[str(i)] for i in range(4)]
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
     outs = {}
-    for name in ("staged", "per-roi", "default"):
+    for name in ("staged", "per-roi", "auto"):
         with route(name), torch.no_grad():
             outs[name] = torch.ops.tvmi.multiscale_roi_align(flist, rois, scales, P, P, 2, aligned, 2, 5, 224.0, 4.0, 1e-6).cpu()
-    assert torch.equal(outs["staged"], outs["per-roi"]) and torch.equal(outs["default"], outs["per-roi"])
+    # the staged kernel sums a bin as (column sums over y) + (the other column), the per-RoI kernels sample by sample:
+    # same products, another association — equal up to fp32 rounding of sums of O(1) terms
+    assert float((outs["staged"] - outs["per-roi"]).abs().max()) <= 4e-6 and float((outs["auto"] - outs["per-roi"]).abs().max()) <= 4e-6
     from vision_amd.poolers import LevelMapper
     levels = LevelMapper(2, 5)(boxes)
     r5 = rois.cpu()
@@ -123,11 +126,11 @@ def test_schema_op_all_routes_on_awkward_maps(tv, H, W):
         for aligned in (False, True):
             ref = _ref(x, rois, 1.0, P, aligned)
             got = {}
-            for name, mbr in (("staged", 8), ("staged", 32), ("per-roi", None), ("default", None)):
+            for name, mbr in (("staged", 8), ("staged", 32), ("per-roi", None), ("auto", None)):
                 with route(name, mbr):
                     got[(name, mbr)] = tv.roi_align(x.to(DEV), rois.to(DEV), 1.0, P, P, 2, aligned).cpu()
                 np.testing.assert_allclose(got[(name, mbr)].numpy(), ref, rtol=0, atol=TOL, err_msg=f"{name} {mbr} P={P} aligned={aligned}")
-            assert torch.equal(got[("staged", 8)], got[("per-roi", None)])
+            assert float((got[("staged", 8)] - got[("per-roi", None)]).abs().max()) <= 4e-6
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 5e-3)])
@@ -142,7 +145,7 @@ def test_staged_route_16bit(tv, dtype, tol):
     for name in ("staged", "per-roi"):
         with route(name):
             res[name] = tv.roi_align(x.to(DEV), rois.to(DEV), 1 / 16, 7, 7, 2, False).cpu()
-    assert res["staged"].dtype == dtype and torch.equal(res["staged"], res["per-roi"])
+    assert res["staged"].dtype == dtype and float((res["staged"].float() - res["per-roi"].float()).abs().max()) <= tol
     ref = _ref(x.float(), rois.float(), 1 / 16, 7)
     np.testing.assert_allclose(res["staged"].float().numpy(), ref, rtol=tol, atol=tol)
     feats = [torch.rand(N, 24, 800 // s, 1344 // s, generator=g).to(dtype).to(DEV) for s in (4, 8, 16, 32)]
@@ -151,7 +154,7 @@ def test_staged_route_16bit(tv, dtype, tol):
     for name in ("staged", "per-roi"):
         with route(name), torch.no_grad():
             res[name] = torch.ops.tvmi.multiscale_roi_align(feats, boxes, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6)
-    assert torch.equal(res["staged"], res["per-roi"])
+    assert float((res["staged"].float() - res["per-roi"].float()).abs().max()) <= tol
 
 
 def test_nonfinite_pixels_next_to_zero_weight_taps(tv):

@@ -35,11 +35,18 @@ def tm(fn, n=24, warm=4):
     return e0.elapsed_time(e1) / n
 
 
+BASE = {"roi_align.shared_staging": 0, "roi_align.min_band_rows": 32, "roi_align.staging_gain_x16": 32,
+        "roi_align.stage_whole_planes": 1, "roi_align.band_channels": 2}
+FORCE = dict(BASE, **{"roi_align.shared_staging": 1, "roi_align.staging_gain_x16": 1 << 20})
 ROUTES = {
-    "per-roi": {"roi_align.shared_staging": 0},
-    "planes": {"roi_align.shared_staging": 1, "roi_align.min_band_rows": 0, "roi_align.staging_gain_x16": 1 << 20},
-    "planes+bands": {"roi_align.shared_staging": 1, "roi_align.min_band_rows": 32, "roi_align.staging_gain_x16": 1 << 20},
-    "default": {"roi_align.shared_staging": 1, "roi_align.min_band_rows": 32, "roi_align.staging_gain_x16": 32},
+    "per-roi": dict(BASE, **{"roi_align.shared_staging": 0}),
+    "planes-only": dict(FORCE, **{"roi_align.min_band_rows": 0}),
+    "bands1-only": dict(FORCE, **{"roi_align.stage_whole_planes": 0, "roi_align.band_channels": 1}),          # P2 + P3 as 1-channel bands
+    "bands2-only": dict(FORCE, **{"roi_align.stage_whole_planes": 0, "roi_align.band_channels": 2, "roi_align.min_band_rows": 16}),
+    "planes+bands1": dict(FORCE, **{"roi_align.band_channels": 1}),
+    "planes+bands2": dict(FORCE, **{"roi_align.band_channels": 2, "roi_align.min_band_rows": 16}),
+    "auto": dict(BASE, **{"roi_align.shared_staging": 1}),
+    "default": dict(BASE),
 }
 out = {}
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ROUTES)
@@ -54,7 +61,7 @@ for dt in (torch.float32, torch.bfloat16):
                 ms = tm(lambda i: torch.ops.tvmi.multiscale_roi_align(fl[i % 4], sets[i % 4]["rois"], scales, *args))
             out[f"{str(dt).split('.')[-1]}_{P}x{P}_{name}"] = round(ms, 4)
             print(f"{dt} {P} {name}: {ms:.4f} ms", flush=True)
-for k, v in ROUTES["default"].items():
+for k, v in BASE.items():
     torch.ops.tvmi.set_option(k, v)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -882,7 +882,7 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
     const int* pkey = nullptr;
     const int* pblocksum = nullptr;
     PlanePlan plan;
-    plan.lv[0] = PlaneLevel{0, 1, 1, 1, 1, 1, 0, 0};
+    plan.lv[0] = PlaneLevel{0, 1, 1, 1, 1, 1, 1, 0, 0};
     plan.gain_x16 = 0;
     plan.N = (int)N;
     if (declined && plane_ws) {

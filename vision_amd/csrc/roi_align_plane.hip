@@ -199,6 +199,27 @@ __device__ __forceinline__ void make_setup(LaneSetup<T, PHT, PWT, SRT>& s, const
   }
 }
 
+// Key scan: thread t of a batch starting at kb owns the keys kb + 4 * (i * kPlaneThreads + t) + {0..3}, i = 0 .. KPT/4 - 1
+// (one 16-byte load each; the key array is 16-byte aligned and padded to a multiple of 4 by the workspace layout).
+template <int KPT>
+__device__ __forceinline__ int key_index(int kb, int j, int tid) {
+  return kb + 4 * ((j >> 2) * kPlaneThreads + tid) + (j & 3);
+}
+template <int KPT>
+__device__ __forceinline__ void load_keys(int (&kv)[KPT], const int* __restrict__ key, int kb, int K, int tid) {
+  static_assert(KPT % 4 == 0, "keys in quads");
+#pragma unroll
+  for (int i = 0; i < KPT / 4; ++i) {
+    const int k0 = kb + 4 * (i * kPlaneThreads + tid);
+    int4 v = make_int4(-1, -1, -1, -1);
+    if (k0 < K) v = *reinterpret_cast<const int4*>(key + k0);   // the tail quad is padded inside the workspace
+    kv[4 * i + 0] = k0 + 0 < K ? v.x : -1;
+    kv[4 * i + 1] = k0 + 1 < K ? v.y : -1;
+    kv[4 * i + 2] = k0 + 2 < K ? v.z : -1;
+    kv[4 * i + 3] = k0 + 3 < K ? v.w : -1;
+  }
+}
+
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv, PlanePlan plan, const int* __restrict__ key,
                                                                      const float2* __restrict__ axis,
@@ -207,12 +228,13 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
   constexpr int PHW = PHT * PWT, NB = (PHW + 63) / 64, NS = SRT * SRT;
   constexpr int LP = plane_lanes_per_roi(PHT, PWT, SRT);
   constexpr int EPP = 16 / (int)sizeof(T);
-  constexpr int KPT = 8;  // keys per thread and scan batch
+  constexpr int KPT = 8;  // keys per thread and scan batch, fetched as two 16-byte loads (VMEM instructions are what this
+                          // kernel is short of: the texture path retires a wave's load in ~20 cycles whatever its width)
   static_assert(SRT == 2, "separable 2x2 sampling");
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   int* const s_list = reinterpret_cast<int*>(smem_all);  // [kPlaneListCap] RoIs this workgroup serves
   char* const smem = smem_all + kPlaneListCap * 4;        // the staged band
-  __shared__ int s_n;
+  __shared__ int s_cnt[64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -237,7 +259,8 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
     }
   const int q = (int)blockIdx.x - pl.block_base;
   const int r = q >> 3;
-  const int gid = (r / pl.nbands) * 8 + (q & 7), band = r % pl.nbands;
+  const int split = r % pl.nsplit, r2 = r / pl.nsplit;
+  const int gid = (r2 / pl.nbands) * 8 + (q & 7), band = r2 % pl.nbands;
   if (gid >= plan.N * pl.ngroups) return;
   // the device-side decision "is this level served here": same integers, same rule as the wave kernel (roi_align.hip)
   if (!plane_level_active(level_window_px(blocksum, l), pl, plan.gain_x16, plan.N, H, W)) return;
@@ -247,16 +270,10 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
   const int n = pl.B * W;                                   // elements of one channel's band
   const int chs = 16 + ((n * (int)sizeof(T) + 15) & ~15);  // bytes per channel region: [16-byte zero cell][band]
   const int want = (img << 16) | (l << 12) | band;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
 
   // ---- the first batch of keys is requested before the band, so that the list is being built while the band lands
   int kv[KPT];
-#pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const int k = j * kPlaneThreads + tid;
-    kv[j] = k < K ? key[k] : -1;
-  }
+  load_keys<KPT>(kv, key, 0, K, tid);
   // ---- stage the band: per channel one contiguous run of n elements, 16-byte LDS-DMA pieces, instruction f = (c, i)
   // issued by wave f % 8; lanes past the run are masked off (they must not write the next channel's region)
   {
@@ -276,36 +293,44 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
     }
     if (tid < cc * 4) reinterpret_cast<int*>(smem + (tid >> 2) * chs)[tid & 3] = 0;  // the zero cells
   }
-  // ---- the RoIs of this (image, level, band): compacted into the LDS list (order irrelevant: every RoI writes its own
-  // outputs); beyond kPlaneListCap entries a thread remembers what it could not list and serves it itself afterwards
+  // ---- the RoIs of this (image, level, band): compacted into the LDS list in a FIXED order (batch, key slot j, wave,
+  // lane) — the nsplit workgroups that share a band each build the list for themselves and must agree on which entry
+  // is whose.  Beyond kPlaneListCap entries a thread remembers what it could not list; split 0 serves those afterwards.
   unsigned unlisted = 0;
+  int n_all = 0;
   for (int kb = 0; kb < K; kb += KPT * kPlaneThreads) {
-    if (kb > 0) {
-#pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const int k = kb + j * kPlaneThreads + tid;
-        kv[j] = k < K ? key[k] : -1;
-      }
-    }
+    if (kb > 0) load_keys<KPT>(kv, key, kb, K, tid);
+    unsigned long long bals[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const bool m = kv[j] == want;
-      const unsigned long long bal = __ballot(m);
-      if (bal) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_n, __popcll(bal));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (m) {
-          if (pos < kPlaneListCap) s_list[pos] = kb + j * kPlaneThreads + tid;
-          else if (kb == 0) unlisted |= 1u << j;   // only the first batch is remembered; later batches are re-derived below
-        }
+      bals[j] = __ballot(kv[j] == want);
+      if (lane == 0) s_cnt[j * (kPlaneThreads / 64) + wave] = __popcll(bals[j]);
+    }
+    __syncthreads();
+    static_assert(KPT * (kPlaneThreads / 64) == 64, "one count per lane");
+    const int cnt = s_cnt[lane];
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    const int excl = incl - cnt;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int base = n_all + __builtin_amdgcn_readlane(excl, j * (kPlaneThreads / 64) + wave);
+      if (kv[j] == want) {
+        const int pos = base + __popcll(bals[j] & ((1ull << lane) - 1ull));
+        if (pos < kPlaneListCap) s_list[pos] = key_index<KPT>(kb, j, tid);
+        else if (kb == 0) unlisted |= 1u << j;   // only the first batch is remembered; later batches are re-derived below
       }
     }
+    n_all += __builtin_amdgcn_readlane(incl, 63);
+    __syncthreads();   // s_cnt is reused by the next batch
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int n_all = s_n, n_list = min(n_all, kPlaneListCap);
+  const int n_list = min(n_all, kPlaneListCap);
 
   const int rowb = W * (int)sizeof(T);
   auto serve = [&](const LaneSetup<T, PHT, PWT, SRT>& su, int k) {
@@ -341,11 +366,12 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
   // RoI would show)
   {
     AxisEntries<PHT, PWT, SRT> cur, nxt;
-    int e = wave;
+    const int estep = (kPlaneThreads / 64) * pl.nsplit;   // this workgroup serves entries e = split (mod nsplit)
+    int e = wave * pl.nsplit + split;
     if (e < n_list) load_axis<PHT, PWT, SRT>(cur, axis + (int64_t)s_list[e] * LP, lane);
-    for (; e < n_list; e += kPlaneThreads / 64) {
+    for (; e < n_list; e += estep) {
       const int k = s_list[e];
-      const int en = e + kPlaneThreads / 64;
+      const int en = e + estep;
       if (en < n_list) load_axis<PHT, PWT, SRT>(nxt, axis + (int64_t)s_list[en] * LP, lane);
       LaneSetup<T, PHT, PWT, SRT> su;
       make_setup<T, PHT, PWT, SRT>(su, cur, r0, H, rowb);
@@ -355,11 +381,12 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
   }
   // ---- overflow of the list (more than kPlaneListCap RoIs on one band of one image): every thread re-derives its own
   // matches in the same order and serves those that did not get a slot — wave by wave, correct and unhurried
-  if (n_all > kPlaneListCap) {
+  if (n_all > kPlaneListCap && split == 0) {
+#pragma unroll 1
     for (int kb = 0; kb < K; kb += KPT * kPlaneThreads) {
-#pragma unroll
+#pragma unroll 1
       for (int j = 0; j < KPT; ++j) {
-        const int k = kb + j * kPlaneThreads + tid;
+        const int k = key_index<KPT>(kb, j, tid);
         bool mine = false;
         if (kb == 0) mine = (unlisted >> j) & 1u;
         else if (k < K && key[k] == want) {   // later batches: listed iff its index is in the list
@@ -382,10 +409,17 @@ __global__ __launch_bounds__(kPlaneThreads) void roi_align_fwd_plane(MsLevels lv
   }
 }
 
+// Measured on BASELINE config 2 (profiles/r03_roi_align_staging_*.txt): staging the map cuts the HBM fetch
+// of the forward 4x (to ~the algorithmic bytes) but the launch is then bound by the lane = bin LDS gather (8-9 LDS cycles
+// per ds_read2_b32 under bank conflicts, ~70 cycles per RoI-channel) and by the texture path's ~20 cycles per VMEM
+// instruction, and ends up 5-25 % SLOWER than the per-RoI LDS-DMA kernel.  It therefore ships switched OFF; tests force
+// it on (tests/test_gpu_roi_plane.py) and tvmi_set_option("roi_align.shared_staging", 1) selects it.
 struct PlaneOptions {
-  int enabled = 1;
+  int enabled = 0;
   int min_band_rows = 32;   // a map that does not fit is cut into bands only if a band holds at least this many rows
   int gain_x16 = 32;        // a level is served by staging the map when 16 * (window pixels the RoIs would stage) * gain/16 >= map pixels * overlap
+  int whole_planes = 1;     // stage levels whose plane fits the LDS budget (at least twice)
+  int band_channels = 2;    // channels per workgroup of a banded level
 };
 PlaneOptions g_opt;
 
@@ -396,7 +430,7 @@ PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, i
   plan.N = (int)N;
   plan.total_blocks = 0;
   plan.gain_x16 = g_opt.gain_x16;
-  for (int i = 0; i < kMaxLevels; ++i) plan.lv[i] = PlaneLevel{0, 1, 1, 1, 1, 1, 0, 0};
+  for (int i = 0; i < kMaxLevels; ++i) plan.lv[i] = PlaneLevel{0, 1, 1, 1, 1, 1, 1, 0, 0};
   const bool shape_ok = sr == 2 && ((PH == 7 && PW == 7) || (PH == 14 && PW == 14));
   if (!g_opt.enabled || !shape_ok || (esize != 4 && esize != 2) || N <= 0 || N >= 32768 || C <= 0 || K <= 0) return plan;
   int64_t blocks = 0;
@@ -407,31 +441,38 @@ PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, i
     if (H < 1 || W < 2 || H > 32767 || W > 32767) continue;
     PlaneLevel& pl = plan.lv[i];
     const int64_t whole = 16 + ((H * W * esize + 15) & ~(int64_t)15);
-    if (whole <= kPlaneImageBytes) {
+    const int64_t nb = (PH * PW + 63) / 64;
+    // The per-RoI set-up (4 table loads per lane) and the texture path's ~20 cycles per VMEM instruction are paid once per
+    // (RoI, workgroup): staging the map only pays with at least two channels per workgroup.  A plane that fits twice is
+    // staged whole, otherwise two channels of a row band (half-overlapping bands of full-width rows).
+    if (2 * whole <= kPlaneImageBytes) {
+      if (!g_opt.whole_planes) continue;
       pl.B = pl.S = (int)H;
       pl.nbands = 1;
-      // channels per workgroup: as many as fit, but not more work per workgroup than ~512 (RoI, channel, bin-group)
-      // units at an even spread of the RoIs over images and levels — a workgroup is LDS-bound on ONE CU, so coarse
-      // levels with many channels per workgroup would become the tail of the launch
-      const int64_t nb = (PH * PW + 63) / 64;
-      const int64_t by_work = std::max<int64_t>(1, 512 * N * lv.n_levels / std::max<int64_t>(K * nb, 1));
-      pl.cg = (int)std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(kPlaneImageBytes / whole, C), 32), by_work);
+      pl.cg = (int)std::min<int64_t>(std::min<int64_t>(kPlaneImageBytes / whole, C), 32);
     } else {
-      const int64_t rows = (kPlaneImageBytes - 32) / (W * esize);
+      const int64_t cgb = std::min<int64_t>(std::max(1, g_opt.band_channels), C);
+      const int64_t rows = std::min<int64_t>((kPlaneImageBytes / cgb - 32) / (W * esize), H);
       if (rows < g_opt.min_band_rows || rows < 4 || g_opt.min_band_rows <= 0) continue;
-      pl.B = (int)(rows & ~(int64_t)1);
-      pl.S = pl.B / 2;
-      pl.nbands = (int)ceil_div(H - pl.B, pl.S) + 1;
-      pl.cg = 1;
+      pl.B = (int)(rows == H ? H : (rows & ~(int64_t)1));
+      pl.S = std::max(1, pl.B / 2);
+      pl.nbands = pl.B >= H ? 1 : (int)ceil_div(H - pl.B, pl.S) + 1;
+      pl.cg = (int)cgb;
       if (pl.nbands > 4095) continue;
     }
+    // a workgroup is bound by ONE CU's LDS and texture path: split a band's RoI list over several workgroups (each stages
+    // the band again — cheap, it is L2-resident by then) so that none holds much more than ~192 (RoI, channel, bin-group) units
+    {
+      const int64_t rois_est = std::max<int64_t>(1, K / (N * std::max<int64_t>(1, lv.n_levels) * pl.nbands));
+      pl.nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(32, ceil_div(rois_est * pl.cg * nb, 192)));
+    }
     pl.ngroups = (int)ceil_div(C, pl.cg);
-    const int64_t nb = 8 * ceil_div(N * pl.ngroups, 8) * pl.nbands;
-    if (blocks + nb > (1ll << 30)) continue;
+    const int64_t nblk = 8 * ceil_div(N * pl.ngroups, 8) * pl.nbands * pl.nsplit;
+    if (blocks + nblk > (1ll << 30)) continue;
     pl.enabled = 1;
     pl.block_base = (int)blocks;
-    pl.nblocks = (int)nb;
-    blocks += nb;
+    pl.nblocks = (int)nblk;
+    blocks += nblk;
   }
   plan.total_blocks = (int)blocks;
   return plan;
@@ -440,9 +481,9 @@ PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, i
 size_t plane_workspace_bytes(int64_t K, int64_t PH, int64_t PW, int64_t sr) {
   if (!(sr == 2 && ((PH == 7 && PW == 7) || (PH == 14 && PW == 14))) || K <= 0) return 0;
   const int LP = plane_lanes_per_roi((int)PH, (int)PW, (int)sr);
-  // [key: K ints][blocksum: kPlanePreBlocks * kMaxLevels ints][pad to 16][axis: K * LP float2]
-  size_t b = (size_t)K * 4 + (size_t)kPlanePreBlocks * kMaxLevels * 4;
-  b = (b + 15) & ~(size_t)15;
+
+  // [key: K ints, padded to a multiple of 4][blocksum: kPlanePreBlocks * kMaxLevels ints][axis: K * LP float2]
+  const size_t b = (((size_t)K + 3) & ~(size_t)3) * 4 + (size_t)kPlanePreBlocks * kMaxLevels * 4;
   return b + (size_t)K * LP * 8;
 }
 
@@ -450,9 +491,8 @@ PlaneBuffers plane_buffers(void* ws, int64_t K) {
   PlaneBuffers pb;
   char* p = static_cast<char*>(ws);
   pb.key = reinterpret_cast<int*>(p);
-  pb.blocksum = pb.key + K;
-  size_t b = (size_t)K * 4 + (size_t)kPlanePreBlocks * kMaxLevels * 4;
-  b = (b + 15) & ~(size_t)15;
+  pb.blocksum = pb.key + (((size_t)K + 3) & ~(size_t)3);
+  const size_t b = (((size_t)K + 3) & ~(size_t)3) * 4 + (size_t)kPlanePreBlocks * kMaxLevels * 4;
   pb.axis = reinterpret_cast<float2*>(p + b);
   return pb;
 }
@@ -507,6 +547,8 @@ int set_plane_option(const char* name, int64_t value) {
   const std::string n(name);
   if (n == "roi_align.shared_staging") g_opt.enabled = value != 0;
   else if (n == "roi_align.min_band_rows") g_opt.min_band_rows = (int)value;
+  else if (n == "roi_align.stage_whole_planes") g_opt.whole_planes = value != 0;
+  else if (n == "roi_align.band_channels") g_opt.band_channels = (int)std::max<int64_t>(1, std::min<int64_t>(value, 32));
   else if (n == "roi_align.staging_gain_x16") g_opt.gain_x16 = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
   else return -1;
   return 0;

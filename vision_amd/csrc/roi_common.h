@@ -127,6 +127,7 @@ struct PlaneLevel {
   int enabled;
   int B, S, nbands;       // band rows, band stride (rows), bands per plane (1: the whole plane)
   int cg, ngroups;        // channels per workgroup, channel groups
+  int nsplit;             // workgroups that share one staged band's RoI list (entry e goes to split e % nsplit)
   int block_base, nblocks;
 };
 
