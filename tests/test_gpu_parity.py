@@ -582,6 +582,38 @@ def test_deform_conv2d_vs_oracle(tv, cfg):
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=TOL)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, C=40, H=37, W=150, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, sigma=1.0),     # several tiles, ragged edges
+    dict(B=1, C=64, H=21, W=70, og=4, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False, sigma=6.0),     # offsets far beyond the staged halo
+    dict(B=2, C=24, H=30, W=41, og=3, stride=(2, 2), pad=(2, 1), dil=(2, 2), mask=True, sigma=2.0),      # stride / dilation / offset groups
+    dict(B=1, C=17, H=9, W=5, og=1, stride=(1, 2), pad=(0, 3), dil=(1, 1), mask=True, sigma=3.0),        # tiny map, odd channel count
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deform_conv2d_depthwise_kernel(cfg, dtype):
+    """groups == C == OC, 3x3: the lane = pixel LDS-window kernel (deform_conv2d.hip dcn_fwd_depthwise3x3) — taps inside the
+    staged window read LDS, taps beyond the +/-4 px halo fall back to the reference arithmetic on global memory, zero
+    padding comes from the zero-filled window border; channel ranges / chunks that do not divide evenly.  Reference:
+    cpu/deform_conv2d_kernel.cpp:95-209 via the oracle; bf16 against fp32 on the rounded tensors at the 16-bit bar."""
+    g = gen(18)
+    C, og = cfg["C"], cfg["og"]
+    if C % og:
+        C = C // og * og
+    oh = (cfg["H"] + 2 * cfg["pad"][0] - (cfg["dil"][0] * 2 + 1)) // cfg["stride"][0] + 1
+    ow = (cfg["W"] + 2 * cfg["pad"][1] - (cfg["dil"][1] * 2 + 1)) // cfg["stride"][1] + 1
+    x = torch.randn(cfg["B"], C, cfg["H"], cfg["W"], generator=g).to(dtype)
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(dtype)
+    off = (torch.randn(cfg["B"], 2 * og * 9, oh, ow, generator=g) * cfg["sigma"]).to(dtype)
+    m = torch.rand(cfg["B"], og * 9, oh, ow, generator=g).to(dtype)
+    b = torch.randn(C, generator=g).to(dtype)
+    y = vision_amd.deform_conv2d(x.to(DEV), off.to(DEV), w.to(DEV), b.to(DEV), cfg["stride"], cfg["pad"], cfg["dil"],
+                                 m.to(DEV) if cfg["mask"] else None)
+    assert y.dtype == dtype and tuple(y.shape) == (cfg["B"], C, oh, ow)
+    ref = O.deform_conv2d(x.float().numpy(), w.float().numpy(), off.float().numpy(), m.float().numpy(), b.float().numpy(),
+                          cfg["stride"], cfg["pad"], cfg["dil"], C, og, cfg["mask"])
+    tol = TOL if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=tol, atol=tol)
+
+
 def test_deform_conv2d_zero_offset_is_conv_and_batch0(tv):
     g = gen(15)
     x = torch.randn(2, 32, 14, 14, generator=g).to(DEV)

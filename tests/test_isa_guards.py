@@ -1,0 +1,56 @@
+"""Assembly-level guards for hand-written inline asm whose correctness depends on what the COMPILER puts around it.
+
+nms.hip routes the lane select of v_writelane through M0 (suppression_row_pair): the compiler rejects "m0" in a clobber
+list, so the code saves M0 before the 64 rows of a tile and restores it afterwards, and relies on nothing else between
+the pair reading or writing M0.  This test compiles the TU for gfx950 exactly like the Makefile and
+checks, in the ISA, that between every `s_mov_b32 sN, m0` (save) and the matching `s_mov_b32 m0, sN` (restore) the only
+instructions that touch M0 are our own `s_mov_b32 m0, <imm>` and `v_writelane_b32 ..., m0` — and that no instruction with
+an IMPLICIT M0 operand (LDS-DMA, movrel, GWS, sendmsg, interp) appears there.  A compiler upgrade that starts using M0 in
+that region fails here instead of silently corrupting suppression masks."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from helpers import ROOT
+
+CSRC = os.path.join(ROOT, "vision_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+IMPLICIT_M0 = re.compile(r"^\s*(s_movrel|v_movrel|ds_gws|s_sendmsg|v_interp|buffer_load\S*\s.*\blds\b|global_load_lds|s_load_lds)")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_nms_m0_save_restore_regions_are_clean(tmp_path):
+    out = tmp_path / "nms.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           f"-I{os.path.join(ROOT, 'include')}", "-S", "--cuda-device-only", os.path.join(CSRC, "nms.hip"), "-o", str(out)]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    lines = out.read_text().splitlines()
+    save_re = re.compile(r"^\s*s_mov_b32\s+(s\d+),\s*m0\b")
+    regions = writes = 0
+    i = 0
+    while i < len(lines):
+        m = save_re.match(lines[i])
+        if not m:
+            i += 1
+            continue
+        sreg = m.group(1)
+        restore_re = re.compile(rf"^\s*s_mov_b32\s+m0,\s*{sreg}\b")
+        j = i + 1
+        while j < len(lines) and not restore_re.match(lines[j]):
+            ln = lines[j].split(";")[0]
+            assert not re.match(r"^\s*s_endpgm", ln), f"M0 saved at line {i + 1} but never restored before s_endpgm"
+            assert not IMPLICIT_M0.match(ln), f"line {j + 1}: instruction with an implicit M0 operand inside a save/restore region: {ln.strip()}"
+            if re.search(r"\bm0\b", ln):
+                ok = re.match(r"^\s*s_mov_b32\s+m0,\s*(0x[0-9a-f]+|\d+)\s*$", ln) or re.match(r"^\s*v_writelane_b32\s+v\d+,\s*(s\d+|vcc_lo|vcc_hi),\s*m0\s*$", ln)
+                assert ok, f"line {j + 1}: unexpected use of M0 inside a save/restore region: {ln.strip()}"
+                writes += 1
+            # the save register must stay untouched until the restore
+            assert not re.match(rf"^\s*\S+\s+{sreg}\b(?!\s*,\s*m0)", ln) or "s_mov_b32 m0" in ln, f"line {j + 1}: save register {sreg} overwritten: {ln.strip()}"
+            j += 1
+        assert j < len(lines), f"M0 saved at line {i + 1} but never restored"
+        regions += 1
+        i = j + 1
+    # the fast tile path exists in every tile kernel (mask tiles, segmented, small segments, diag / keyed variants)
+    assert regions >= 3 and writes >= 3 * 96, (regions, writes)

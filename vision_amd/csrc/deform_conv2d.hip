@@ -356,6 +356,188 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
   }
 }
 
+// ------------------------------------------------------------------ depthwise forward (groups == C == OC, 3x3)
+// Reference shape: cuda/deform_conv2d_kernel.cu:136-209 writes columns[C*9, B*oh*ow] and runs C GEMMs of 1 x 9.  The
+// generic direct kernel above re-derives the tap geometry per (pixel, channel) and gathers 36 scattered dwords per output
+// from L2 (0.249 ms at config 4 = 0.03 of the HBM roofline: the texture path retires ~1 scattered lane per clock).
+// Here:  workgroup = (image, 8 x 64 output tile, offset group, channel range).  lane = pixel: the 9 taps of a pixel
+// {LDS offset of the top-left corner, lw, (1-lh)*mask, lh*mask} are computed ONCE and kept in registers for every channel
+// of the range; the input window of the tile (+/- kHalo px of offset reach, zero-filled outside the image: the
+// reference's zero-padding semantics, cpu/deform_conv2d_kernel.cpp:95-132, become plain reads) is staged per chunk of
+// channels in LDS, double-buffered through registers, and the 4 corners of a tap are two LDS pair reads.  A tap that leaves
+// the staged window (offset beyond the halo) is flagged per lane and served from global memory with the exact
+// reference arithmetic — correct for any offset, fast for offsets within the halo.  Stores are 256-byte rows.
+constexpr int kDwTH = 8, kDwTW = 64, kDwThreads = kDwTH * kDwTW, kDwHalo = 4, kDwMaxStage = 12;
+
+struct DwGeom {
+  int tile_h, tile_w, tile_sz;   // staged input window of one output tile (rows, cols, elements)
+  int ntx, nty;                  // output tiles
+  int CB, nstage;                // channels per chunk, staged elements per thread and chunk
+  int csplit, cper;              // channel ranges per offset group, channels per range
+};
+
+// TWC: the staged window's row pitch as a compile-time constant (75 for stride 1 / dilation 1: the second tap row is then an
+// immediate offset of the LDS pair read) or 0 = run-time pitch.
+template <typename T, int TWC>
+__global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3(const T* __restrict__ input, const T* __restrict__ weight,
+                                                                     const T* __restrict__ offset, const T* __restrict__ mask,
+                                                                     const T* __restrict__ bias, T* __restrict__ out,
+                                                                     DcnParams p, DwGeom g) {
+  constexpr int KK = 9;
+  extern __shared__ __attribute__((aligned(16))) float dw_lds[];   // [2][CB][tile_h][tile_w]
+  const int tile_w = TWC > 0 ? TWC : g.tile_w;
+  const int tid = threadIdx.x;
+  const int px = tid & (kDwTW - 1), py = tid >> 6;
+  const int tx0 = (blockIdx.x % g.ntx) * kDwTW, ty0 = (blockIdx.x / g.ntx) * kDwTH;
+  const int og = blockIdx.y / g.csplit, cs = blockIdx.y - og * g.csplit;
+  const int b = blockIdx.z;
+  const int c_begin = og * p.cpog + cs * g.cper, c_end = min((og + 1) * p.cpog, c_begin + g.cper);
+  if (c_begin >= c_end) return;
+  const int ox = tx0 + px, oy = ty0 + py;
+  const bool live = ox < p.ow && oy < p.oh;
+  const int in_y0 = ty0 * p.sh - p.ph - kDwHalo, in_x0 = tx0 * p.sw - p.pw - kDwHalo;
+  const int64_t plane = (int64_t)p.H * p.W, oplane = (int64_t)p.oh * p.ow;
+
+  // ---- tap geometry of this lane's pixel, once for all channels
+  int toff[KK];
+  float lw[KK], hhm[KK], lhm[KK];
+  unsigned far = 0;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    toff[t] = 0;
+    lw[t] = hhm[t] = lhm[t] = 0.f;
+    if (live) {
+      const int i = t / 3, j = t - 3 * i;
+      const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * oplane + (int64_t)oy * p.ow + ox;
+      const float off_h = ld(optr + (int64_t)(2 * t) * oplane), off_w = ld(optr + (int64_t)(2 * t + 1) * oplane);
+      float m = 1.f;
+      if (p.use_mask) m = ld(mask + ((int64_t)(b * p.ogroups + og) * KK + t) * oplane + (int64_t)oy * p.ow + ox);
+      const float y = (float)(oy * p.sh - p.ph) + (float)(i * p.dh) + off_h;
+      const float x = (float)(ox * p.sw - p.pw) + (float)(j * p.dw) + off_w;
+      if (!(y <= -1.f || (float)p.H <= y || x <= -1.f || (float)p.W <= x)) {   // else: the sample is zero (reference :99-101)
+        const float fy = floorf(y), fx = floorf(x);
+        const int ty = (int)fy - in_y0, tx = (int)fx - in_x0;
+        if (ty >= 0 && ty + 1 < g.tile_h && tx >= 0 && tx + 1 < tile_w) {
+          const float lh = y - fy;
+          toff[t] = ty * tile_w + tx;
+          lw[t] = x - fx;
+          hhm[t] = (1.f - lh) * m;
+          lhm[t] = lh * m;
+        } else {
+          far |= 1u << t;   // inside the image but outside the staged window
+        }
+      }
+    }
+  }
+  const bool any_far = __ballot(far != 0) != 0ull;
+
+  // ---- staging plan of this thread: element e = tid + i * threads of the chunk image [CB][tile_h][tile_w]
+  int gsrc[kDwMaxStage];   // offset inside the chunk's first input plane (cb * plane + y * W + x), -1 = zero fill / nothing
+#pragma unroll
+  for (int i = 0; i < kDwMaxStage; ++i) {
+    gsrc[i] = -1;
+    const int e = tid + i * kDwThreads;
+    if (i < g.nstage && e < g.CB * g.tile_sz) {
+      const int cb = e / g.tile_sz, rem = e - cb * g.tile_sz;
+      const int r = rem / tile_w, c = rem - r * tile_w;
+      const int iy = in_y0 + r, ix = in_x0 + c;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) gsrc[i] = cb * (int)plane + iy * p.W + ix;
+    }
+  }
+  const int nchunks = (c_end - c_begin + g.CB - 1) / g.CB;
+  float stage[kDwMaxStage];
+  auto fetch = [&](int chunk) {
+    const int c0 = c_begin + chunk * g.CB;
+    const T* src = input + ((int64_t)b * p.C + c0) * plane;
+    const int lim = (c_end - c0) * (int)plane;   // channels past the range are not touched
+#pragma unroll
+    for (int i = 0; i < kDwMaxStage; ++i) {
+      stage[i] = 0.f;
+      if (i < g.nstage && gsrc[i] >= 0 && gsrc[i] < lim) stage[i] = ld(src + gsrc[i]);
+    }
+  };
+  auto park = [&](int buf) {
+    float* dst = dw_lds + buf * g.CB * g.tile_sz;
+#pragma unroll
+    for (int i = 0; i < kDwMaxStage; ++i) {
+      const int e = tid + i * kDwThreads;
+      if (i < g.nstage && e < g.CB * g.tile_sz) dst[e] = stage[i];
+    }
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) fetch(chunk + 1);   // the next chunk's window is in flight while this one is used
+    const float* tile = dw_lds + (chunk & 1) * g.CB * g.tile_sz;
+    const int c0 = c_begin + chunk * g.CB, nc = min(g.CB, c_end - c0);
+    for (int cb = 0; cb < nc; ++cb) {
+      const int c = c0 + cb;   // depthwise: output channel = input channel = weight row
+      const float* tc = tile + cb * g.tile_sz;
+      const T* wrow = weight + (int64_t)c * KK;
+      // the 9 weights and the bias of this channel are wave-uniform: fp32 -> scalar loads; 16-bit types have no scalar
+      // load, so ONE vector load (lane t = weight t, lane 9 = bias) and readlane broadcasts instead of 10 VMEM instructions
+      float wv = 0.f;
+      if constexpr (!std::is_same<T, float>::value) {
+        const int wl_ = tid & 63;
+        if (wl_ < KK) wv = ld(wrow + wl_);
+        else if (wl_ == KK) wv = ld(bias + c);
+      }
+      auto wt = [&](int t) -> float {
+        if constexpr (std::is_same<T, float>::value) return t < KK ? wrow[t] : bias[c];
+        else return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), t));
+      };
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const float* q = tc + toff[t];
+        const float top = __builtin_fmaf(lw[t], q[1], (1.f - lw[t]) * q[0]);
+        const float bot = __builtin_fmaf(lw[t], q[tile_w + 1], (1.f - lw[t]) * q[tile_w]);
+        const float val = __builtin_fmaf(lhm[t], bot, hhm[t] * top);
+        acc = __builtin_fmaf(wt(t), val, acc);
+      }
+      if (any_far) {   // taps outside the staged window: the reference arithmetic on global memory
+        const T* pl = input + ((int64_t)b * p.C + c) * plane;
+        for (int t = 0; t < KK; ++t)
+          if ((far >> t) & 1u) {
+            Tap<float> tp;
+            load_tap<T, float>(tp, p, offset, mask, b, og, t, oy, ox);
+            acc = __builtin_fmaf(wt(t), sample_tap<T, float>(tp, pl), acc);
+          }
+      }
+      if (live) st(out + ((int64_t)b * p.OC + c) * oplane + (int64_t)oy * p.ow + ox, acc + wt(KK));
+    }
+    if (chunk + 1 < nchunks) park((chunk + 1) & 1);
+    __syncthreads();
+  }
+}
+
+// geometry of the depthwise kernel for a problem, or .CB = 0 when it does not apply
+inline DwGeom depthwise_geom(const DcnParams& p, tvmi_dtype dt) {
+  DwGeom g{};
+  g.CB = 0;
+  if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16)) return g;
+  if (!(p.ICg == 1 && p.OCg == 1 && p.kh == 3 && p.kw == 3)) return g;
+  g.tile_h = (kDwTH - 1) * p.sh + 2 * p.dh + 2 * kDwHalo + 2;
+  g.tile_w = (kDwTW - 1) * p.sw + 2 * p.dw + 2 * kDwHalo + 2;
+  g.tile_sz = g.tile_h * g.tile_w;
+  const int64_t budget = 48 * 1024 / 4;   // floats of LDS per workgroup (3 workgroups per CU), two buffers
+  const int64_t cb = std::min<int64_t>(std::min<int64_t>(budget / (2 * (int64_t)g.tile_sz), 8), p.cpog);
+  if (cb < 1 || (int64_t)p.H * p.W * cb >= (1ll << 31)) return g;
+  g.nstage = (int)ceil_div(cb * g.tile_sz, kDwThreads);
+  if (g.nstage > kDwMaxStage) return g;
+  g.ntx = (int)ceil_div(p.ow, kDwTW);
+  g.nty = (int)ceil_div(p.oh, kDwTH);
+  // enough workgroups to fill the chip ~3 times, but at least 16 channels per range so the tap set-up amortises
+  const int64_t tiles = (int64_t)g.ntx * g.nty * p.B * p.ogroups;
+  int64_t csplit = std::max<int64_t>(1, std::min<int64_t>(ceil_div(3 * 256, tiles), std::max<int64_t>(1, p.cpog / 16)));
+  g.cper = (int)ceil_div(ceil_div(p.cpog, csplit), cb) * (int)cb;   // whole chunks per range
+  g.csplit = (int)ceil_div(p.cpog, g.cper);
+  if ((int64_t)g.csplit * p.ogroups > 65535 || p.B > 65535) return g;
+  g.CB = (int)cb;
+  return g;
+}
+
 // ------------------------------------------------------------------ backward building blocks
 // columns layout: [C*kh*kw][B*oh*ow]  (k = (c*kh + i)*kw + j ; n = (b*oh + y)*ow + x)
 template <typename T>
@@ -577,6 +759,24 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
       if (eight) TVMI_DCN(1, 8, 2, 1); else TVMI_DCN(1, 4, 2, 2);
     }
 #undef TVMI_DCN
+  } else if (const DwGeom dg = depthwise_geom(p, dt); dg.CB > 0) {
+    const dim3 grid((unsigned)(dg.ntx * dg.nty), (unsigned)(dg.csplit * p.ogroups), (unsigned)p.B);
+    const size_t lds = (size_t)2 * dg.CB * dg.tile_sz * sizeof(float);
+#define TVMI_DW(scalar_t)                                                                                         \
+  do {                                                                                                            \
+    if (dg.tile_w == 75)                                                                                          \
+      dcn_fwd_depthwise3x3<scalar_t, 75><<<grid, dim3(kDwThreads), lds, s>>>(                                     \
+          (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,        \
+          (const scalar_t*)bias, (scalar_t*)output, p, dg);                                                       \
+    else                                                                                                          \
+      dcn_fwd_depthwise3x3<scalar_t, 0><<<grid, dim3(kDwThreads), lds, s>>>(                                      \
+          (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,        \
+          (const scalar_t*)bias, (scalar_t*)output, p, dg);                                                       \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_DW(float);
+    else if (dt == TVMI_F16) TVMI_DW(__half);
+    else TVMI_DW(__hip_bfloat16);
+#undef TVMI_DW
   } else {
     TVMI_DISPATCH_FLOAT(dt, "deform_conv2d_forward",
                         dcn_fwd_direct<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(

@@ -40,6 +40,13 @@ constexpr int kBigCap = 1024;       // oversized-window RoIs listed for the seco
 constexpr int kUnset = 0x7f7f7f7f;  // memset pattern of the per-image RoI ranges and of the oversized-window counter
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Global-memory vector loads whose addresses are only dword-aligned (a channel's grads start at k*C*PH*PW + c*PH*PW floats,
+// a lane's table columns at an odd offset): the types say so — gfx950 serves dword-aligned 8 / 16-byte global
+// loads in one instruction either way.
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) F2u { float x, y; };
+__device__ __forceinline__ float4 ld4u(const float* p) { const F4u v = *reinterpret_cast<const F4u*>(p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ v2f ld2u(const float* p) { const F2u v = *reinterpret_cast<const F2u*>(p); return v2f{v.x, v.y}; }
 
 // ---------------------------------------------------------------------------------------
 // workspace layout (all device memory, written by the pre-pass, read-only for the owner kernel)
@@ -50,13 +57,15 @@ struct OwnWorkspace {
   int* biglist;   // [kBigCap] indices of the RoIs with oversized windows (unordered; the second pass sorts them)
   float* ayt;     // [K][kTile + kRCap + kTile][PH]  AyD rows, window-relative, 16 zero rows before and behind
   float* axt;     // [K][PW][kTile + kRCap + kTile]  AxD rows (column index fastest), window-relative, zero columns on both sides
+  float* roisf;   // [K][5] the RoIs as float32 (single-level calls hand 16-bit RoIs over with 16-bit gradients; the owner
+                  //        kernels only ever read these)
 };
 
 constexpr int pad4(int v) { return (v + 3) & ~3; }
 
 inline size_t own_workspace_bytes(int64_t N, int64_t K, int PH, int PW) {
   const size_t tab = (size_t)K * ((size_t)kAyRows * PH + (size_t)kAyRows * PW) * sizeof(float);
-  return (size_t)K * (sizeof(int2) + sizeof(int4)) + (size_t)(2 * N + 4 + kBigCap) * sizeof(int) + tab + 512;
+  return (size_t)K * (sizeof(int2) + sizeof(int4) + 5 * sizeof(float)) + (size_t)(2 * N + 4 + kBigCap) * sizeof(int) + tab + 576;
 }
 
 inline OwnWorkspace carve_workspace(void* base, int64_t N, int64_t K, int PH, int PW) {
@@ -77,6 +86,9 @@ inline OwnWorkspace carve_workspace(void* base, int64_t N, int64_t K, int PH, in
   p += (size_t)K * kAyRows * PH * sizeof(float);
   p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~uintptr_t(63));
   w.axt = reinterpret_cast<float*>(p);
+  p += (size_t)K * kAyRows * PW * sizeof(float);
+  p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~uintptr_t(63));
+  w.roisf = reinterpret_cast<float*>(p);
   return w;
 }
 
@@ -129,23 +141,24 @@ __device__ __forceinline__ bool axis_window(int dim, float start, float bin, int
 }
 
 // Pre-pass: one wave per RoI.
-template <int PH, int PW>
-__global__ __launch_bounds__(kThreads) void roi_bwd_prepass(const float* __restrict__ rois, int K, OwnLevels lv, int sr,
+template <typename RT, int PH, int PW>
+__global__ __launch_bounds__(kThreads) void roi_bwd_prepass(const RT* __restrict__ rois, int K, OwnLevels lv, int sr,
                                                             int aligned, OwnWorkspace ws) {
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (k >= K) return;
-  const float* roi = rois + (int64_t)k * 5;
-  const int l = lv.use_ms ? fpn_level<float>(roi, lv.ms) : 0;
+  const RT* roi = rois + (int64_t)k * 5;
+  if (lane < 5) ws.roisf[(int64_t)k * 5 + lane] = ld(roi + lane);   // what the owner kernels read
+  const int l = lv.use_ms ? fpn_level<RT>(roi, lv.ms) : 0;
   const int H = lv.ms.H[l], W = lv.ms.W[l];
-  const RoiGeom<float> g = roi_geom<float, float>(roi, lv.ms.scale[l], PH, PW, sr, aligned != 0);
+  const RoiGeom<float> g = roi_geom<RT, float>(roi, lv.ms.scale[l], PH, PW, sr, aligned != 0);
   int y0 = 0, y1 = -1, x0 = 0, x1 = -1;
   const bool batch_ok = g.batch >= 0 && g.batch < lv.N;
   if (batch_ok && lane == 0) {
     // RoI index range of every image, from the run boundaries of the batch column only: RoI lists are normally
     // grouped by image, and thousands of same-address atomics would cost more than the rest of this kernel
-    const int prevb = k > 0 ? (int)rois[(int64_t)(k - 1) * 5] : -1;
-    const int nextb = k + 1 < K ? (int)rois[(int64_t)(k + 1) * 5] : -1;
+    const int prevb = k > 0 ? (int)ld(rois + (int64_t)(k - 1) * 5) : -1;
+    const int nextb = k + 1 < K ? (int)ld(rois + (int64_t)(k + 1) * 5) : -1;
     if (prevb != g.batch) atomicMin(&ws.imgrange[2 * g.batch], k);
     if (nextb != g.batch) atomicMin(&ws.imgrange[2 * g.batch + 1], -(k + 1));
   }
@@ -204,20 +217,55 @@ __device__ __forceinline__ void load_coefs(float (&cf)[N], const float* __restri
   for (int q = 0; q < N; ++q) cf[q] = p[q];
 }
 
+// 16-bit storage -> float, from raw bits
+template <typename GT>
+__device__ __forceinline__ float from16(unsigned short h) {
+  if constexpr (std::is_same<GT, __half>::value) return __half2float(__ushort_as_half(h));
+  else return __uint_as_float((unsigned)h << 16);   // bfloat16 = the upper half of an fp32
+}
+struct __attribute__((packed, aligned(4))) U4u { unsigned x, y, z, w; };
+struct __attribute__((packed, aligned(4))) U2u { unsigned x, y; };
+
+// 16-bit grads of one channel: NG elements starting at gp.  The element offset of a channel's grads is (k*C + c)*PH*PW:
+// always a multiple of 4 elements for 14x14 (8-byte loads), any parity for 7x7 (element loads; only the rare
+// oversized-window pass reads 7x7 grads through this routine).
+template <int NG, typename GT>
+__device__ __forceinline__ void load_grads16(v2f (&G2)[(NG + 1) / 2], const GT* __restrict__ gp16) {
+  const unsigned short* gp = reinterpret_cast<const unsigned short*>(gp16);
+  if constexpr (NG % 4 == 2 || NG % 4 == 0) {
+    if ((reinterpret_cast<uintptr_t>(gp) & 7) == 0) {
+#pragma unroll
+      for (int e = 0; e + 4 <= NG; e += 4) {
+        const U2u v = *reinterpret_cast<const U2u*>(gp + e);
+        G2[e / 2] = v2f{from16<GT>((unsigned short)(v.x & 0xffffu)), from16<GT>((unsigned short)(v.x >> 16))};
+        G2[e / 2 + 1] = v2f{from16<GT>((unsigned short)(v.y & 0xffffu)), from16<GT>((unsigned short)(v.y >> 16))};
+      }
+      if constexpr (NG % 4 == 2) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(gp + NG - 2);
+        G2[NG / 2 - 1] = v2f{from16<GT>((unsigned short)(v & 0xffffu)), from16<GT>((unsigned short)(v >> 16))};
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e + 2 <= NG; e += 2) G2[e / 2] = v2f{from16<GT>(gp[e]), from16<GT>(gp[e + 1])};
+  if constexpr (NG & 1) G2[NG / 2] = v2f{from16<GT>(gp[NG - 1]), 0.f};
+}
+
 // the PH*PW grads of one channel as pairs (the packed FMAs pick the low / high half by op_sel)
 template <int NG>
 __device__ __forceinline__ void load_grads(v2f (&G2)[(NG + 1) / 2], const float* __restrict__ gp) {
   constexpr int NG2 = (NG + 1) / 2;
 #pragma unroll
   for (int e4 = 0; e4 + 4 <= NG; e4 += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(gp + e4);
+    const float4 v = ld4u(gp + e4);
     G2[e4 / 2] = v2f{v.x, v.y};
     G2[e4 / 2 + 1] = v2f{v.z, v.w};
   }
   if constexpr ((NG & 3) == 1) G2[NG2 - 1] = v2f{gp[NG - 1], 0.f};
-  if constexpr ((NG & 3) == 2) G2[NG2 - 1] = *reinterpret_cast<const v2f*>(gp + NG - 2);
+  if constexpr ((NG & 3) == 2) G2[NG2 - 1] = ld2u(gp + NG - 2);
   if constexpr ((NG & 3) == 3) {
-    G2[NG2 - 2] = *reinterpret_cast<const v2f*>(gp + NG - 3);
+    G2[NG2 - 2] = ld2u(gp + NG - 3);
     G2[NG2 - 1] = v2f{gp[NG - 1], 0.f};
   }
 }
@@ -241,14 +289,15 @@ __device__ __forceinline__ void contract_x(v2f* t, const v2f (&G2)[(NPH * PW + 1
 
 // all PH bin rows, the grads fetched GB rows at a time (14x14: two batches of 7 rows, so that the grads of a
 // channel never occupy more than ~50 VGPRs)
-template <int PH, int PW>
-__device__ __forceinline__ void grads_times_axd(v2f (&t)[PH], const float* __restrict__ gp, const v2f (&axd)[PW], bool ch_ok) {
+template <int PH, int PW, typename GT>
+__device__ __forceinline__ void grads_times_axd(v2f (&t)[PH], const GT* __restrict__ gp, const v2f (&axd)[PW], bool ch_ok) {
   constexpr int GB = PH <= 7 ? PH : 7;
   static_assert(PH % GB == 0, "bin rows must split evenly into grad batches");
 #pragma unroll
   for (int p0 = 0; p0 < PH; p0 += GB) {
     v2f G2[(GB * PW + 1) / 2];
-    load_grads<GB * PW>(G2, gp + p0 * PW);
+    if constexpr (std::is_same<GT, float>::value) load_grads<GB * PW>(G2, gp + p0 * PW);
+    else load_grads16<GB * PW, GT>(G2, gp + p0 * PW);
     contract_x<GB, PW>(t + p0, G2, axd, ch_ok);
     if (p0 + GB < PH) __builtin_amdgcn_sched_barrier(0);
   }
@@ -283,8 +332,8 @@ struct OwnShared {
 // kBig = false: RoIs whose window fits the coefficient tables; the tile is WRITTEN (zeros where nothing reaches).
 // kBig = true : the RoIs with larger windows (rare); factors are evaluated here and the tile is read-add-written —
 //               still one owner per pixel, still a fixed order (this pass runs after the first one).
-template <bool kBig, int PH, int PW>
-__device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float* __restrict__ grad, const float* __restrict__ rois,
+template <typename GT, bool kBig, int PH, int PW>
+__device__ __forceinline__ void owner_item(OwnShared& sh, int item, const GT* __restrict__ grad, const float* __restrict__ rois,
                                            const OwnLevels& lv, int C, int K, int nchunks, int sr, int aligned, int64_t ns,
                                            int64_t cs, const OwnWorkspace& ws, const int* klist = nullptr, int nlist = 0) {
   constexpr int RB = PH <= 7 ? 4 : 2;  // tile rows per scalar-load batch (RB * PH coefficient SGPRs, two batches in flight)
@@ -390,19 +439,43 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
         };
         float4 gin[NLD];
         auto issue_run = [&](int k) {
-          const float* run = grad + (int64_t)k * ns + (int64_t)ch0w * cs;
+          const GT* run = grad + (int64_t)k * ns + (int64_t)ch0w * cs;
+          if constexpr (std::is_same<GT, float>::value) {
 #pragma unroll
-          for (int u = 0; u < NLD; ++u) {
-            const int f0 = 4 * (u * 64 + lane);  // first float of this lane's piece
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f0 + 4 <= nvalid) {
-              v = *reinterpret_cast<const float4*>(run + f0);
-            } else if (f0 < nvalid) {  // the piece that straddles the end of the run (never read past the tensor)
-              v.x = run[f0];
-              if (f0 + 1 < nvalid) v.y = run[f0 + 1];
-              if (f0 + 2 < nvalid) v.z = run[f0 + 2];
+            for (int u = 0; u < NLD; ++u) {
+              const int f0 = 4 * (u * 64 + lane);  // first float of this lane's piece
+              float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (f0 + 4 <= nvalid) {
+                v = ld4u(run + f0);
+              } else if (f0 < nvalid) {  // the piece that straddles the end of the run (never read past the tensor)
+                v.x = run[f0];
+                if (f0 + 1 < nvalid) v.y = run[f0 + 1];
+                if (f0 + 2 < nvalid) v.z = run[f0 + 2];
+              }
+              gin[u] = v;
             }
-            gin[u] = v;
+          } else {
+            // 16-bit grads: the run of 8 channels is 8*PH*PW*2 bytes = NPIECE/2 pieces of 16 bytes (8 elements): ONE load
+            // per lane, converted to fp32 on the way into LDS.  (C is even on this path: the run starts dword-aligned.)
+            static_assert(NLD == 2 && (NGW % 8) == 0, "7x7: 392 elements = 49 pieces of 8");
+            const unsigned short* r16 = reinterpret_cast<const unsigned short*>(run);
+            const int f0 = 8 * lane;
+            U4u v{0u, 0u, 0u, 0u};
+            if (f0 + 8 <= nvalid) {
+              v = *reinterpret_cast<const U4u*>(r16 + f0);
+            } else if (f0 < nvalid) {
+              unsigned short e[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) e[q] = f0 + q < nvalid ? r16[f0 + q] : (unsigned short)0;
+              v.x = e[0] | ((unsigned)e[1] << 16);
+              v.y = e[2] | ((unsigned)e[3] << 16);
+              v.z = e[4] | ((unsigned)e[5] << 16);
+              v.w = e[6] | ((unsigned)e[7] << 16);
+            }
+            gin[0] = make_float4(from16<GT>((unsigned short)(v.x & 0xffffu)), from16<GT>((unsigned short)(v.x >> 16)),
+                                 from16<GT>((unsigned short)(v.y & 0xffffu)), from16<GT>((unsigned short)(v.y >> 16)));
+            gin[1] = make_float4(from16<GT>((unsigned short)(v.z & 0xffffu)), from16<GT>((unsigned short)(v.z >> 16)),
+                                 from16<GT>((unsigned short)(v.w & 0xffffu)), from16<GT>((unsigned short)(v.w >> 16)));
           }
         };
         int k = 0, y0 = 0, x0 = 0, wh = 0;
@@ -412,9 +485,16 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
         }
         for (int e = 0; e < total; ++e) {
           float* gb = gl + (e & 1) * 400;
+          if constexpr (std::is_same<GT, float>::value) {
 #pragma unroll
-          for (int u = 0; u < NLD; ++u)
-            if (u * 64 + lane < NPIECE) *reinterpret_cast<float4*>(gb + 4 * (u * 64 + lane)) = gin[u];
+            for (int u = 0; u < NLD; ++u)
+              if (u * 64 + lane < NPIECE) *reinterpret_cast<float4*>(gb + 4 * (u * 64 + lane)) = gin[u];
+          } else {
+            if (8 * lane < NGW) {   // this lane's 8 elements: floats 8*lane .. 8*lane + 7 of the staged run
+              *reinterpret_cast<float4*>(gb + 8 * lane) = gin[0];
+              *reinterpret_cast<float4*>(gb + 8 * lane + 4) = gin[1];
+            }
+          }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -432,7 +512,7 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
           v2f axd[PW];
           const float* xt = ws.axt + (int64_t)k * PW * kAyRows + (xl - x0 + kTile);
 #pragma unroll
-          for (int pw = 0; pw < PW; ++pw) axd[pw] = *reinterpret_cast<const v2f*>(xt + pw * kAyRows);
+          for (int pw = 0; pw < PW; ++pw) axd[pw] = ld2u(xt + pw * kAyRows);
           // grads row by row out of LDS, one row ahead of the FMAs that consume it (14 VGPRs instead of 49)
           const float* gch = gb + cslot * (PH * PW);
           v2f t[PH];
@@ -479,7 +559,7 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
       for (int i = 0; i < nseg; ++i) {
         const OwnEntry e = sh.list[seg][i];
         const int k = TVMI_UNIFORM(e.k), y0 = TVMI_UNIFORM(e.y0), x0 = TVMI_UNIFORM(e.x0), wh = TVMI_UNIFORM(e.wh);
-        const float* gp = grad + (int64_t)k * ns + (int64_t)chc * cs;
+        const GT* gp = grad + (int64_t)k * ns + (int64_t)chc * cs;
         if constexpr (!kBig) {
           // tile row r <-> table row (ybase - y0) + 16 + r: one base address per RoI, immediate offsets per row.
           // The AyD rows are wave-uniform: scalar loads, RB rows per batch, two batches in flight.
@@ -492,9 +572,9 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
           v2f axd[PW];
           const float* xt = ws.axt + (int64_t)k * PW * kAyRows + (xl - x0 + kTile);
 #pragma unroll
-          for (int pw = 0; pw < PW; ++pw) axd[pw] = *reinterpret_cast<const v2f*>(xt + pw * kAyRows);
+          for (int pw = 0; pw < PW; ++pw) axd[pw] = ld2u(xt + pw * kAyRows);
           v2f t[PH];
-          grads_times_axd<PH, PW>(t, gp, axd, ch_ok);
+          grads_times_axd<PH, PW, GT>(t, gp, axd, ch_ok);
           // -- acc[r] += sum_ph AyD[r][ph] * t[ph]
           // groups of RB tile rows that lie entirely outside the window have all-zero coefficient rows: their FMAs are
           // skipped (uniform branch); the scalar loads stay unconditional so that they remain two batches ahead
@@ -517,7 +597,7 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
           for (int pw = 0; pw < PW; ++pw)
             axd[pw] = v2f{axis_coef(W, g.start_w, g.bin_w, g.gw, pw, xl), axis_coef(W, g.start_w, g.bin_w, g.gw, pw, xl + 1)};
           v2f t[PH];
-          grads_times_axd<PH, PW>(t, gp, axd, ch_ok);
+          grads_times_axd<PH, PW, GT>(t, gp, axd, ch_ok);
           float ayv[PH];  // AyD row of tile row `lane` (lanes 0..15)
 #pragma unroll
           for (int ph = 0; ph < PH; ++ph) ayv[ph] = axis_coef(H, g.start_h, g.bin_h, g.gh, ph, ybase + (lane & 15));
@@ -536,40 +616,45 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const float*
   if (kBig && touched == 0) return;  // nothing to add to this tile
   // ---- every pixel of the tile is written exactly once per pass
   if (ch_ok && xl < W) {
-    float* plane = static_cast<float*>(const_cast<void*>(lv.ms.ptr[l])) + ((int64_t)n * C + ch) * H * W;
+    GT* plane = static_cast<GT*>(const_cast<void*>(lv.ms.ptr[l])) + ((int64_t)n * C + ch) * H * W;
     const bool both = xl + 1 < W;
 #pragma unroll
     for (int r = 0; r < kTile; ++r) {
       const int y = ybase + r;
       if (y < H) {
-        float* p = plane + (int64_t)y * W + xl;
+        GT* p = plane + (int64_t)y * W + xl;
         v2f v = acc[r];
         if constexpr (kBig) {
-          v.x += p[0];
-          if (both) v.y += p[1];
+          v.x += ld(p);
+          if (both) v.y += ld(p + 1);
         }
-        if (both)
-          *reinterpret_cast<v2f*>(p) = v;
-        else
-          p[0] = v.x;
+        if constexpr (std::is_same<GT, float>::value) {
+          if (both)
+            *reinterpret_cast<v2f*>(p) = v;
+          else
+            p[0] = v.x;
+        } else {   // fp32 sums rounded to the 16-bit type ONCE (the oversized-window pass, if any, rounds a second time)
+          st(p, v.x);
+          if (both) st(p + 1, v.y);
+        }
       }
     }
   }
 }
 
-template <int PH, int PW>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_owner(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                                OwnLevels lv, int C, int K, int nchunks, int sr, int aligned,
-                                                                int64_t ns, int64_t cs, OwnWorkspace ws) {
+template <typename GT, int PH, int PW>
+__global__ __launch_bounds__(kThreads) void roi_align_bwd_owner(const GT* __restrict__ grad, OwnLevels lv, int C, int K,
+                                                                int nchunks, int sr, int aligned, int64_t ns, int64_t cs,
+                                                                OwnWorkspace ws) {
   __shared__ OwnShared sh;
-  owner_item<false, PH, PW>(sh, (int)blockIdx.x, grad, rois, lv, C, K, nchunks, sr, aligned, ns, cs, ws);
+  owner_item<GT, false, PH, PW>(sh, (int)blockIdx.x, grad, ws.roisf, lv, C, K, nchunks, sr, aligned, ns, cs, ws);
 }
 
 // second pass: only does anything when the pre-pass counted RoIs with oversized windows
-template <int PH, int PW>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_owner_big(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                                    OwnLevels lv, int C, int K, int nchunks, int nitems, int sr,
-                                                                    int aligned, int64_t ns, int64_t cs, OwnWorkspace ws) {
+template <typename GT, int PH, int PW>
+__global__ __launch_bounds__(kThreads) void roi_align_bwd_owner_big(const GT* __restrict__ grad, OwnLevels lv, int C, int K,
+                                                                    int nchunks, int nitems, int sr, int aligned, int64_t ns,
+                                                                    int64_t cs, OwnWorkspace ws) {
   __shared__ OwnShared sh;
   __shared__ int s_raw[kBigCap], s_sorted[kBigCap];
   const int nbig = ws.imgrange[2 * lv.N] - kUnset;
@@ -587,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_bwd_owner_big(const float*
     __syncthreads();
   }
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    owner_item<true, PH, PW>(sh, item, grad, rois, lv, C, K, nchunks, sr, aligned, ns, cs, ws, listed ? s_sorted : nullptr, nbig);
+    owner_item<GT, true, PH, PW>(sh, item, grad, ws.roisf, lv, C, K, nchunks, sr, aligned, ns, cs, ws, listed ? s_sorted : nullptr, nbig);
     __syncthreads();
   }
 }
@@ -839,7 +924,10 @@ bool owner_shape(int64_t PH, int64_t PW) { return (PH == 7 && PW == 7) || (PH ==
 // deterministic)?  The launchers and the `*_overwrites` queries share this predicate.
 bool owner_applies(tvmi_dtype dt, int64_t N, int64_t C, int64_t K, int64_t PH, int64_t PW, const int64_t* heights,
                    const int64_t* widths, int64_t n_levels, int64_t cs, int64_t hs, int64_t ws, size_t workspace_bytes) {
-  if (dt != TVMI_F32 || !owner_shape(PH, PW) || N <= 0 || N >= (1 << 24) || C <= 0 || K < 0 || K >= (1ll << 30)) return false;
+  if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16) || !owner_shape(PH, PW) || N <= 0 || N >= (1 << 24) || C <= 0 || K < 0 ||
+      K >= (1ll << 30))
+    return false;
+  if (dt != TVMI_F32 && (C & 1)) return false;  // 16-bit grads are fetched in 16-byte pieces that must start dword-aligned
   if (ws != 1 || hs != PW || cs != PH * PW) return false;  // the [C, PH, PW] block of a RoI must be contiguous
   if (n_levels < 1 || n_levels > kMaxLevels) return false;
   int64_t tiles = 0;
@@ -851,22 +939,22 @@ bool owner_applies(tvmi_dtype dt, int64_t N, int64_t C, int64_t K, int64_t PH, i
   return workspace_bytes >= own_workspace_bytes(N, K, (int)PH, (int)PW);
 }
 
-template <int PH, int PW>
-int launch_owner(const float* grad, const float* rois, OwnLevels lv, int64_t N, int64_t C, int64_t K, int sr, int aligned,
+template <typename GT, typename RT, int PH, int PW>
+int launch_owner(const GT* grad, const RT* rois, OwnLevels lv, int64_t N, int64_t C, int64_t K, int sr, int aligned,
                  int64_t ns, int64_t cs, void* workspace, hipStream_t stream) {
   const OwnWorkspace w = carve_workspace(workspace, N, K, PH, PW);
   hipError_t e = hipMemsetAsync(w.imgrange, 0x7f, (size_t)(2 * N + 1) * sizeof(int), stream);
   if (e != hipSuccess) return set_error((int)e, "roi_align_backward: memset");
   if (K > 0)
-    roi_bwd_prepass<PH, PW><<<dim3((unsigned)ceil_div(K, kThreads / 64)), dim3(kThreads), 0, stream>>>(rois, (int)K, lv, sr, aligned, w);
+    roi_bwd_prepass<RT, PH, PW><<<dim3((unsigned)ceil_div(K, kThreads / 64)), dim3(kThreads), 0, stream>>>(rois, (int)K, lv, sr, aligned, w);
   const int nchunks = (int)ceil_div(C, kOwnChunk);
   const int64_t tiles = lv.tile_end[0];
   const int nitems = (int)(tiles * nchunks);
-  roi_align_bwd_owner<PH, PW><<<dim3((unsigned)nitems), dim3(kThreads), 0, stream>>>(grad, rois, lv, (int)C, (int)K, nchunks, sr,
-                                                                                     aligned, ns, cs, w);
+  roi_align_bwd_owner<GT, PH, PW><<<dim3((unsigned)nitems), dim3(kThreads), 0, stream>>>(grad, lv, (int)C, (int)K, nchunks, sr,
+                                                                                         aligned, ns, cs, w);
   if (K > 0)
-    roi_align_bwd_owner_big<PH, PW><<<dim3((unsigned)std::min(nitems, 2048)), dim3(kThreads), 0, stream>>>(
-        grad, rois, lv, (int)C, (int)K, nchunks, nitems, sr, aligned, ns, cs, w);
+    roi_align_bwd_owner_big<GT, PH, PW><<<dim3((unsigned)std::min(nitems, 2048)), dim3(kThreads), 0, stream>>>(
+        grad, lv, (int)C, (int)K, nchunks, nitems, sr, aligned, ns, cs, w);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_backward");
 }
 
@@ -885,14 +973,26 @@ OwnLevels make_levels(const MsLevels& ms, int64_t N, int use_ms) {
   return lv;
 }
 
-int dispatch_owner(const void* grad, const void* rois, const MsLevels& ms, int use_ms, int64_t N, int64_t C, int64_t K,
-                   int64_t PH, int64_t PW, int64_t sr, int aligned, int64_t ns, int64_t cs, void* workspace,
+// grads (and the maps written) are `dt`; the RoIs are `dt` too in the single-level call and float32 in the multi-scale one
+template <typename GT, typename RT>
+int dispatch_owner_t(const void* grad, const void* rois, const OwnLevels& lv, int64_t N, int64_t C, int64_t K, int64_t PH,
+                     int64_t sr, int aligned, int64_t ns, int64_t cs, void* workspace, hipStream_t stream) {
+  const GT* g = static_cast<const GT*>(grad);
+  const RT* r = static_cast<const RT*>(rois);
+  if (PH == 7) return launch_owner<GT, RT, 7, 7>(g, r, lv, N, C, K, (int)sr, aligned, ns, cs, workspace, stream);
+  return launch_owner<GT, RT, 14, 14>(g, r, lv, N, C, K, (int)sr, aligned, ns, cs, workspace, stream);
+}
+
+int dispatch_owner(tvmi_dtype dt, bool rois_f32, const void* grad, const void* rois, const MsLevels& ms, int use_ms, int64_t N,
+                   int64_t C, int64_t K, int64_t PH, int64_t PW, int64_t sr, int aligned, int64_t ns, int64_t cs, void* workspace,
                    hipStream_t stream) {
   const OwnLevels lv = make_levels(ms, N, use_ms);
-  const float* g = static_cast<const float*>(grad);
-  const float* r = static_cast<const float*>(rois);
-  if (PH == 7) return launch_owner<7, 7>(g, r, lv, N, C, K, (int)sr, aligned, ns, cs, workspace, stream);
-  return launch_owner<14, 14>(g, r, lv, N, C, K, (int)sr, aligned, ns, cs, workspace, stream);
+  if (dt == TVMI_F32) return dispatch_owner_t<float, float>(grad, rois, lv, N, C, K, PH, sr, aligned, ns, cs, workspace, stream);
+  if (dt == TVMI_F16)
+    return rois_f32 ? dispatch_owner_t<__half, float>(grad, rois, lv, N, C, K, PH, sr, aligned, ns, cs, workspace, stream)
+                    : dispatch_owner_t<__half, __half>(grad, rois, lv, N, C, K, PH, sr, aligned, ns, cs, workspace, stream);
+  return rois_f32 ? dispatch_owner_t<__hip_bfloat16, float>(grad, rois, lv, N, C, K, PH, sr, aligned, ns, cs, workspace, stream)
+                  : dispatch_owner_t<__hip_bfloat16, __hip_bfloat16>(grad, rois, lv, N, C, K, PH, sr, aligned, ns, cs, workspace, stream);
 }
 
 template <typename T>
@@ -968,7 +1068,8 @@ extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void*
     tvmi::MsLevels ms;
     void* ptr = grad_input;
     tvmi::fill_levels(ms, &ptr, &H, &W, &spatial_scale, 1, 0, 0, 224.0, 4.0, 1e-6);
-    return tvmi::dispatch_owner(grad, rois, ms, 0, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, n_stride, c_stride, workspace, s);
+    return tvmi::dispatch_owner(dt, /*rois_f32=*/false, grad, rois, ms, 0, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, n_stride,
+                                c_stride, workspace, s);
   }
   if (K * C == 0) return 0;
   TVMI_DISPATCH_FLOAT(dt, "roi_align_backward",
@@ -999,7 +1100,8 @@ extern "C" int tvmi_multiscale_roi_align_backward(const void* grad, const void* 
   if (C == 0 || N == 0) return 0;
   TVMI_CHECK_ARG(grad_inputs && heights && widths && spatial_scales && (K == 0 || (grad && rois)),
                  "multiscale_roi_align_backward: null pointer");
-  TVMI_CHECK_ARG(dt == TVMI_F32, "multiscale_roi_align_backward: float32 gradients only (RoIs are always float32)");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16,
+                 "multiscale_roi_align_backward: float32 / float16 / bfloat16 gradients (RoIs are always float32)");
   TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align_backward: size exceeds 32-bit launch limits");
   for (int64_t i = 0; i < n_levels; ++i)
     TVMI_CHECK_ARG(grad_inputs[i] != nullptr && heights[i] > 0 && widths[i] > 0 && heights[i] * widths[i] * C < (1ll << 31),
@@ -1008,8 +1110,11 @@ extern "C" int tvmi_multiscale_roi_align_backward(const void* grad, const void* 
   tvmi::fill_levels(ms, grad_inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (workspace && tvmi::owner_applies(dt, N, C, K, pooled_h, pooled_w, heights, widths, n_levels, c_stride, h_stride, w_stride, workspace_bytes))
-    return tvmi::dispatch_owner(grad, rois, ms, 1, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, n_stride, c_stride, workspace, s);
+    return tvmi::dispatch_owner(dt, /*rois_f32=*/true, grad, rois, ms, 1, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, n_stride,
+                                c_stride, workspace, s);
   if (K == 0) return 0;
+  TVMI_CHECK_ARG(dt == TVMI_F32, "multiscale_roi_align_backward: 16-bit gradients need the tile-owner regime (workspace, contiguous "
+                                 "7x7 / 14x14 bins, even channel count)");
   // H / W / scale / grad_input of the single-level signature are placeholders: every RoI takes them from its level
   return tvmi::launch_atomic<float>(grad, rois, grad_inputs[0], C, heights[0], widths[0], K, pooled_h, pooled_w, spatial_scales[0],
                                     sampling_ratio, aligned, n_stride, c_stride, h_stride, w_stride, s, &ms);

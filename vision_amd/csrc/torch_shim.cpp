@@ -205,6 +205,14 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
   return output;
 }
 
+// The tile-owner backward keeps ~9 KB (7x7) / ~18 KB (14x14) of coefficient tables per RoI.  That scratch is absent in the
+// reference: it is only taken while it stays within 2x the tensors the call moves anyway (or 256 MiB) — a call with very many
+// RoIs on small maps takes the atomic regime instead of gigabytes of tables.
+bool owner_workspace_is_reasonable(size_t ws_bytes, const at::Tensor& grad, int64_t grad_input_numel) {
+  const size_t moved = (size_t)(grad.numel() + grad_input_numel) * (size_t)grad.element_size();
+  return ws_bytes <= std::max<size_t>(size_t(256) << 20, 2 * moved);
+}
+
 at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, double spatial_scale,
                               int64_t pooled_height, int64_t pooled_width, int64_t batch_size,
                               int64_t channels, int64_t height, int64_t width, int64_t sampling_ratio,
@@ -215,29 +223,29 @@ at::Tensor roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, do
   TORCH_CHECK(grad.scalar_type() == rois.scalar_type(),
               "roi_align_backward_kernel: grad and rois must have the same type");
   c10::DeviceGuard guard(grad.device());
-  if (grad.numel() != 0 && (grad.scalar_type() == at::kHalf || grad.scalar_type() == at::kBFloat16)) {
-    // 16-bit gradients: accumulate in fp32 (native float atomics, the dense kernel) and round once at the end.
-    // The reference accumulates with 16-bit atomics (cuda/roi_align_kernel.cu:317-330); this is both faster on
-    // gfx950 (no CAS loops) and closer to the exact sum.
-    return roi_align_backward(grad.to(at::kFloat), rois.to(at::kFloat), spatial_scale, pooled_height, pooled_width,
-                              batch_size, channels, height, width, sampling_ratio, aligned)
-        .to(grad.scalar_type());
-  }
+  const bool low = grad.scalar_type() == at::kHalf || grad.scalar_type() == at::kBFloat16;
   if (batch_size * channels * height * width == 0 || rois.size(0) == 0)
     return at::zeros({batch_size, channels, height, width}, grad.options());
   at::Tensor rois_ = rois.contiguous();
-  // The tile-owner backward (fp32, 7x7 / 14x14 bins) wants the bins of a channel contiguous; it writes every pixel
-  // of grad_input exactly once (no zero-fill, no atomics, deterministic).  Everything else accumulates atomically
-  // into a zero-filled tensor like the reference (cuda/roi_align_kernel.cu:440).
+  // The tile-owner backward (fp32 / fp16 / bf16 grads, 7x7 / 14x14 bins) wants the bins of a channel contiguous; it reads
+  // the grads in their own type, accumulates in fp32 registers and writes every pixel of grad_input exactly once, rounded
+  // once (no zero-fill, no atomics, deterministic).  Everything else accumulates atomically into a zero-filled tensor like
+  // the reference (cuda/roi_align_kernel.cu:440); 16-bit grads then go through fp32 (native float atomics instead of
+  // 16-bit CAS loops, one rounding at the end).
   at::Tensor g = grad;
-  const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, rois.size(0), pooled_height, pooled_width);
-  if (ws_bytes != 0 && grad.scalar_type() == at::kFloat &&
+  size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, rois.size(0), pooled_height, pooled_width);
+  if (!owner_workspace_is_reasonable(ws_bytes, grad, batch_size * channels * height * width)) ws_bytes = 0;
+  if (ws_bytes != 0 && (grad.scalar_type() == at::kFloat || low) &&
       !(grad.stride(3) == 1 && grad.stride(2) == pooled_width && grad.stride(1) == pooled_height * pooled_width))
     g = grad.contiguous();
   const tvmi_dtype dt = dtype_of(g, "_roi_align_backward");
   const bool overwrites = ws_bytes != 0 && tvmi_roi_align_backward_overwrites(dt, batch_size, channels, height, width, rois.size(0),
                                                                               pooled_height, pooled_width, g.stride(1), g.stride(2),
                                                                               g.stride(3), ws_bytes) != 0;
+  if (low && !overwrites)
+    return roi_align_backward(grad.to(at::kFloat), rois.to(at::kFloat), spatial_scale, pooled_height, pooled_width,
+                              batch_size, channels, height, width, sampling_ratio, aligned)
+        .to(grad.scalar_type());
   at::Tensor grad_input = overwrites ? at::empty({batch_size, channels, height, width}, g.options())
                                      : at::zeros({batch_size, channels, height, width}, g.options());
   if (!overwrites) at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
@@ -748,39 +756,52 @@ std::vector<at::Tensor> multiscale_roi_align_backward(const at::Tensor& grad, co
               "multiscale_roi_align_backward: 1..8 levels with one height / width / scale each");
   c10::DeviceGuard guard(grad.device());
   const bool low = grad.scalar_type() == at::kHalf || grad.scalar_type() == at::kBFloat16;
-  // 16-bit gradients accumulate in fp32 and are rounded once (see roi_align_backward)
-  at::Tensor g = low ? grad.to(at::kFloat) : grad;
+  TORCH_CHECK(grad.scalar_type() == at::kFloat || low, "multiscale_roi_align_backward: float32 / float16 / bfloat16 only");
   at::Tensor r = rois.to(at::kFloat).contiguous();
-  TORCH_CHECK(g.scalar_type() == at::kFloat, "multiscale_roi_align_backward: float32 / float16 / bfloat16 only");
-  const int64_t K = g.size(0), C = g.size(1);
+  const int64_t K = grad.size(0), C = grad.size(1);
   std::vector<int64_t> hs(heights.begin(), heights.end()), ws(widths.begin(), widths.end());
-  const size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, K, pooled_height, pooled_width);
-  if (ws_bytes != 0 && !(g.stride(3) == 1 && g.stride(2) == pooled_width && g.stride(1) == pooled_height * pooled_width))
-    g = g.contiguous();
-  const bool overwrites = ws_bytes != 0 && K != 0 && C != 0 && batch_size != 0 &&
-                          tvmi_multiscale_roi_align_backward_overwrites(TVMI_F32, batch_size, C, K, hs.data(), ws.data(),
-                                                                        (int64_t)hs.size(), pooled_height, pooled_width, g.stride(1),
-                                                                        g.stride(2), g.stride(3), ws_bytes) != 0;
-  std::vector<at::Tensor> outs;
-  std::vector<void*> ptrs;
-  for (size_t i = 0; i < heights.size(); ++i) {
-    outs.push_back(overwrites ? at::empty({batch_size, C, heights[i], widths[i]}, g.options())
-                              : at::zeros({batch_size, C, heights[i], widths[i]}, g.options()));
-    ptrs.push_back(outs.back().mutable_data_ptr());
+  size_t ws_bytes = tvmi_roi_align_backward_workspace_bytes(batch_size, K, pooled_height, pooled_width);
+  {
+    int64_t map_numel = 0;
+    for (size_t i = 0; i < heights.size(); ++i) map_numel += batch_size * C * heights[i] * widths[i];
+    if (!owner_workspace_is_reasonable(ws_bytes, grad, map_numel)) ws_bytes = 0;
   }
-  if (g.numel() != 0 && batch_size != 0) {
-    if (!overwrites) at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
-    at::Tensor wsp = at::empty({(int64_t)(overwrites ? ws_bytes : 0)}, g.options().dtype(at::kByte));
-    check_status(tvmi_multiscale_roi_align_backward(g.const_data_ptr(), r.const_data_ptr(), ptrs.data(), hs.data(), ws.data(),
-                                                    scales.data(), (int64_t)heights.size(), TVMI_F32, batch_size, C, K,
-                                                    pooled_height, pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max,
-                                                    canonical_scale, canonical_level, eps, g.stride(0), g.stride(1),
-                                                    g.stride(2), g.stride(3), overwrites ? wsp.mutable_data_ptr() : nullptr,
-                                                    overwrites ? ws_bytes : 0, current_stream(grad)),
-                 "multiscale_roi_align_backward");
-  }
-  if (low)
+  // 16-bit gradients are read natively by the tile-owner kernel (fp32 accumulation, one rounding per pixel); when that
+  // regime does not apply they are widened and take the fp32 atomic path (see roi_align_backward)
+  auto run = [&](at::Tensor g) {
+    if (ws_bytes != 0 && !(g.stride(3) == 1 && g.stride(2) == pooled_width && g.stride(1) == pooled_height * pooled_width))
+      g = g.contiguous();
+    const tvmi_dtype dt = dtype_of(g, "multiscale_roi_align_backward");
+    const bool overwrites = ws_bytes != 0 && K != 0 && C != 0 && batch_size != 0 &&
+                            tvmi_multiscale_roi_align_backward_overwrites(dt, batch_size, C, K, hs.data(), ws.data(), (int64_t)hs.size(),
+                                                                          pooled_height, pooled_width, g.stride(1), g.stride(2),
+                                                                          g.stride(3), ws_bytes) != 0;
+    std::vector<at::Tensor> outs;
+    if (!overwrites && g.scalar_type() != at::kFloat) return outs;   // caller widens
+    std::vector<void*> ptrs;
+    for (size_t i = 0; i < heights.size(); ++i) {
+      outs.push_back(overwrites ? at::empty({batch_size, C, heights[i], widths[i]}, g.options())
+                                : at::zeros({batch_size, C, heights[i], widths[i]}, g.options()));
+      ptrs.push_back(outs.back().mutable_data_ptr());
+    }
+    if (g.numel() != 0 && batch_size != 0) {
+      if (!overwrites) at::globalContext().alertNotDeterministic("roi_align_backward_kernel");
+      at::Tensor wsp = at::empty({(int64_t)(overwrites ? ws_bytes : 0)}, g.options().dtype(at::kByte));
+      check_status(tvmi_multiscale_roi_align_backward(g.const_data_ptr(), r.const_data_ptr(), ptrs.data(), hs.data(), ws.data(),
+                                                      scales.data(), (int64_t)heights.size(), dt, batch_size, C, K, pooled_height,
+                                                      pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max, canonical_scale,
+                                                      canonical_level, eps, g.stride(0), g.stride(1), g.stride(2), g.stride(3),
+                                                      overwrites ? wsp.mutable_data_ptr() : nullptr, overwrites ? ws_bytes : 0,
+                                                      current_stream(grad)),
+                   "multiscale_roi_align_backward");
+    }
+    return outs;
+  };
+  std::vector<at::Tensor> outs = run(grad);
+  if (outs.empty() && heights.size() > 0) {   // 16-bit grads outside the owner regime
+    outs = run(grad.to(at::kFloat));
     for (auto& o : outs) o = o.to(grad.scalar_type());
+  }
   return outs;
 }
 
