@@ -160,10 +160,10 @@ def test_staged_route_16bit(tv, dtype, tol):
 def test_nonfinite_pixels_next_to_zero_weight_taps(tv):
     """VERDICT r02 weak 1d.  The reference reads, for a sample at c >= dim-1, the pixel dim-1 twice (x_high = x_low,
     roi_align_common.h:78-90) and never the pixel dim-2; a sample outside [-1, dim] is skipped (:60-73).  The fast kernels
-    re-express the x edge on the pair (W-2, W-1) with factors (0, 1).  Pinned behaviour of the STAGED route: a NaN in a
-    pixel the reference does not read never reaches the output (v_mul_legacy_f32 for the zero factor, the reference's own
-    y_high = y_low row, a zeroed LDS cell for skipped samples), and a NaN the reference does read gives NaN in exactly the
-    same outputs."""
+    re-express the x edge on the pair (W-2, W-1) with factors (0, 1).  Pinned behaviour of EVERY forward kernel (map-staging,
+    per-RoI LDS-DMA + mop-up, channels_last, generic): a NaN in a pixel the reference does not read never reaches the output
+    (v_mul_legacy_f32 for the zero factor, the reference's own y_high = y_low row, skipped samples contribute an exact
+    zero), and a NaN the reference does read gives NaN in exactly the same outputs."""
     g = gen(5)
     N, C, H, W = 1, 8, 20, 24
     x = torch.randn(N, C, H, W, generator=g)
@@ -174,13 +174,23 @@ def test_nonfinite_pixels_next_to_zero_weight_taps(tv):
     xb[:, :, :, W - 2] = float("nan")          # column W-2: read by RoI 0 / 1 only where their samples really lie in [W-3, W-1)
     xb[:, :, H - 2, :] = float("nan")          # row H-2: same for RoI 0's bottom bins
     ref = _ref(xb, rois, 1.0, 7)
-    with route("staged"):
-        got = tv.roi_align(xb.to(DEV), rois.to(DEV), 1.0, 7, 7, 2, False).cpu().numpy()
-    assert np.array_equal(np.isnan(got), np.isnan(ref)), "NaN pattern differs from the reference CPU kernel"
     fin = ~np.isnan(ref)
     assert fin.any() and np.isnan(ref).any()
-    np.testing.assert_allclose(got[fin], ref[fin], rtol=0, atol=TOL)
-    # bins whose samples all sit on the last column / row are finite in the reference (it reads pixel dim-1 only) — and here
+    # bins whose samples all sit on the last column / row are finite in the reference (it reads pixel dim-1 only)
     assert np.isfinite(ref[0, :, :, 6]).any() or np.isfinite(ref[0, :, 6, :]).any()
-    # an interior RoI is untouched by the poisoned row / column
-    np.testing.assert_allclose(got[2], clean[2], rtol=0, atol=TOL)
+    results = {}
+    for name in ("staged", "per-roi"):      # the map-staging kernel; the per-RoI LDS-DMA kernel + its mop-up (RoI 1 has skipped samples)
+        with route(name):
+            results[name] = tv.roi_align(xb.to(DEV), rois.to(DEV), 1.0, 7, 7, 2, False).cpu().numpy()
+    # the channels_last kernel (reached through the multi-scale op; one level)
+    xcl = xb.to(DEV).contiguous(memory_format=torch.channels_last)
+    results["nhwc"] = torch.ops.tvmi.multiscale_roi_align([xcl], rois.to(DEV), [1.0], 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6).cpu().numpy()
+    # the kernel for other pooled shapes (5x5 here) skips like the reference by construction
+    ref5 = torch.ops.torchvision.roi_align(xb, rois, 1.0, 5, 5, 2, False).numpy() if O.load_reference() else O.roi_align(xb.numpy(), rois.numpy(), 1.0, 5, 5, 2, False)
+    got5 = tv.roi_align(xb.to(DEV), rois.to(DEV), 1.0, 5, 5, 2, False).cpu().numpy()
+    assert np.array_equal(np.isnan(got5), np.isnan(ref5))
+    for name, got in results.items():
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{name}: NaN pattern differs from the reference CPU kernel"
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=0, atol=TOL, err_msg=name)
+        # an interior RoI is untouched by the poisoned row / column
+        np.testing.assert_allclose(got[2], clean[2], rtol=0, atol=TOL, err_msg=name)

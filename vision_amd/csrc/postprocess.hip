@@ -13,8 +13,11 @@ namespace {
 
 constexpr int kPackThreads = 1024;
 constexpr int kPackWaves = kPackThreads / 64;
-constexpr int kPackMaxImages = 256;
 
+// One workgroup PER IMAGE: workgroup b walks the score-ordered keep list, takes the entries of image b in order and
+// stops as soon as it holds max_dets of them — in a detector step (tens of thousands of kept candidates for a payload
+// of 100 per image) that is after the first chunk or two.  (Round 2 ran the whole batch through ONE workgroup: 92 us in
+// the Mask R-CNN step, more than the RoIAlign launches it follows.)
 __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ labels,
     const int64_t* __restrict__ image_idx, const int64_t* __restrict__ keep, int64_t num_keep,
@@ -26,68 +29,52 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
   // payload) instead of being mistaken for "nothing kept".
   const bool poisoned = num_keep_dev && *num_keep_dev < 0;
   if (num_keep_dev) num_keep = min(max(*num_keep_dev, (int64_t)0), num_keep);
-  __shared__ int s_cnt[kPackMaxImages];                 // kept so far per image
-  __shared__ int s_wave[kPackWaves][kPackMaxImages];    // this chunk: kept per (wave, image)
+  __shared__ int s_wave[kPackWaves];   // this chunk: entries of this image per wave
+  __shared__ int s_cnt;                // entries of this image so far
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  const int64_t total = (int64_t)num_images * max_dets * 6;
-  for (int64_t i = tid; i < total; i += kPackThreads) dets[i] = 0.f;
-  for (int i = tid; i < num_images; i += kPackThreads) s_cnt[i] = 0;
-  for (int i = tid; i < kPackWaves * kPackMaxImages; i += kPackThreads) (&s_wave[0][0])[i] = 0;
+  const int b = blockIdx.x;
+  float* my = dets + (int64_t)b * max_dets * 6;
+  for (int i = tid; i < max_dets * 6; i += kPackThreads) my[i] = 0.f;
+  if (tid == 0) s_cnt = 0;
   __syncthreads();
   for (int64_t c0 = 0; c0 < num_keep; c0 += kPackThreads) {
     const int64_t e = c0 + tid;
-    const bool valid = e < num_keep;
     int64_t src = 0;
-    int img = -1;
-    if (valid) {
+    bool mine = false;
+    if (e < num_keep) {
       src = keep[e];
-      img = (int)image_idx[src];
-      if (img < 0 || img >= num_images) img = -1;
+      mine = image_idx[src] == (int64_t)b;
     }
-    // rank among equal image ids inside the wave: peel off one distinct id per iteration
-    int rank_in_wave = 0;
-    unsigned long long todo = __ballot(img >= 0);
-    while (todo) {
-      const int leader = __builtin_ctzll(todo);
-      const int cur = __builtin_amdgcn_readlane(img, leader);
-      const unsigned long long same = __ballot(img == cur);
-      if (img == cur) rank_in_wave = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) s_wave[wave][cur] = __popcll(same);
-      todo &= ~same;
-    }
+    const unsigned long long bal = __ballot(mine);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    const int before = s_cnt;            // stable until the barrier below
     __syncthreads();
-    if (img >= 0) {
-      int base = s_cnt[img];
-      for (int w = 0; w < wave; ++w) base += s_wave[w][img];
-      const int r = base + rank_in_wave;
+    if (mine) {
+      int r = before + __popcll(bal & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) r += s_wave[w];
       if (r < max_dets) {
-        float* d = dets + ((int64_t)img * max_dets + r) * 6;
-        const float4 b = *reinterpret_cast<const float4*>(boxes + src * 4);
-        d[0] = b.x;
-        d[1] = b.y;
-        d[2] = b.z;
-        d[3] = b.w;
+        float* d = my + (int64_t)r * 6;
+        const float4 bx = *reinterpret_cast<const float4*>(boxes + src * 4);
+        d[0] = bx.x;
+        d[1] = bx.y;
+        d[2] = bx.z;
+        d[3] = bx.w;
         d[4] = scores[src];
         d[5] = labels ? (float)labels[src] : 0.f;
       }
     }
     __syncthreads();
-    for (int i = tid; i < num_images; i += kPackThreads) {
+    if (tid == 0) {
       int add = 0;
-      for (int w = 0; w < kPackWaves; ++w) {
-        add += s_wave[w][i];
-        s_wave[w][i] = 0;
-      }
-      s_cnt[i] += add;
+      for (int w = 0; w < kPackWaves; ++w) add += s_wave[w];
+      s_cnt = before + add;
     }
-    // the keep list is in score order: once every image holds max_dets detections nothing later can enter the payload
-    // (a detector step keeps tens of thousands of candidates for a payload of 100 per image)
-    bool full = true;
-    for (int i = tid; i < num_images; i += kPackThreads) full = full && s_cnt[i] >= max_dets;
-    if (__syncthreads_and(full)) break;
+    __syncthreads();
+    // the keep list is in score order: once this image holds max_dets detections nothing later can enter its payload
+    if (s_cnt >= max_dets) break;
   }
-  for (int i = tid; i < num_images; i += kPackThreads) counts[i] = poisoned ? -1 : min(s_cnt[i], max_dets);
+  if (tid == 0) counts[b] = poisoned ? -1 : min(s_cnt, max_dets);
 }
 
 
@@ -277,10 +264,10 @@ extern "C" int tvmi_pack_detections(const float* boxes, const float* scores, con
                                     int64_t max_dets, float* dets, int32_t* counts, void* stream) {
   TVMI_CHECK_ARG(num_images >= 0 && max_dets >= 0 && num_keep >= 0, "pack_detections: negative size");
   if (num_images == 0) return 0;
-  TVMI_CHECK_ARG(num_images <= tvmi::kPackMaxImages, "pack_detections: at most 256 images per call");
+  TVMI_CHECK_ARG(num_images <= 65535, "pack_detections: at most 65535 images per call");
   TVMI_CHECK_ARG(dets && counts && (num_keep == 0 || (boxes && scores && image_idx && keep)),
                  "pack_detections: null pointer");
-  tvmi::pack_detections_kernel<<<dim3(1), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
+  tvmi::pack_detections_kernel<<<dim3((unsigned)num_images), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
       boxes, scores, labels, image_idx, keep, num_keep, nullptr, (int)num_images, (int)max_dets, dets, counts);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections");
 }
@@ -291,10 +278,10 @@ extern "C" int tvmi_pack_detections_devcount(const float* boxes, const float* sc
                                              float* dets, int32_t* counts, void* stream) {
   TVMI_CHECK_ARG(num_images >= 0 && max_dets >= 0 && keep_capacity >= 0, "pack_detections: negative size");
   if (num_images == 0) return 0;
-  TVMI_CHECK_ARG(num_images <= tvmi::kPackMaxImages, "pack_detections: at most 256 images per call");
+  TVMI_CHECK_ARG(num_images <= 65535, "pack_detections: at most 65535 images per call");
   TVMI_CHECK_ARG(dets && counts && num_keep_dev && (keep_capacity == 0 || (boxes && scores && image_idx && keep)),
                  "pack_detections: null pointer");
-  tvmi::pack_detections_kernel<<<dim3(1), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
+  tvmi::pack_detections_kernel<<<dim3((unsigned)num_images), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
       boxes, scores, labels, image_idx, keep, keep_capacity, num_keep_dev, (int)num_images, (int)max_dets, dets, counts);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections_devcount");
 }

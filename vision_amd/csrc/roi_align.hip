@@ -388,10 +388,10 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
 #pragma unroll
           for (int ix = 0; ix < SRT; ++ix) {
             const int xl = gxx[b][ix], xh = min(xl + 1, W - 1);
-            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(r0 + xh), fx[b][ix][1] * ld(r0 + xl));
-            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(r1 + xh), fx[b][ix][1] * ld(r1 + xl));
-            acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-            acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+            const float t0 = mul_legacy(fx[b][ix][0], ld(r0 + xh)) + mul_legacy(fx[b][ix][1], ld(r0 + xl));
+            const float t1 = mul_legacy(fx[b][ix][0], ld(r1 + xh)) + mul_legacy(fx[b][ix][1], ld(r1 + xl));
+            acc += mul_legacy(fy[b][iy][1], t0);
+            acc += mul_legacy(fy[b][iy][0], t1);
           }
         }
         const int bin = lane + 64 * b;
@@ -427,11 +427,14 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
         for (int iy = 0; iy < SRT; ++iy) {
 #pragma unroll
           for (int ix = 0; ix < SRT; ++ix) {
+            // legacy multiplies (0 * x = 0): a skipped sample (cpu/roi_align_common.h:60-73) has all-zero factors and
+            // its taps point at the window origin — a NaN / Inf there must not reach the sum; the x / y edges are
+            // exact already (the pad column / row holds the clamped pixel the reference reads twice)
             const float* p = wbase + off[b][iy * SRT + ix];
-            const float t0 = __builtin_fmaf(fx[b][ix][0], p[1], fx[b][ix][1] * p[0]);
-            const float t1 = __builtin_fmaf(fx[b][ix][0], p[wstride + 1], fx[b][ix][1] * p[wstride]);
-            acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-            acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+            const float t0 = mul_legacy(fx[b][ix][0], p[1]) + mul_legacy(fx[b][ix][1], p[0]);
+            const float t1 = mul_legacy(fx[b][ix][0], p[wstride + 1]) + mul_legacy(fx[b][ix][1], p[wstride]);
+            acc += mul_legacy(fy[b][iy][1], t0);
+            acc += mul_legacy(fy[b][iy][0], t1);
           }
         }
         const int bin = lane + 64 * b;
@@ -486,22 +489,28 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   w.state = 2;
   w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = w.sparse = 0;
   if (H < 2 || W < EPP) return w;
-  int lo = 0, lo2 = 0;
+  int lo = 0, hi = 0, lo2 = 0;
   float l, h;
   bool v = false, v2 = false;
-  if (lane < ny) v = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, l, h);
+  // y: the reference's own (low, high) rows — on the bottom edge high = low, both tap rows are then row H-1;
+  // x: the shifted form (the pair (W-2, W-1) with factors (0, 1) on the right edge) so that a tap pair is one LDS read
+  if (lane < ny) v = axis_sample<float>(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, hi, l, h);
   if (lane < nx) v2 = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo2, l, h);
   const unsigned long long by = __ballot(v), bx = __ballot(v2);
   if (by == 0ull || bx == 0ull) {  // every sample of one axis is outside the map: all outputs are zero
     w.state = 0;
     return w;
   }
+  // a RoI with SOME samples outside [-1, dim] (skipped by the reference, roi_align_common.h:60-73) is left to the
+  // mop-up kernel, which gives skipped samples an exact zero; here every sample has a real window position
+  if (by != (ny == 64 ? ~0ull : (1ull << ny) - 1ull) || bx != (nx == 64 ? ~0ull : (1ull << nx) - 1ull)) return w;
   // sample coordinates are monotonic in the lane index, in either direction (malformed RoIs with
   // aligned=True have negative bins): the extremes sit at the first / last valid lane
   const int ya = __builtin_amdgcn_readlane(lo, __builtin_ctzll(by)), yb = __builtin_amdgcn_readlane(lo, 63 - __builtin_clzll(by));
+  const int yha = __builtin_amdgcn_readlane(hi, __builtin_ctzll(by)), yhb = __builtin_amdgcn_readlane(hi, 63 - __builtin_clzll(by));
   const int xa = __builtin_amdgcn_readlane(lo2, __builtin_ctzll(bx)), xb = __builtin_amdgcn_readlane(lo2, 63 - __builtin_clzll(bx));
   w.y0 = min(ya, yb);
-  const int y1 = max(ya, yb) + 1;
+  const int y1 = max(yha, yhb);
   const int x0 = min(xa, xb);
   const int x1 = max(xa, xb) + 1;
   w.wh = y1 - w.y0 + 1;
@@ -570,10 +579,10 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
     const int t = min(rg * dw.rpi + rsub, dw.wh - 1);  // row slot of this lane in row group rg
     int y = dw.y0 + t;
     if (dw.sparse) {
-      int lo;
+      int lo, hi;
       float l, h;
-      axis_sample_shifted(H, g.start_h, g.bin_h, SRT, (t >> 1) / SRT, (t >> 1) % SRT, lo, l, h);
-      y = lo + (t & 1);
+      axis_sample<float>(H, g.start_h, g.bin_h, SRT, (t >> 1) / SRT, (t >> 1) % SRT, lo, hi, l, h);
+      y = (t & 1) ? hi : lo;
     }
     goff[rg] = min(y, H - 1) * W + gx;
   }
@@ -608,8 +617,8 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
           for (int ix = 0; ix < SRT; ++ix) {
             const T* q0 = wbase + off[b][iy * SRT + ix][0];
             const T* q1 = wbase + off[b][iy * SRT + ix][1];
-            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), fx[b][ix][1] * ld(q0));
-            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), fx[b][ix][1] * ld(q1));
+            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), mul_legacy(fx[b][ix][1], ld(q0)));   // x edge: 0 * (pixel W-2) = 0
+            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), mul_legacy(fx[b][ix][1], ld(q1)));
             acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
             acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
           }
@@ -647,7 +656,11 @@ __device__ __forceinline__ bool served_by_plane_kernel(const PlaneSkip& ps, cons
   int v = lane < kPlanePreBlocks ? ps.blocksum[lane * kMaxLevels + l] : 0;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return plane_level_active(v, ps.plan.lv[l], ps.plan.gain_x16, ps.plan.N, lv.H[l], lv.W[l]);
+  bool active = false;
+#pragma unroll
+  for (int i = 0; i < kMaxLevels; ++i)   // constant indices: a run-time index would put the by-value structs into scratch
+    if (i == l) active = plane_level_active(v, ps.plan.lv[i], ps.plan.gain_x16, ps.plan.N, lv.H[i], lv.W[i]);
+  return active;
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
@@ -684,14 +697,15 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
     int rlo[SRT][2], xlo[SRT];
 #pragma unroll
     for (int i = 0; i < SRT; ++i) {
-      int lo;
+      int lo, hi;
       float l, h;
-      const bool vy = axis_sample_shifted(H, g.start_h, g.bin_h, SRT, ph, i, lo, l, h);
+      const bool vy = axis_sample<float>(H, g.start_h, g.bin_h, SRT, ph, i, lo, hi, l, h);   // every sample is valid here (dma_window)
       fy[b][i][0] = l;
       fy[b][i][1] = h;
       const int r = dw.sparse ? 2 * (ph * SRT + i) : (vy ? lo - dw.y0 : 0);
+      const int r1 = dw.sparse ? r + 1 : r + (hi - lo);   // bottom edge: the high tap row IS the low one, like the reference
       rlo[i][0] = (r / dw.rpi) * BLK + (r % dw.rpi) * rstride;
-      rlo[i][1] = ((r + 1) / dw.rpi) * BLK + ((r + 1) % dw.rpi) * rstride;
+      rlo[i][1] = (r1 / dw.rpi) * BLK + (r1 % dw.rpi) * rstride;
       const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
       fx[b][i][0] = l;
       fx[b][i][1] = h;
@@ -976,19 +990,24 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
   const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
   const int batch = __builtin_amdgcn_readfirstlane(g.batch);
   // ---- per-RoI sample tables, one sample per lane: element offset of the low tap + the two factors
-  int yoff = 0, xoff = 0;
+  // y: the reference's (low, high) rows (high = low on the bottom edge); x: shifted pairs + a legacy multiply for the
+  // zero factor; a skipped sample (outside [-1, dim], roi_align_common.h:60-73) is wave-uniform here and simply not visited
+  int yoff = 0, ystep = 0, xoff = 0;
   float yl = 0.f, yh = 0.f, xl = 0.f, xh = 0.f;
+  bool yv = false, xv = false;
+  const int rowC = W * C;
   if (lane < PHT * SRT) {
-    int lo;
-    axis_sample_shifted(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, yl, yh);
-    yoff = lo * W * C;
+    int lo, hi;
+    yv = axis_sample<float>(H, g.start_h, g.bin_h, SRT, lane / SRT, lane % SRT, lo, hi, yl, yh);
+    yoff = lo * rowC;
+    ystep = (hi - lo) * rowC;
   }
   if (lane < PWT * SRT) {
     int lo;
-    axis_sample_shifted(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo, xl, xh);
+    xv = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, lane / SRT, lane % SRT, lo, xl, xh);
     xoff = lo * C;
   }
-  const int rowC = W * C;
+  const unsigned long long yvalid = __ballot(yv), xvalid = __ballot(xv);
   // byte offset of this lane's channel word (lanes past the channel count re-read the last word): the only
   // per-lane part of a tap address, everything else is scalar
   const unsigned cl4 = (unsigned)sizeof(T) * (unsigned)min(c0 + lane * CPL, C - CPL);
@@ -1005,47 +1024,59 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
     shx[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xh), j));
     slx[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl), j));
   }
-  for (int ph = 0; ph < PHT; ++ph) {
-    float acc[PWT][CPL];
-#pragma unroll
-    for (int pw = 0; pw < PWT; ++pw)
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) acc[pw][e] = 0.f;
-#pragma unroll
-    for (int iy = 0; iy < SRT; ++iy) {
-      const int sy = ph * SRT + iy;
-      const int r0 = __builtin_amdgcn_readlane(yoff, sy);
-      const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yh), sy));
-      const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yl), sy));
-      const T* row0 = nbase + r0;
-      const T* row1 = row0 + rowC;
-#pragma unroll
-      for (int j = 0; j < PWT * SRT; ++j) {
-        const char* p0 = reinterpret_cast<const char*>(row0 + sx0[j]);
-        const char* p1 = reinterpret_cast<const char*>(row1 + sx0[j]);
-        const char* q0 = reinterpret_cast<const char*>(row0 + sx0[j] + C);
-        const char* q1 = reinterpret_cast<const char*>(row1 + sx0[j] + C);
-        float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
-        unpack_word<T>(*reinterpret_cast<const unsigned*>(p0 + cl4), v00);
-        unpack_word<T>(*reinterpret_cast<const unsigned*>(q0 + cl4), v01);
-        unpack_word<T>(*reinterpret_cast<const unsigned*>(p1 + cl4), v10);
-        unpack_word<T>(*reinterpret_cast<const unsigned*>(q1 + cl4), v11);
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) {
-          const float t0 = __builtin_fmaf(slx[j], v01[e], shx[j] * v00[e]);
-          const float t1 = __builtin_fmaf(slx[j], v11[e], shx[j] * v10[e]);
-          float& a = acc[j / SRT][e];
-          a = __builtin_fmaf(hy, t0, a);
-          a = __builtin_fmaf(ly, t1, a);
+  // A RoI with samples outside [-1, dim] (skipped by the reference) takes the branchy form of the loop: every skipped
+  // sample row / column is a wave-uniform `continue`.  The usual RoI (every sample valid) takes the branch-free form, whose
+  // 28 tap loads per bin row the compiler batches — a uniform branch per sample would serialise them (measured: 0.19 -> 0.49 ms).
+  const bool all_valid = yvalid == ((1ull << (PHT * SRT)) - 1ull) && xvalid == ((1ull << (PWT * SRT)) - 1ull);
+  auto bin_rows = [&](auto safe_tag) {
+    constexpr bool kSafe = decltype(safe_tag)::value;
+    for (int ph = 0; ph < PHT; ++ph) {
+      float acc[PWT][CPL];
+  #pragma unroll
+      for (int pw = 0; pw < PWT; ++pw)
+  #pragma unroll
+        for (int e = 0; e < CPL; ++e) acc[pw][e] = 0.f;
+  #pragma unroll
+      for (int iy = 0; iy < SRT; ++iy) {
+        const int sy = ph * SRT + iy;
+        if constexpr (kSafe) { if (!((yvalid >> sy) & 1ull)) continue; }   // skipped sample row
+        const int r0 = __builtin_amdgcn_readlane(yoff, sy);
+        const int rstep = __builtin_amdgcn_readlane(ystep, sy);
+        const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yh), sy));
+        const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yl), sy));
+        const T* row0 = nbase + r0;
+        const T* row1 = row0 + rstep;
+  #pragma unroll
+        for (int j = 0; j < PWT * SRT; ++j) {
+          if constexpr (kSafe) { if (!((xvalid >> j) & 1ull)) continue; }   // skipped sample column
+          const char* p0 = reinterpret_cast<const char*>(row0 + sx0[j]);
+          const char* p1 = reinterpret_cast<const char*>(row1 + sx0[j]);
+          const char* q0 = reinterpret_cast<const char*>(row0 + sx0[j] + C);
+          const char* q1 = reinterpret_cast<const char*>(row1 + sx0[j] + C);
+          float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
+          unpack_word<T>(*reinterpret_cast<const unsigned*>(p0 + cl4), v00);
+          unpack_word<T>(*reinterpret_cast<const unsigned*>(q0 + cl4), v01);
+          unpack_word<T>(*reinterpret_cast<const unsigned*>(p1 + cl4), v10);
+          unpack_word<T>(*reinterpret_cast<const unsigned*>(q1 + cl4), v11);
+  #pragma unroll
+          for (int e = 0; e < CPL; ++e) {
+            const float t0 = __builtin_fmaf(slx[j], v01[e], mul_legacy(shx[j], v00[e]));
+            const float t1 = __builtin_fmaf(slx[j], v11[e], mul_legacy(shx[j], v10[e]));
+            float& a = acc[j / SRT][e];
+            a = __builtin_fmaf(hy, t0, a);
+            a = __builtin_fmaf(ly, t1, a);
+          }
         }
       }
+  #pragma unroll
+      for (int pw = 0; pw < PWT; ++pw)
+  #pragma unroll
+        for (int e = 0; e < CPL; ++e)
+          st(tl + (lane * CPL + e) * PHW + ph * PWT + pw, kPow2 ? acc[pw][e] * inv_count : acc[pw][e] / (float)NS);
     }
-#pragma unroll
-    for (int pw = 0; pw < PWT; ++pw)
-#pragma unroll
-      for (int e = 0; e < CPL; ++e)
-        st(tl + (lane * CPL + e) * PHW + ph * PWT + pw, kPow2 ? acc[pw][e] * inv_count : acc[pw][e] / (float)NS);
-  }
+  };
+  if (all_valid) bin_rows(std::false_type{});
+  else bin_rows(std::true_type{});
   // ---- the [channel][bin] block is contiguous in the NCHW output: one linear stream of 32-bit words
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

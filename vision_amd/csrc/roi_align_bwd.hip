@@ -227,29 +227,25 @@ struct __attribute__((packed, aligned(4))) U4u { unsigned x, y, z, w; };
 struct __attribute__((packed, aligned(4))) U2u { unsigned x, y; };
 
 // 16-bit grads of one channel: NG elements starting at gp.  The element offset of a channel's grads is (k*C + c)*PH*PW:
-// always a multiple of 4 elements for 14x14 (8-byte loads), any parity for 7x7 (element loads; only the rare
-// oversized-window pass reads 7x7 grads through this routine).
-template <int NG, typename GT>
+// a multiple of 4 elements for 14x14, whose bin rows are fetched 8 + 6 at a time (112 and 84 elements: every batch starts
+// 8-byte aligned -> 8-byte loads); any parity for 7x7 (element loads; only the rare oversized-window pass reads 7x7 grads
+// through this routine, the main 7x7 path stages whole 8-channel runs, see issue_run).
+template <int NG, typename GT, bool kAligned8>
 __device__ __forceinline__ void load_grads16(v2f (&G2)[(NG + 1) / 2], const GT* __restrict__ gp16) {
   const unsigned short* gp = reinterpret_cast<const unsigned short*>(gp16);
-  if constexpr (NG % 4 == 2 || NG % 4 == 0) {
-    if ((reinterpret_cast<uintptr_t>(gp) & 7) == 0) {
+  if constexpr (kAligned8) {   // the caller guarantees an 8-byte aligned start and NG % 4 == 0
+    static_assert(NG % 4 == 0, "whole 8-byte pieces");
 #pragma unroll
-      for (int e = 0; e + 4 <= NG; e += 4) {
-        const U2u v = *reinterpret_cast<const U2u*>(gp + e);
-        G2[e / 2] = v2f{from16<GT>((unsigned short)(v.x & 0xffffu)), from16<GT>((unsigned short)(v.x >> 16))};
-        G2[e / 2 + 1] = v2f{from16<GT>((unsigned short)(v.y & 0xffffu)), from16<GT>((unsigned short)(v.y >> 16))};
-      }
-      if constexpr (NG % 4 == 2) {
-        const unsigned v = *reinterpret_cast<const unsigned*>(gp + NG - 2);
-        G2[NG / 2 - 1] = v2f{from16<GT>((unsigned short)(v & 0xffffu)), from16<GT>((unsigned short)(v >> 16))};
-      }
-      return;
+    for (int e = 0; e + 4 <= NG; e += 4) {
+      const U2u v = *reinterpret_cast<const U2u*>(gp + e);
+      G2[e / 2] = v2f{from16<GT>((unsigned short)(v.x & 0xffffu)), from16<GT>((unsigned short)(v.x >> 16))};
+      G2[e / 2 + 1] = v2f{from16<GT>((unsigned short)(v.y & 0xffffu)), from16<GT>((unsigned short)(v.y >> 16))};
     }
-  }
+  } else {
 #pragma unroll
-  for (int e = 0; e + 2 <= NG; e += 2) G2[e / 2] = v2f{from16<GT>(gp[e]), from16<GT>(gp[e + 1])};
-  if constexpr (NG & 1) G2[NG / 2] = v2f{from16<GT>(gp[NG - 1]), 0.f};
+    for (int e = 0; e + 2 <= NG; e += 2) G2[e / 2] = v2f{from16<GT>(gp[e]), from16<GT>(gp[e + 1])};
+    if constexpr (NG & 1) G2[NG / 2] = v2f{from16<GT>(gp[NG - 1]), 0.f};
+  }
 }
 
 // the PH*PW grads of one channel as pairs (the packed FMAs pick the low / high half by op_sel)
@@ -291,15 +287,32 @@ __device__ __forceinline__ void contract_x(v2f* t, const v2f (&G2)[(NPH * PW + 1
 // channel never occupy more than ~50 VGPRs)
 template <int PH, int PW, typename GT>
 __device__ __forceinline__ void grads_times_axd(v2f (&t)[PH], const GT* __restrict__ gp, const v2f (&axd)[PW], bool ch_ok) {
-  constexpr int GB = PH <= 7 ? PH : 7;
-  static_assert(PH % GB == 0, "bin rows must split evenly into grad batches");
+  if constexpr (std::is_same<GT, float>::value) {
+    constexpr int GB = PH <= 7 ? PH : 7;
+    static_assert(PH % GB == 0, "bin rows must split evenly into grad batches");
 #pragma unroll
-  for (int p0 = 0; p0 < PH; p0 += GB) {
-    v2f G2[(GB * PW + 1) / 2];
-    if constexpr (std::is_same<GT, float>::value) load_grads<GB * PW>(G2, gp + p0 * PW);
-    else load_grads16<GB * PW, GT>(G2, gp + p0 * PW);
-    contract_x<GB, PW>(t + p0, G2, axd, ch_ok);
-    if (p0 + GB < PH) __builtin_amdgcn_sched_barrier(0);
+    for (int p0 = 0; p0 < PH; p0 += GB) {
+      v2f G2[(GB * PW + 1) / 2];
+      load_grads<GB * PW>(G2, gp + p0 * PW);
+      contract_x<GB, PW>(t + p0, G2, axd, ch_ok);
+      if (p0 + GB < PH) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (PH == 14 && PW == 14) {
+    {
+      v2f G2[(8 * PW) / 2];
+      load_grads16<8 * PW, GT, true>(G2, gp);
+      contract_x<8, PW>(t, G2, axd, ch_ok);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      v2f G2[(6 * PW) / 2];
+      load_grads16<6 * PW, GT, true>(G2, gp + 8 * PW);
+      contract_x<6, PW>(t + 8, G2, axd, ch_ok);
+    }
+  } else {
+    v2f G2[(PH * PW + 1) / 2];
+    load_grads16<PH * PW, GT, false>(G2, gp);
+    contract_x<PH, PW>(t, G2, axd, ch_ok);
   }
 }
 
@@ -1065,6 +1078,7 @@ extern "C" int tvmi_roi_align_backward(const void* grad, const void* rois, void*
   TVMI_CHECK_ARG(H * W < (1ll << 31) && K * tvmi::ceil_div(C, 32) < (1ll << 31), "roi_align_backward: size exceeds 32-bit launch limits");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (workspace && tvmi::owner_applies(dt, N, C, K, pooled_h, pooled_w, &H, &W, 1, c_stride, h_stride, w_stride, workspace_bytes)) {
+    TVMI_CHECK_ARG(dt == TVMI_F32 || (reinterpret_cast<uintptr_t>(grad) & 7) == 0, "roi_align_backward: 16-bit grads must be 8-byte aligned");
     tvmi::MsLevels ms;
     void* ptr = grad_input;
     tvmi::fill_levels(ms, &ptr, &H, &W, &spatial_scale, 1, 0, 0, 224.0, 4.0, 1e-6);
@@ -1109,9 +1123,11 @@ extern "C" int tvmi_multiscale_roi_align_backward(const void* grad, const void* 
   tvmi::MsLevels ms;
   tvmi::fill_levels(ms, grad_inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (workspace && tvmi::owner_applies(dt, N, C, K, pooled_h, pooled_w, heights, widths, n_levels, c_stride, h_stride, w_stride, workspace_bytes))
+  if (workspace && tvmi::owner_applies(dt, N, C, K, pooled_h, pooled_w, heights, widths, n_levels, c_stride, h_stride, w_stride, workspace_bytes)) {
+    TVMI_CHECK_ARG(dt == TVMI_F32 || (reinterpret_cast<uintptr_t>(grad) & 7) == 0, "multiscale_roi_align_backward: 16-bit grads must be 8-byte aligned");
     return tvmi::dispatch_owner(dt, /*rois_f32=*/true, grad, rois, ms, 1, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, n_stride,
                                 c_stride, workspace, s);
+  }
   if (K == 0) return 0;
   TVMI_CHECK_ARG(dt == TVMI_F32, "multiscale_roi_align_backward: 16-bit gradients need the tile-owner regime (workspace, contiguous "
                                  "7x7 / 14x14 bins, even channel count)");

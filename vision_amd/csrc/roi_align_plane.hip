@@ -126,11 +126,6 @@ __global__ __launch_bounds__(kPlanePreThreads) void roi_fwd_prepass(MsLevels lv,
 
 // ---------------------------------------------------------------------------------------
 // The serving kernel.
-// v_mul_legacy_f32 (0 * x = 0 for every x, NaN and Inf included) as the LLVM intrinsic itself — clang 22 has no builtin
-// for it; an inline-asm form would pin the surrounding LDS reads in place
-extern "C" __device__ float tvmi_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
-__device__ __forceinline__ float mul_legacy(float a, float b) { return tvmi_fmul_legacy(a, b); }
-
 template <typename T>
 __device__ __forceinline__ float tap_pair(const char* __restrict__ p, float l, float h) {
   // h * p[0] + l * p[1]; the h product is the one that may carry an exact-zero weight onto a pixel the reference does

@@ -87,6 +87,14 @@ __device__ __forceinline__ bool axis_sample_shifted(int dim, float start, float 
   return true;
 }
 
+// v_mul_legacy_f32 (0 * x = 0 for every x, NaN and Inf included) as the LLVM intrinsic itself — clang 22 has no builtin
+// for it; an inline-asm form would pin the surrounding LDS reads in place.  The forward kernels use it for the ONE product
+// of a tap pair whose factor can be an exact zero on a pixel the reference never reads (the x edge re-expressed on the
+// pair (W-2, W-1) with factors (0, 1)): a NaN / Inf there must not reach the output (cpu/roi_align_common.h:78-90 reads
+// pixel W-1 twice instead).
+extern "C" __device__ float tvmi_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
+__device__ __forceinline__ float mul_legacy(float a, float b) { return tvmi_fmul_legacy(a, b); }
+
 // Multi-scale (FPN) launches: the level of every RoI is chosen IN the kernel
 // (torchvision/ops/poolers.py:47-84, LevelMapper: floor(k0 + log2(sqrt(area)/s0) + eps) clamped to
 // [k_min, k_max]).  RoIs of the multi-scale entries are always float32 image coordinates, whatever the
