@@ -272,7 +272,7 @@ int tvmi_deformable_col2im_coord(const void* columns, const void* input, const v
  * label) zero padded, counts [num_images] int32.  Replaces the index / split / top-k glue of
  * torchvision/models/detection/roi_heads.py:720-735 and the pickled all_gather_object of
  * references/detection/utils.py:70-83.  boxes [N,4] fp32, scores [N] fp32, labels [N] int64 or
- * NULL, image_idx [N] int64, keep [num_keep] int64 (descending score).  num_images <= 256.
+ * NULL, image_idx [N] int64, keep [num_keep] int64 (descending score).  One workgroup per image; num_images <= 65535.
  */
 int tvmi_pack_detections(const float* boxes, const float* scores, const int64_t* labels,
                          const int64_t* image_idx, const int64_t* keep, int64_t num_keep, int64_t num_images,

