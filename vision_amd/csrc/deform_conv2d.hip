@@ -356,6 +356,253 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
   }
 }
 
+// ------------------------------------------------------------------ fused MFMA forward, 16-bit tensors
+// fp16 / bf16 tensors on v_mfma_f32_32x32x16_{f16,bf16}: the same fused structure as the fp32 kernel above — offset-gather +
+// bilinear "im2col" values of a K slab produced straight into LDS, weights from a [tap][ic slab][oc][16] re-layout — but
+// ONE matrix instruction per 32x32 block and 16-deep slab (16x the fp32 MFMA rate), fp32 accumulation.  The sampled values
+// are rounded to the 16-bit type when they enter LDS: exactly what the reference does (its `columns` tensor has the input
+// dtype, cuda/deform_conv2d_kernel.cu:1234-1239), while its addmm_ also ACCUMULATES in 16 bits — the products here are
+// exact (16-bit x 16-bit fits fp32) and the sum is fp32, so the result sits inside the reference's own 16-bit error.
+// LDS rows are [row][k] with a 48-byte pitch: a lane's 8 consecutive k of one row is a single 16-byte read, and 16 lanes x
+// 48 bytes tile the 64 banks without conflict.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kRowPitch16 = 24;   // 16-bit elements per LDS row: 16 k-values + 8 of padding (48 bytes)
+
+template <typename T>
+__device__ __forceinline__ f32x16v mfma16(uint4 a, uint4 b, f32x16v c) {
+  if constexpr (std::is_same<T, __half>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ unsigned short to16(float v) {
+  if constexpr (std::is_same<T, __half>::value) return __half_as_ushort(__float2half(v));
+  else {
+    const __hip_bfloat16 b = __float2bfloat16(v);
+    return *reinterpret_cast<const unsigned short*>(&b);
+  }
+}
+template <typename T>
+__device__ __forceinline__ float from16bits(unsigned short h) {
+  if constexpr (std::is_same<T, __half>::value) return __half2float(__ushort_as_half(h));
+  else return __uint_as_float((unsigned)h << 16);
+}
+
+// weight [OC, ICg, kh, kw] (T) -> wt16 [groups][tap][ICg_pad / 16][OCg_pad][16] (T, zero padded)
+template <typename T>
+__global__ void dcn_weight_relayout16(const T* __restrict__ w, T* __restrict__ wt, DcnParams p, int ICg_pad, int OCg_pad) {
+  const int KK = p.kh * p.kw;
+  const int64_t total = (int64_t)p.groups * KK * ICg_pad * OCg_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % 16);
+    const int oc = (int)((idx / 16) % OCg_pad);
+    const int slab = (int)((idx / ((int64_t)16 * OCg_pad)) % (ICg_pad / 16));
+    const int tap = (int)((idx / ((int64_t)OCg_pad * ICg_pad)) % KK);
+    const int g = (int)(idx / ((int64_t)OCg_pad * ICg_pad * KK));
+    const int ic = slab * 16 + k;
+    float v = 0.f;
+    if (oc < p.OCg && ic < p.ICg) v = ld(w + (((int64_t)(g * p.OCg + oc)) * p.ICg + ic) * KK + tap);
+    st(wt + idx, v);
+  }
+}
+
+template <typename T, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restrict__ input, const T* __restrict__ wt,
+                                                                const T* __restrict__ offset, const T* __restrict__ mask,
+                                                                const T* __restrict__ bias, T* __restrict__ out, DcnParams p,
+                                                                int ICg_pad, int OCg_pad) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+  constexpr int NSUB = NT / BN;          // channel subsets among the B-tile producers
+  constexpr int BPT = kBK / NSUB;        // consecutive channels per thread and slab (one packed LDS write)
+  constexpr int AQ = BM * 2;             // 16-byte pieces of the A slab ([BM][16] 16-bit)
+  constexpr int AV = (AQ + NT - 1) / NT;
+  static_assert(NT % BN == 0 && kBK % NSUB == 0 && BPT % 2 == 0 && kBK == 16, "tile shape does not divide evenly");
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][BM][kRowPitch16];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN][kRowPitch16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = blockIdx.z;
+  const int oc0 = blockIdx.y * BM;
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+  const int KK = p.kh * p.kw;
+  const int64_t in_plane = (int64_t)p.H * p.W;
+  const int nslab = ICg_pad / 16;
+
+  const int pn = tid % BN, csub = tid / BN;
+  const int64_t my_pix = pix0 + pn;
+  const bool pix_ok = my_pix < npix;
+  int pb = 0, poy = 0, pox = 0;
+  if (pix_ok) {
+    pox = (int)(my_pix % p.ow);
+    poy = (int)((my_pix / p.ow) % p.oh);
+    pb = (int)(my_pix / ((int64_t)p.ow * p.oh));
+  }
+  const T* in_b = input + ((int64_t)pb * p.C + (int64_t)g * p.ICg) * in_plane;
+
+  f32x16v acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  unsigned bv[BPT][2];   // staged corner pairs (two 16-bit pixels per dword) of the next slab: top pair, bottom pair
+  uint4 av[AV];          // staged weights of the next slab
+  Tap<float> tap_cur;
+  tap_cur.o1 = tap_cur.o2 = tap_cur.o3 = tap_cur.o4 = 0;
+  tap_cur.w1 = tap_cur.w2 = tap_cur.w3 = tap_cur.w4 = 0.f;
+  tap_cur.m = 0.f;
+  PairPlan plan;
+  plan.b0 = plan.b1 = 0;
+  plan.sel = 1;
+
+  int s_tap = 0, s_ic = 0, s_seg_end = 0;
+  bool have = KK > 0 && p.ICg > 0;
+  auto begin_segment = [&](int tap, int ic) {
+    const int og = (g * p.ICg + ic) / p.cpog;
+    s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
+    if (pix_ok) {
+      load_tap<T, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+      plan = make_pair_plan(tap_cur, p.W);
+    }
+  };
+  auto issue_loads = [&](int tap, int ic0, int kmax) {
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      const int kk = csub * BPT + e;
+      bv[e][0] = bv[e][1] = 0u;
+      if (kk < kmax && pix_ok) {
+        const T* pl = in_b + (int64_t)(ic0 + kk) * in_plane;
+        __builtin_memcpy(&bv[e][0], pl + plan.b0, 4);   // two adjacent pixels: ONE dword load at 2-byte alignment
+        __builtin_memcpy(&bv[e][1], pl + plan.b1, 4);
+      }
+    }
+    // a slab never straddles an offset-group segment boundary in the re-laid-out weights: the slab index is ic0 / 16 only
+    // when ic0 is a multiple of 16; segments that start elsewhere are served from the slab that contains them with the
+    // rows before ic0 zeroed by kmax / the B side (their im2col values are zero)
+    const T* wsrc = wt + ((((int64_t)g * KK + tap) * nslab + ic0 / 16) * OCg_pad + oc0) * 16;
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int piece = tid + e * NT;
+      const int m = piece >> 1, half = piece & 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (piece < AQ && oc0 + m < OCg_pad) v = *reinterpret_cast<const uint4*>(wsrc + (int64_t)m * 16 + half * 8);
+      av[e] = v;
+    }
+  };
+  auto commit = [&](int buf, int kbase, int len) {
+    unsigned short hv[BPT];
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      const float lo0 = from16bits<T>((unsigned short)(bv[e][0] & 0xffffu)), hi0 = from16bits<T>((unsigned short)(bv[e][0] >> 16));
+      const float lo1 = from16bits<T>((unsigned short)(bv[e][1] & 0xffffu)), hi1 = from16bits<T>((unsigned short)(bv[e][1] >> 16));
+      const float v1 = plan.sel == 2 ? hi0 : lo0, v2 = plan.sel == 1 ? lo0 : hi0;
+      const float v3 = plan.sel == 2 ? hi1 : lo1, v4 = plan.sel == 1 ? lo1 : hi1;
+      hv[e] = to16<T>(tap_cur.m * (tap_cur.w1 * v1 + tap_cur.w2 * v2 + tap_cur.w3 * v3 + tap_cur.w4 * v4));
+    }
+    if (len == kBK) {   // whole slab (kbase = 0): this thread's BPT consecutive k as packed dwords
+      unsigned* dst = reinterpret_cast<unsigned*>(&Bs[buf][pn][csub * BPT]);
+#pragma unroll
+      for (int e = 0; e < BPT / 2; ++e) dst[e] = (unsigned)hv[2 * e] | ((unsigned)hv[2 * e + 1] << 16);
+    } else {            // piece of a slab: only its k positions, element by element (the rest of the row was zeroed)
+#pragma unroll
+      for (int e = 0; e < BPT; ++e)
+        if (csub * BPT + e < len) Bs[buf][pn][kbase + csub * BPT + e] = hv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int piece = tid + e * NT;
+      if (piece < AQ) *reinterpret_cast<uint4*>(&As[buf][piece >> 1][(piece & 1) * 8]) = av[e];
+    }
+  };
+
+  // A segment that does not start on a slab boundary (offset groups whose channel count is not a multiple of 16) is walked
+  // in pieces that stay inside one weight slab: ic0 advances to the next multiple of 16, the k positions of the piece inside
+  // the slab are kbase = ic0 % 16 .. and the B rows outside it are zeroed (zero x weight = nothing).
+  auto slab_len = [&](int ic) { return min(min(kBK - (ic & 15), s_seg_end - ic), kBK); };
+  int buf = 0;
+  int cur_len = 0, cur_base = 0;
+  if (have) {
+    begin_segment(0, 0);
+    cur_len = slab_len(0);
+    cur_base = 0;
+    issue_loads(0, 0, cur_len);
+  }
+  // zero both B buffers once: rows of a partial slab that no producer writes must read as zero
+  for (int i = tid; i < 2 * BN * kRowPitch16 / 2; i += NT) reinterpret_cast<unsigned*>(&Bs[0][0][0])[i] = 0u;
+  __syncthreads();
+  while (have) {
+    const bool partial = cur_len < kBK;
+    if (partial) {   // clear this buffer's B rows first (another slab's values may sit in the k positions this one skips)
+      for (int i = tid; i < BN * kRowPitch16 / 2; i += NT) reinterpret_cast<unsigned*>(&Bs[buf][0][0])[i] = 0u;
+      __syncthreads();
+    }
+    commit(buf, cur_base, cur_len);
+    __syncthreads();
+    int n_tap = s_tap, n_ic = s_ic + cur_len;
+    bool n_have = true;
+    if (n_ic >= s_seg_end) {
+      n_ic = s_seg_end;
+      if (n_ic >= p.ICg) {
+        n_ic = 0;
+        n_tap = s_tap + 1;
+        if (n_tap >= KK) n_have = false;
+      }
+      if (n_have) begin_segment(n_tap, n_ic);
+    }
+    int n_len = 0, n_base = 0;
+    if (n_have) {
+      n_len = slab_len(n_ic);
+      n_base = n_ic & 15;
+      issue_loads(n_tap, n_ic, n_len);
+    }
+    const int kq = lane >> 5, l31 = lane & 31;
+    uint4 a[MI], b[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const uint4*>(&As[buf][(wm * MI + mi) * 32 + l31][kq * 8]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const uint4*>(&Bs[buf][(wn * NI + ni) * 32 + l31][kq * 8]);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16<T>(a[mi], b[ni], acc[mi][ni]);
+    s_tap = n_tap;
+    s_ic = n_ic;
+    cur_len = n_len;
+    cur_base = n_base;
+    have = n_have;
+    buf ^= 1;
+  }
+
+  // epilogue: D[row][col], col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (oc)
+  const int l31 = lane & 31, kq = lane >> 5;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
+    if (pix >= npix) continue;
+    const int ox = (int)(pix % p.ow);
+    const int oy = (int)((pix / p.ow) % p.oh);
+    const int b = (int)(pix / ((int64_t)p.ow * p.oh));
+    T* obase = out + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * p.oh * p.ow + (int64_t)oy * p.ow + ox;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + ld(bias + g * p.OCg + oc));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ depthwise forward (groups == C == OC, 3x3)
 // Reference shape: cuda/deform_conv2d_kernel.cu:136-209 writes columns[C*9, B*oh*ow] and runs C GEMMs of 1 x 9.  The
 // generic direct kernel above re-derives the tap geometry per (pixel, channel) and gathers 36 scattered dwords per output
@@ -704,6 +951,9 @@ int fill_params(DcnParams& p, int64_t B, int64_t C, int64_t H, int64_t W, int64_
 inline bool use_mfma(const DcnParams& p, tvmi_dtype dt) {
   return dt == TVMI_F32 && p.OCg >= 16 && p.ICg >= 4 && p.W >= 2;  // W >= 2: the corner pairs are 8-byte loads
 }
+inline bool use_mfma16(const DcnParams& p, tvmi_dtype dt) {
+  return (dt == TVMI_F16 || dt == TVMI_BF16) && p.OCg >= 16 && p.ICg >= 4 && p.W >= 2;
+}
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1 << 20)); }
 
@@ -714,9 +964,9 @@ using namespace tvmi;
 
 extern "C" size_t tvmi_deform_conv2d_workspace_bytes(tvmi_dtype dt, int64_t C, int64_t OC, int64_t kh, int64_t kw,
                                                      int64_t groups) {
-  if (dt != TVMI_F32 || groups <= 0 || C <= 0 || OC <= 0) return 0;
+  if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16) || groups <= 0 || C <= 0 || OC <= 0) return 0;
   const int ICg_pad = round_up((int)(C / groups), kBK), OCg_pad = round_up((int)(OC / groups), 64);
-  return (size_t)groups * kh * kw * ICg_pad * OCg_pad * sizeof(float);
+  return (size_t)groups * kh * kw * ICg_pad * OCg_pad * (dt == TVMI_F32 ? sizeof(float) : 2);   // the re-laid-out weights
 }
 
 extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight, const void* offset,
@@ -759,6 +1009,30 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
       if (eight) TVMI_DCN(1, 8, 2, 1); else TVMI_DCN(1, 4, 2, 2);
     }
 #undef TVMI_DCN
+  } else if (use_mfma16(p, dt)) {
+    const int ICg_pad = round_up(p.ICg, kBK), OCg_pad = round_up(p.OCg, 64);
+    TVMI_CHECK_ARG(workspace && workspace_bytes >= tvmi_deform_conv2d_workspace_bytes(dt, C, OC, kh, kw, groups),
+                   "deform_conv2d: workspace too small");
+    const int64_t wtotal = (int64_t)p.groups * kh * kw * ICg_pad * OCg_pad;
+    const int64_t npix = (int64_t)B * p.oh * p.ow;
+#define TVMI_DCN16_T(scalar_t, WM, WN, MI, NI)                                                                         \
+  dcn_fwd_mfma_16<scalar_t, WM, WN, MI, NI>                                                                             \
+      <<<dim3((unsigned)ceil_div(npix, 32 * NI * WN), (unsigned)ceil_div(p.OCg, 32 * MI * WM), (unsigned)p.groups),     \
+         dim3(64 * WM * WN), 0, s>>>((const scalar_t*)input, (const scalar_t*)workspace, (const scalar_t*)offset,      \
+                                     (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, ICg_pad, OCg_pad)
+#define TVMI_DCN16(scalar_t)                                                                                           \
+  do {                                                                                                                 \
+    dcn_weight_relayout16<scalar_t><<<grid1d(wtotal), dim3(256), 0, s>>>((const scalar_t*)weight, (scalar_t*)workspace, p, \
+                                                                         ICg_pad, OCg_pad);                            \
+    /* the matrix work is 16x cheaper than in fp32: the kernel is gather-bound, so always 8 waves per tile */          \
+    if (p.OCg > 128) TVMI_DCN16_T(scalar_t, 4, 2, 2, 1);                                                               \
+    else if (p.OCg > 64) TVMI_DCN16_T(scalar_t, 2, 4, 2, 1);                                                           \
+    else TVMI_DCN16_T(scalar_t, 1, 8, 2, 1);                                                                           \
+  } while (0)
+    if (dt == TVMI_F16) TVMI_DCN16(__half);
+    else TVMI_DCN16(__hip_bfloat16);
+#undef TVMI_DCN16
+#undef TVMI_DCN16_T
   } else if (const DwGeom dg = depthwise_geom(p, dt); dg.CB > 0) {
     const dim3 grid((unsigned)(dg.ntx * dg.nty), (unsigned)(dg.csplit * p.ogroups), (unsigned)p.B);
     const size_t lds = (size_t)2 * dg.CB * dg.tile_sz * sizeof(float);

@@ -233,7 +233,9 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
           const float4 xe = s.xtab[pw * gw + ix];
           const int xlo = __float_as_int(xe.x), xhi = min(xlo + 1, W - 1);
           const float lx = xe.y, hx = xe.z;
-          acc += (hy * hx) * ld(r0 + xlo) + (hy * lx) * ld(r0 + xhi) + (ly * hx) * ld(r1 + xlo) + (ly * lx) * ld(r1 + xhi);
+          // legacy multiplies: a skipped sample has all-zero factors and points at the window origin
+          acc += mul_legacy(hy * hx, ld(r0 + xlo)) + mul_legacy(hy * lx, ld(r0 + xhi)) + mul_legacy(ly * hx, ld(r1 + xlo)) +
+                 mul_legacy(ly * lx, ld(r1 + xhi));
         }
       }
       st(out + o, pow2 ? acc * inv_count : acc / count);
@@ -271,7 +273,10 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
           const float4 xe = s.xtab[pw * gw + ix];
           const float* p = row + __float_as_int(xe.x);
           const float lx = xe.y, hx = xe.z;
-          acc += (hy * hx) * p[0] + (hy * lx) * p[1] + (ly * hx) * p[wstride] + (ly * lx) * p[wstride + 1];
+          // legacy multiplies (0 * x = 0): a sample the reference skips (roi_align_common.h:60-73) has all-zero factors and
+          // points at the window origin; the x / y edges are exact (the pad column / row holds the clamped pixel)
+          acc += mul_legacy(hy * hx, p[0]) + mul_legacy(hy * lx, p[1]) + mul_legacy(ly * hx, p[wstride]) +
+                 mul_legacy(ly * lx, p[wstride + 1]);
         }
       }
       st(out + cg * PHW + o, pow2 ? acc * inv_count : acc / count);

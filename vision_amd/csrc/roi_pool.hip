@@ -344,16 +344,21 @@ __global__ __launch_bounds__(kThreads) void roi_pool_bwd(const T* __restrict__ g
 constexpr int kPlaneMaxPixels = 36864;  // 144 KB of LDS for the plane + 4 KB for the RoI list
 constexpr int kPlaneList = 1024;
 
+// A plane above kPlaneMaxPixels (a 200x336 FPN level) is cut into `nstrips` strips of `strip_px` pixels (whole rows); the
+// wave that owns strip s of plane (b, c) walks the same gradient stream and keeps the contributions whose argmax pixel
+// lies in its strip — still one owner per pixel, still program order, still no global atomics.
 template <typename T>
 __global__ __launch_bounds__(64) void roi_pool_bwd_plane(const T* __restrict__ grad, const T* __restrict__ rois,
                                                          const int* __restrict__ argmax, T* __restrict__ grad_input, int K,
-                                                         int C, int HW, int bins, int PW, int64_t ns, int64_t cs,
-                                                         int64_t hs, int64_t ws) {
+                                                         int C, int HW_all, int strip_px, int nstrips, int bins, int PW,
+                                                         int64_t ns, int64_t cs, int64_t hs, int64_t ws) {
   extern __shared__ float smem[];
   float* plane = smem;
-  int* list = reinterpret_cast<int*>(smem + HW);
+  int* list = reinterpret_cast<int*>(smem + strip_px);
   const int lane = threadIdx.x;
-  const int b = blockIdx.x / C, c = blockIdx.x % C;
+  const int strip = blockIdx.x % nstrips, bc = blockIdx.x / nstrips;
+  const int b = bc / C, c = bc % C;
+  const int p0 = strip * strip_px, HW = min(strip_px, HW_all - p0);   // this wave's pixels: [p0, p0 + HW)
   for (int i = lane; i < HW; i += 64) plane[i] = 0.f;
   for (int k0 = 0; k0 < K; k0 += kPlaneList) {
     // RoIs of image b among [k0, k0 + kPlaneList), in index order
@@ -381,24 +386,36 @@ __global__ __launch_bounds__(64) void roi_pool_bwd_plane(const T* __restrict__ g
         if (e < total) {
           const int r = e / bins, bin = e - r * bins;
           const int64_t k = list[r];
-          am[u] = argmax[(k * C + c) * bins + bin];
+          am[u] = argmax[(k * C + c) * bins + bin] - p0;
           g[u] = ld(grad + k * ns + c * cs + (bin / PW) * hs + (bin % PW) * ws);
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (am[u] >= 0) atomicAdd(&plane[am[u]], g[u]);  // ds_add_f32, program order
+        if (am[u] >= 0 && am[u] < HW) atomicAdd(&plane[am[u]], g[u]);  // ds_add_f32, program order (argmax -1 = empty bin stays out)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  T* dst = grad_input + ((int64_t)b * C + c) * HW;
+  T* dst = grad_input + ((int64_t)b * C + c) * HW_all + p0;
   for (int i = lane; i < HW; i += 64) st(dst + i, plane[i]);
 }
 
 inline bool roi_pool_bwd_plane_applies(tvmi_dtype dt, int64_t H, int64_t W, int64_t N, int64_t C) {
   return dt != TVMI_F64 && H * W <= kPlaneMaxPixels && H * W > 0 && N * C < (1ll << 31);
+}
+// RoIPool only: planes up to 8 strips of whole rows (the PS variants keep the single-plane regime)
+constexpr int kPoolMaxStrips = 8;
+inline int roi_pool_strips(int64_t H, int64_t W) {
+  if (H * W <= kPlaneMaxPixels) return 1;
+  if (W <= 0 || W > kPlaneMaxPixels) return 0;
+  const int64_t rows = kPlaneMaxPixels / W;              // rows per strip
+  const int64_t n = (H + rows - 1) / rows;
+  return n <= kPoolMaxStrips ? (int)n : 0;
+}
+inline bool roi_pool_bwd_strips_apply(tvmi_dtype dt, int64_t H, int64_t W, int64_t N, int64_t C) {
+  return dt != TVMI_F64 && H * W > 0 && roi_pool_strips(H, W) > 0 && N * C * kPoolMaxStrips < (1ll << 31);
 }
 
 // ---- bilinear helpers of the PS-RoIAlign CPU kernel (cpu/ps_roi_align_kernel.cpp:17-70,153-217)
@@ -762,19 +779,28 @@ extern "C" int tvmi_roi_pool_backward(const void* grad, const void* rois, const 
                                       int64_t w_stride, void* stream) {
   const int64_t total = K * C * pooled_h * pooled_w;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (total == 0) return tvmi::zero_planes_if_owner(dt, grad_input, N, C, H, W, s, "roi_pool_backward: zero fill");
+  if (total == 0) {   // K == 0: honour the "overwrites" contract of the owner regime
+    if (N * C * H * W == 0 || !tvmi::roi_pool_bwd_strips_apply(dt, H, W, N, C)) return 0;
+    TVMI_CHECK_ARG(grad_input, "roi_pool_backward: null pointer");
+    const size_t esz = dt == TVMI_F32 ? 4 : 2;
+    const hipError_t e = hipMemsetAsync(grad_input, 0, (size_t)(N * C * H * W) * esz, s);
+    return e == hipSuccess ? 0 : ::tvmi::set_error((int)e, "roi_pool_backward: zero fill");
+  }
   if (N * C * H * W == 0) return 0;
   TVMI_CHECK_ARG(grad && rois && argmax && grad_input, "roi_pool_backward: null pointer");
-  if (tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C)) {
-    const size_t lds = (size_t)(H * W + tvmi::kPlaneList) * sizeof(float);
+  if (tvmi::roi_pool_bwd_strips_apply(dt, H, W, N, C)) {
+    const int nstrips = tvmi::roi_pool_strips(H, W);
+    const int64_t strip_px = nstrips == 1 ? H * W : ((H + nstrips - 1) / nstrips) * W;   // whole rows, evenly
+    const size_t lds = (size_t)(strip_px + tvmi::kPlaneList) * sizeof(float);
 #define TVMI_POOL_PLANE(scalar_t)                                                                                      \
   do {                                                                                                                 \
     auto kern = tvmi::roi_pool_bwd_plane<scalar_t>;                                                                    \
     if (lds > 64 * 1024)                                                                                               \
       TVMI_CHECK_ARG(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess, \
                      "roi_pool_backward: cannot reserve the LDS plane");                                               \
-    kern<<<dim3((unsigned)(N * C)), dim3(64), lds, s>>>((const scalar_t*)grad, (const scalar_t*)rois, argmax,          \
+    kern<<<dim3((unsigned)(N * C * nstrips)), dim3(64), lds, s>>>((const scalar_t*)grad, (const scalar_t*)rois, argmax, \
                                                         (scalar_t*)grad_input, (int)K, (int)C, (int)(H * W),          \
+                                                        (int)strip_px, nstrips,                                        \
                                                         (int)(pooled_h * pooled_w), (int)pooled_w, n_stride, c_stride, \
                                                         h_stride, w_stride);                                           \
   } while (0)
@@ -794,7 +820,7 @@ extern "C" int tvmi_roi_pool_backward(const void* grad, const void* rois, const 
 }
 
 extern "C" int tvmi_roi_pool_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W) {
-  return tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C) ? 1 : 0;
+  return tvmi::roi_pool_bwd_strips_apply(dt, H, W, N, C) ? 1 : 0;
 }
 
 extern "C" int tvmi_ps_roi_align_forward(const void* input, const void* rois, void* output,

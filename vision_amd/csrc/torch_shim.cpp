@@ -448,16 +448,9 @@ at::Tensor deform_conv2d_forward(const at::Tensor& input, const at::Tensor& weig
   const DcnShape s = dcn_check(input_c, weight_c, offset_c, mask_c, bias_c, stride_h, stride_w, pad_h, pad_w,
                                dilation_h, dilation_w, n_weight_grps, n_offset_grps, use_mask);
   c10::DeviceGuard guard(input.device());
-  const bool low = input.scalar_type() == at::kHalf || input.scalar_type() == at::kBFloat16;
-  if (low && input.numel() != 0 && s.OC / n_weight_grps >= 16 && s.C / n_weight_grps >= 4 && s.W >= 2) {
-    // 16-bit tensors with a real channel contraction: the fused gather + MFMA kernel is fp32 (exact products, fp32
-    // accumulation); widen, run it, round the result once.  (The reference's Half path rounds the sampled columns to
-    // 16 bits before its GEMM; this is at least as accurate.)  Depthwise-like shapes stay on the direct 16-bit kernel.
-    return deform_conv2d_forward(input_c.to(at::kFloat), weight_c.to(at::kFloat), offset_c.to(at::kFloat), mask_c.to(at::kFloat),
-                                 bias_c.to(at::kFloat), stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, n_weight_grps,
-                                 n_offset_grps, use_mask)
-        .to(input.scalar_type());
-  }
+  // 16-bit tensors run natively: v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation for real channel contractions
+  // (the sampled values are rounded to 16 bits like the reference's `columns`, the sum stays fp32), the lane = pixel LDS
+  // kernel for depthwise 3x3, the direct kernel otherwise — no widening copies.
   at::Tensor out = at::empty({s.B, s.OC, s.oh, s.ow}, input_c.options());
   if (out.numel() == 0) return out;
   const tvmi_dtype dt = dtype_of(input_c, "deform_conv2d");
