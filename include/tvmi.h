@@ -213,9 +213,12 @@ int tvmi_roi_pool_backward(const void* grad, const void* rois, const int32_t* ar
 /* roi_pool backward has two regimes, like roi_align's: when a gradient plane (H*W fp32) fits the LDS of a CU and the
  * dtype is F32 / F16 / BF16, one wave owns each plane, accumulates in LDS in a fixed order and WRITES every pixel of
  * grad_input (deterministic, no global atomics, no zero-fill needed) — tvmi_roi_pool_backward_overwrites(...) == 1;
- * otherwise it adds into a caller-zeroed grad_input with hardware atomics (cuda/roi_pool_kernel.cu:80-125).
- * tvmi_ps_roi_align_backward / tvmi_ps_roi_pool_backward switch regimes on the same predicate. */
+ * otherwise it adds into a caller-zeroed grad_input with hardware atomics (cuda/roi_pool_kernel.cu:80-125).  A plane
+ * above one LDS plane (36,864 pixels) is cut into up to 8 strips of whole rows with one owner wave each (roi_pool only);
+ * tvmi_ps_roi_align_backward / tvmi_ps_roi_pool_backward own whole planes only: tvmi_ps_roi_backward_overwrites. */
 int tvmi_roi_pool_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W);
+/* The same question for tvmi_ps_roi_align_backward / tvmi_ps_roi_pool_backward (whole planes only). */
+int tvmi_ps_roi_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W);
 int tvmi_ps_roi_align_forward(const void* input, const void* rois, void* output,
                               int32_t* channel_mapping, tvmi_dtype dt, int64_t N, int64_t C, int64_t H,
                               int64_t W, int64_t K, int64_t pooled_h, int64_t pooled_w,

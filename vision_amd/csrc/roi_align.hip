@@ -179,7 +179,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
       y0 = min(__builtin_amdgcn_readlane(lo, fl), __builtin_amdgcn_readlane(lo, ll));
       y1 = max(__builtin_amdgcn_readlane(hi, fl), __builtin_amdgcn_readlane(hi, ll));
     }
-    if (lane < ny) s.ytab[lane] = make_float4(__int_as_float(v ? lo : y0), l, h, 0.f);
+    if (lane < ny) s.ytab[lane] = make_float4(__int_as_float(v ? lo : y0), l, h, v ? 1.f : 0.f);
   }
   {
     int lo = 0, hi = 0;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
       x0 = min(__builtin_amdgcn_readlane(lo, fl), __builtin_amdgcn_readlane(lo, ll));
       x1 = max(__builtin_amdgcn_readlane(hi, fl), __builtin_amdgcn_readlane(hi, ll));
     }
-    if (lane < nx) s.xtab[lane] = make_float4(__int_as_float(v ? lo : x0), l, h, 0.f);
+    if (lane < nx) s.xtab[lane] = make_float4(__int_as_float(v ? lo : x0), l, h, v ? 1.f : 0.f);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -233,9 +233,10 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
           const float4 xe = s.xtab[pw * gw + ix];
           const int xlo = __float_as_int(xe.x), xhi = min(xlo + 1, W - 1);
           const float lx = xe.y, hx = xe.z;
-          // legacy multiplies: a skipped sample has all-zero factors and points at the window origin
-          acc += mul_legacy(hy * hx, ld(r0 + xlo)) + mul_legacy(hy * lx, ld(r0 + xhi)) + mul_legacy(ly * hx, ld(r1 + xlo)) +
-                 mul_legacy(ly * lx, ld(r1 + xhi));
+          // a sample the reference skips (roi_align_common.h:60-73) contributes an exact zero; a VALID sample keeps the
+          // reference's own 0 * pixel products (a NaN under a zero weight is a NaN there too)
+          const float sv = (hy * hx) * ld(r0 + xlo) + (hy * lx) * ld(r0 + xhi) + (ly * hx) * ld(r1 + xlo) + (ly * lx) * ld(r1 + xhi);
+          acc += (ye.w != 0.f && xe.w != 0.f) ? sv : 0.f;
         }
       }
       st(out + o, pow2 ? acc * inv_count : acc / count);
@@ -273,10 +274,11 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
           const float4 xe = s.xtab[pw * gw + ix];
           const float* p = row + __float_as_int(xe.x);
           const float lx = xe.y, hx = xe.z;
-          // legacy multiplies (0 * x = 0): a sample the reference skips (roi_align_common.h:60-73) has all-zero factors and
-          // points at the window origin; the x / y edges are exact (the pad column / row holds the clamped pixel)
-          acc += mul_legacy(hy * hx, p[0]) + mul_legacy(hy * lx, p[1]) + mul_legacy(ly * hx, p[wstride]) +
-                 mul_legacy(ly * lx, p[wstride + 1]);
+          // a sample the reference skips (roi_align_common.h:60-73) contributes an exact zero (its taps point at the window
+          // origin); valid samples keep the reference's 0 * pixel products; the x / y edges are exact (the pad column / row
+          // holds the clamped pixel the reference reads twice)
+          const float sv = (hy * hx) * p[0] + (hy * lx) * p[1] + (ly * hx) * p[wstride] + (ly * lx) * p[wstride + 1];
+          acc += (ye.w != 0.f && xe.w != 0.f) ? sv : 0.f;
         }
       }
       st(out + cg * PHW + o, pow2 ? acc * inv_count : acc / count);
@@ -351,11 +353,13 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
   int off[NB][NS];
   float fy[NB][SRT][2], fx[NB][SRT][2];  // {l, h} per axis sample
   int gy[NB][SRT], gxx[NB][SRT];         // absolute low indices (global-gather fallback)
+  unsigned vmask[NB];                    // bit iy*SRT+ix: the sample is one the reference evaluates (not skipped)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int bin = min(lane + 64 * b, PHW - 1);
     const int ph = bin / PWT, pw = bin - ph * PWT;
     int ylo[SRT], xlo[SRT];
+    bool vys[SRT], vxs[SRT];
 #pragma unroll
     for (int i = 0; i < SRT; ++i) {
       int hi;
@@ -365,12 +369,19 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
       fy[b][i][1] = h;
       if (!vy) ylo[i] = y0;
       gy[b][i] = ylo[i];
+      vys[i] = vy;
       const bool vx = axis_sample<float>(W, g.start_w, g.bin_w, SRT, pw, i, xlo[i], hi, l, h);
       fx[b][i][0] = l;
       fx[b][i][1] = h;
       if (!vx) xlo[i] = x0;
       gxx[b][i] = xlo[i];
+      vxs[i] = vx;
     }
+    vmask[b] = 0;
+#pragma unroll
+    for (int iy = 0; iy < SRT; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < SRT; ++ix) vmask[b] |= (vys[iy] && vxs[ix]) ? (1u << (iy * SRT + ix)) : 0u;
 #pragma unroll
     for (int iy = 0; iy < SRT; ++iy)
 #pragma unroll
@@ -393,10 +404,11 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
 #pragma unroll
           for (int ix = 0; ix < SRT; ++ix) {
             const int xl = gxx[b][ix], xh = min(xl + 1, W - 1);
-            const float t0 = mul_legacy(fx[b][ix][0], ld(r0 + xh)) + mul_legacy(fx[b][ix][1], ld(r0 + xl));
-            const float t1 = mul_legacy(fx[b][ix][0], ld(r1 + xh)) + mul_legacy(fx[b][ix][1], ld(r1 + xl));
-            acc += mul_legacy(fy[b][iy][1], t0);
-            acc += mul_legacy(fy[b][iy][0], t1);
+            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(r0 + xh), fx[b][ix][1] * ld(r0 + xl));
+            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(r1 + xh), fx[b][ix][1] * ld(r1 + xl));
+            float a2 = __builtin_fmaf(fy[b][iy][1], t0, acc);
+            a2 = __builtin_fmaf(fy[b][iy][0], t1, a2);
+            acc = ((vmask[b] >> (iy * SRT + ix)) & 1u) ? a2 : acc;   // a sample the reference skips adds an exact zero
           }
         }
         const int bin = lane + 64 * b;
@@ -432,14 +444,16 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
         for (int iy = 0; iy < SRT; ++iy) {
 #pragma unroll
           for (int ix = 0; ix < SRT; ++ix) {
-            // legacy multiplies (0 * x = 0): a skipped sample (cpu/roi_align_common.h:60-73) has all-zero factors and
-            // its taps point at the window origin — a NaN / Inf there must not reach the sum; the x / y edges are
-            // exact already (the pad column / row holds the clamped pixel the reference reads twice)
+            // a skipped sample (cpu/roi_align_common.h:60-73) has its taps pointed at the window origin: it adds an exact
+            // zero (select, not a product — a NaN / Inf there must not reach the sum); valid samples keep the reference's
+            // products, zero weights included; the x / y edges are exact already (the pad column / row holds the clamped
+            // pixel the reference reads twice)
             const float* p = wbase + off[b][iy * SRT + ix];
-            const float t0 = mul_legacy(fx[b][ix][0], p[1]) + mul_legacy(fx[b][ix][1], p[0]);
-            const float t1 = mul_legacy(fx[b][ix][0], p[wstride + 1]) + mul_legacy(fx[b][ix][1], p[wstride]);
-            acc += mul_legacy(fy[b][iy][1], t0);
-            acc += mul_legacy(fy[b][iy][0], t1);
+            const float t0 = __builtin_fmaf(fx[b][ix][0], p[1], fx[b][ix][1] * p[0]);
+            const float t1 = __builtin_fmaf(fx[b][ix][0], p[wstride + 1], fx[b][ix][1] * p[wstride]);
+            float a2 = __builtin_fmaf(fy[b][iy][1], t0, acc);
+            a2 = __builtin_fmaf(fy[b][iy][0], t1, a2);
+            acc = ((vmask[b] >> (iy * SRT + ix)) & 1u) ? a2 : acc;
           }
         }
         const int bin = lane + 64 * b;

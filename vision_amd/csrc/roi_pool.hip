@@ -386,13 +386,15 @@ __global__ __launch_bounds__(64) void roi_pool_bwd_plane(const T* __restrict__ g
         if (e < total) {
           const int r = e / bins, bin = e - r * bins;
           const int64_t k = list[r];
-          am[u] = argmax[(k * C + c) * bins + bin] - p0;
+          am[u] = argmax[(k * C + c) * bins + bin];   // raw: arithmetic on it here would put a wait between the loads
           g[u] = ld(grad + k * ns + c * cs + (bin / PW) * hs + (bin % PW) * ws);
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (am[u] >= 0 && am[u] < HW) atomicAdd(&plane[am[u]], g[u]);  // ds_add_f32, program order (argmax -1 = empty bin stays out)
+      for (int u = 0; u < U; ++u) {
+        const int a = am[u] - p0;   // argmax -1 (empty bin) and pixels of other strips stay out
+        if (am[u] >= 0 && a >= 0 && a < HW) atomicAdd(&plane[a], g[u]);  // ds_add_f32, program order
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -821,6 +823,10 @@ extern "C" int tvmi_roi_pool_backward(const void* grad, const void* rois, const 
 
 extern "C" int tvmi_roi_pool_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W) {
   return tvmi::roi_pool_bwd_strips_apply(dt, H, W, N, C) ? 1 : 0;
+}
+// the position-sensitive backward entries own whole planes only (no strips)
+extern "C" int tvmi_ps_roi_backward_overwrites(tvmi_dtype dt, int64_t N, int64_t C, int64_t H, int64_t W) {
+  return tvmi::roi_pool_bwd_plane_applies(dt, H, W, N, C) ? 1 : 0;
 }
 
 extern "C" int tvmi_ps_roi_align_forward(const void* input, const void* rois, void* output,

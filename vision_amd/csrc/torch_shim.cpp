@@ -349,7 +349,7 @@ at::Tensor ps_roi_common_backward(const char* name, bool align, const at::Tensor
   if (grad.numel() == 0) return at::zeros({batch_size, channels, height, width}, grad.options());
   // plane-owner regime (a gradient plane fits a CU's LDS): every pixel is written, fixed summation order — the same
   // predicate as roi_pool's
-  const bool overwrites = tvmi_roi_pool_backward_overwrites(dtype_of(grad, name), batch_size, channels, height, width) != 0;
+  const bool overwrites = tvmi_ps_roi_backward_overwrites(dtype_of(grad, name), batch_size, channels, height, width) != 0;
   at::Tensor grad_input = overwrites ? at::empty({batch_size, channels, height, width}, grad.options())
                                      : at::zeros({batch_size, channels, height, width}, grad.options());
   if (!overwrites) at::globalContext().alertNotDeterministic(name);
