@@ -330,10 +330,15 @@ struct OwnEntry {
   int k, y0, x0, wh;
 };
 
+// gstage: per wave, the grads of its 8 channels for one RoI as fp32 (8 * PH*PW floats: 392 for 7x7, 1568 for 14x14).  7x7 keeps
+// two buffers; 14x14 one (the wave writes entry e + 1 only after it has consumed entry e — program order, in-order LDS).
+template <int PH, int PW>
 struct OwnShared {
+  static constexpr int kRun = (8 * PH * PW + 15) & ~15;
+  static constexpr int kBufs = PH <= 7 ? 2 : 1;
   OwnEntry list[4][kScanChunk / 4];  // per-wave segments of the tile's RoI list (ascending RoI index)
   int count[4];
-  __attribute__((aligned(16))) float gstage[4][2][400];  // per wave: two buffers of 8 channels x 7x7 grads (392 floats)
+  __attribute__((aligned(16))) float gstage[4][kBufs][kRun];
 };
 
 #define TVMI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -346,7 +351,7 @@ struct OwnShared {
 // kBig = true : the RoIs with larger windows (rare); factors are evaluated here and the tile is read-add-written —
 //               still one owner per pixel, still a fixed order (this pass runs after the first one).
 template <typename GT, bool kBig, int PH, int PW>
-__device__ __forceinline__ void owner_item(OwnShared& sh, int item, const GT* __restrict__ grad, const float* __restrict__ rois,
+__device__ __forceinline__ void owner_item(OwnShared<PH, PW>& sh, int item, const GT* __restrict__ grad, const float* __restrict__ rois,
                                            const OwnLevels& lv, int C, int K, int nchunks, int sr, int aligned, int64_t ns,
                                            int64_t cs, const OwnWorkspace& ws, const int* klist = nullptr, int nlist = 0) {
   constexpr int RB = PH <= 7 ? 4 : 2;  // tile rows per scalar-load batch (RB * PH coefficient SGPRs, two batches in flight)
@@ -424,22 +429,25 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const GT* __
     if (lane == 0) sh.count[wave] = cnt;
     __syncthreads();
     // ---- accumulate the listed RoIs (every wave walks all four segments, in order)
-    if constexpr (!kBig && PH <= 7) {
+    if constexpr (!kBig) {
       {
-        // The grads of the wave's 8 channels are ONE contiguous run of 8 * PH*PW floats: the wave fetches it with two
-        // coalesced 16-byte-per-lane loads (13 cache lines) into its private LDS region and every lane reads its channel
-        // from there — instead of 13 loads per lane whose 64 lanes ask for 8 scattered 16-byte pieces each (104 line
-        // requests per RoI and wave at the texture addresser, 50 VGPRs in flight).  The loads of entry e + 1 are issued
-        // as soon as entry e sits in LDS, so their latency runs under the ~160 packed FMAs of entry e.
-        constexpr int NGW = 8 * PH * PW;             // floats per wave and RoI
-        constexpr int NPIECE = (NGW + 3) / 4;        // 16-byte pieces (98 for 7x7)
-        constexpr int NLD = (NPIECE + 63) / 64;      // load instructions per lane (2)
-        static_assert(NGW <= 400, "the per-wave staging buffers hold 7x7 bins");
+        // The grads of the wave's 8 channels are ONE contiguous run of 8 * PH*PW elements: the wave fetches it with coalesced
+        // 16-byte-per-lane loads into its private LDS region (as fp32, whatever the storage type) and every lane reads its
+        // channel from there row by row — instead of per-lane loads whose 64 lanes ask for 8 scattered 16-byte pieces each
+        // (104 line requests per RoI and wave at the texture addresser for 7x7) and, for 14x14, instead of holding 98 grads
+        // per lane in registers (194 VGPRs, two waves per SIMD).  The loads of entry e + 1 are issued as soon as entry e
+        // sits in LDS, so their latency runs under the packed FMAs of entry e.
+        constexpr int NGW = 8 * PH * PW;                            // elements per wave and RoI
+        constexpr int EPP = std::is_same<GT, float>::value ? 4 : 8; // elements per 16-byte piece
+        constexpr int NPIECE = NGW / EPP;                           // 98 / 392 (fp32), 49 / 196 (16-bit)
+        constexpr int NLD = (NPIECE + 63) / 64;                     // load instructions per lane
+        constexpr int RUN = OwnShared<PH, PW>::kRun, BUFS = OwnShared<PH, PW>::kBufs;
+        static_assert(NGW % 8 == 0 && NGW <= RUN, "whole 16-byte pieces, run fits the staging buffer");
         const int n0 = TVMI_UNIFORM(sh.count[0]), n1 = n0 + TVMI_UNIFORM(sh.count[1]), n2 = n1 + TVMI_UNIFORM(sh.count[2]);
         const int total = n2 + TVMI_UNIFORM(sh.count[3]);
         touched += total;
         const int ch0w = chunk * kOwnChunk + wave * 8;            // first channel of this wave
-        const int nvalid = max(0, min(8, C - ch0w)) * PH * PW;    // floats of the run that exist
+        const int nvalid = max(0, min(8, C - ch0w)) * PH * PW;    // elements of the run that exist
         float* gl = &sh.gstage[wave][0][0];
         auto entry_at = [&](int e, int& k, int& y0, int& x0, int& wh) {
           const int seg = (e >= n0 ? 1 : 0) + (e >= n1 ? 1 : 0) + (e >= n2 ? 1 : 0);
@@ -450,45 +458,52 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const GT* __
           x0 = TVMI_UNIFORM(en.x0);
           wh = TVMI_UNIFORM(en.wh);
         };
-        float4 gin[NLD];
+        U4u gin[NLD];   // raw 16-byte pieces (4 floats, or 8 16-bit elements; C is even on the 16-bit path: dword-aligned runs)
         auto issue_run = [&](int k) {
           const GT* run = grad + (int64_t)k * ns + (int64_t)ch0w * cs;
-          if constexpr (std::is_same<GT, float>::value) {
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-              const int f0 = 4 * (u * 64 + lane);  // first float of this lane's piece
-              float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (f0 + 4 <= nvalid) {
-                v = ld4u(run + f0);
-              } else if (f0 < nvalid) {  // the piece that straddles the end of the run (never read past the tensor)
-                v.x = run[f0];
-                if (f0 + 1 < nvalid) v.y = run[f0 + 1];
-                if (f0 + 2 < nvalid) v.z = run[f0 + 2];
-              }
-              gin[u] = v;
-            }
-          } else {
-            // 16-bit grads: the run of 8 channels is 8*PH*PW*2 bytes = NPIECE/2 pieces of 16 bytes (8 elements): ONE load
-            // per lane, converted to fp32 on the way into LDS.  (C is even on this path: the run starts dword-aligned.)
-            static_assert(NLD == 2 && (NGW % 8) == 0, "7x7: 392 elements = 49 pieces of 8");
-            const unsigned short* r16 = reinterpret_cast<const unsigned short*>(run);
-            const int f0 = 8 * lane;
+          for (int u = 0; u < NLD; ++u) {
+            const int f0 = EPP * (u * 64 + lane);  // first element of this lane's piece
             U4u v{0u, 0u, 0u, 0u};
-            if (f0 + 8 <= nvalid) {
-              v = *reinterpret_cast<const U4u*>(r16 + f0);
-            } else if (f0 < nvalid) {
-              unsigned short e[8];
+            if (f0 + EPP <= nvalid) {
+              v = *reinterpret_cast<const U4u*>(run + f0);
+            } else if (f0 < nvalid) {  // the piece that straddles the end of the run (never read past the tensor)
+              if constexpr (std::is_same<GT, float>::value) {
+                v.x = __float_as_uint(run[f0]);
+                if (f0 + 1 < nvalid) v.y = __float_as_uint(run[f0 + 1]);
+                if (f0 + 2 < nvalid) v.z = __float_as_uint(run[f0 + 2]);
+              } else {
+                const unsigned short* r16 = reinterpret_cast<const unsigned short*>(run);
+                unsigned short e[8];
 #pragma unroll
-              for (int q = 0; q < 8; ++q) e[q] = f0 + q < nvalid ? r16[f0 + q] : (unsigned short)0;
-              v.x = e[0] | ((unsigned)e[1] << 16);
-              v.y = e[2] | ((unsigned)e[3] << 16);
-              v.z = e[4] | ((unsigned)e[5] << 16);
-              v.w = e[6] | ((unsigned)e[7] << 16);
+                for (int q = 0; q < 8; ++q) e[q] = f0 + q < nvalid ? r16[f0 + q] : (unsigned short)0;
+                v.x = e[0] | ((unsigned)e[1] << 16);
+                v.y = e[2] | ((unsigned)e[3] << 16);
+                v.z = e[4] | ((unsigned)e[5] << 16);
+                v.w = e[6] | ((unsigned)e[7] << 16);
+              }
             }
-            gin[0] = make_float4(from16<GT>((unsigned short)(v.x & 0xffffu)), from16<GT>((unsigned short)(v.x >> 16)),
-                                 from16<GT>((unsigned short)(v.y & 0xffffu)), from16<GT>((unsigned short)(v.y >> 16)));
-            gin[1] = make_float4(from16<GT>((unsigned short)(v.z & 0xffffu)), from16<GT>((unsigned short)(v.z >> 16)),
-                                 from16<GT>((unsigned short)(v.w & 0xffffu)), from16<GT>((unsigned short)(v.w >> 16)));
+            gin[u] = v;
+          }
+        };
+        auto stage_run = [&](float* gb) {   // registers -> this wave's LDS run, as fp32
+#pragma unroll
+          for (int u = 0; u < NLD; ++u) {
+            const int piece = u * 64 + lane;
+            if (piece < NPIECE) {
+              const U4u v = gin[u];
+              if constexpr (std::is_same<GT, float>::value) {
+                *reinterpret_cast<float4*>(gb + 4 * piece) =
+                    make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+              } else {
+                *reinterpret_cast<float4*>(gb + 8 * piece) =
+                    make_float4(from16<GT>((unsigned short)(v.x & 0xffffu)), from16<GT>((unsigned short)(v.x >> 16)),
+                                from16<GT>((unsigned short)(v.y & 0xffffu)), from16<GT>((unsigned short)(v.y >> 16)));
+                *reinterpret_cast<float4*>(gb + 8 * piece + 4) =
+                    make_float4(from16<GT>((unsigned short)(v.z & 0xffffu)), from16<GT>((unsigned short)(v.z >> 16)),
+                                from16<GT>((unsigned short)(v.w & 0xffffu)), from16<GT>((unsigned short)(v.w >> 16)));
+              }
+            }
           }
         };
         int k = 0, y0 = 0, x0 = 0, wh = 0;
@@ -497,17 +512,8 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const GT* __
           issue_run(k);
         }
         for (int e = 0; e < total; ++e) {
-          float* gb = gl + (e & 1) * 400;
-          if constexpr (std::is_same<GT, float>::value) {
-#pragma unroll
-            for (int u = 0; u < NLD; ++u)
-              if (u * 64 + lane < NPIECE) *reinterpret_cast<float4*>(gb + 4 * (u * 64 + lane)) = gin[u];
-          } else {
-            if (8 * lane < NGW) {   // this lane's 8 elements: floats 8*lane .. 8*lane + 7 of the staged run
-              *reinterpret_cast<float4*>(gb + 8 * lane) = gin[0];
-              *reinterpret_cast<float4*>(gb + 8 * lane + 4) = gin[1];
-            }
-          }
+          float* gb = gl + (BUFS == 2 ? (e & 1) : 0) * RUN;
+          stage_run(gb);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -655,11 +661,12 @@ __device__ __forceinline__ void owner_item(OwnShared& sh, int item, const GT* __
   }
 }
 
+// 14x14: at most 168 VGPRs, so that three waves share a SIMD (the LDS-staged grads brought it down from 194)
 template <typename GT, int PH, int PW>
-__global__ __launch_bounds__(kThreads) void roi_align_bwd_owner(const GT* __restrict__ grad, OwnLevels lv, int C, int K,
+__global__ __launch_bounds__(kThreads, (PH <= 7 ? 1 : 3)) void roi_align_bwd_owner(const GT* __restrict__ grad, OwnLevels lv, int C, int K,
                                                                 int nchunks, int sr, int aligned, int64_t ns, int64_t cs,
                                                                 OwnWorkspace ws) {
-  __shared__ OwnShared sh;
+  __shared__ OwnShared<PH, PW> sh;
   owner_item<GT, false, PH, PW>(sh, (int)blockIdx.x, grad, ws.roisf, lv, C, K, nchunks, sr, aligned, ns, cs, ws);
 }
 
@@ -668,7 +675,7 @@ template <typename GT, int PH, int PW>
 __global__ __launch_bounds__(kThreads) void roi_align_bwd_owner_big(const GT* __restrict__ grad, OwnLevels lv, int C, int K,
                                                                     int nchunks, int nitems, int sr, int aligned, int64_t ns,
                                                                     int64_t cs, OwnWorkspace ws) {
-  __shared__ OwnShared sh;
+  __shared__ OwnShared<PH, PW> sh;
   __shared__ int s_raw[kBigCap], s_sorted[kBigCap];
   const int nbig = ws.imgrange[2 * lv.N] - kUnset;
   if (nbig <= 0) return;  // no oversized window anywhere
