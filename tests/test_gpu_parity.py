@@ -760,6 +760,26 @@ def test_resize_antialias_tile_kernel_shapes(mode):
     np.testing.assert_allclose(out16.float().cpu().numpy(), ref16.numpy(), rtol=0, atol=4e-3)
 
 
+@pytest.mark.parametrize("mode,aa", [("nearest", False), ("nearest-exact", False), ("bilinear", False), ("bicubic", False), ("bilinear", True), ("bicubic", True)])
+def test_interpolate_gradient_matches_torch(mode, aa):
+    """vision_amd.interpolate on an input that requires grad: forward on our kernel, gradient from the matching aten
+    `upsample_*_backward` kernel — the same split autograd makes under override_aten_upsample(True).  Equal to the
+    gradient of F.interpolate on the same device tensor (the forward value of which differs by rounding only)."""
+    g = gen(52)
+    x = torch.rand(2, 3, 19, 23, generator=g).to(DEV)
+    kw = {} if mode.startswith("nearest") else dict(align_corners=False, antialias=aa)
+    for size in ((31, 40), (11, 9)):
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        ya = vision_amd.interpolate(a, size=size, mode=mode, **kw)
+        yb = F.interpolate(b, size=size, mode=mode, **kw)
+        w = torch.randn(ya.shape, generator=g).to(DEV)
+        (ya * w).sum().backward()
+        (yb * w).sum().backward()
+        assert float((ya - yb).abs().max()) <= TOL
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-5)
+
+
 def test_resize_image_wrapper_uint8():
     g = gen(19)
     img = torch.randint(0, 256, (3, 120, 160), generator=g, dtype=torch.uint8)

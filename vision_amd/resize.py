@@ -8,7 +8,8 @@
 nearest / nearest-exact / bilinear / bicubic (+ antialias); `resize` has resize_image's
 meaning (size int -> shorter edge, max_size, uint8 handled as float32 + round + clamp exactly
 like the reference does on GPU tensors, _geometry.py:316-360).  CUDA tensors run on
-`tvmi::interpolate2d`; there is no fallback to ATen.
+`tvmi::interpolate2d`; there is no fallback to ATen for the forward.  Inputs that require grad get
+ATen's `upsample_*_backward` kernels as the gradient (the same split as under the aten override).
 """
 import math
 from typing import List, Optional, Sequence, Union
@@ -54,11 +55,37 @@ def interpolate(input: Tensor, size=None, scale_factor=None, mode: str = "neares
         if not recompute_scale_factor:
             scale_h, scale_w = float(sf[0]), float(sf[1])
     if input.requires_grad and torch.is_grad_enabled():
-        # tvmi::interpolate2d is the forward kernel only; silently dropping the gradient would be worse than refusing
-        raise RuntimeError("vision_amd.interpolate is inference-only (no backward kernel): call it under torch.no_grad(), or "
-                           "use torch.nn.functional.interpolate with vision_amd.override_aten_upsample(True), which keeps "
-                           "aten's autograd formula and runs our forward kernel")
+        # forward on our kernel, backward on ATen's own `*_backward` kernels — exactly what autograd does under
+        # override_aten_upsample(True) (the resize kernels of this library are forward arithmetic)
+        return _Interpolate2d.apply(input, oh, ow, mode, align, bool(antialias), scale_h, scale_w)
     return torch.ops.tvmi.interpolate2d(input, oh, ow, _MODES[mode], align, bool(antialias), scale_h, scale_w)
+
+
+class _Interpolate2d(torch.autograd.Function):
+    """tvmi::interpolate2d with the gradient of the matching aten op (ATen kernel; deterministic-mode warnings are ATen's)."""
+
+    @staticmethod
+    def forward(ctx, input, oh, ow, mode, align, antialias, scale_h, scale_w):
+        ctx.cfg = (tuple(input.shape), oh, ow, mode, align, antialias, scale_h, scale_w)
+        return torch.ops.tvmi.interpolate2d(input, oh, ow, _MODES[mode], align, antialias, scale_h, scale_w)
+
+    @staticmethod
+    def backward(ctx, grad):
+        shape, oh, ow, mode, align, antialias, scale_h, scale_w = ctx.cfg
+        sh = None if scale_h <= 0 else scale_h
+        sw = None if scale_w <= 0 else scale_w
+        a, g = torch.ops.aten, grad.contiguous()
+        if mode == "nearest":
+            gi = a.upsample_nearest2d_backward(g, [oh, ow], list(shape), sh, sw)
+        elif mode == "nearest-exact":
+            gi = a._upsample_nearest_exact2d_backward(g, [oh, ow], list(shape), sh, sw)
+        elif mode == "bilinear":
+            op = a._upsample_bilinear2d_aa_backward if antialias else a.upsample_bilinear2d_backward
+            gi = op(g, [oh, ow], list(shape), align, sh, sw)
+        else:
+            op = a._upsample_bicubic2d_aa_backward if antialias else a.upsample_bicubic2d_backward
+            gi = op(g, [oh, ow], list(shape), align, sh, sw)
+        return gi, None, None, None, None, None, None, None
 
 
 def _compute_resized_output_size(canvas_size, size: Optional[Sequence[int]], max_size: Optional[int] = None) -> List[int]:
