@@ -255,11 +255,20 @@ def main():
         del flist_cl
     alg_bytes = algorithmic_bytes(feats, BATCH * PROPOSALS)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
+    # `traffic` is a committed PMC measurement (separate rocprofv3 --pmc passes, tools/gpu_round.sh + tools/pmc_traffic.py);
+    # the line says whether the kernel sources it was taken on are the ones shipped now
+    traffic, traffic_current = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("roi_align_fwd_ms_dma", {}).get("hbm_bytes_per_launch")
+            import hashlib
+
+            tj = json.load(open(tpath))
+            traffic = tj.get("roi_align_fwd_ms_dma", {}).get("hbm_bytes_per_launch")
+            h = hashlib.sha256()
+            for name in ("roi_align.hip", "roi_common.h"):
+                h.update(open(os.path.join(ROOT, "vision_amd", "csrc", name), "rb").read())
+            traffic_current = tj.get("_measured_on", {}).get("roi_align_sources_sha16") == h.hexdigest()[:16]
         except Exception:
             traffic = None
 
@@ -302,6 +311,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "launch_ms": round(k_ms, 4),
             "traffic": traffic,
+            "traffic_measured_on_shipped_sources": traffic_current,
         },
     }
 

@@ -22,8 +22,8 @@ import sys
 CASES = {
     "roi7": [("roi_align_fwd_ms_dma", 1.33)],
     "roi7cl": [("roi_align_fwd_nhwc", 2.0)],
-    "bwd7": [("roi_align_bwd_owner<7", 2.0), ("roi_bwd_prepass", 2.0)],
-    "bwd14": [("roi_align_bwd_owner<14", 2.0), ("roi_bwd_prepass", 2.0)],
+    "bwd7": [("roi_align_bwd_owner<float, 7", 2.0), ("roi_bwd_prepass", 2.0)],
+    "bwd14": [("roi_align_bwd_owner<float, 14", 2.0), ("roi_bwd_prepass", 2.0)],
     "nms100k": [("nms_mask_tiles", 2.0), ("nms_resolve_wide", 2.0), ("nms_colreduce", 2.0)],
 }
 
@@ -72,11 +72,18 @@ def main():
                 "fetch factor per tools/pmc_traffic.py")
         js = {}
         for key, src in (("roi_align_fwd_ms_dma", "roi7:roi_align_fwd_ms_dma"), ("roi_align_fwd_nhwc", "roi7cl:roi_align_fwd_nhwc"),
-                         ("roi_align_bwd_owner_7", "bwd7:roi_align_bwd_owner<7"), ("roi_align_bwd_owner_14", "bwd14:roi_align_bwd_owner<14"),
+                         ("roi_align_bwd_owner_7", "bwd7:roi_align_bwd_owner<float, 7"), ("roi_align_bwd_owner_14", "bwd14:roi_align_bwd_owner<float, 14"),
                          ("nms_mask_tiles_100k", "nms100k:nms_mask_tiles")):
             if src in out:
                 js[key] = dict(out[src], note=note)
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        # fingerprint of the kernel sources the counters were taken on: bench.py reports whether the shipped sources still
+        # match (the traffic figure is a committed measurement, not a constant of nature)
+        import hashlib
+        h = hashlib.sha256()
+        for name in ("roi_align.hip", "roi_common.h"):
+            h.update(open(os.path.join(root, "vision_amd", "csrc", name), "rb").read())
+        js["_measured_on"] = {"roi_align_sources_sha16": h.hexdigest()[:16], "directory": os.path.basename(os.path.normpath(d))}
         json.dump(js, open(os.path.join(root, "profiles", "roofline_traffic.json"), "w"), indent=1)
         print("wrote profiles/roofline_traffic.json")
 

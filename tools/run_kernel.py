@@ -56,6 +56,15 @@ with torch.no_grad():
         idx = torch.cat([torch.full((1000,), i, device=dev, dtype=torch.int64) for i in range(4)])
         for _ in range(reps):
             vision_amd.batched_nms(b, s, idx, 0.5)
+    elif which in ("dcn_dw", "dcn_bf16"):
+        g = torch.Generator().manual_seed(0)
+        dt = torch.bfloat16 if which == "dcn_bf16" else torch.float32
+        groups = 256 if which == "dcn_dw" else 1
+        x = torch.randn(2, 256, 100, 136, generator=g).to(dev).to(dt)
+        w = (torch.randn(256, 256 // groups, 3, 3, generator=g) * 0.01).to(dev).to(dt)
+        off = torch.randn(2, 18, 100, 136, generator=g).to(dev).to(dt)
+        for _ in range(reps):
+            vision_amd.deform_conv2d(x, off, w, padding=1)
     elif which == "dcn":
         g = torch.Generator().manual_seed(0)
         x = torch.randn(2, 256, 100, 136, generator=g).to(dev); w = (torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(dev)
