@@ -1232,6 +1232,52 @@ def test_small_score_sort_equals_stable_descending_sort():
         assert torch.equal(got, want), n
 
 
+def test_large_score_sort_equals_stable_descending_sort():
+    """Above 4096 scores the order comes from score_sort.hip (key pass + radix sort of (key, index) pairs): same
+    contract — ties by ascending index, NaN (any sign / payload) first, +-inf, -0 == +0, denormals."""
+    g = gen(12)
+    for n in (4097, 10_000, 100_000, 300_001):
+        s = torch.randn(n, generator=g)
+        s = (s * 64).round() / 64                    # many exact ties
+        s[3] = float("nan"); s[7] = float("inf"); s[8] = float("-inf"); s[5] = -0.0; s[6] = 0.0; s[9] = float("nan")
+        s[n - 1] = -0.0; s[n - 2] = 0.0; s[n // 2] = float("nan"); s[11] = 1e-42; s[12] = -1e-42
+        s[13] = torch.tensor(-0x400000, dtype=torch.int32).view(torch.float32)   # a negative NaN with another payload
+        want = torch.sort(s, stable=True, descending=True)[1]
+        got = torch.ops.tvmi.sort_scores_desc(s.to(DEV)).cpu()
+        assert torch.equal(got, want), n
+
+
+def test_nms_replanning_on_survivors_is_invisible(tv):
+    """torchvision::nms re-plans large problems on the boxes the first chunk(s) left alive (tvmi_nms_blocking): the index
+    list must be the one of the single-pass pipeline (re-planning off) for every depth / first-phase size, with and
+    without segment ids on the global path, for survivor counts that end in the one-workgroup sweep, and for a list
+    whose tail is wiped out completely; one size also against the oracle."""
+    g = gen(33)
+    opt = torch.ops.tvmi.set_option
+    cases = []
+    for n, canvas in ((30_011, 300), (30_011, 2000), (50_000, 150)):
+        cases.append((random_boxes(n, canvas, canvas, 1, 101, g), torch.rand(n, generator=g), None))
+    b = random_boxes(26_000, 400, 400, 5, 80, g)
+    cases.append((b, torch.rand(26_000, generator=g), torch.randint(0, 3, (26_000,), generator=g)))
+    # a handful of big high-scoring boxes that cover everything: no survivor after the first chunk
+    big = torch.tensor([[0.0, 0.0, 100.0, 100.0]]).repeat(5000, 1)
+    small = torch.tensor([[0.0, 0.0, 100.0, 99.0]]).repeat(25_000, 1)
+    cases.append((torch.cat([big, small]), torch.cat([torch.linspace(1.0, 0.9, 5000), torch.rand(25_000, generator=g) * 0.5]), None))
+    try:
+        for boxes, scores, idxs in cases:
+            bd, sd = boxes.to(DEV), scores.to(DEV)
+            call = (lambda: tv.nms(bd, sd, 0.5)) if idxs is None else (lambda: torch.ops.tvmi.nms_segmented(bd, sd, idxs.to(DEV), 0.5, 0))
+            opt("nms.replan_min_boxes", 0)
+            want = call().cpu()
+            for min_boxes, divisor, depth in ((8192, 8, 1), (8192, 4, 3), (4097, 100, 6), (16384, 2, 2)):
+                opt("nms.replan_min_boxes", min_boxes); opt("nms.replan_divisor", divisor); opt("nms.replan_max", depth)
+                assert torch.equal(call().cpu(), want), (boxes.shape[0], min_boxes, divisor, depth)
+        boxes, scores, _ = cases[0]
+        assert np.array_equal(tv.nms(boxes.to(DEV), scores.to(DEV), 0.5).cpu().numpy(), O.nms(boxes.numpy(), scores.numpy(), 0.5))
+    finally:
+        opt("nms.replan_min_boxes", 24576); opt("nms.replan_divisor", 16); opt("nms.replan_max", 3)
+
+
 # ------------------------------------------------------------------ tile-owner RoIAlign backward (deterministic)
 @pytest.mark.parametrize("P,sr,aligned", [(7, 2, False), (14, 2, True), (7, 0, False), (14, 3, False)])
 def test_roi_align_backward_owner_path_layouts(tv, P, sr, aligned):

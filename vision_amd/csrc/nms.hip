@@ -32,7 +32,9 @@
 //      order and the running count stays on the device — no masked_select pass.
 //   Up to 4096 boxes one mask launch + nms_sweep_small; batched NMS: segment-major kernels further down.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     double thr, ThrBand band, u64* __restrict__ mask, int rb0, const u64* removed) {
   __shared__ __attribute__((aligned(16))) T s_row[5][64];  // x1,y1,x2,y2,area of the row block, component-major
   __shared__ long long s_seg[64];
+  __shared__ u64 s_skip;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int rb = rb0 + blockIdx.y;  // large problems are launched in chunks of row blocks (see launch())
@@ -290,10 +293,22 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
   if ((int)(blockIdx.x * kMaskWaves + kMaskWaves - 1) < rb) return;  // whole workgroup left of the diagonal
   const int row0 = rb * 64;
   if (threadIdx.x < 64) {
+    // Rows already known to be suppressed (by kept boxes of chunks the sweep has finished) are never read by anybody: a
+    // kept row is by definition not removed, and both the column reduction and the resolve step only use kept rows.  The
+    // word may be stale (the sweep runs concurrently on other streams and only ever ADDS bits): stale = fewer rows
+    // dropped.  The surviving rows are COMPACTED to the front of the LDS block (the dropped ones and the rows past n
+    // become zero boxes behind them), so that the tile loop below runs over ceil(survivors / 2) row pairs instead of
+    // testing pair by pair whether both rows happen to be dropped; every wave of the workgroup uses the one word read here.
+    u64 skip = 0ull;
+    if (removed) skip = uniform64(__hip_atomic_load(&removed[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int r = row0 + lane;
+    const u64 below = (1ull << lane) - 1ull;
+    const u64 surv = ~skip & __ballot(r < n);
+    const bool live = (surv >> lane) & 1ull;
+    const int slot = live ? __popcll(surv & below) : __popcll(surv) + __popcll(~surv & below);
     T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     long long sg = 0;
-    if (r < n) {
+    if (live) {
       const int64_t oi = order[r];
       const Box<T> b = load_box<T>(dets, oi);
       x1 = b.x1;
@@ -302,12 +317,13 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
       y2 = b.y2;
       if (seg) sg = seg[oi];
     }
-    s_row[0][lane] = x1;
-    s_row[1][lane] = y1;
-    s_row[2][lane] = x2;
-    s_row[3][lane] = y2;
-    s_row[4][lane] = (x2 - x1) * (y2 - y1);
-    s_seg[lane] = sg;
+    s_row[0][slot] = x1;
+    s_row[1][slot] = y1;
+    s_row[2][slot] = x2;
+    s_row[3][slot] = y2;
+    s_row[4][slot] = (x2 - x1) * (y2 - y1);
+    s_seg[slot] = sg;
+    if (lane == 0) s_skip = ~surv;  // dropped or non-existent
   }
   __syncthreads();
   if (cb < rb || cb >= CB) return;
@@ -325,17 +341,19 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles(
     if (seg) jseg = seg[oj];
   }
   const T jarea = (jx2 - jx1) * (jy2 - jy1);
-  // rows already known to be suppressed (by kept boxes of chunks the sweep has finished) are never read by anybody: a
-  // kept row is by definition not removed, and both the column reduction and the resolve step only use kept rows.  The
-  // word may be stale (the sweep runs concurrently on other streams and only ever ADDS bits): stale = fewer rows skipped.
-  u64 skip_rows = 0ull;
-  if (removed) {
-    const u64 r = __hip_atomic_load(&removed[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    skip_rows = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(r >> 32)) << 32) |
-                (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r);
+  const u64 dropped = uniform64(s_skip);
+  const int nsurv = 64 - __popcll(dropped);
+  // compact row k sits in lane k of `packed`; the row pairs at and beyond nsurv are skipped as a whole
+  const u64 packed = suppression_tile<T, 64>(&s_row[0][0], seg ? s_seg : nullptr, nsurv, jx1, jy1, jx2, jy2, jarea, jseg, jvalid,
+                                             false, thr, band, nsurv >= 64 ? 0ull : ~0ull << nsurv);
+  u64 mine = packed;
+  if (dropped) {  // wave-uniform: back to one word per ORIGINAL row (lane r <- compact slot of row r; dropped rows: 0)
+    const int src = __popcll(~dropped & ((1ull << lane) - 1ull)) << 2;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)packed);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(packed >> 32));
+    mine = ((dropped >> lane) & 1ull) ? 0ull : (((u64)hi << 32) | (u64)lo);
   }
-  const u64 mine = suppression_tile<T, 64>(&s_row[0][0], seg ? s_seg : nullptr, min(64, n - row0), jx1, jy1, jx2, jy2, jarea,
-                                           jseg, jvalid, cb == rb, thr, band, skip_rows);
+  if (cb == rb) mine &= lane < 63 ? ~0ull << (lane + 1) : 0ull;  // diagonal tile: only the columns after the row
   mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
 }
 
@@ -510,7 +528,7 @@ constexpr int kSmallCB = 64;
 __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __restrict__ mask,
                                                                   const int64_t* __restrict__ order, int n, int CB,
                                                                   int64_t* __restrict__ keep_out,
-                                                                  int64_t* __restrict__ num_keep) {
+                                                                  int64_t* __restrict__ num_keep, bool append) {
   __shared__ u64 s_keepbits[kSmallCB];
   __shared__ int s_base[kSmallCB + 1];
   const int lane = threadIdx.x & 63;
@@ -565,16 +583,62 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_small(const u64* __r
       run += __popcll(s_keepbits[b]);
     }
     s_base[CB] = run;
-    *num_keep = run;
   }
+  const int64_t base = append ? *num_keep : 0;  // append: the survivors of a re-planned large problem (see launch())
   __syncthreads();
   for (int b = c_loc; b < CB; b += kSuper) {
     const u64 kb = s_keepbits[b];
     if ((kb >> lane) & 1ull) {
       const u64 below = kb & ((1ull << lane) - 1ull);
-      keep_out[s_base[b] + __popcll(below)] = order[(int64_t)b * 64 + lane];
+      keep_out[base + s_base[b] + __popcll(below)] = order[(int64_t)b * 64 + lane];
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) *num_keep = base + s_base[CB];
+}
+
+// ---- re-planning on the survivors (see launch()): the boxes of column blocks >= pb that no kept box has removed,
+// in score order.  Two small kernels: per-block survivor counts -> exclusive offsets (+ the total, also written to
+// pinned host memory), then one wave per block copies its surviving entries of `order`.
+__global__ __launch_bounds__(1024) void nms_survivor_offsets(const u64* __restrict__ removed, int n, int CB, int pb,
+                                                             int* __restrict__ offsets, int* __restrict__ total_host) {
+  __shared__ int s_part[1024];
+  const int words = CB - pb;
+  const int per = (words + 1023) / 1024;
+  const int w0 = threadIdx.x * per, w1 = min(words, w0 + per);
+  int sum = 0;
+  for (int w = w0; w < w1; ++w) {
+    const int rows = min(64, n - (pb + w) * 64);
+    const u64 valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+    sum += __popcll(~removed[pb + w] & valid);
+  }
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan of the 1024 partial sums
+    const int v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = s_part[threadIdx.x] - sum;
+  for (int w = w0; w < w1; ++w) {
+    const int rows = min(64, n - (pb + w) * 64);
+    const u64 valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+    offsets[w] = run;
+    run += __popcll(~removed[pb + w] & valid);
+  }
+  if (threadIdx.x == 1023) *total_host = s_part[1023];
+}
+__global__ __launch_bounds__(256) void nms_compact_order(const u64* __restrict__ removed, const int64_t* __restrict__ order,
+                                                         int n, int CB, int pb, const int* __restrict__ offsets,
+                                                         int64_t* __restrict__ order_out) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= CB - pb) return;
+  const int rows = min(64, n - (pb + w) * 64);
+  const u64 valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+  const u64 surv = ~removed[pb + w] & valid;
+  if ((surv >> lane) & 1ull) order_out[offsets[w] + __popcll(surv & ((1ull << lane) - 1ull))] = order[(int64_t)(pb + w) * 64 + lane];
 }
 
 // Fork / join helpers of the large-problem path.  The mask kernel (throughput-bound, fills the chip) is launched in
@@ -587,6 +651,7 @@ struct SweepStreams {
   hipStream_t mask_stream = nullptr, sweep_stream = nullptr, far_stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr, join_far = nullptr;
   std::vector<hipEvent_t> chunk_done, resolved, far_done;
+  int* host_count = nullptr;  // pinned host word the survivor count of a re-planned problem is read back through
   bool ready = false;
   bool ensure(int nchunks) {
     if (!ready) {  // first use on this thread for this device (the caller has made it current)
@@ -598,6 +663,10 @@ struct SweepStreams {
       if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
       if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
       if (hipEventCreateWithFlags(&join_far, hipEventDisableTiming) != hipSuccess) return false;
+      if (hipHostMalloc(reinterpret_cast<void**>(&host_count), 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        host_count = nullptr;  // no re-planning, everything else works
+      }
       ready = true;
     }
     for (std::vector<hipEvent_t>* v : {&chunk_done, &resolved, &far_done})
@@ -618,6 +687,7 @@ struct SweepStreams {
       if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {mask_stream, sweep_stream, far_stream})
       if (st) (void)hipStreamDestroy(st);
+    if (host_count) (void)hipHostFree(host_count);
   }
 };
 // one set per (host thread, device): a thread that alternates between GPUs keeps both sets instead of re-creating
@@ -634,80 +704,175 @@ struct SweepStreamsByDevice {
 };
 thread_local SweepStreamsByDevice g_sweep_streams;
 
+// Options of the large path (tvmi_set_option): "nms.replan_min_boxes" — problems at least this large are re-planned on
+// their survivors (0 = never); "nms.replan_divisor" — the first 1/divisor of the row chunks is swept before the re-plan;
+// "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
+std::atomic<int64_t> g_replan_min_boxes{24576};
+std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000};
+
+// Workspace of the large path: mask tiles | removed[CB] | keepbits[CB] | survivor offsets[CB] (int) | two score-order
+// buffers of n indices (re-planning ping-pongs between them).
+struct LargeWorkspace {
+  u64 *mask, *removed, *keepbits;
+  int* offsets;
+  int64_t* order_buf[2];
+};
+inline size_t large_state_bytes(size_t n) {
+  const size_t CB = ceil_div(n, (size_t)64);
+  return 2 * CB * sizeof(u64) + ceil_div(CB, (size_t)2) * 2 * sizeof(int) + 2 * n * sizeof(int64_t);
+}
+inline LargeWorkspace carve(void* workspace, size_t n) {
+  const size_t CB = ceil_div(n, (size_t)64);
+  LargeWorkspace w;
+  w.mask = static_cast<u64*>(workspace);
+  w.removed = w.mask + CB * CB * 64;
+  w.keepbits = w.removed + CB;
+  w.offsets = reinterpret_cast<int*>(w.keepbits + CB);
+  w.order_buf[0] = reinterpret_cast<int64_t*>(w.offsets + ceil_div(CB, (size_t)2) * 2);
+  w.order_buf[1] = w.order_buf[0] + n;
+  return w;
+}
+
 template <typename T>
 int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr, void* workspace,
-           int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
-  const int CB = (int)ceil_div(n, 64);
-  u64* mask = static_cast<u64*>(workspace);
-  u64* removed = mask + (size_t)CB * CB * 64;
-  u64* keepbits = removed + CB;
+           int64_t* keep_out, int64_t* num_keep, hipStream_t stream, bool may_sync) {
   const T* d = static_cast<const T*>(dets);
   const ThrBand band = thr_band(thr);
-  if (CB <= kSmallCB) {  // latency-bound sizes: one mask launch, the whole sweep is one more
+  if (ceil_div(n, 64) <= kSmallCB) {  // latency-bound sizes: one mask launch, the whole sweep is one more
+    const int CB = (int)ceil_div(n, 64);
+    u64* mask = static_cast<u64*>(workspace);
     const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
     nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(d, order, seg, (int)n, CB, thr, band, mask, 0, nullptr);
-    nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, (int)n, CB, keep_out, num_keep);
+    nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, order, (int)n, CB, keep_out, num_keep, false);
     TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
   }
-  hipError_t e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
+  const LargeWorkspace ws = carve(workspace, (size_t)n);
+  u64 *mask = ws.mask, *removed = ws.removed, *keepbits = ws.keepbits;
+  hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
-  const int nchunks = (int)ceil_div(CB, kWide);
   static SweepStreams no_streams;  // never ensure()d: only names the members below when the device query failed
   SweepStreams* ssp = g_sweep_streams.current();
   SweepStreams& ss = ssp ? *ssp : no_streams;
-  const bool forked = ssp && ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
-                      hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
-                      hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess &&
-                      hipStreamWaitEvent(ss.far_stream, ss.fork, 0) == hipSuccess;
-  hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream, fs = forked ? ss.far_stream : stream;
-  auto mask_chunk = [&](int c, bool skip_known) {
-    const int r0 = c * kWide, r1 = std::min(CB, r0 + kWide);
-    // row block r only has tiles for column blocks >= r: workgroups left of the chunk's first row block exit at once
-    const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)(r1 - r0));
-    nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, ms>>>(d, order, seg, (int)n, CB, thr, band, mask, r0,
-                                                                 skip_known ? removed : nullptr);
-  };
-  auto push = [&](hipStream_t st, int rlo, int rhi, int c0, int c1) {  // rows kept in [rlo, rhi) -> removed[c0..c1)
-    if (c1 <= c0 || rhi <= rlo) return;
-    const dim3 rgrid((unsigned)(c1 - c0), (unsigned)ceil_div(rhi - rlo, 4 * kReduceRows));
-    nms_colreduce<<<rgrid, dim3(256), 0, st>>>(mask, keepbits, removed, CB, rlo, rhi, c0, c1);
-  };
-  auto resolve = [&](int c) {
-    const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
-    nms_resolve_wide<<<dim3(1), dim3(kSuper * kWave), 0, sw>>>(mask, order, removed, keepbits, (int)n, CB, b0, b1, keep_out,
-                                                               num_keep);
-  };
+  // RE-PLANNING ON THE SURVIVORS.  The pair tests of a sorted list are wasted on boxes that an early, high-scoring
+  // box has already removed: after the first eighth of the rows has been swept (and its removals pushed to EVERY later
+  // column) typically half (sparse scenes) to nine tenths (dense scenes) of the remaining boxes are gone.  Dropping
+  // the removed ROWS of later tiles (nms_mask_tiles) only saves that fraction once; restarting on the compacted list
+  // of survivors saves it in both dimensions, and shortens the serial sweep by the same factor.  The price is one
+  // host synchronisation per re-plan (the survivor count sizes the next grids), so it is only done for large
+  // problems, never under stream capture, and `tvmi_set_option("nms.replan_min_boxes", 0)` turns it off.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  const bool may_replan = may_sync && ssp && hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusNone;
+  const size_t mask_lds = (size_t)g_mask_lds_bytes.load(std::memory_order_relaxed);
+  const int64_t replan_min = g_replan_min_boxes.load(std::memory_order_relaxed);
+  const int divisor = std::max(2, g_replan_divisor.load(std::memory_order_relaxed));
+  int replans_left = g_replan_max.load(std::memory_order_relaxed);
+  const int64_t* cur = order;
+  int flip = 0;
   bool ok = true;
-  if (forked) {
-    // PUSH pipeline on three streams.  Chunk c: its mask tiles (mask stream), then — sweep stream, the serial link —
-    // resolve(c) and the NEAR push (rows kept in chunk c -> removed[] of chunk c + 1, all resolve(c + 1) still lacks),
-    // then — far stream, off the critical path — the FAR push to every later column block, which has the whole of
-    // resolve(c + 1) to finish before resolve(c + 2) needs it.  Because removed[] of a chunk is now filled as the
-    // sweep advances (not just before its own resolve), the mask kernel of chunk c can SKIP the rows that are already
-    // known to be suppressed; it is held back until the far push of chunk c - 3 is done, so that it sees (at least)
-    // every removal caused by chunks <= c - 3 — in a sorted list that is nearly all of them.
-    for (int c = 0; c < nchunks; ++c) {
-      const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide), b2 = std::min(CB, b1 + kWide);
-      if (c >= 3) ok = ok && hipStreamWaitEvent(ms, ss.far_done[c - 3], 0) == hipSuccess;
-      mask_chunk(c, true);
-      ok = ok && hipEventRecord(ss.chunk_done[c], ms) == hipSuccess && hipStreamWaitEvent(sw, ss.chunk_done[c], 0) == hipSuccess;
-      if (c >= 2) ok = ok && hipStreamWaitEvent(sw, ss.far_done[c - 2], 0) == hipSuccess;
-      resolve(c);
-      push(sw, b0, b1, b1, b2);
-      ok = ok && hipEventRecord(ss.resolved[c], sw) == hipSuccess && hipStreamWaitEvent(fs, ss.resolved[c], 0) == hipSuccess;
-      push(fs, b0, b1, b2, CB);
-      ok = ok && hipEventRecord(ss.far_done[c], fs) == hipSuccess;
+  bool side_streams_open = false;  // a re-plan leaves the three side streams forked, idle and ahead of `stream`
+  while (true) {
+    const int CB = (int)ceil_div(n, 64);
+    if (CB <= kSmallCB) {  // what survived a re-plan fits the one-workgroup sweep: append to the list (streams are idle)
+      const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)CB);
+      nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), 0, stream>>>(d, cur, seg, (int)n, CB, thr, band, mask, 0, nullptr);
+      nms_sweep_small<<<dim3(1), dim3(kSuper * kWave), 0, stream>>>(mask, cur, (int)n, CB, keep_out, num_keep, true);
+      break;
     }
-    // the sweep stream has waited for every mask chunk: joining it and the far stream joins all three
-    ok = ok && hipEventRecord(ss.join, sw) == hipSuccess && hipStreamWaitEvent(stream, ss.join, 0) == hipSuccess;
-    ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
-  } else {  // no side streams (creation failed): same kernels, serially on the caller's stream
-    for (int c = 0; c < nchunks; ++c) mask_chunk(c, false);
-    for (int c = 0; c < nchunks; ++c) {
+    const int nchunks = (int)ceil_div(CB, kWide);
+    bool forked = side_streams_open;
+    if (!forked) {
+      e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
+      if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
+      forked = ssp && ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
+               hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
+               hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess &&
+               hipStreamWaitEvent(ss.far_stream, ss.fork, 0) == hipSuccess;
+    }
+    hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream, fs = forked ? ss.far_stream : stream;
+    const bool replan = may_replan && forked && ss.host_count && replans_left > 0 && replan_min > 0 && n >= replan_min;
+    const int limit = replan ? std::max(1, (nchunks + divisor / 2) / divisor) : nchunks;  // row chunks swept at this level
+    auto mask_chunk = [&](int c, bool skip_known) {
+      const int r0 = c * kWide, r1 = std::min(CB, r0 + kWide);
+      // row block r only has tiles for column blocks >= r: workgroups left of the chunk's first row block exit at once
+      const dim3 grid((unsigned)ceil_div(CB, kMaskWaves), (unsigned)(r1 - r0));
+      // From the second chunk on a resolve step runs under the mask kernel.  Its ONE 16-wave workgroup can only start on
+      // a CU with four free wave slots on every SIMD, which a chip saturated by 4-wave workgroups offers rarely
+      // (kernel-trace: resolve 33 us alone, 110-180 us under a full mask kernel).  Dynamic LDS the kernel never touches
+      // caps these launches at four workgroups (16 of 32 wave slots) per CU: the resolver starts at once (37-47 us),
+      // and the rows its pushes remove are dropped by the mask workgroups that start after them.  The cap costs the
+      // mask kernel ~13 % of its throughput, so the first chunk — which runs alone — is launched without it.
+      nms_mask_tiles<T><<<grid, dim3(kMaskWaves * kWave), c >= 1 ? mask_lds : 0, ms>>>(d, cur, seg, (int)n, CB, thr, band, mask, r0,
+                                                                                      skip_known ? removed : nullptr);
+    };
+    auto push = [&](hipStream_t st, int rlo, int rhi, int c0, int c1) {  // rows kept in [rlo, rhi) -> removed[c0..c1)
+      if (c1 <= c0 || rhi <= rlo) return;
+      const dim3 rgrid((unsigned)(c1 - c0), (unsigned)ceil_div(rhi - rlo, 4 * kReduceRows));
+      nms_colreduce<<<rgrid, dim3(256), 0, st>>>(mask, keepbits, removed, CB, rlo, rhi, c0, c1);
+    };
+    auto resolve = [&](int c) {
       const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
-      resolve(c);
-      push(stream, b0, b1, b1, CB);
+      nms_resolve_wide<<<dim3(1), dim3(kSuper * kWave), 0, sw>>>(mask, cur, removed, keepbits, (int)n, CB, b0, b1, keep_out,
+                                                                 num_keep);
+    };
+    if (forked) {
+      // PUSH pipeline on three streams.  Chunk c: its mask tiles (mask stream), then — sweep stream, the serial link —
+      // resolve(c) and the NEAR push (rows kept in chunk c -> removed[] of chunk c + 1, all resolve(c + 1) still lacks),
+      // then — far stream, off the critical path — the FAR push to every later column block, which has the whole of
+      // resolve(c + 1) to finish before resolve(c + 2) needs it.  Because removed[] of a chunk is now filled as the
+      // sweep advances (not just before its own resolve), the mask kernel of chunk c can DROP the rows that are already
+      // known to be suppressed; it is held back until the far push of chunk c - 3 is done, so that it sees (at least)
+      // every removal caused by chunks <= c - 3 — in a sorted list that is nearly all of them.
+      for (int c = 0; c < limit; ++c) {
+        const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide), b2 = std::min(CB, b1 + kWide);
+        const bool last_before_replan = replan && c == limit - 1 && limit < nchunks;
+        if (c >= 3) ok = ok && hipStreamWaitEvent(ms, ss.far_done[c - 3], 0) == hipSuccess;
+        mask_chunk(c, true);
+        ok = ok && hipEventRecord(ss.chunk_done[c], ms) == hipSuccess && hipStreamWaitEvent(sw, ss.chunk_done[c], 0) == hipSuccess;
+        if (c >= 2) ok = ok && hipStreamWaitEvent(sw, ss.far_done[c - 2], 0) == hipSuccess;
+        resolve(c);
+        if (!last_before_replan) push(sw, b0, b1, b1, b2);
+        ok = ok && hipEventRecord(ss.resolved[c], sw) == hipSuccess && hipStreamWaitEvent(fs, ss.resolved[c], 0) == hipSuccess;
+        push(fs, b0, b1, last_before_replan ? b1 : b2, CB);  // nobody waits for a near part before a re-plan: one launch
+        ok = ok && hipEventRecord(ss.far_done[c], fs) == hipSuccess;
+      }
+    } else {  // no side streams (creation failed): same kernels, serially on the caller's stream
+      for (int c = 0; c < nchunks; ++c) mask_chunk(c, false);
+      for (int c = 0; c < nchunks; ++c) {
+        const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
+        resolve(c);
+        push(stream, b0, b1, b1, CB);
+      }
+    }
+    if (!ok || limit >= nchunks) {
+      if (forked) {  // the sweep stream has waited for every mask chunk: joining it and the far stream joins all three
+        ok = ok && hipEventRecord(ss.join, sw) == hipSuccess && hipStreamWaitEvent(stream, ss.join, 0) == hipSuccess;
+        ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
+      }
+      break;
+    }
+    // Every kept row of blocks < pb has been pushed to every column once the far stream is through: compact the rest
+    // there (no event hop), clear the sweep state for the next level, and wait for exactly that stream — everything
+    // the other two did at this level precedes it.  The side streams stay forked: the next level's launches go
+    // straight to them, an idle machine needs no fork.
+    const int pb = limit * kWide;
+    int64_t* next = ws.order_buf[flip];
+    flip ^= 1;
+    nms_survivor_offsets<<<dim3(1), dim3(1024), 0, fs>>>(removed, (int)n, CB, pb, ws.offsets, ss.host_count);
+    nms_compact_order<<<dim3((unsigned)ceil_div(CB - pb, 4)), dim3(256), 0, fs>>>(removed, cur, (int)n, CB, pb, ws.offsets, next);
+    e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, fs);
+    if (e == hipSuccess) e = hipStreamSynchronize(fs);
+    if (e != hipSuccess) return set_error((int)e, "tvmi_nms: synchronising for the survivor count");
+    side_streams_open = true;
+    const int survivors = *static_cast<volatile int*>(ss.host_count);
+    cur = next;
+    n = survivors;
+    --replans_left;
+    if (survivors <= 0) {  // nothing left: close the fork
+      ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
+      break;
+    }
+    if (ceil_div(n, 64) <= kSmallCB) {  // the one-workgroup sweep runs on the caller's stream: it follows the far stream
+      ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
     }
   }
   if (!ok) return set_error((int)hipErrorUnknown, "tvmi_nms: stream fork / join failed");
@@ -1295,32 +1460,67 @@ int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, cons
 }
 
 }  // namespace
+
+int set_nms_option(const char* name, int64_t value) {
+  if (std::strcmp(name, "nms.replan_min_boxes") == 0) {
+    g_replan_min_boxes.store(std::max<int64_t>(0, value), std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "nms.replan_divisor") == 0) {
+    g_replan_divisor.store((int)std::max<int64_t>(2, std::min<int64_t>(value, 1024)), std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "nms.mask_lds_bytes") == 0) {
+    g_mask_lds_bytes.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 60000)), std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "nms.replan_max") == 0) {
+    g_replan_max.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 16)), std::memory_order_relaxed);
+    return 0;
+  }
+  return -1;
+}
 }  // namespace tvmi
 
 extern "C" size_t tvmi_nms_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
   const size_t CB = (size_t)tvmi::ceil_div(n, 64);
-  return (CB * CB * 64 + 2 * CB) * sizeof(unsigned long long);
+  if (CB <= (size_t)tvmi::kSmallCB) return CB * CB * 64 * sizeof(unsigned long long);
+  return CB * CB * 64 * sizeof(unsigned long long) + tvmi::large_state_bytes((size_t)n);
 }
 
-extern "C" int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
-                        double iou_threshold, tvmi_dtype dt, void* workspace,
-                        size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
-                        void* stream) {
+namespace tvmi {
+namespace {
+int nms_entry(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double iou_threshold, tvmi_dtype dt,
+              void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream, bool may_sync) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   TVMI_CHECK_ARG(n >= 0, "nms: negative box count");
   TVMI_CHECK_ARG(num_keep_out != nullptr, "nms: num_keep_out is null");
   if (n == 0) {
     hipError_t e = hipMemsetAsync(num_keep_out, 0, sizeof(int64_t), s);
-    return e == hipSuccess ? 0 : tvmi::set_error((int)e, "tvmi_nms: memset");
+    return e == hipSuccess ? 0 : set_error((int)e, "tvmi_nms: memset");
   }
   TVMI_CHECK_ARG(dets && order && keep_out && workspace, "nms: null pointer");
   TVMI_CHECK_ARG(n <= 1200000, "nms: more than 1.2M boxes is not supported by the bitmask path");
   TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_workspace_bytes(n), "nms: workspace too small");
   TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms: dets must be float32 or float64");
-  if (dt == TVMI_F32)
-    return tvmi::launch<float>(dets, order, seg, n, iou_threshold, workspace, keep_out, num_keep_out, s);
-  return tvmi::launch<double>(dets, order, seg, n, iou_threshold, workspace, keep_out, num_keep_out, s);
+  if (dt == TVMI_F32) return launch<float>(dets, order, seg, n, iou_threshold, workspace, keep_out, num_keep_out, s, may_sync);
+  return launch<double>(dets, order, seg, n, iou_threshold, workspace, keep_out, num_keep_out, s, may_sync);
+}
+}  // namespace
+}  // namespace tvmi
+
+extern "C" int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
+                        double iou_threshold, tvmi_dtype dt, void* workspace,
+                        size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
+                        void* stream) {
+  return tvmi::nms_entry(dets, order, seg, n, iou_threshold, dt, workspace, workspace_bytes, keep_out, num_keep_out, stream, false);
+}
+extern "C" int tvmi_nms_blocking(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
+                                 double iou_threshold, tvmi_dtype dt, void* workspace,
+                                 size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
+                                 void* stream) {
+  return tvmi::nms_entry(dets, order, seg, n, iou_threshold, dt, workspace, workspace_bytes, keep_out, num_keep_out, stream, true);
 }
 
 extern "C" size_t tvmi_nms_segmented_workspace_bytes(int64_t n) {

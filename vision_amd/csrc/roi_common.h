@@ -167,5 +167,6 @@ template <typename T, typename R>
 int launch_plane(const MsLevels& lv, const PlanePlan& plan, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
                  int aligned, int multiscale, const PlaneBuffers& pb, hipStream_t s);
 int set_plane_option(const char* name, int64_t value);
+int set_nms_option(const char* name, int64_t value);  // nms.hip
 
 }  // namespace tvmi

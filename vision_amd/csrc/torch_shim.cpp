@@ -95,6 +95,16 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
     order = at::empty({n}, dets.options().dtype(at::kLong));
     check_status(tvmi_sort_scores_desc(sc.const_data_ptr<float>(), n, order.mutable_data_ptr<int64_t>(), current_stream(dets)),
                  "sort_scores_desc");
+  } else if (scores.scalar_type() == at::kFloat && n < (1ll << 31)) {
+    // larger lists: key pass + rocPRIM radix sort of (key, 32-bit index) pairs (score_sort.hip), a third of the time of
+    // at::sort's (float, int64) merge sort at 100k scores
+    at::Tensor sc = scores.contiguous();
+    order = at::empty({n}, dets.options().dtype(at::kLong));
+    const size_t sb = tvmi_sort_scores_desc_workspace_bytes(n);
+    at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
+    check_status(tvmi_sort_scores_desc_large(sc.const_data_ptr<float>(), n, order.mutable_data_ptr<int64_t>(),
+                                             sws.mutable_data_ptr(), sb, current_stream(dets)),
+                 "sort_scores_desc_large");
   } else {
     order = std::get<1>(at::sort(scores, /*stable=*/true, /*dim=*/0, /*descending=*/true));
   }
@@ -136,10 +146,12 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
   }
   const size_t ws_bytes = tvmi_nms_workspace_bytes(n);
   at::Tensor workspace = at::empty({(int64_t)ws_bytes}, dets.options().dtype(at::kByte));
-  check_status(tvmi_nms(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), seg_ptr, n, iou_threshold,
-                        dtype_of(boxes, "nms"), workspace.mutable_data_ptr(), ws_bytes,
-                        keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(),
-                        current_stream(dets)),
+  // callers that read the size on the host anyway take the re-planning form (one stream sync per re-plan above
+  // "nms.replan_min_boxes" boxes); the padded / capturable form never synchronises
+  check_status((allow_sync ? tvmi_nms_blocking : tvmi_nms)(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), seg_ptr, n,
+                                                            iou_threshold, dtype_of(boxes, "nms"), workspace.mutable_data_ptr(),
+                                                            ws_bytes, keep.mutable_data_ptr<int64_t>(),
+                                                            num.mutable_data_ptr<int64_t>(), current_stream(dets)),
                "nms");
   return std::make_tuple(keep, num);
 }
@@ -1030,14 +1042,22 @@ at::Tensor normalize_resize_batch(at::TensorList images, at::IntArrayRef out_hei
 }
 
 at::Tensor sort_scores_desc(const at::Tensor& scores) {
-  TORCH_CHECK(scores.is_cuda() && scores.dim() == 1 && scores.scalar_type() == at::kFloat && scores.size(0) <= 4096,
-              "sort_scores_desc: a 1d float32 CUDA tensor with at most 4096 elements expected");
+  TORCH_CHECK(scores.is_cuda() && scores.dim() == 1 && scores.scalar_type() == at::kFloat && scores.size(0) < (1ll << 31),
+              "sort_scores_desc: a 1d float32 CUDA tensor with fewer than 2^31 elements expected");
   c10::DeviceGuard guard(scores.device());
   at::Tensor sc = scores.contiguous();
-  at::Tensor order = at::empty({sc.size(0)}, sc.options().dtype(at::kLong));
-  check_status(tvmi_sort_scores_desc(sc.const_data_ptr<float>(), sc.size(0), order.mutable_data_ptr<int64_t>(),
-                                     current_stream(scores)),
-               "sort_scores_desc");
+  const int64_t n = sc.size(0);
+  at::Tensor order = at::empty({n}, sc.options().dtype(at::kLong));
+  if (n <= 4096) {
+    check_status(tvmi_sort_scores_desc(sc.const_data_ptr<float>(), n, order.mutable_data_ptr<int64_t>(), current_stream(scores)),
+                 "sort_scores_desc");
+  } else {
+    const size_t sb = tvmi_sort_scores_desc_workspace_bytes(n);
+    at::Tensor sws = at::empty({(int64_t)sb}, sc.options().dtype(at::kByte));
+    check_status(tvmi_sort_scores_desc_large(sc.const_data_ptr<float>(), n, order.mutable_data_ptr<int64_t>(),
+                                             sws.mutable_data_ptr(), sb, current_stream(scores)),
+                 "sort_scores_desc_large");
+  }
   return order;
 }
 
@@ -1116,7 +1136,7 @@ TORCH_LIBRARY(tvmi, m) {
   // models/detection/transform.py:119-255 (normalize + resize + zero-padded batching) as one launch
   m.def(
       "normalize_resize_batch(Tensor[] images, int[] out_heights, int[] out_widths, float[] mean, float[] std, int padded_h, int padded_w) -> Tensor");
-  // indices of aten::sort(scores, stable=True, descending=True) for <= 4096 float32 scores, one launch
+  // indices of aten::sort(scores, stable=True, descending=True) for float32 scores (one launch up to 4096, radix sort above)
   m.def("sort_scores_desc(Tensor scores) -> Tensor");
   // ops/boxes.py:314-391 / 409-436 (box_iou / generalized_box_iou of xyxy boxes) as one launch
   m.def("box_iou_pairwise(Tensor boxes1, Tensor boxes2, int mode, float eps=1e-07) -> Tensor");

@@ -102,7 +102,7 @@ Tensor nms_kernel(const Tensor& dets, const Tensor& scores, double iou_threshold
   Tensor num = empty_like_device(dets, {1}, ScalarType::Long);
   const size_t ws_bytes = tvmi_nms_workspace_bytes(n);
   Tensor workspace = empty_like_device(dets, {(int64_t)ws_bytes}, ScalarType::Byte);
-  check_status(tvmi_nms(boxes.const_data_ptr(), static_cast<const int64_t*>(order.const_data_ptr()), nullptr, n, iou_threshold,
+  check_status(tvmi_nms_blocking(boxes.const_data_ptr(), static_cast<const int64_t*>(order.const_data_ptr()), nullptr, n, iou_threshold,
                         dtype_of(boxes, "nms"), workspace.mutable_data_ptr(), ws_bytes,
                         static_cast<int64_t*>(keep.mutable_data_ptr()), static_cast<int64_t*>(num.mutable_data_ptr()),
                         current_stream(dets)),
