@@ -22,7 +22,9 @@
 // Backward pieces (im2col, col2im, col2im_coord) are separate kernels combined with plain
 // library GEMMs by the dispatcher glue.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "tvmi_common.h"
@@ -157,6 +159,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ inpu
     st(out + idx, acc + ld(bias + oc));
   }
 }
+
+std::atomic<int> g_f32_tile{0}, g_f16_tile{0};  // options "dcn.f32_tile" / "dcn.f16_tile": workgroup tile of the MFMA kernels (0 = by size)
 
 // ------------------------------------------------------------------ fused MFMA forward (fp32)
 constexpr int kBK = 16;
@@ -958,6 +962,18 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1 << 20)); }
 
 }  // namespace
+
+int set_dcn_option(const char* name, int64_t value) {
+  if (std::strcmp(name, "dcn.f32_tile") == 0) {
+    g_f32_tile.store((int)value, std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.f16_tile") == 0) {
+    g_f16_tile.store((int)value, std::memory_order_relaxed);
+    return 0;
+  }
+  return -1;
+}
 }  // namespace tvmi
 
 using namespace tvmi;
@@ -1001,7 +1017,14 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     // per tile instead of 4 (more waves per SIMD to hide the gather latency behind)
     const int64_t ntiles = ceil_div(npix, p.OCg > 128 ? 64 : (p.OCg > 64 ? 128 : 256)) * ceil_div(p.OCg, p.OCg > 128 ? 256 : (p.OCg > 64 ? 128 : 64)) * p.groups;
     const bool eight = ntiles < 3 * 768;
-    if (p.OCg > 128) {
+    const int variant = g_f32_tile.load(std::memory_order_relaxed);
+    if (p.OCg > 128 && variant == 1) {
+      TVMI_DCN(8, 1, 1, 1);
+    } else if (p.OCg > 128 && variant == 2) {
+      TVMI_DCN(4, 1, 2, 1);
+    } else if (p.OCg > 128 && variant == 3) {
+      TVMI_DCN(4, 1, 2, 2);
+    } else if (p.OCg > 128) {
       if (eight) TVMI_DCN(4, 2, 2, 1); else TVMI_DCN(4, 1, 2, 2);
     } else if (p.OCg > 64) {
       if (eight) TVMI_DCN(2, 4, 2, 1); else TVMI_DCN(2, 2, 2, 2);
@@ -1025,7 +1048,8 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     dcn_weight_relayout16<scalar_t><<<grid1d(wtotal), dim3(256), 0, s>>>((const scalar_t*)weight, (scalar_t*)workspace, p, \
                                                                          ICg_pad, OCg_pad);                            \
     /* the matrix work is 16x cheaper than in fp32: the kernel is gather-bound, so always 8 waves per tile */          \
-    if (p.OCg > 128) TVMI_DCN16_T(scalar_t, 4, 2, 2, 1);                                                               \
+    if (p.OCg > 128 && g_f16_tile.load(std::memory_order_relaxed) == 2) TVMI_DCN16_T(scalar_t, 4, 1, 2, 1);            \
+    else if (p.OCg > 128) TVMI_DCN16_T(scalar_t, 4, 2, 2, 1);                                                          \
     else if (p.OCg > 64) TVMI_DCN16_T(scalar_t, 2, 4, 2, 1);                                                           \
     else TVMI_DCN16_T(scalar_t, 1, 8, 2, 1);                                                                           \
   } while (0)

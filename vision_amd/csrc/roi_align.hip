@@ -1180,6 +1180,7 @@ extern "C" size_t tvmi_roi_align_forward_workspace_bytes(int64_t K, int64_t pool
 extern "C" int tvmi_set_option(const char* name, int64_t value) {
   if (tvmi::set_plane_option(name, value) == 0) return 0;
   if (tvmi::set_nms_option(name, value) == 0) return 0;
+  if (tvmi::set_dcn_option(name, value) == 0) return 0;
   return tvmi::set_error((int)hipErrorInvalidValue, "tvmi_set_option: unknown option");
 }
 

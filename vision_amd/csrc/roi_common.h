@@ -168,5 +168,6 @@ int launch_plane(const MsLevels& lv, const PlanePlan& plan, const void* rois, vo
                  int aligned, int multiscale, const PlaneBuffers& pb, hipStream_t s);
 int set_plane_option(const char* name, int64_t value);
 int set_nms_option(const char* name, int64_t value);  // nms.hip
+int set_dcn_option(const char* name, int64_t value);  // deform_conv2d.hip
 
 }  // namespace tvmi
