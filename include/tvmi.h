@@ -47,6 +47,7 @@ int tvmi_version(void);
  *                                the device-side decision which levels are staged
  *   "roi_align.stage_whole_planes" 1 / 0: stage levels whose plane fits the LDS budget twice
  *   "roi_align.band_channels"    channels per workgroup of a banded level (default 2)
+ *   "dcn.channels_last_gather"   1 (default) / 0: the 16-bit MFMA deform_conv2d kernel samples a [B, H*W, C] copy of the input
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)
@@ -271,6 +272,13 @@ int tvmi_ps_roi_pool_backward(const void* grad, const void* rois, const int32_t*
  */
 size_t tvmi_deform_conv2d_workspace_bytes(tvmi_dtype dt, int64_t C, int64_t OC, int64_t kh, int64_t kw,
                                           int64_t groups);
+/* Workspace of the forward call for a given input: the re-laid-out weights and, for fp16 / bf16 inputs whose channel counts
+ * (C, C / groups, C / offset_groups) are multiples of 8, a [B, H*W, C] copy of the input that the fused MFMA kernel samples
+ * with one 16-byte load per corner and channel octet, in 32-deep K slabs.  A caller that only provides
+ * tvmi_deform_conv2d_workspace_bytes() gets the planar-gather kernel: same values (the same bits when C / offset_groups is a
+ * multiple of 16), slower. */
+size_t tvmi_deform_conv2d_forward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC,
+                                                  int64_t kh, int64_t kw, int64_t groups, int64_t offset_groups);
 int tvmi_deform_conv2d_forward(const void* input, const void* weight, const void* offset, const void* mask,
                                const void* bias, void* output, tvmi_dtype dt, int64_t B, int64_t C,
                                int64_t H, int64_t W, int64_t OC, int64_t kh, int64_t kw, int64_t stride_h,

@@ -1232,6 +1232,40 @@ def test_small_score_sort_equals_stable_descending_sort():
         assert torch.equal(got, want), n
 
 
+def test_deform_conv2d_channels_last_gather_is_bit_identical():
+    """The 16-bit MFMA kernel samples a [B, H*W, C] copy of the input when the channel counts allow 16-byte octets
+    (dcn.channels_last_gather, 32-deep K slabs): same corner values, same rounding, exact products, fp32 sums grouped in
+    16s from the start of every offset-group segment => the same bits as the planar-gather kernel when the channels per
+    offset group are a multiple of 16, and the same values up to the order of fp32 additions otherwise; every workgroup
+    tile, offset groups that cut the slabs, weight groups, stride / dilation, mask on and off; shapes whose channel counts
+    are not multiples of 8 silently keep the planar kernel."""
+    g = gen(77)
+    opt = torch.ops.tvmi.set_option
+    try:
+        for dt in (torch.bfloat16, torch.float16):
+            for (B, C, H, W, OC, groups, ogroups, stride, dil) in ((2, 64, 23, 31, 256, 1, 1, 1, 1), (1, 48, 17, 19, 160, 1, 2, 2, 1),
+                                                                  (2, 144, 16, 21, 96, 2, 6, 1, 2), (1, 40, 9, 11, 32, 1, 5, 1, 1),
+                                                                  (1, 20, 9, 11, 32, 1, 5, 1, 1), (1, 160, 12, 13, 192, 1, 2, 1, 1)):
+                x = torch.randn(B, C, H, W, generator=g).to(DEV, dt)
+                w = (torch.randn(OC, C // groups, 3, 3, generator=g) * 0.1).to(DEV, dt)
+                oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
+                off = (torch.randn(B, 2 * 9 * ogroups, oh, ow, generator=g) * 3).to(DEV, dt)
+                msk = torch.rand(B, 9 * ogroups, oh, ow, generator=g).to(DEV, dt)
+                bias = torch.randn(OC, generator=g).to(DEV, dt)
+                for m in (None, msk):
+                    opt("dcn.channels_last_gather", 0)
+                    want = vision_amd.deform_conv2d(x, off, w, bias, stride=stride, padding=dil, dilation=dil, mask=m)
+                    opt("dcn.channels_last_gather", 1)
+                    got = vision_amd.deform_conv2d(x, off, w, bias, stride=stride, padding=dil, dilation=dil, mask=m)
+                    if (C // ogroups) % 16 == 0 or C % 8 != 0:
+                        assert torch.equal(got, want), (dt, C, OC, groups, ogroups, m is not None)
+                    else:   # same products, another grouping of the fp32 additions, then one rounding to 16 bits
+                        err = (got.float() - want.float()).abs().max().item()
+                        assert err <= 2.0 ** (-7 if dt == torch.bfloat16 else -10) * want.float().abs().max().item(), (dt, C, err)
+    finally:
+        opt("dcn.channels_last_gather", 1)
+
+
 def test_large_score_sort_equals_stable_descending_sort():
     """Above 4096 scores the order comes from score_sort.hip (key pass + radix sort of (key, index) pairs): same
     contract — ties by ascending index, NaN (any sign / payload) first, +-inf, -0 == +0, denormals."""

@@ -24,23 +24,23 @@ def tm(fn, n=20, warm=3):
 
 
 g = torch.Generator().manual_seed(0)
-for dt, opt in ((torch.float32, "dcn.f32_tile"), (torch.bfloat16, "dcn.f16_tile")):
+for dt in (torch.bfloat16, torch.float16, torch.float32):
     x = torch.randn(2, 256, 100, 136, generator=g).to(dev).to(dt)
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(dev).to(dt)
     off = torch.randn(2, 18, 100, 136, generator=g).to(dev).to(dt)
     msk = torch.rand(2, 9, 100, 136, generator=g).to(dev).to(dt)
     want = None
-    for variant in (0, 1, 2, 3) if dt == torch.float32 else (0, 2):
-        torch.ops.tvmi.set_option(opt, variant)
+    for cl in (0, 1, 0, 1):
+        torch.ops.tvmi.set_option("dcn.channels_last_gather", cl)
         y = vision_amd.deform_conv2d(x, off, w, padding=1, mask=msk)
         if want is None:
             want = y
         err = float((y.float() - want.float()).abs().max())
         t0 = tm(lambda: vision_amd.deform_conv2d(x, off, w, padding=1))
         t1 = tm(lambda: vision_amd.deform_conv2d(x, off, w, padding=1, mask=msk))
-        key = f"dcn_g1_{str(dt)[6:]}_tile{variant}"
-        res[key] = dict(ms_nomask=round(t0, 4), ms_mask=round(t1, 4), max_abs_diff_vs_default=err)
+        key = f"dcn_g1_{str(dt)[6:]}_channels_last_gather{cl}" + ("" if f"dcn_g1_{str(dt)[6:]}_channels_last_gather{cl}" not in res else "_again")
+        res[key] = dict(ms_nomask=round(t0, 4), ms_mask=round(t1, 4), max_abs_diff_vs_planar=err)
         print(key, res[key], flush=True)
-    torch.ops.tvmi.set_option(opt, 0)
+    torch.ops.tvmi.set_option("dcn.channels_last_gather", 1)
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ inpu
   }
 }
 
-std::atomic<int> g_f32_tile{0}, g_f16_tile{0};  // options "dcn.f32_tile" / "dcn.f16_tile": workgroup tile of the MFMA kernels (0 = by size)
+std::atomic<int> g_cl_gather{1};  // option "dcn.channels_last_gather": the 16-bit MFMA kernel samples a [B, H*W, C] copy
 
 // ------------------------------------------------------------------ fused MFMA forward (fp32)
 constexpr int kBK = 16;
@@ -607,6 +607,229 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
   }
 }
 
+// ------------------------------------------------------------------ fused MFMA forward, 16-bit tensors, channels-last gather
+// What bounds dcn_fwd_mfma_16 at config 4 (0.20 ms) is neither the texture addresser nor the matrix pipe: a channels-last
+// gather with a QUARTER of the scattered lane-loads ran in the same time (profiles/r03_dcn16_channels_last_k16_variants.json).
+// Its loop has ONE 16-deep slab of global loads in flight per workgroup, the matrix work of a slab is a handful of MFMAs, so
+// every one of the 144 iterations of a tile costs a full L2 round trip (~0.7 us).  This kernel does the same contraction
+// with half the iterations and a quarter of the lane-loads:
+//   * a pre-pass rewrites the input as [B, H*W, C] (dcn_to_channels_last: 14 MB at config 4, ~10 us); one 16-byte lane-load
+//     then fetches a corner for EIGHT channels — producer item = (pixel, channel octet), 4 loads and one 16-byte LDS write;
+//   * K slabs are 32 deep (two v_mfma_f32_32x32x16 steps per 32x32 block) in [row][k] LDS rows of 80 bytes (16 lanes x 80 B
+//     tile the 64 banks without conflict);
+//   * weights come from an octet-major re-layout [tap][ic / 8][oc][8], so a slab may start at any multiple of 8 channels
+//     (offset-group boundaries cut slabs, never octets) and the positions past its end are written as zeros — no partial-slab
+//     passes.
+// Same corner values and the same rounding to the 16-bit type as the planar kernel; the k products are exact and summed in
+// fp32 — grouped in 16s from the start of each offset-group segment, which is the planar kernel's grouping when the channels
+// per offset group are a multiple of 16 (then the two kernels agree bit for bit).  Needs C, C / groups and C / offset_groups
+// divisible by 8.
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_to_channels_last(const T* __restrict__ in, T* __restrict__ out, int C, int HW) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z, hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const T* src = in + (int64_t)b * C * HW;
+  T* dst = out + (int64_t)b * HW * C;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (c0 + r < C && hw0 + tx < HW) tile[r][tx] = src[(int64_t)(c0 + r) * HW + hw0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (hw0 + r < HW && c0 + tx < C) dst[(int64_t)(hw0 + r) * C + c0 + tx] = tile[tx][r];
+}
+
+// weight [OC, ICg, kh, kw] (T) -> wt8 [groups][tap][ICg / 8][OCg_pad][8] (T, zero padded in oc)
+template <typename T>
+__global__ void dcn_weight_relayout8(const T* __restrict__ w, T* __restrict__ wt, DcnParams p, int OCg_pad) {
+  const int KK = p.kh * p.kw;
+  const int64_t total = (int64_t)p.groups * KK * p.ICg * OCg_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % 8);
+    const int oc = (int)((idx / 8) % OCg_pad);
+    const int oct = (int)((idx / ((int64_t)8 * OCg_pad)) % (p.ICg / 8));
+    const int tap = (int)((idx / ((int64_t)OCg_pad * p.ICg)) % KK);
+    const int g = (int)(idx / ((int64_t)OCg_pad * p.ICg * KK));
+    const int ic = oct * 8 + k;
+    float v = 0.f;
+    if (oc < p.OCg) v = ld(w + (((int64_t)(g * p.OCg + oc)) * p.ICg + ic) * KK + tap);
+    st(wt + idx, v);
+  }
+}
+
+// BK: slab depth (32 channels as shipped); LDS rows are [row][k] with 8 elements of padding (80 bytes: 16 lanes tile the 64 banks)
+template <typename T, int WM, int WN, int MI, int NI, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __restrict__ input_cl, const T* __restrict__ wt8,
+                                                                   const T* __restrict__ offset, const T* __restrict__ mask,
+                                                                   const T* __restrict__ bias, T* __restrict__ out, DcnParams p,
+                                                                   int OCg_pad) {
+  constexpr int kClBK = BK, kClOct = BK / 8, kClPitch = BK + 8;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+  constexpr int PI = (kClOct * BN + NT - 1) / NT;   // producer items (pixel, octet) per thread and slab
+  constexpr int AQ = BM * kClOct;                   // 16-byte pieces of the A slab
+  constexpr int AV = (AQ + NT - 1) / NT;
+  static_assert(NT % BN == 0, "a thread's producer items must share one pixel");
+  extern __shared__ __attribute__((aligned(16))) unsigned short dcn16_cl_lds[];
+  unsigned short(*As)[BM][kClPitch] = reinterpret_cast<unsigned short(*)[BM][kClPitch]>(dcn16_cl_lds);
+  unsigned short(*Bs)[BN][kClPitch] = reinterpret_cast<unsigned short(*)[BN][kClPitch]>(dcn16_cl_lds + 2 * BM * kClPitch);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = blockIdx.z;
+  const int oc0 = blockIdx.y * BM;
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+  const int KK = p.kh * p.kw;
+  const int noct = p.ICg / 8;
+
+  const int pn = tid % BN, oct0 = tid / BN;   // item r of this thread: octet oct0 + r * (NT / BN)
+  const int64_t my_pix = pix0 + pn;
+  const bool pix_ok = my_pix < npix;
+  int pb = 0, poy = 0, pox = 0;
+  if (pix_ok) {
+    pox = (int)(my_pix % p.ow);
+    poy = (int)((my_pix / p.ow) % p.oh);
+    pb = (int)(my_pix / ((int64_t)p.ow * p.oh));
+  }
+  const T* in_b = input_cl + (int64_t)pb * p.H * p.W * p.C + (int64_t)g * p.ICg;
+
+  f32x16v acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  uint4 cv[PI][4];   // the four corners of the next slab's octets
+  uint4 av[AV];      // staged weights of the next slab
+  Tap<float> tap_cur;
+  tap_cur.o1 = tap_cur.o2 = tap_cur.o3 = tap_cur.o4 = 0;
+  tap_cur.w1 = tap_cur.w2 = tap_cur.w3 = tap_cur.w4 = 0.f;
+  tap_cur.m = 0.f;
+
+  int s_tap = 0, s_ic = 0, s_seg_end = 0;
+  bool have = KK > 0 && p.ICg > 0;
+  auto begin_segment = [&](int tap, int ic) {
+    const int og = (g * p.ICg + ic) / p.cpog;
+    s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
+    if (pix_ok) load_tap<T, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+  };
+  auto issue_loads = [&](int tap, int ic0, int kmax) {   // kmax: channels of the slab (a multiple of 8)
+#pragma unroll
+    for (int r = 0; r < PI; ++r) {
+      const int oct = oct0 + r * (NT / BN);
+      cv[r][0] = cv[r][1] = cv[r][2] = cv[r][3] = make_uint4(0u, 0u, 0u, 0u);
+      if (oct < kClOct && 8 * oct < kmax && pix_ok) {
+        const T* base = in_b + ic0 + 8 * oct;
+        cv[r][0] = *reinterpret_cast<const uint4*>(base + (int64_t)tap_cur.o1 * p.C);
+        cv[r][1] = *reinterpret_cast<const uint4*>(base + (int64_t)tap_cur.o2 * p.C);
+        cv[r][2] = *reinterpret_cast<const uint4*>(base + (int64_t)tap_cur.o3 * p.C);
+        cv[r][3] = *reinterpret_cast<const uint4*>(base + (int64_t)tap_cur.o4 * p.C);
+      }
+    }
+    const T* wsrc = wt8 + ((((int64_t)g * KK + tap) * noct + ic0 / 8) * OCg_pad + oc0) * 8;
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int piece = tid + e * NT;
+      const int m = piece % BM, oct = piece / BM;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (piece < AQ && 8 * oct < kmax && oc0 + m < OCg_pad) v = *reinterpret_cast<const uint4*>(wsrc + ((int64_t)oct * OCg_pad + m) * 8);
+      av[e] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < PI; ++r) {
+      const int oct = oct0 + r * (NT / BN);
+      if (oct >= kClOct) continue;
+      const unsigned* c0 = reinterpret_cast<const unsigned*>(&cv[r][0]);
+      const unsigned* c1 = reinterpret_cast<const unsigned*>(&cv[r][1]);
+      const unsigned* c2 = reinterpret_cast<const unsigned*>(&cv[r][2]);
+      const unsigned* c3 = reinterpret_cast<const unsigned*>(&cv[r][3]);
+      unsigned packed[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned short h[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int sh = 16 * half;
+          const float v1 = from16bits<T>((unsigned short)(c0[d] >> sh)), v2 = from16bits<T>((unsigned short)(c1[d] >> sh));
+          const float v3 = from16bits<T>((unsigned short)(c2[d] >> sh)), v4 = from16bits<T>((unsigned short)(c3[d] >> sh));
+          h[half] = to16<T>(tap_cur.m * (tap_cur.w1 * v1 + tap_cur.w2 * v2 + tap_cur.w3 * v3 + tap_cur.w4 * v4));
+        }
+        packed[d] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+      }
+      *reinterpret_cast<uint4*>(&Bs[buf][pn][8 * oct]) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int piece = tid + e * NT;
+      if (piece < AQ) *reinterpret_cast<uint4*>(&As[buf][piece % BM][8 * (piece / BM)]) = av[e];
+    }
+  };
+
+  int buf = 0;
+  if (have) {
+    begin_segment(0, 0);
+    issue_loads(0, 0, min(kClBK, s_seg_end));
+  }
+  while (have) {
+    commit(buf);   // uses tap_cur of the slab that was loaded
+    __syncthreads();
+    int n_tap = s_tap, n_ic = s_ic + kClBK;
+    bool n_have = true;
+    if (n_ic >= s_seg_end) {
+      n_ic = s_seg_end;
+      if (n_ic >= p.ICg) {
+        n_ic = 0;
+        n_tap = s_tap + 1;
+        if (n_tap >= KK) n_have = false;
+      }
+      if (n_have) begin_segment(n_tap, n_ic);
+    }
+    if (n_have) issue_loads(n_tap, n_ic, min(kClBK, s_seg_end - n_ic));
+    const int kq = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int step = 0; step < kClBK / 16; ++step) {
+      uint4 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const uint4*>(&As[buf][(wm * MI + mi) * 32 + l31][16 * step + kq * 8]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const uint4*>(&Bs[buf][(wn * NI + ni) * 32 + l31][16 * step + kq * 8]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16<T>(a[mi], b[ni], acc[mi][ni]);
+    }
+    s_tap = n_tap;
+    s_ic = n_ic;
+    have = n_have;
+    buf ^= 1;
+  }
+
+  const int l31 = lane & 31, kq = lane >> 5;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
+    if (pix >= npix) continue;
+    const int ox = (int)(pix % p.ow);
+    const int oy = (int)((pix / p.ow) % p.oh);
+    const int b = (int)(pix / ((int64_t)p.ow * p.oh));
+    T* obase = out + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * p.oh * p.ow + (int64_t)oy * p.ow + ox;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + ld(bias + g * p.OCg + oc));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ depthwise forward (groups == C == OC, 3x3)
 // Reference shape: cuda/deform_conv2d_kernel.cu:136-209 writes columns[C*9, B*oh*ow] and runs C GEMMs of 1 x 9.  The
 // generic direct kernel above re-derives the tap geometry per (pixel, channel) and gathers 36 scattered dwords per output
@@ -959,17 +1182,39 @@ inline bool use_mfma16(const DcnParams& p, tvmi_dtype dt) {
   return (dt == TVMI_F16 || dt == TVMI_BF16) && p.OCg >= 16 && p.ICg >= 4 && p.W >= 2;
 }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline bool can_gather_channels_last(const DcnParams& p, tvmi_dtype dt) {   // 16-byte octets of 16-bit channels
+  return use_mfma16(p, dt) && p.C % 8 == 0 && p.ICg % 8 == 0 && p.cpog % 8 == 0;
+}
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+template <typename T, int WM, int WN, int MI, int NI, int BK>
+int launch_cl16(const T* input_cl, const T* wt8, const T* offset, const T* mask, const T* bias, T* out, const DcnParams& p,
+                int OCg_pad, hipStream_t s) {
+  constexpr int NT = 64 * WM * WN, BM = 32 * MI * WM, BN = 32 * NI * WN;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(unsigned short);
+  auto kern = dcn_fwd_mfma_16_cl<T, WM, WN, MI, NI, BK>;
+  if (lds > 64 * 1024) {
+    static bool attr_set[64] = {};  // per instantiation and device; racing threads set the same value
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error((int)hipErrorInvalidValue, "deform_conv2d: cannot reserve the LDS slabs");
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  kern<<<dim3((unsigned)ceil_div(npix, BN), (unsigned)ceil_div(p.OCg, BM), (unsigned)p.groups), dim3(NT), lds, s>>>(
+      input_cl, wt8, offset, mask, bias, out, p, OCg_pad);
+  return 0;
+}
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1 << 20)); }
 
 }  // namespace
 
 int set_dcn_option(const char* name, int64_t value) {
-  if (std::strcmp(name, "dcn.f32_tile") == 0) {
-    g_f32_tile.store((int)value, std::memory_order_relaxed);
-    return 0;
-  }
-  if (std::strcmp(name, "dcn.f16_tile") == 0) {
-    g_f16_tile.store((int)value, std::memory_order_relaxed);
+  if (std::strcmp(name, "dcn.channels_last_gather") == 0) {
+    g_cl_gather.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
   return -1;
@@ -983,6 +1228,15 @@ extern "C" size_t tvmi_deform_conv2d_workspace_bytes(tvmi_dtype dt, int64_t C, i
   if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16) || groups <= 0 || C <= 0 || OC <= 0) return 0;
   const int ICg_pad = round_up((int)(C / groups), kBK), OCg_pad = round_up((int)(OC / groups), 64);
   return (size_t)groups * kh * kw * ICg_pad * OCg_pad * (dt == TVMI_F32 ? sizeof(float) : 2);   // the re-laid-out weights
+}
+
+extern "C" size_t tvmi_deform_conv2d_forward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W,
+                                                             int64_t OC, int64_t kh, int64_t kw, int64_t groups,
+                                                             int64_t offset_groups) {
+  const size_t weights = tvmi_deform_conv2d_workspace_bytes(dt, C, OC, kh, kw, groups);
+  if (!(dt == TVMI_F16 || dt == TVMI_BF16) || groups <= 0 || offset_groups <= 0 || B <= 0 || H <= 0 || W <= 0) return weights;
+  if (C % 8 != 0 || (C / groups) % 8 != 0 || (C / offset_groups) % 8 != 0) return weights;
+  return align256(weights) + (size_t)B * C * H * W * 2;   // + the [B, H*W, C] copy the 16-bit MFMA kernel samples
 }
 
 extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight, const void* offset,
@@ -1017,14 +1271,7 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     // per tile instead of 4 (more waves per SIMD to hide the gather latency behind)
     const int64_t ntiles = ceil_div(npix, p.OCg > 128 ? 64 : (p.OCg > 64 ? 128 : 256)) * ceil_div(p.OCg, p.OCg > 128 ? 256 : (p.OCg > 64 ? 128 : 64)) * p.groups;
     const bool eight = ntiles < 3 * 768;
-    const int variant = g_f32_tile.load(std::memory_order_relaxed);
-    if (p.OCg > 128 && variant == 1) {
-      TVMI_DCN(8, 1, 1, 1);
-    } else if (p.OCg > 128 && variant == 2) {
-      TVMI_DCN(4, 1, 2, 1);
-    } else if (p.OCg > 128 && variant == 3) {
-      TVMI_DCN(4, 1, 2, 2);
-    } else if (p.OCg > 128) {
+    if (p.OCg > 128) {
       if (eight) TVMI_DCN(4, 2, 2, 1); else TVMI_DCN(4, 1, 2, 2);
     } else if (p.OCg > 64) {
       if (eight) TVMI_DCN(2, 4, 2, 1); else TVMI_DCN(2, 2, 2, 2);
@@ -1038,6 +1285,29 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
                    "deform_conv2d: workspace too small");
     const int64_t wtotal = (int64_t)p.groups * kh * kw * ICg_pad * OCg_pad;
     const int64_t npix = (int64_t)B * p.oh * p.ow;
+    const size_t cl_at = align256((size_t)wtotal * 2), cl_bytes = (size_t)B * C * H * W * 2;
+    if (g_cl_gather.load(std::memory_order_relaxed) && can_gather_channels_last(p, dt) && workspace_bytes >= cl_at + cl_bytes) {
+      void* in_cl = static_cast<char*>(workspace) + cl_at;
+      const int64_t w8total = (int64_t)p.groups * kh * kw * p.ICg * OCg_pad;   // <= wtotal
+#define TVMI_DCN16_CL(scalar_t)                                                                                        \
+  do {                                                                                                                 \
+    dcn_weight_relayout8<scalar_t><<<grid1d(w8total), dim3(256), 0, s>>>((const scalar_t*)weight, (scalar_t*)workspace, p, OCg_pad); \
+    dcn_to_channels_last<scalar_t><<<dim3((unsigned)ceil_div(H * W, 32), (unsigned)ceil_div(C, 32), (unsigned)B), dim3(256), 0, s>>>( \
+        (const scalar_t*)input, (scalar_t*)in_cl, (int)C, (int)(H * W));                                               \
+    const scalar_t* icl = (const scalar_t*)in_cl;                                                                      \
+    const scalar_t* w8 = (const scalar_t*)workspace;                                                                   \
+    if (p.OCg > 128) st = launch_cl16<scalar_t, 4, 2, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
+    else if (p.OCg > 64) st = launch_cl16<scalar_t, 2, 4, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
+    else st = launch_cl16<scalar_t, 1, 8, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
+  } while (0)
+      // (64-deep slabs — 92 KB of LDS, one workgroup per CU — were measured too: 0.185 ms against 0.154 ms at config 4)
+      int st = 0;
+      if (dt == TVMI_F16) TVMI_DCN16_CL(__half);
+      else TVMI_DCN16_CL(__hip_bfloat16);
+      if (st) return st;
+#undef TVMI_DCN16_CL
+      TVMI_RETURN_LAUNCH_STATUS("tvmi_deform_conv2d_forward (channels-last gather)");
+    }
 #define TVMI_DCN16_T(scalar_t, WM, WN, MI, NI)                                                                         \
   dcn_fwd_mfma_16<scalar_t, WM, WN, MI, NI>                                                                             \
       <<<dim3((unsigned)ceil_div(npix, 32 * NI * WN), (unsigned)ceil_div(p.OCg, 32 * MI * WM), (unsigned)p.groups),     \
@@ -1048,8 +1318,7 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     dcn_weight_relayout16<scalar_t><<<grid1d(wtotal), dim3(256), 0, s>>>((const scalar_t*)weight, (scalar_t*)workspace, p, \
                                                                          ICg_pad, OCg_pad);                            \
     /* the matrix work is 16x cheaper than in fp32: the kernel is gather-bound, so always 8 waves per tile */          \
-    if (p.OCg > 128 && g_f16_tile.load(std::memory_order_relaxed) == 2) TVMI_DCN16_T(scalar_t, 4, 1, 2, 1);            \
-    else if (p.OCg > 128) TVMI_DCN16_T(scalar_t, 4, 2, 2, 1);                                                          \
+    if (p.OCg > 128) TVMI_DCN16_T(scalar_t, 4, 2, 2, 1);                                                               \
     else if (p.OCg > 64) TVMI_DCN16_T(scalar_t, 2, 4, 2, 1);                                                           \
     else TVMI_DCN16_T(scalar_t, 1, 8, 2, 1);                                                                           \
   } while (0)

@@ -466,7 +466,8 @@ at::Tensor deform_conv2d_forward(const at::Tensor& input, const at::Tensor& weig
   at::Tensor out = at::empty({s.B, s.OC, s.oh, s.ow}, input_c.options());
   if (out.numel() == 0) return out;
   const tvmi_dtype dt = dtype_of(input_c, "deform_conv2d");
-  const size_t ws_bytes = tvmi_deform_conv2d_workspace_bytes(dt, s.C, s.OC, s.kh, s.kw, n_weight_grps);
+  const size_t ws_bytes = tvmi_deform_conv2d_forward_workspace_bytes(dt, s.B, s.C, s.H, s.W, s.OC, s.kh, s.kw, n_weight_grps,
+                                                                     n_offset_grps);
   at::Tensor ws = at::empty({(int64_t)ws_bytes}, input_c.options().dtype(at::kByte));
   check_status(tvmi_deform_conv2d_forward(input_c.const_data_ptr(), weight_c.const_data_ptr(),
                                           offset_c.const_data_ptr(), mask_c.const_data_ptr(), bias_c.const_data_ptr(),
