@@ -9,7 +9,7 @@ dev = torch.device("cuda:0"); tv = torch.ops.torchvision
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 def ri(a, b): return int(torch.randint(a, b + 1, (1,), generator=g))
 t0 = time.time(); cases = 0
-while time.time() - t0 < 40:
+while time.time() - t0 < 60:
     # ---- NMS / batched NMS
     n = ri(1, 6000) if ri(0, 7) else ri(6000, 25000); canvas = float(ri(20, 800)); S = ri(1, 40)
     xy = torch.rand(n, 2, generator=g) * canvas; wh = torch.rand(n, 2, generator=g) * ri(2, 120)
@@ -23,6 +23,9 @@ while time.time() - t0 < 40:
     if ri(0, 2) == 0: s = (s * ri(2, 50)).floor() / 16
     idx = torch.randint(0, S, (n,), generator=g)
     thr = [0.3, 0.5, 0.7, float(torch.rand(1, generator=g))][ri(0, 3)]
+    if n > 4200:   # the large path re-plans on its survivors: fuzz the threshold, the first-phase share and the depth
+        torch.ops.tvmi.set_option("nms.replan_min_boxes", [0, 4097, ri(4097, n), 24576][ri(0, 3)])
+        torch.ops.tvmi.set_option("nms.replan_divisor", ri(2, 40)); torch.ops.tvmi.set_option("nms.replan_max", ri(1, 5))
     want = O.nms(b.numpy(), s.numpy(), thr)
     got = tv.nms(b.to(dev), s.to(dev), thr).cpu().numpy()
     assert np.array_equal(got, want), ("nms", n, canvas, thr)

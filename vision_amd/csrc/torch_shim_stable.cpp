@@ -95,6 +95,16 @@ Tensor nms_kernel(const Tensor& dets, const Tensor& scores, double iou_threshold
     check_status(tvmi_sort_scores_desc(static_cast<const float*>(sc.const_data_ptr()), n,
                                        static_cast<int64_t*>(order.mutable_data_ptr()), current_stream(dets)),
                  "sort_scores_desc");
+  } else if (scores.scalar_type() == ScalarType::Float && n < (1ll << 31)) {
+    // larger lists: key pass + rocPRIM radix sort of (key, 32-bit index) pairs (score_sort.hip)
+    const Tensor sc = torch::stable::contiguous(scores);
+    order = empty_like_device(dets, {n}, ScalarType::Long);
+    const size_t sb = tvmi_sort_scores_desc_workspace_bytes(n);
+    Tensor sws = empty_like_device(dets, {(int64_t)sb}, ScalarType::Byte);
+    check_status(tvmi_sort_scores_desc_large(static_cast<const float*>(sc.const_data_ptr()), n,
+                                             static_cast<int64_t*>(order.mutable_data_ptr()), sws.mutable_data_ptr(), sb,
+                                             current_stream(dets)),
+                 "sort_scores_desc_large");
   } else {
     order = torch::stable::contiguous(stable_descending_order(scores));
   }
