@@ -9,7 +9,10 @@ workload : BASELINE config 2 — a batch of 4 padded 800x1344 images per GPU, 4 
            over that batch: MultiScaleRoIAlign 7x7 (sampling_ratio 2) of the 4000 proposals, then per-image
            NMS (batched_nms over the image index, IoU 0.5), packing of the padded top-100 detections of every
            image (fixed shape) and — when N > 1 — their one RCCL all-gather.  The per-rank part has no host
-           synchronisation, so the launches queue back to back (--graph replays them from a captured hipGraph).
+           synchronisation, so the launches queue back to back (--graph replays them from captured hipGraphs, one
+           per input set).  The NMS + packing chain does not depend on the RoIAlign output: it runs on a second HIP
+           stream under the RoIAlign launch (forked from / joined into the step's stream); `--serial` keeps one stream
+           and the line carries that time too (config.one_stream_ms_per_step).
 inputs   : synthetic (seeded), resident in HBM before the timed region.
 scaling  : weak — every rank owns its own batch of images (the path shards over images; no data-path
            collective besides the detection all-gather).  value = boxes processed by ALL ranks / time.
@@ -90,6 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="run the NMS chain of a step on the same stream as the RoIAlign launch")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -136,30 +140,50 @@ def main():
     img_idx = torch.cat([torch.full((PROPOSALS,), i, device=device, dtype=torch.int64) for i in range(BATCH)])
     counter = {"i": 0}
 
+    nms_stream = torch.cuda.Stream(device=device)
+    overlap = {"on": not args.serial}
+
     def device_step(which=None):
-        # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable)
+        # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable).  The two halves of the
+        # step do not depend on each other (RoIAlign reads the maps and the boxes, NMS the boxes and the scores), and the
+        # NMS chain is ~8 short latency-bound launches: it runs on a second HIP stream UNDER the RoIAlign launch, forked
+        # from and joined back into the step's stream (`--serial` = one stream; both times are in the line).
         d = sets[counter["i"] % N_SETS if which is None else which]
         counter["i"] += 1
+        cur = torch.cuda.current_stream()
+        side = nms_stream if overlap["on"] else cur
+        if side is not cur:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
+            # padded top-MAX_DETS detections per image, fixed shape, ONE launch, keep length read on the device
+            dets, counts = sharding.pack_kept_detections(d["all_boxes"], d["all_scores"], img_idx, keep, BATCH, MAX_DETS, num_keep=num)
         pooled = pool(d["feats"], d["boxes"], image_shapes)                                 # [4000, 256, 7, 7], 1 launch
-        keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
-        # padded top-MAX_DETS detections per image, fixed shape, ONE launch, keep length read on the device
-        dets, counts = sharding.pack_kept_detections(d["all_boxes"], d["all_scores"], img_idx, keep, BATCH, MAX_DETS, num_keep=num)
+        if side is not cur:
+            cur.wait_stream(side)
+            for t in (keep, num, dets, counts):
+                t.record_stream(cur)     # produced on the side stream, consumed (all-gather, parity check) on this one
         return pooled, num, dets, counts, keep
 
     graph, static_out = None, None
     if args.graph:
-        # launch-bound chain (~12 short kernels behind the RoIAlign launch): capture it once, replay per step
+        # launch-bound chain (~12 short kernels next to the RoIAlign launch): capture it once PER INPUT SET (the rotation of
+        # the sets is what keeps the Infinity Cache from serving one step's maps to the next), replay round-robin
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(3):
-                    device_step(0)
+                for i in range(N_SETS):
+                    device_step(i)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(graph):
-                static_out = device_step(0)   # a captured graph replays ONE input set
+            graph, static_out = [], []
+            for i in range(N_SETS):
+                gph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(gph):
+                    o = device_step(i)
+                graph.append(gph)
+                static_out.append(o)
         except Exception as exc:  # pragma: no cover - depends on the runtime
             print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             graph, static_out = None, None
@@ -168,8 +192,10 @@ def main():
     def step():
         with torch.no_grad():
             if graph is not None:
-                graph.replay()
-                pooled, num, dets, counts, _ = static_out
+                i = counter["i"] % N_SETS
+                counter["i"] += 1
+                graph[i].replay()
+                pooled, num, dets, counts, _ = static_out[i]
             else:
                 pooled, num, dets, counts, _ = device_step()
             gd, gc = sharding.all_gather_detections(dets, counts)   # the one collective (no-op at world 1)
@@ -195,6 +221,19 @@ def main():
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     boxes_per_step = BATCH * PROPOSALS * world
     value = boxes_per_step / (ms_per_step / 1e3)
+    # the same K steps on ONE stream (reported next to `value`; round 1-2 lines were measured this way)
+    serial_ms = ms_per_step
+    if overlap["on"] and graph is None:
+        overlap["on"] = False
+        for _ in range(min(args.warmup, 5)):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        serial_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
+        overlap["on"] = True
 
     # ---- roofline of the dominant kernel, measured live with events on the launch stream (input sets rotated)
     from vision_amd.poolers import LevelMapper, _convert_to_roi_format
@@ -298,6 +337,8 @@ def main():
             "schema_ops_ms_per_step": round(schema_ms, 4),
             "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
             "rotated_input_sets": N_SETS,
+            "streams": "NMS + packing chain on a second HIP stream under the RoIAlign launch" if not args.serial else "one stream",
+            "one_stream_ms_per_step": round(serial_ms, 4),
             "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
         },

@@ -116,6 +116,9 @@ if "c3" in sections:
         t = tm(lambda: tv.nms(b, s, 0.5), n=10)
         pairs = n * (n - 1) / 2
         put(f"c3_nms_100k_canvas{canvas}", t, kept=kept, Gpairs_per_s=round(pairs / t / 1e6, 1))
+        if canvas == 1000:
+            b30, s30 = b[:30_000].contiguous(), s[:30_000].contiguous()
+            put("c3_nms_30k_canvas1000", tm(lambda: tv.nms(b30, s30, 0.5), n=10), kept=tv.nms(b30, s30, 0.5).numel())
         keptb = vision_amd.batched_nms(b, s, idx, 0.5).numel()
         put(f"c3_batched_nms_100k_x80_canvas{canvas}", tm(lambda: vision_amd.batched_nms(b, s, idx, 0.5), n=10), kept=keptb)
 
