@@ -10,9 +10,9 @@ workload : BASELINE config 2 — a batch of 4 padded 800x1344 images per GPU, 4 
            NMS (batched_nms over the image index, IoU 0.5), packing of the padded top-100 detections of every
            image (fixed shape) and — when N > 1 — their one RCCL all-gather.  The per-rank part has no host
            synchronisation, so the launches queue back to back (--graph replays them from captured hipGraphs, one
-           per input set).  The NMS + packing chain does not depend on the RoIAlign output: it runs on a second HIP
-           stream under the RoIAlign launch (forked from / joined into the step's stream); `--serial` keeps one stream
-           and the line carries that time too (config.one_stream_ms_per_step).
+           per input set).  The NMS + packing chain does not depend on the RoIAlign output: `--overlap` runs it on a
+           second HIP stream under the RoIAlign launch; the line is measured on one stream and carries the two-stream
+           time beside it (config.two_stream_ms_per_step: -4 % in one visit, +25 % in another — not the default).
 inputs   : synthetic (seeded), resident in HBM before the timed region.
 scaling  : weak — every rank owns its own batch of images (the path shards over images; no data-path
            collective besides the detection all-gather).  value = boxes processed by ALL ranks / time.
@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="run the NMS chain of a step on the same stream as the RoIAlign launch")
+    ap.add_argument("--overlap", action="store_true", help="run the NMS + packing chain of a step on a second HIP stream under the "
+                    "RoIAlign launch (measured: -4 %% at best, +25 %% on a noisy box; the default is one stream)")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -141,13 +142,15 @@ def main():
     counter = {"i": 0}
 
     nms_stream = torch.cuda.Stream(device=device)
-    overlap = {"on": not args.serial}
+    overlap = {"on": args.overlap}
 
     def device_step(which=None):
         # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable).  The two halves of the
         # step do not depend on each other (RoIAlign reads the maps and the boxes, NMS the boxes and the scores), and the
-        # NMS chain is ~8 short latency-bound launches: it runs on a second HIP stream UNDER the RoIAlign launch, forked
-        # from and joined back into the step's stream (`--serial` = one stream; both times are in the line).
+        # NMS chain is ~8 short latency-bound launches: with `--overlap` it runs on a second HIP stream UNDER the RoIAlign
+        # launch, forked from and joined back into the step's stream.  Measured on the box: 0.335 vs 0.350 ms per step in
+        # one visit, 0.438 vs 0.338 ms in another — the chain's 1024-thread workgroups wait for wave slots the RoIAlign
+        # kernel occupies — so the contract line is measured on ONE stream and the overlapped time is reported beside it.
         d = sets[counter["i"] % N_SETS if which is None else which]
         counter["i"] += 1
         cur = torch.cuda.current_stream()
@@ -221,10 +224,10 @@ def main():
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     boxes_per_step = BATCH * PROPOSALS * world
     value = boxes_per_step / (ms_per_step / 1e3)
-    # the same K steps on ONE stream (reported next to `value`; round 1-2 lines were measured this way)
-    serial_ms = ms_per_step
-    if overlap["on"] and graph is None:
-        overlap["on"] = False
+    # the same K steps with the NMS chain on a second stream (reported next to `value`, never `value` itself)
+    two_stream_ms = None
+    if graph is None:
+        overlap["on"] = True
         for _ in range(min(args.warmup, 5)):
             step()
         sync()
@@ -232,8 +235,8 @@ def main():
         for _ in range(args.steps):
             step()
         sync()
-        serial_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
-        overlap["on"] = True
+        two_stream_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
+        overlap["on"] = args.overlap
 
     # ---- roofline of the dominant kernel, measured live with events on the launch stream (input sets rotated)
     from vision_amd.poolers import LevelMapper, _convert_to_roi_format
@@ -337,8 +340,8 @@ def main():
             "schema_ops_ms_per_step": round(schema_ms, 4),
             "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
             "rotated_input_sets": N_SETS,
-            "streams": "NMS + packing chain on a second HIP stream under the RoIAlign launch" if not args.serial else "one stream",
-            "one_stream_ms_per_step": round(serial_ms, 4),
+            "streams": "NMS + packing chain on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream",
+            "two_stream_ms_per_step": None if two_stream_ms is None else round(two_stream_ms, 4),
             "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
         },
