@@ -1303,13 +1303,14 @@ def test_nms_replanning_on_survivors_is_invisible(tv):
             call = (lambda: tv.nms(bd, sd, 0.5)) if idxs is None else (lambda: torch.ops.tvmi.nms_segmented(bd, sd, idxs.to(DEV), 0.5, 0))
             opt("nms.replan_min_boxes", 0)
             want = call().cpu()
-            for min_boxes, divisor, depth in ((8192, 8, 1), (8192, 4, 3), (4097, 100, 6), (16384, 2, 2)):
+            for min_boxes, divisor, depth, handoff in ((8192, 8, 1, 1), (8192, 4, 3, 0), (4097, 100, 6, 1), (16384, 2, 2, 1), (0, 8, 1, 0)):
                 opt("nms.replan_min_boxes", min_boxes); opt("nms.replan_divisor", divisor); opt("nms.replan_max", depth)
-                assert torch.equal(call().cpu(), want), (boxes.shape[0], min_boxes, divisor, depth)
+                opt("nms.device_handoff", handoff)   # resolver <-> push hand-offs through memory words / through stream events
+                assert torch.equal(call().cpu(), want), (boxes.shape[0], min_boxes, divisor, depth, handoff)
         boxes, scores, _ = cases[0]
         assert np.array_equal(tv.nms(boxes.to(DEV), scores.to(DEV), 0.5).cpu().numpy(), O.nms(boxes.numpy(), scores.numpy(), 0.5))
     finally:
-        opt("nms.replan_min_boxes", 24576); opt("nms.replan_divisor", 16); opt("nms.replan_max", 3)
+        opt("nms.replan_min_boxes", 24576); opt("nms.replan_divisor", 16); opt("nms.replan_max", 3); opt("nms.device_handoff", 1)
 
 
 # ------------------------------------------------------------------ tile-owner RoIAlign backward (deterministic)

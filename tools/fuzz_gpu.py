@@ -26,6 +26,7 @@ while time.time() - t0 < 60:
     if n > 4200:   # the large path re-plans on its survivors: fuzz the threshold, the first-phase share and the depth
         torch.ops.tvmi.set_option("nms.replan_min_boxes", [0, 4097, ri(4097, n), 24576][ri(0, 3)])
         torch.ops.tvmi.set_option("nms.replan_divisor", ri(2, 40)); torch.ops.tvmi.set_option("nms.replan_max", ri(1, 5))
+        torch.ops.tvmi.set_option("nms.device_handoff", ri(0, 1))
     want = O.nms(b.numpy(), s.numpy(), thr)
     got = tv.nms(b.to(dev), s.to(dev), thr).cpu().numpy()
     assert np.array_equal(got, want), ("nms", n, canvas, thr)

@@ -3,7 +3,7 @@ Usage: nms_timeline.py <trace dir> [max rows]"""
 import csv, glob, os, sys
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-NAMES = ("score_keys", "widen_index", "nms_mask_tiles", "nms_resolve_wide", "nms_colreduce", "nms_survivor_offsets", "nms_compact_order", "nms_sweep_small",
+NAMES = ("score_keys", "widen_index", "nms_push", "nms_mask_tiles", "nms_resolve_wide", "nms_colreduce", "nms_survivor_offsets", "nms_compact_order", "nms_sweep_small",
          "fillBuffer", "copyBuffer", "radix_sort", "merge", "transform", "fill_reverse")
 def nm(r):
     for t in NAMES:

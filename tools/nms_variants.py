@@ -34,28 +34,22 @@ for canvas in (1000, 200):
 g = torch.Generator().manual_seed(11)
 cases["30k_500"] = (random_boxes(30_000, 500, 500, 1, 101, g).to(dev), torch.rand(30_000, generator=g).to(dev))
 want = {}
-variants = [(0, 8, 1, 0), (24576, 16, 3, 36000), (24576, 16, 3, 0), (24576, 8, 2, 36000), (0, 8, 1, 36000), (24576, 16, 3, 36000)]
-for min_boxes, divisor, max_replans, lds in variants:
+variants = [(0, 16, 3, 0), (24576, 16, 3, 0), (24576, 16, 3, 1), (24576, 16, 3, 0), (24576, 16, 3, 1), (0, 16, 3, 1), (24576, 8, 2, 1), (16384, 16, 4, 1)]
+for min_boxes, divisor, max_replans, handoff in variants:
     torch.ops.tvmi.set_option("nms.replan_min_boxes", min_boxes)
     torch.ops.tvmi.set_option("nms.replan_divisor", divisor)
     torch.ops.tvmi.set_option("nms.replan_max", max_replans)
-    torch.ops.tvmi.set_option("nms.mask_lds_bytes", lds)
+    torch.ops.tvmi.set_option("nms.device_handoff", handoff)
     for name, (b, s) in cases.items():
         keep = torch.ops.torchvision.nms(b, s, 0.5)
         if name not in want:
             want[name] = keep
         same = bool(keep.numel() == want[name].numel() and torch.equal(keep, want[name]))
         t = tm(lambda: torch.ops.torchvision.nms(b, s, 0.5))
-        key = f"nms_{name}_replan_min{min_boxes}_div{divisor}_max{max_replans}_lds{lds}"
+        key = f"nms_{name}_replan_min{min_boxes}_div{divisor}_max{max_replans}_handoff{handoff}"
         key += "_again" if key in res else ""
         res[key] = dict(ms=round(t, 4), kept=int(keep.numel()), same_as_first=same)
         print(key, res[key], flush=True)
         assert same
-# the score sort alone
-for n in (10_000, 100_000, 1_000_000):
-    sc = torch.rand(n, device=dev)
-    res[f"sort_{n}_ours"] = round(tm(lambda: torch.ops.tvmi.sort_scores_desc(sc)), 4)
-    res[f"sort_{n}_aten"] = round(tm(lambda: torch.sort(sc, stable=True, descending=True)), 4)
-    print(n, res[f"sort_{n}_ours"], res[f"sort_{n}_aten"], flush=True)
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)

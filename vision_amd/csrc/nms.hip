@@ -49,6 +49,7 @@ namespace {
 constexpr int kMaskWaves = 4;    // waves (= tiles of one row block) per workgroup in K1
 constexpr int kSuper = 16;       // 64-box blocks per super-block
 constexpr int kReduceRows = 8;   // row blocks folded per wave in K2
+constexpr int kWide = 64;        // 64-box blocks per chunk of the large path (one resolve launch)
 typedef unsigned long long u64;
 
 template <typename T>
@@ -381,18 +382,79 @@ __global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mas
   if (lane == 0 && red) atomicOr(&removed[cb], red);
 }
 
+// ---- device-side hand-offs of the sweep ("nms.device_handoff", see launch()).  The resolve workgroup of chunk c and the push
+// kernel of chunk c run in DIFFERENT launches on different streams and meet through two words per chunk: `flag` (set by the
+// resolver once the chunk's keep bits are in memory) and the arrival counter of the near-push kernel, which the resolver of
+// the next chunk polls.  No fences: on the 8-XCD part an agent-scope release is a write-back
+// of the whole L2 slice — which the mask kernel keeps full of dirty tiles — and cost more than the event hops it replaced
+// (measured).  Instead everything that crosses between the two launches is an agent-scope (write-through /
+// L2-bypassing) atomic — keepbits[], removed[], the three words — and a signal is preceded by `s_waitcnt vmcnt(0)`: the
+// writer's stores and atomics are acknowledged before the word that announces them is written (the idiom nms_small_seg_sweep's
+// ticket already uses).  The mask tiles a push kernel reads were written by a mask kernel that completed before the resolver
+// started (stream event), and nobody reads a tile before it is written, so no stale copy of one can sit in any L2.
+// A poll that outlives its bound (seconds: only a broken launch order can do that) traps instead of hanging the queue.
+struct SweepSync {  // one per chunk, zeroed with removed[] at the start of a level
+  int flag, near_done, pad[2];
+};
+__device__ __forceinline__ void poll_until_equal(const int* p, int want) {
+  int polls = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+    __builtin_amdgcn_s_sleep(4);
+    if (++polls > (1 << 23)) __builtin_trap();
+  }
+}
+__device__ __forceinline__ void signal_after_my_stores(int* p) {  // one thread, after the workgroup's barrier
+  __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The NEAR push of chunk [b0, b1) with device-side hand-offs: a fixed grid of 4-wave workgroups that is ALREADY RESIDENT
+// (polling the chunk's flag) when the resolver finishes; folds the chunk's kept rows into removed[] of the next chunk's column
+// blocks [b1, b2) — all the next resolver still lacks — and reports.  The FAR push (every later column block) is the wide
+// nms_colreduce launch right behind it on the same stream, whose workgroups report to the chunk's far counter.
+constexpr int kPushGroups = 128;
+__global__ __launch_bounds__(256) void nms_push(const u64* __restrict__ mask, const u64* keepbits, u64* __restrict__ removed, int CB,
+                                                int b0, int b1, int b2, SweepSync* sync) {
+  __shared__ u64 s_kb[kWide];
+  __builtin_amdgcn_s_setprio(2);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (threadIdx.x == 0) poll_until_equal(&sync->flag, 1);
+  __syncthreads();
+  // this kernel started before the resolver wrote them: agent-scope loads (the far push, a later launch, reads them plainly)
+  if ((int)threadIdx.x < b1 - b0) s_kb[threadIdx.x] = __hip_atomic_load(&keepbits[b0 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int groups = (b1 - b0 + kReduceRows - 1) / kReduceRows;
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  for (int item = gw; item < (b2 - b1) * groups; item += nw) {
+    const int cb = b1 + item / groups, g = item % groups;
+    u64 acc = 0ull;
+#pragma unroll
+    for (int q = 0; q < kReduceRows; ++q) {
+      const int r = g * kReduceRows + q;   // row block within the chunk
+      if (r < b1 - b0) {
+        const u64 w = mask[((size_t)(b0 + r) * CB + cb) * 64 + lane];
+        if ((s_kb[r] >> lane) & 1ull) acc |= w;
+      }
+    }
+    const u64 red = wave_or64(acc);
+    if (lane == 0 && red) atomicOr(&removed[cb], red);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my atomics are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) signal_after_my_stores(&sync->near_done);
+}
+
 // K3 for large problems: ONE workgroup resolves a WIDE super-block (chunk) of up to kWide 64-box blocks [b0, b1): it
 // walks it in mini super-blocks of kSuper blocks; removed[] (filled by the pushes of the earlier chunks, nms_colreduce)
 // carries what every earlier chunk suppresses, the rows of earlier mini super-blocks of THIS chunk are pulled here by
 // the wave that owns the column (keep bits in LDS), then the diagonal blocks are resolved in registers.
-constexpr int kWide = 64;
 constexpr int kJacobiRounds = 24;  // parallel fixed-point rounds tried per mini super-block before the serial walk
 __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __restrict__ mask,
                                                                    const int64_t* __restrict__ order,
                                                                    const u64* __restrict__ removed,
                                                                    u64* __restrict__ keepbits, int n, int CB, int b0, int b1,
                                                                    int64_t* __restrict__ keep_out,
-                                                                   int64_t* __restrict__ num_keep) {
+                                                                   int64_t* __restrict__ num_keep, SweepSync* sync, int chunk) {
   __shared__ u64 s_keep[kWide];
   __shared__ u64 s_jac[2][kSuper];
   __shared__ int s_changed[3];
@@ -403,6 +465,13 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
   const int lane = threadIdx.x & 63;
   const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nb = b1 - b0;
+  if (sync) {  // device hand-offs: removed[b0..b1) is complete once the push kernels of the two previous chunks have reported
+    if (threadIdx.x == 0) {
+      // (the far push of chunk - 2 precedes the near push of chunk - 1 on their in-order stream: one poll covers both)
+      if (chunk >= 1) poll_until_equal(&sync[chunk - 1].near_done, kPushGroups);
+    }
+    __syncthreads();
+  }
   for (int m0 = 0; m0 < nb; m0 += kSuper) {
     const int lb = m0 + c_loc;  // local block of this wave in the wide super-block
     const int cb = b0 + lb;
@@ -411,7 +480,8 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
     u64 rem = 0ull;
     if (have) {
       diag = mask[((size_t)cb * CB + cb) * 64 + lane];
-      rem = removed[cb];
+      // written by atomics of push kernels that may still be running for LATER chunks: read at agent scope
+      rem = __hip_atomic_load(&removed[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int q = 0; q < kSuper - 1; ++q) {
@@ -468,7 +538,7 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
     if (converged) {
       if (lane == 0 && have) {
         s_keep[lb] = my_keep;
-        keepbits[cb] = my_keep;
+        __hip_atomic_store(&keepbits[cb], my_keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       continue;
@@ -485,7 +555,7 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
         }
         if (lane == 0) {
           s_keep[lb] = ~r & valid;
-          keepbits[cb] = ~r & valid;
+          __hip_atomic_store(&keepbits[cb], ~r & valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       __syncthreads();
@@ -495,6 +565,11 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
         rem |= wave_or64(contrib);
       }
     }
+  }
+  if (sync) {  // the keep bits of the chunk are acknowledged stores: release the push kernel before the index list is emitted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) signal_after_my_stores(&sync[chunk].flag);
   }
   // append the kept original indices in score order
   if (threadIdx.x == 0) {
@@ -708,26 +783,30 @@ thread_local SweepStreamsByDevice g_sweep_streams;
 // their survivors (0 = never); "nms.replan_divisor" — the first 1/divisor of the row chunks is swept before the re-plan;
 // "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
 std::atomic<int64_t> g_replan_min_boxes{24576};
-std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000};
+std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000}, g_device_handoff{1};
 
 // Workspace of the large path: mask tiles | removed[CB] | keepbits[CB] | survivor offsets[CB] (int) | two score-order
 // buffers of n indices (re-planning ping-pongs between them).
 struct LargeWorkspace {
   u64 *mask, *removed, *keepbits;
+  SweepSync* sync;   // one per chunk, directly behind keepbits[] (cleared with them)
   int* offsets;
   int64_t* order_buf[2];
 };
 inline size_t large_state_bytes(size_t n) {
   const size_t CB = ceil_div(n, (size_t)64);
-  return 2 * CB * sizeof(u64) + ceil_div(CB, (size_t)2) * 2 * sizeof(int) + 2 * n * sizeof(int64_t);
+  return 2 * CB * sizeof(u64) + ceil_div(CB, (size_t)kWide) * sizeof(SweepSync) + ceil_div(CB, (size_t)2) * 2 * sizeof(int) +
+         2 * n * sizeof(int64_t);
 }
+inline size_t sweep_state_bytes(size_t CB) { return 2 * CB * sizeof(u64) + ceil_div(CB, (size_t)kWide) * sizeof(SweepSync); }
 inline LargeWorkspace carve(void* workspace, size_t n) {
   const size_t CB = ceil_div(n, (size_t)64);
   LargeWorkspace w;
   w.mask = static_cast<u64*>(workspace);
   w.removed = w.mask + CB * CB * 64;
   w.keepbits = w.removed + CB;
-  w.offsets = reinterpret_cast<int*>(w.keepbits + CB);
+  w.sync = reinterpret_cast<SweepSync*>(w.keepbits + CB);
+  w.offsets = reinterpret_cast<int*>(w.sync + ceil_div(CB, (size_t)kWide));
   w.order_buf[0] = reinterpret_cast<int64_t*>(w.offsets + ceil_div(CB, (size_t)2) * 2);
   w.order_buf[1] = w.order_buf[0] + n;
   return w;
@@ -748,6 +827,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   }
   const LargeWorkspace ws = carve(workspace, (size_t)n);
   u64 *mask = ws.mask, *removed = ws.removed, *keepbits = ws.keepbits;
+  const size_t state_bytes = sweep_state_bytes((size_t)ceil_div(n, 64));   // removed[] + keepbits[] + the hand-off words
   hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
   static SweepStreams no_streams;  // never ensure()d: only names the members below when the device query failed
@@ -761,7 +841,8 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   // host synchronisation per re-plan (the survivor count sizes the next grids), so it is only done for large
   // problems, never under stream capture, and `tvmi_set_option("nms.replan_min_boxes", 0)` turns it off.
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-  const bool may_replan = may_sync && ssp && hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusNone;
+  const bool capturing = !(hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusNone);
+  const bool may_replan = may_sync && ssp && !capturing;
   const size_t mask_lds = (size_t)g_mask_lds_bytes.load(std::memory_order_relaxed);
   const int64_t replan_min = g_replan_min_boxes.load(std::memory_order_relaxed);
   const int divisor = std::max(2, g_replan_divisor.load(std::memory_order_relaxed));
@@ -781,7 +862,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     const int nchunks = (int)ceil_div(CB, kWide);
     bool forked = side_streams_open;
     if (!forked) {
-      e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, stream);
+      e = hipMemsetAsync(removed, 0, state_bytes, stream);
       if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
       forked = ssp && ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
                hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
@@ -789,6 +870,9 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
                hipStreamWaitEvent(ss.far_stream, ss.fork, 0) == hipSuccess;
     }
     hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream, fs = forked ? ss.far_stream : stream;
+    // device-side hand-offs need the three streams to really run concurrently: not under capture (a graph may serialise
+    // its branches — may_sync is false there anyway only for tvmi_nms, so ask), and not without the side streams
+    const bool handoff = forked && !capturing && g_device_handoff.load(std::memory_order_relaxed) != 0;
     const bool replan = may_replan && forked && ss.host_count && replans_left > 0 && replan_min > 0 && n >= replan_min;
     const int limit = replan ? std::max(1, (nchunks + divisor / 2) / divisor) : nchunks;  // row chunks swept at this level
     auto mask_chunk = [&](int c, bool skip_known) {
@@ -812,7 +896,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     auto resolve = [&](int c) {
       const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
       nms_resolve_wide<<<dim3(1), dim3(kSuper * kWave), 0, sw>>>(mask, cur, removed, keepbits, (int)n, CB, b0, b1, keep_out,
-                                                                 num_keep);
+                                                                 num_keep, handoff ? ws.sync : nullptr, c);
     };
     if (forked) {
       // PUSH pipeline on three streams.  Chunk c: its mask tiles (mask stream), then — sweep stream, the serial link —
@@ -828,6 +912,22 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
         if (c >= 3) ok = ok && hipStreamWaitEvent(ms, ss.far_done[c - 3], 0) == hipSuccess;
         mask_chunk(c, true);
         ok = ok && hipEventRecord(ss.chunk_done[c], ms) == hipSuccess && hipStreamWaitEvent(sw, ss.chunk_done[c], 0) == hipSuccess;
+        if (handoff) {
+          // Device-side hand-offs: the sweep stream carries ONE event wait per chunk (the chunk's tiles) and back-to-back
+          // resolve launches; the push kernel of the chunk is already resident on the far stream, polling the resolver's
+          // flag, and the resolvers of the next two chunks poll its two arrival counters.  An event hop between streams
+          // costs ~10 us of command-processor latency here and the event form has two of them on the serial chain of
+          // every chunk (58 us per chunk for 33 us of resolve).  Every wait targets work that was enqueued earlier, so
+          // any interleaving of the three queues — even a single shared one — makes progress.
+          resolve(c);
+          if (b1 < CB) nms_push<<<dim3(kPushGroups), dim3(256), 0, fs>>>(mask, keepbits, removed, CB, b0, b1, b2, ws.sync + c);
+          // the FAR push needs no counter: the far stream is in order, so the near push of chunk c + 1 — whose counter the
+          // resolver of chunk c + 2 polls — cannot even start before this launch has finished
+          push(fs, b0, b1, b2, CB);
+          ok = ok && hipEventRecord(ss.far_done[c], fs) == hipSuccess;
+          (void)last_before_replan;
+          continue;
+        }
         if (c >= 2) ok = ok && hipStreamWaitEvent(sw, ss.far_done[c - 2], 0) == hipSuccess;
         resolve(c);
         if (!last_before_replan) push(sw, b0, b1, b1, b2);
@@ -859,7 +959,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     flip ^= 1;
     nms_survivor_offsets<<<dim3(1), dim3(1024), 0, fs>>>(removed, (int)n, CB, pb, ws.offsets, ss.host_count);
     nms_compact_order<<<dim3((unsigned)ceil_div(CB - pb, 4)), dim3(256), 0, fs>>>(removed, cur, (int)n, CB, pb, ws.offsets, next);
-    e = hipMemsetAsync(removed, 0, sizeof(u64) * 2 * (size_t)CB, fs);
+    e = hipMemsetAsync(removed, 0, state_bytes, fs);
     if (e == hipSuccess) e = hipStreamSynchronize(fs);
     if (e != hipSuccess) return set_error((int)e, "tvmi_nms: synchronising for the survivor count");
     side_streams_open = true;
@@ -1468,6 +1568,10 @@ int set_nms_option(const char* name, int64_t value) {
   }
   if (std::strcmp(name, "nms.replan_divisor") == 0) {
     g_replan_divisor.store((int)std::max<int64_t>(2, std::min<int64_t>(value, 1024)), std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "nms.device_handoff") == 0) {
+    g_device_handoff.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
   if (std::strcmp(name, "nms.mask_lds_bytes") == 0) {
