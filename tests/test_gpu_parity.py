@@ -1232,6 +1232,34 @@ def test_small_score_sort_equals_stable_descending_sort():
         assert torch.equal(got, want), n
 
 
+def test_nms_large_path_from_two_host_threads(tv):
+    """Two host threads run the large path on the same GPU at once (own side streams each).  Only one call per device may
+    use the device-side hand-offs at a time — polling kernels of two threads on shared hardware queues could otherwise wait
+    for each other — the other one takes the stream-event form; both must finish and give the single-thread index lists."""
+    import threading
+    g = gen(41)
+    cases = [(random_boxes(n, c, c, 1, 101, g).to(DEV), torch.rand(n, generator=g).to(DEV)) for n, c in ((30_000, 400), (45_000, 900))]
+    want = [tv.nms(b, s, 0.5).cpu() for b, s in cases]
+    errors = []
+
+    def worker(i):
+        try:
+            b, s = cases[i]
+            for _ in range(6):
+                if not torch.equal(tv.nms(b, s, 0.5).cpu(), want[i]):
+                    errors.append(("mismatch", i))
+        except Exception as exc:   # pragma: no cover - the assertion below reports it
+            errors.append((repr(exc), i))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t_ in threads:
+        t_.start()
+    for t_ in threads:
+        t_.join(timeout=120)
+    assert not any(t_.is_alive() for t_ in threads), "a thread is stuck in nms"
+    assert not errors, errors
+
+
 def test_deform_conv2d_channels_last_gather_is_bit_identical():
     """The 16-bit MFMA kernel samples a [B, H*W, C] copy of the input when the channel counts allow 16-byte octets
     (dcn.channels_last_gather, 32-deep K slabs): same corner values, same rounding, exact products, fp32 sums grouped in

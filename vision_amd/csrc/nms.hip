@@ -39,6 +39,7 @@
 #include <utility>
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "tvmi_common.h"
@@ -779,6 +780,36 @@ struct SweepStreamsByDevice {
 };
 thread_local SweepStreamsByDevice g_sweep_streams;
 
+// ONE call per device at a time may use the device-side hand-offs.  Every poll in them targets work that the SAME host thread
+// enqueued earlier, so one call can never block itself however its streams are mapped to hardware queues — but two host
+// threads whose polling kernels sit at the heads of each other's shared in-order queues could.  A second call that arrives
+// while the first one's work is still on the device therefore takes the stream-event form (whose kernels never wait).
+struct HandoffClaim {
+  std::mutex mu;
+  bool enqueuing = false;     // a call that took the hand-off form is still enqueueing its launches
+  hipEvent_t done = nullptr;  // recorded behind the last such call
+};
+HandoffClaim g_handoff_claim[64];
+inline bool claim_handoff(int dev) {
+  if (dev < 0 || dev >= 64) return false;
+  HandoffClaim& h = g_handoff_claim[dev];
+  std::lock_guard<std::mutex> lock(h.mu);
+  if (h.enqueuing) return false;
+  if (h.done && hipEventQuery(h.done) != hipSuccess) {
+    (void)hipGetLastError();   // hipErrorNotReady is not an error of this call
+    return false;
+  }
+  h.enqueuing = true;
+  return true;
+}
+inline void release_handoff(int dev, hipStream_t stream) {
+  HandoffClaim& h = g_handoff_claim[dev];
+  std::lock_guard<std::mutex> lock(h.mu);
+  if (!h.done && hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess) h.done = nullptr;
+  if (h.done) (void)hipEventRecord(h.done, stream);
+  h.enqueuing = false;
+}
+
 // Options of the large path (tvmi_set_option): "nms.replan_min_boxes" — problems at least this large are re-planned on
 // their survivors (0 = never); "nms.replan_divisor" — the first 1/divisor of the row chunks is swept before the re-plan;
 // "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
@@ -850,6 +881,16 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   const int64_t* cur = order;
   int flip = 0;
   bool ok = true;
+  bool claim_tried = false, claimed = false;   // the device-side hand-offs of this call (see HandoffClaim)
+  int claim_dev = -1;
+  struct ClaimRelease {   // on every way out: "done" is recorded behind whatever this call enqueued on the caller's stream
+    bool& claimed;
+    int& dev;
+    hipStream_t stream;
+    ~ClaimRelease() {
+      if (claimed) release_handoff(dev, stream);
+    }
+  } claim_release{claimed, claim_dev, stream};
   bool side_streams_open = false;  // a re-plan leaves the three side streams forked, idle and ahead of `stream`
   while (true) {
     const int CB = (int)ceil_div(n, 64);
@@ -872,7 +913,12 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream, fs = forked ? ss.far_stream : stream;
     // device-side hand-offs need the three streams to really run concurrently: not under capture (a graph may serialise
     // its branches — may_sync is false there anyway only for tvmi_nms, so ask), and not without the side streams
-    const bool handoff = forked && !capturing && g_device_handoff.load(std::memory_order_relaxed) != 0;
+    if (!claim_tried && forked && !capturing && g_device_handoff.load(std::memory_order_relaxed) != 0) {
+      claim_tried = true;
+      (void)hipGetDevice(&claim_dev);
+      claimed = claim_handoff(claim_dev);
+    }
+    const bool handoff = forked && claimed;
     const bool replan = may_replan && forked && ss.host_count && replans_left > 0 && replan_min > 0 && n >= replan_min;
     const int limit = replan ? std::max(1, (nchunks + divisor / 2) / divisor) : nchunks;  // row chunks swept at this level
     auto mask_chunk = [&](int c, bool skip_known) {
