@@ -52,6 +52,8 @@ int tvmi_version(void);
  *                                (default 24576; 0 = never)
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)
  *   "nms.replan_max"             re-plans per call (default 3)
+ *   "nms.device_handoff"         1 (default) / 0: resolver <-> push hand-offs of the large path through memory words (agent-scope
+ *                                atomics, no fences) instead of stream events; one call per device at a time, never under capture
  *   "nms.mask_lds_bytes"         dynamic LDS per mask workgroup of the large path (all chunks but the first) — an
  *                                occupancy cap that keeps wave slots free for the sweep's 16-wave workgroup
  *                                (default 36000 = four workgroups per CU; 0 = no cap) */
@@ -84,8 +86,8 @@ int tvmi_nms(const void* dets, const int64_t* order, const int64_t* seg, int64_t
  * nms ends in a device-to-host copy, cuda/nms_kernel.cu:226-236): above "nms.replan_min_boxes" boxes the call sweeps
  * the first chunk(s) of the sorted list, drops every box they removed and starts over on the survivors.  That saves the
  * removed fraction in BOTH dimensions of the pair tests and shortens the serial sweep, and costs one
- * host synchronisation per re-plan (the survivor count sizes the next grids).  100k boxes: 2.1 -> 1.45 ms (38 % kept),
- * 1.8 -> 0.8 ms (9 % kept).  Never re-plans under stream capture; tvmi_nms never synchronises. */
+ * host synchronisation per re-plan (the survivor count sizes the next grids).  100k boxes: 2.2 -> 1.27 ms (38 % kept),
+ * 1.9 -> 0.69 ms (9 % kept).  Never re-plans under stream capture; tvmi_nms never synchronises. */
 int tvmi_nms_blocking(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
                       double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
                       int64_t* keep_out, int64_t* num_keep_out, void* stream);
