@@ -479,8 +479,10 @@ constexpr int kDmaPerPass = 4;                   // DMA instructions (x 1 KiB) p
 constexpr int kDmaBlk = 260;                     // LDS floats per DMA instruction block (256 + 4 skew, 16-B aligned)
 constexpr int kDmaBuf = kDmaPerPass * kDmaBlk;   // floats per buffer
 
+constexpr int kDmaStage = 400;   // floats: finished [channel][bin] rows of a wave, parked until they leave as 16-byte stores
 struct DmaShared {
   __attribute__((aligned(16))) float buf[2 * kDmaBuf];
+  __attribute__((aligned(16))) float stage[kDmaStage];
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -605,6 +607,34 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
     }
     goff[rg] = min(y, H - 1) * W + gx;
   }
+  // Output rows are parked in LDS and leave SC channels at a time: the [channel][bin] block of a wave unit is contiguous
+  // in the NCHW output, so 8 channels of 7 x 7 bins (1568 B) are two full-width 16-byte store instructions instead of eight
+  // 49-lane dword stores — the texture path charges ~20 cycles per wave instruction whatever its width, and the stores were
+  // a quarter of this kernel's VMEM instructions.  Same wave writes and reads the block: LDS order is program order.
+  constexpr bool kStaged = sizeof(T) == 4;
+  constexpr int SC = (kDmaStage * 4 / (int)sizeof(T)) / PHW >= 8 ? 8 : ((kDmaStage * 4 / (int)sizeof(T)) / PHW >= 2 ? 2 : 1);
+  constexpr int kGroupVec = SC * PHW * (int)sizeof(T) / 16;          // 16-byte pieces of a full group
+  static_assert(SC * PHW * (int)sizeof(T) % 16 == 0 && SC * PHW * (int)sizeof(T) <= kDmaStage * 4, "stage block");
+  T* const stage = reinterpret_cast<T*>(s.stage);
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // wave-uniform (the unit's output base)
+  int staged = 0;                                                    // channels parked in the stage block
+  auto flush = [&](int first_ch, int nch) {
+    asm volatile("" ::: "memory");
+    if (nch == SC && vec_ok) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4* src = reinterpret_cast<const f32x4*>(stage);
+      f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)first_ch * PHW);
+#pragma unroll
+      for (int i = 0; i < (kGroupVec + 63) / 64; ++i) {
+        const int v = lane + 64 * i;
+        if (v < kGroupVec) __builtin_nontemporal_store(src[v], dst + v);
+      }
+    } else {
+      for (int i = lane; i < nch * PHW; i += 64) out[(int64_t)first_ch * PHW + i] = stage[i];
+    }
+    // the reads above are complete before the block is written again
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   const int npass = (cc + G - 1) / G;
   if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
   for (int p = 0; p < npass; ++p) {
@@ -645,10 +675,14 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
         const int bin = lane + 64 * b;
         if (bin < PHW) {
           const float r = kPow2 ? acc * inv_count : acc / (float)NS;
-          if constexpr (std::is_same<T, float>::value)
-            __builtin_nontemporal_store(r, out + (cg + ch) * PHW + bin);
-          else
-            st(out + (cg + ch) * PHW + bin, r);
+          if constexpr (kStaged) stage[staged * PHW + bin] = r;
+          else st(out + (cg + ch) * PHW + bin, r);   // 16-bit outputs: sub-dword LDS writes cost more than the stores save (measured)
+        }
+      }
+      if constexpr (kStaged) {
+        if (++staged == SC) {
+          flush(cg + ch + 1 - SC, SC);
+          staged = 0;
         }
       }
     }
@@ -656,6 +690,7 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
     // overwrite this buffer
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  if (kStaged && staged) flush(cc - staged, staged);
 }
 
 // A RoI the shared-staging kernel (roi_align_plane.hip) serves is not this kernel's: key >= 0 names its level, and the
