@@ -645,7 +645,7 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
       if (p + 1 < npass) {
         dma_issue_pass<T, NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
                                bytes + ((p + 1) & 1) * (kDmaBuf * 4));
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything older than those 4 DMAs has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NRG) : "memory");  // everything older than the DMAs just issued has landed
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -777,6 +777,8 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
     roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 2)
     roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+  else if (dw.nrg <= 3)   // 28 sampled rows of <= 5 pieces: three DMA instructions per channel, not four
+    roi_align_dma_passes<T, PHT, PWT, SRT, 3>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 4)
     roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else
