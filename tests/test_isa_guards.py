@@ -54,3 +54,46 @@ def test_nms_m0_save_restore_regions_are_clean(tmp_path):
         i = j + 1
     # the fast tile path exists in every tile kernel (mask tiles, segmented, small segments, diag / keyed variants)
     assert regions >= 3 and writes >= 3 * 96, (regions, writes)
+
+
+def _kernel_resources(src, tmp_path):
+    """Compile one TU like the Makefile and return {kernel name: {vgpr, spill, lds, scratch}} from its code-object metadata."""
+    out = tmp_path / (os.path.basename(src) + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           f"-I{os.path.join(ROOT, 'include')}", "-S", "--cuda-device-only", src, "-o", str(out)]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    res = {}
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:", text, re.S):
+        blk = m.group(0)
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+
+        def num(key, blk=blk):
+            mm = re.search(rf"\.{key}:\s+(\d+)", blk)
+            return int(mm.group(1)) if mm else 0
+        res[name] = dict(vgpr=num("vgpr_count"), spill=num("vgpr_spill_count"), lds=num("group_segment_fixed_size"),
+                         scratch=num("private_segment_fixed_size"))
+    return text, res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_occupancy_assumptions_of_the_hot_kernels(tmp_path):
+    """DESIGN.md quotes occupancies that follow from compiler output: the fp32 RoIAlign DMA kernel must keep FOUR 256-thread
+    workgroups per CU (LDS <= 40 KB per workgroup, <= 128 VGPRs) after its output staging block was added, the 16-bit
+    channels-last deform_conv2d kernel two 512-thread workgroups (<= 128 VGPRs, < 64 KB of LDS), none of them may spill, and
+    the three-instruction row groups of the DMA kernel need their own counted wait (vmcnt(3), never the vmcnt(4) of the other
+    instantiations)."""
+    text, roi = _kernel_resources(os.path.join(CSRC, "roi_align.hip"), tmp_path)
+    dma = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi7ELi7ELi2E" in k}
+    assert len(dma) == 1, list(roi)
+    (r,) = dma.values()
+    assert r["spill"] == 0 and r["vgpr"] <= 128 and 0 < r["lds"] <= 40 * 1024, r
+    assert 4 * r["lds"] <= 160 * 1024
+    assert re.search(r"s_waitcnt vmcnt\(3\)", text) and re.search(r"s_waitcnt vmcnt\(4\)", text)
+    _, dcn = _kernel_resources(os.path.join(CSRC, "deform_conv2d.hip"), tmp_path)
+    cl = {k: v for k, v in dcn.items() if "dcn_fwd_mfma_16_cl" in k and "Li4ELi2ELi2ELi1E" in k}
+    assert len(cl) == 2, list(dcn)          # fp16 and bf16
+    for r in cl.values():
+        assert r["spill"] == 0 and r["vgpr"] <= 128, r
+    dw = {k: v for k, v in dcn.items() if "dcn_fwd_depthwise3x3IfLi75E" in k}
+    assert len(dw) == 1 and all(v["spill"] == 0 and v["vgpr"] <= 128 for v in dw.values()), dw
