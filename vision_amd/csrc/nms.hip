@@ -19,7 +19,8 @@
 //      (rb, cb) is 64 consecutive words, so both this store and every later read of a tile
 //      is one coalesced 512-byte access.  Boxes are gathered through `order` in-kernel.
 //      Two rows per step with packed fp32 and a division-free band test (see thr_band below); above 4096 boxes the
-//      kernel runs in chunks of 64 row blocks and skips the rows the sweep already knows to be suppressed.
+//      kernel runs in chunks of 64 row blocks and drops the rows the sweep already knows to be suppressed: the row block
+//      is compacted as it is staged, the pair loop covers the survivors only.
 //   The greedy sweep is blocked and runs UNDER the mask kernels on side streams (see launch()):
 //   K2 nms_colreduce   : removed[cb] |= OR over the rows kept in a range of row blocks of tile(rb, cb)[row] —
 //      thousands of independent waves, each a masked 512-byte load + a DPP OR-reduction + one atomic.  Used as the
@@ -30,6 +31,10 @@
 //      diagonal blocks are resolved by parallel fixed-point rounds (exact when two rounds agree) with the serial walk
 //      over the not-yet-removed bits (s_ff1 + v_readlane) as fallback.  Kept original indices are written in score
 //      order and the running count stays on the device — no masked_select pass.
+//   Large problems are RE-PLANNED on their survivors (tvmi_nms_blocking, see launch()): after the first chunks have been swept
+//   and pushed to every later column, the score order is compacted to the boxes still alive and the pipeline starts over
+//   on that list.  The resolver and the push kernels hand over through memory words (agent-scope atomics, no fences:
+//   SweepSync) instead of stream events wherever the three streams are known to run concurrently.
 //   Up to 4096 boxes one mask launch + nms_sweep_small; batched NMS: segment-major kernels further down.
 #include <algorithm>
 #include <atomic>
