@@ -63,6 +63,44 @@ def test_c_abi_nms_on_raw_device_pointers():
     assert lib.tvmi_last_error()
 
 
+def test_c_abi_score_sort_and_blocking_nms_of_a_large_list():
+    """The two entries a non-torch host would chain for a large list: tvmi_sort_scores_desc_large (the processing order) and
+    tvmi_nms_blocking (re-plans on the survivors, one host synchronisation per re-plan) — raw pointers only, against the
+    reference CPU algorithm; tvmi_nms (stream-ordered, never synchronises) must give the same list."""
+    lib = _lib()
+    lib.tvmi_sort_scores_desc_workspace_bytes.restype = ctypes.c_size_t
+    lib.tvmi_sort_scores_desc_workspace_bytes.argtypes = [i64]
+    lib.tvmi_sort_scores_desc_large.restype = ctypes.c_int
+    lib.tvmi_sort_scores_desc_large.argtypes = [vp, i64, vp, vp, ctypes.c_size_t, vp]
+    lib.tvmi_nms_blocking.restype = ctypes.c_int
+    lib.tvmi_nms_blocking.argtypes = lib.tvmi_nms.argtypes
+    g = gen(5)
+    n, thr = 40_000, 0.5
+    xy = torch.rand(n, 2, generator=g) * 600
+    boxes = torch.cat([xy, xy + 4 + torch.rand(n, 2, generator=g) * 90], 1)
+    scores = (torch.rand(n, generator=g) * 4096).floor() / 4096      # ties: the order must be the stable one
+    d_boxes, d_scores = boxes.to(DEV), scores.to(DEV)
+    order = torch.empty(n, dtype=torch.int64, device=DEV)
+    sb = lib.tvmi_sort_scores_desc_workspace_bytes(n)
+    sws = torch.empty(sb, dtype=torch.uint8, device=DEV)
+    assert sws.data_ptr() % 256 == 0
+    st = lib.tvmi_sort_scores_desc_large(d_scores.data_ptr(), n, order.data_ptr(), sws.data_ptr(), sb, _stream())
+    assert st == 0, lib.tvmi_last_error()
+    torch.cuda.synchronize()
+    assert np.array_equal(order.cpu().numpy(), O.stable_descending_order(scores.numpy()))
+    want = O.nms(boxes.numpy(), scores.numpy(), thr)
+    wb = lib.tvmi_nms_workspace_bytes(n)
+    ws = torch.empty(wb, dtype=torch.uint8, device=DEV)
+    for entry in (lib.tvmi_nms_blocking, lib.tvmi_nms):
+        keep = torch.empty(n, dtype=torch.int64, device=DEV)
+        num = torch.zeros(1, dtype=torch.int64, device=DEV)
+        st = entry(d_boxes.data_ptr(), order.data_ptr(), None, n, thr, TVMI_F32, ws.data_ptr(), wb, keep.data_ptr(), num.data_ptr(),
+                   _stream())
+        assert st == 0, lib.tvmi_last_error()
+        torch.cuda.synchronize()
+        assert np.array_equal(keep[: int(num)].cpu().numpy(), want)
+
+
 def test_c_abi_roi_align_forward_and_owner_backward():
     lib = _lib()
     g = gen(3)
