@@ -53,7 +53,11 @@ int tvmi_version(void);
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)
  *   "nms.replan_max"             re-plans per call (default 3)
  *   "nms.device_handoff"         1 (default) / 0: resolver <-> push hand-offs of the large path through memory words (agent-scope
- *                                atomics, no fences) instead of stream events; one call per device at a time, never under capture
+ *                                atomics, no fences) instead of stream events; one call per device at a time, never under capture.
+ *                                Needs the call's three streams to run concurrently: switched off automatically when
+ *                                rocprofv3 collects counters (it runs one kernel at a time and says so in the environment:
+ *                                ROCPROF_COUNTER_COLLECTION); set it to 0 under any other tool that serialises kernels —
+ *                                a poll that cannot be satisfied traps after about a second
  *   "nms.mask_lds_bytes"         dynamic LDS per mask workgroup of the large path (all chunks but the first) — an
  *                                occupancy cap that keeps wave slots free for the sweep's 16-wave workgroup
  *                                (default 36000 = four workgroups per CU; 0 = no cap) */

@@ -18,7 +18,7 @@ timeout 600 python tools/gpu_matrix.py $OUT/matrix.json > $OUT/matrix.log 2>&1; 
 cd /tmp
 for K in roi7 roi7cl bwd7 bwd14 nms100k; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_${K}_$C -o p -- python $ROOTDIR/tools/run_kernel.py $K 6 > $ROOTDIR/$OUT/pmc_${K}_$C.log 2>&1
+    TVMI_TOOL_SERIALIZED_PROFILER=1 timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_${K}_$C -o p -- python $ROOTDIR/tools/run_kernel.py $K 6 > $ROOTDIR/$OUT/pmc_${K}_$C.log 2>&1
   done
 done
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_bwd7 -o k -- python $ROOTDIR/tools/run_kernel.py bwd7 20 > /dev/null 2>&1
@@ -28,7 +28,7 @@ cd $ROOTDIR
 # probe binaries are not tracked: build the calibration probe here if it did not travel with the snapshot
 [ -x $ROOTDIR/tools/probe/fetch_calib ] || hipcc --offload-arch=gfx950 -O3 -o $ROOTDIR/tools/probe/fetch_calib $ROOTDIR/tools/probe/fetch_calib.hip > /dev/null 2>&1
 cd /tmp
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/calib_fetch -o p -- $ROOTDIR/tools/probe/fetch_calib > $ROOTDIR/$OUT/calib_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/calib_write -o p -- $ROOTDIR/tools/probe/fetch_calib > $ROOTDIR/$OUT/calib_write.log 2>&1
+TVMI_TOOL_SERIALIZED_PROFILER=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/calib_fetch -o p -- $ROOTDIR/tools/probe/fetch_calib > $ROOTDIR/$OUT/calib_fetch.log 2>&1
+TVMI_TOOL_SERIALIZED_PROFILER=1 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $ROOTDIR/$OUT/calib_write -o p -- $ROOTDIR/tools/probe/fetch_calib > $ROOTDIR/$OUT/calib_write.log 2>&1
 cd $ROOTDIR
 python tools/pmc_traffic.py $OUT > $OUT/traffic_summary.txt 2>&1; cat $OUT/traffic_summary.txt

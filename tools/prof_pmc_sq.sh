@@ -11,7 +11,7 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
          "TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   [ $i -le $SKIP ] && continue
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $OUT/p$i -o p -- python $ROOTDIR/tools/run_kernel.py $WHICH 3 > $OUT/p$i.log 2>&1
+  TVMI_TOOL_SERIALIZED_PROFILER=1 timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $OUT/p$i -o p -- python $ROOTDIR/tools/run_kernel.py $WHICH 3 > $OUT/p$i.log 2>&1
 done
 cd $ROOTDIR
 python tools/pmc_summary.py $OUT ${3:-} > $OUT/summary.txt 2>&1

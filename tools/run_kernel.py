@@ -3,6 +3,10 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, vision_amd, bench
+if os.environ.get("TVMI_TOOL_SERIALIZED_PROFILER"):
+    # rocprofv3 --pmc runs ONE kernel at a time: the polling push kernel of the large-NMS hand-offs would wait for a resolver
+    # that cannot start.  Counter passes use the stream-event form of the same pipeline.
+    torch.ops.tvmi.set_option("nms.device_handoff", 0)
 which = sys.argv[1] if len(sys.argv) > 1 else "roi7"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")

@@ -406,7 +406,7 @@ __device__ __forceinline__ void poll_until_equal(const int* p, int want) {
   int polls = 0;
   while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
     __builtin_amdgcn_s_sleep(4);
-    if (++polls > (1 << 23)) __builtin_trap();
+    if (++polls > (1 << 20)) __builtin_trap();   // >= 1 s of polling: the launch order is broken (see kernels_are_serialised)
   }
 }
 __device__ __forceinline__ void signal_after_my_stores(int* p) {  // one thread, after the workgroup's barrier
@@ -795,8 +795,14 @@ struct HandoffClaim {
   hipEvent_t done = nullptr;  // recorded behind the last such call
 };
 HandoffClaim g_handoff_claim[64];
+// A profiler that collects hardware counters per dispatch runs ONE kernel at a time (rocprofv3 --pmc: measured — the polling
+// push kernel then waits for a resolver that is never started).  rocprofv3 announces that mode to the process it launches.
+inline bool kernels_are_serialised() {
+  static const bool yes = std::getenv("ROCPROF_COUNTER_COLLECTION") != nullptr || std::getenv("ROCPROF_COUNTERS") != nullptr;
+  return yes;
+}
 inline bool claim_handoff(int dev) {
-  if (dev < 0 || dev >= 64) return false;
+  if (dev < 0 || dev >= 64 || kernels_are_serialised()) return false;
   HandoffClaim& h = g_handoff_claim[dev];
   std::lock_guard<std::mutex> lock(h.mu);
   if (h.enqueuing) return false;
