@@ -104,7 +104,8 @@ int tvmi_nms_blocking(const void* dets, const int64_t* order, const int64_t* seg
 int tvmi_sort_scores_desc(const float* scores, int64_t n, int64_t* order, void* stream);
 /* The same order for any n < 2^31 (score_sort.hip): a key pass that encodes the NaN / signed-zero rules, rocPRIM's radix
  * sort of (key, index) pairs, an index-widening pass.  workspace: 256-byte aligned device scratch of at least
- * tvmi_sort_scores_desc_workspace_bytes(n) bytes. */
+ * tvmi_sort_scores_desc_workspace_bytes(n) bytes (the query asks rocPRIM for its temporary storage on the CURRENT device:
+ * it returns 0 for n <= 0, n >= 2^31 and when no device is available). */
 size_t tvmi_sort_scores_desc_workspace_bytes(int64_t n);
 int tvmi_sort_scores_desc_large(const float* scores, int64_t n, int64_t* order, void* workspace,
                                 size_t workspace_bytes, void* stream);
