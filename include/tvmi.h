@@ -35,18 +35,18 @@ typedef enum tvmi_dtype {
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
  * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
-#define TVMI_ABI_VERSION 301
+#define TVMI_ABI_VERSION 302
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
- *   "roi_align.shared_staging"   0 (default) / 1: serve FPN levels by staging the map (roi_align_plane.hip); measured
- *                                slower than the per-RoI kernel at the FPN workload (LDS-gather bound), kept as an option
- *   "roi_align.min_band_rows"    maps that do not fit the LDS are cut into row bands only if a band holds this many rows
- *                                (default 32; 0 = never cut, only whole planes are staged)
- *   "roi_align.staging_gain_x16" weight (x/16, default 32 = 2.0) of the RoIs' window pixels against the map pixels in
- *                                the device-side decision which levels are staged
- *   "roi_align.stage_whole_planes" 1 / 0: stage levels whose plane fits the LDS budget twice
- *   "roi_align.band_channels"    channels per workgroup of a banded level (default 2)
+ *   "roi_align.pin_chunks"       1 (default) / 0: the fp32 / 16-bit LDS-DMA forward kernels pin channel chunks to XCDs (every
+ *                                byte of a feature map is then wanted by one private L2 only) when the chunk count is a
+ *                                multiple of 8; 0 = every XCD walks a contiguous RoI range chunk by chunk
+ *   "roi_align.order"            1 (default) / 0: with pinned chunks, RoIs start in (image, level, window-top band) order
+ *                                (a one-workgroup counting sort in front of the launch; needs the forward workspace)
+ *   "roi_align.order_bands"      bands per (image, level) in that order key (default 16, 1..64)
+ *   "roi_align.tap_reads"        0 / 1: a bilinear tap pair leaves LDS as one ds_read2_b32 (two ds_read_u16 for 16-bit maps) /
+ *                                as ONE ds_read_b64 (ds_read_b32) at element alignment
  *   "dcn.channels_last_gather"   1 (default) / 0: the 16-bit MFMA deform_conv2d kernel samples a [B, H*W, C] copy of the input
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)
@@ -62,6 +62,8 @@ int tvmi_version(void);
  *                                occupancy cap that keeps wave slots free for the sweep's 16-wave workgroup
  *                                (default 36000 = four workgroups per CU; 0 = no cap) */
 int tvmi_set_option(const char* name, int64_t value);
+/* Current value of a switch of tvmi_set_option (0, or an error for an unknown name). */
+int tvmi_get_option(const char* name, int64_t* value);
 /* Static string of the gfx arch the kernels were compiled for ("gfx950"). */
 const char* tvmi_arch(void);
 /* Human-readable text for the last non-zero status returned on this thread. */

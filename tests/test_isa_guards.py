@@ -85,10 +85,10 @@ def test_occupancy_assumptions_of_the_hot_kernels(tmp_path):
     instantiations)."""
     text, roi = _kernel_resources(os.path.join(CSRC, "roi_align.hip"), tmp_path)
     dma = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi7ELi7ELi2E" in k}
-    assert len(dma) == 1, list(roi)
-    (r,) = dma.values()
-    assert r["spill"] == 0 and r["vgpr"] <= 128 and 0 < r["lds"] <= 40 * 1024, r
-    assert 4 * r["lds"] <= 160 * 1024
+    assert len(dma) == 2, list(roi)          # tap pairs as ds_read2_b32 / as ds_read_b64
+    for r in dma.values():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 96 and 0 < r["lds"] <= 40 * 1024, r
+        assert 4 * r["lds"] <= 160 * 1024
     assert re.search(r"s_waitcnt vmcnt\(3\)", text) and re.search(r"s_waitcnt vmcnt\(4\)", text)
     _, dcn = _kernel_resources(os.path.join(CSRC, "deform_conv2d.hip"), tmp_path)
     cl = {k: v for k, v in dcn.items() if "dcn_fwd_mfma_16_cl" in k and "Li4ELi2ELi2ELi1E" in k}
@@ -97,3 +97,40 @@ def test_occupancy_assumptions_of_the_hot_kernels(tmp_path):
         assert r["spill"] == 0 and r["vgpr"] <= 128, r
     dw = {k: v for k, v in dcn.items() if "dcn_fwd_depthwise3x3IfLi75E" in k}
     assert len(dw) == 1 and all(v["spill"] == 0 and v["vgpr"] <= 128 for v in dw.values()), dw
+
+
+def _kernel_bodies(text, needle):
+    """{mangled name: ISA text up to s_endpgm} of the kernels whose name contains `needle`."""
+    out = {}
+    for m in re.finditer(r"^(_ZN4tvmi\S+):\s+; @\S+\n(.*?)s_endpgm", text, re.S | re.M):
+        if needle in m.group(1):
+            out[m.group(1)] = m.group(2)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_roi_align_dma_loop_keeps_its_prefetch_in_flight(tmp_path):
+    """The LDS-DMA forward kernels double-buffer by hand: the DMAs of pass p+1 are issued, a COUNTED `s_waitcnt vmcnt(N)` retires
+    pass p, and the arithmetic of pass p runs while p+1 is in flight.  Two things the compiler did to that loop in round 3,
+    both of which put `s_waitcnt vmcnt(0)` in front of every channel's arithmetic (= wait for the prefetch just issued):
+      * {l, h} of axis_sample_shifted lived in a scratch pair (conditional stores through references) and the scratch loads'
+        VM-counter dependency was carried into the loop;
+      * plain C++ stores into the LDS output staging block are 'may alias a pending LDS-DMA' for the waitcnt pass.
+    Guard: no scratch, and the only vmcnt(0) waits are the ones written in the source (one per row-group instantiation: the
+    last pass / the single-buffer NRG=8 form, plus the RoI loads of the 16-bit single-level entry).  Also the tap pairing:
+    8 pair reads per channel and instantiation, no split halves."""
+    src = os.path.join(CSRC, "roi_align.hip")
+    text, _ = _kernel_resources(src, tmp_path)
+    bodies = _kernel_bodies(text, "roi_align_fwd_")
+    dma = {k: v for k, v in bodies.items() if "_dmaI" in k}
+    assert len(dma) == 24, sorted(dma)      # {single level, multi-scale} x {fp32, fp16, bf16} x {two tap-read forms} x {7x7, 14x14}
+    for name, body in dma.items():
+        assert "scratch_" not in body, name
+        n0 = len(re.findall(r"s_waitcnt vmcnt\(0\)", body))
+        assert n0 <= 6, (name, n0)
+        assert not re.search(r"s_waitcnt vmcnt\(0\) lgkmcnt", body), name     # a compiler-made combined wait inside the channel loop
+        nb = 1 if "Li7ELi7E" in name else 4
+        if "IfLi" in name and name.split("Li2ELi")[1].startswith("0"):
+            assert len(re.findall(r"ds_read2_b32", body)) == 5 * 8 * nb, name
+        if "IfLi" in name and name.split("Li2ELi")[1].startswith("1"):
+            assert len(re.findall(r"ds_read_b64", body)) == 5 * 8 * nb, name

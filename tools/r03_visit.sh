@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 for STEP in "$@"; do
   case $STEP in
-    plane)    timeout 900 python -m pytest tests/test_gpu_roi_plane.py tests/test_gpu_dist.py -x -q > $OUT/t_plane.log 2>&1; tail -25 $OUT/t_plane.log ;;
+    plane)    timeout 900 python -m pytest tests/test_gpu_roi_routes.py tests/test_gpu_dist.py -x -q > $OUT/t_plane.log 2>&1; tail -25 $OUT/t_plane.log ;;
     variants) timeout 600 python tools/roi_variants.py $OUT/variants.json > $OUT/variants.log 2>&1; tail -20 $OUT/variants.log ;;
     sizes)    timeout 1500 python -m pytest tests/test_gpu_baseline_sizes.py -q > $OUT/t_sizes.log 2>&1; tail -25 $OUT/t_sizes.log ;;
     overlay)  timeout 1200 python -m pytest tests/test_overlay.py -q -m gpu > $OUT/t_overlay.log 2>&1; tail -25 $OUT/t_overlay.log ;;

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Times the multi-scale RoIAlign forward of BASELINE config 2 under the forward routes (tvmi_set_option):
-per-roi (round-2 kernels only), planes (whole-plane levels staged, no bands), planes+bands, default (device-side decision),
-for 7x7 / 14x14, fp32 / bf16.  4 rotated input sets, HIP events.  usage: roi_variants.py out.json"""
+"""Times the multi-scale RoIAlign forward of BASELINE config 2 under the launch routes of the LDS-DMA kernels
+(tvmi_set_option: roi_align.pin_chunks / order / order_bands / tap_reads) for 7x7 / 14x14, fp32 / bf16, NCHW; plus the
+channels_last kernel.  4 rotated input sets, HIP events, every route timed `reps` times interleaved (min and median kept).
+usage: roi_variants.py out.json [route,route,...]"""
 import json
 import os
+import statistics
 import sys
 
 import torch
@@ -35,33 +37,53 @@ def tm(fn, n=24, warm=4):
     return e0.elapsed_time(e1) / n
 
 
-BASE = {"roi_align.shared_staging": 0, "roi_align.min_band_rows": 32, "roi_align.staging_gain_x16": 32,
-        "roi_align.stage_whole_planes": 1, "roi_align.band_channels": 2}
-FORCE = dict(BASE, **{"roi_align.shared_staging": 1, "roi_align.staging_gain_x16": 1 << 20})
+KEYS = ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands", "roi_align.tap_reads")
+SAVED = {k: int(torch.ops.tvmi.get_option(k)) for k in KEYS}
+
+
+def R(pin, order, bands, taps):
+    return dict(zip(KEYS, (pin, order, bands, taps)))
+
+
 ROUTES = {
-    "per-roi": dict(BASE, **{"roi_align.shared_staging": 0}),
-    "planes-only": dict(FORCE, **{"roi_align.min_band_rows": 0}),
-    "bands1-only": dict(FORCE, **{"roi_align.stage_whole_planes": 0, "roi_align.band_channels": 1}),          # P2 + P3 as 1-channel bands
-    "bands2-only": dict(FORCE, **{"roi_align.stage_whole_planes": 0, "roi_align.band_channels": 2, "roi_align.min_band_rows": 16}),
-    "planes+bands1": dict(FORCE, **{"roi_align.band_channels": 1}),
-    "planes+bands2": dict(FORCE, **{"roi_align.band_channels": 2, "roi_align.min_band_rows": 16}),
-    "auto": dict(BASE, **{"roi_align.shared_staging": 1}),
-    "default": dict(BASE),
+    "ranges": R(0, 0, 16, 0),
+    "pinned": R(1, 0, 16, 0),
+    "pinned+order1": R(1, 1, 1, 0),
+    "pinned+order4": R(1, 1, 4, 0),
+    "pinned+order16": R(1, 1, 16, 0),
+    "pinned+order64": R(1, 1, 64, 0),
+    "ranges+wide": R(0, 0, 16, 1),
+    "pinned+wide": R(1, 0, 16, 1),
+    "pinned+order16+wide": R(1, 1, 16, 1),
 }
 out = {}
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ROUTES)
+reps = 3
 for dt in (torch.float32, torch.bfloat16):
     fl = [[f.to(dt) for f in s["flist"]] for s in sets]
     for P in (7, 14):
+        args = (P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6)
+        acc = {name: [] for name in only}
+        for _ in range(reps):
+            for name in only:
+                for k, v in ROUTES[name].items():
+                    torch.ops.tvmi.set_option(k, v)
+                with torch.no_grad():
+                    acc[name].append(tm(lambda i: torch.ops.tvmi.multiscale_roi_align(fl[i % 4], sets[i % 4]["rois"], scales, *args)))
         for name in only:
-            for k, v in ROUTES[name].items():
-                torch.ops.tvmi.set_option(k, v)
-            args = (P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6)
-            with torch.no_grad():
-                ms = tm(lambda i: torch.ops.tvmi.multiscale_roi_align(fl[i % 4], sets[i % 4]["rois"], scales, *args))
-            out[f"{str(dt).split('.')[-1]}_{P}x{P}_{name}"] = round(ms, 4)
-            print(f"{dt} {P} {name}: {ms:.4f} ms", flush=True)
-for k, v in BASE.items():
+            key = f"{str(dt).split('.')[-1]}_{P}x{P}_{name}"
+            out[key] = {"min": round(min(acc[name]), 4), "median": round(statistics.median(acc[name]), 4)}
+            print(f"{key}: min {min(acc[name]):.4f} median {statistics.median(acc[name]):.4f} ms", flush=True)
+    if dt == torch.float32:
+        for k, v in SAVED.items():
+            torch.ops.tvmi.set_option(k, v)
+        flcl = [[f.contiguous(memory_format=torch.channels_last) for f in s] for s in fl]
+        with torch.no_grad():
+            ms = [tm(lambda i: torch.ops.tvmi.multiscale_roi_align(flcl[i % 4], sets[i % 4]["rois"], scales, 7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6)) for _ in range(reps)]
+        out["float32_7x7_channels_last"] = {"min": round(min(ms), 4), "median": round(statistics.median(ms), 4)}
+        print("float32_7x7_channels_last", out["float32_7x7_channels_last"], flush=True)
+        del flcl
+for k, v in SAVED.items():
     torch.ops.tvmi.set_option(k, v)
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -1219,6 +1219,14 @@ int set_dcn_option(const char* name, int64_t value) {
   }
   return -1;
 }
+
+int get_dcn_option(const char* name, int64_t* value) {
+  if (std::strcmp(name, "dcn.channels_last_gather") == 0) {
+    *value = g_cl_gather.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  return -1;
+}
 }  // namespace tvmi
 
 using namespace tvmi;

@@ -1641,6 +1641,16 @@ int set_nms_option(const char* name, int64_t value) {
   }
   return -1;
 }
+
+int get_nms_option(const char* name, int64_t* value) {
+  if (std::strcmp(name, "nms.replan_min_boxes") == 0) *value = (int64_t)g_replan_min_boxes.load(std::memory_order_relaxed);
+  else if (std::strcmp(name, "nms.replan_divisor") == 0) *value = g_replan_divisor.load(std::memory_order_relaxed);
+  else if (std::strcmp(name, "nms.device_handoff") == 0) *value = g_device_handoff.load(std::memory_order_relaxed) ? 1 : 0;
+  else if (std::strcmp(name, "nms.mask_lds_bytes") == 0) *value = g_mask_lds_bytes.load(std::memory_order_relaxed);
+  else if (std::strcmp(name, "nms.replan_max") == 0) *value = g_replan_max.load(std::memory_order_relaxed);
+  else return -1;
+  return 0;
+}
 }  // namespace tvmi
 
 extern "C" size_t tvmi_nms_workspace_bytes(int64_t n) {

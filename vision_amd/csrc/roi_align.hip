@@ -15,6 +15,8 @@
 //   * channels_last maps: lane = channel kernel (roi_align_fwd_nhwc), no layout copy;
 //   * fp64: one thread per output element, arithmetic on the fly.
 // Multi-scale (FPN) entries pick the level of every RoI in the kernel and serve all levels with one launch.
+#include <algorithm>
+#include <string>
 #include <type_traits>
 
 #include "roi_common.h"
@@ -573,7 +575,51 @@ __device__ __forceinline__ void dma_issue_pass(const T* __restrict__ in_pass, in
   }
 }
 
-template <typename T, int PHT, int PWT, int SRT, int NRG>
+// LDS accesses the COMPILER must not see (fp32 staged outputs).  An LDS-DMA is a pending LDS write on the VM counter, and
+// the waitcnt pass cannot tell the `stage` block from the DMA buffers: a plain C++ store into `stage` made it put
+// `s_waitcnt vmcnt(0)` in front of every channel's arithmetic — i.e. wait for the DMAs of the NEXT pass that had just been
+// issued, which serialised the double buffer (ISA of round 3: `s_waitcnt vmcnt(0) lgkmcnt(0)` in every pass loop; guarded
+// now by tests/test_isa_guards.py).  The wave's own program order already orders these accesses against each other, and
+// nothing DMA-written is ever touched here.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(lds_ptr_t)const_cast<void*>(p);
+}
+__device__ __forceinline__ void lds_store_f32_opaque(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4_t lds_load_f32x4_opaque(unsigned addr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ float lds_load_f32_opaque(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+// one 32-bit word of channels -> CPL floats
+template <typename T>
+__device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)sizeof(T)]) {
+  if constexpr (std::is_same<T, float>::value) {
+    v[0] = __builtin_bit_cast(float, w);
+  } else if constexpr (std::is_same<T, __half>::value) {
+    v[0] = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu)));
+    v[1] = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
+  } else {  // bfloat16: the upper half of an fp32
+    v[0] = __builtin_bit_cast(float, w << 16);
+    v[1] = __builtin_bit_cast(float, w & 0xffff0000u);
+  }
+}
+
+// TAPS = how a lane fetches the two horizontally adjacent floats of a bilinear tap pair from the window image:
+//   0  plain C++ loads, the whole bin computed under the lane mask so that the pair stays ONE ds_read2_b32
+//   1  (fp32) ONE ds_read_b64 per pair at 4-byte alignment — half the LDS cycles of a ds_read2_b32 when conflict-free
+//      (MI355X_MICROARCH.md, LDS table); the 2 * NS reads of a channel are issued back to back and retired by one wait;
+//      (fp16 / bf16) ONE ds_read_b32 per pair at 2-byte alignment instead of two ds_read_u16
+template <typename T, int PHT, int PWT, int SRT, int NRG, int TAPS>
 __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __restrict__ in0, T* __restrict__ out,
                                                      int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
                                                      const RoiGeom<float>& g,
@@ -615,25 +661,21 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   constexpr int SC = (kDmaStage * 4 / (int)sizeof(T)) / PHW >= 8 ? 8 : ((kDmaStage * 4 / (int)sizeof(T)) / PHW >= 2 ? 2 : 1);
   constexpr int kGroupVec = SC * PHW * (int)sizeof(T) / 16;          // 16-byte pieces of a full group
   static_assert(SC * PHW * (int)sizeof(T) % 16 == 0 && SC * PHW * (int)sizeof(T) <= kDmaStage * 4, "stage block");
-  T* const stage = reinterpret_cast<T*>(s.stage);
+  const unsigned stage_addr = lds_addr(s.stage);
   const bool vec_ok = (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // wave-uniform (the unit's output base)
   int staged = 0;                                                    // channels parked in the stage block
   auto flush = [&](int first_ch, int nch) {
-    asm volatile("" ::: "memory");
     if (nch == SC && vec_ok) {
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4* src = reinterpret_cast<const f32x4*>(stage);
-      f32x4* dst = reinterpret_cast<f32x4*>(out + (int64_t)first_ch * PHW);
+      f32x4_t* dst = reinterpret_cast<f32x4_t*>(out + (int64_t)first_ch * PHW);
 #pragma unroll
       for (int i = 0; i < (kGroupVec + 63) / 64; ++i) {
         const int v = lane + 64 * i;
-        if (v < kGroupVec) __builtin_nontemporal_store(src[v], dst + v);
+        if (v < kGroupVec) __builtin_nontemporal_store(lds_load_f32x4_opaque(stage_addr + 16u * (unsigned)v), dst + v);
       }
     } else {
-      for (int i = lane; i < nch * PHW; i += 64) out[(int64_t)first_ch * PHW + i] = stage[i];
+      for (int i = lane; i < nch * PHW; i += 64)
+        st(out + (int64_t)first_ch * PHW + i, lds_load_f32_opaque(stage_addr + 4u * (unsigned)i));
     }
-    // the reads above are complete before the block is written again
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   const int npass = (cc + G - 1) / G;
   if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
@@ -659,23 +701,80 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
       const T* wbase = cur + ch * (NRG * BLK);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        float acc = 0.f;
-#pragma unroll
-        for (int iy = 0; iy < SRT; ++iy) {
-#pragma unroll
-          for (int ix = 0; ix < SRT; ++ix) {
-            const T* q0 = wbase + off[b][iy * SRT + ix][0];
-            const T* q1 = wbase + off[b][iy * SRT + ix][1];
-            const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), mul_legacy(fx[b][ix][1], ld(q0)));   // x edge: 0 * (pixel W-2) = 0
-            const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), mul_legacy(fx[b][ix][1], ld(q1)));
-            acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-            acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
-          }
-        }
         const int bin = lane + 64 * b;
-        if (bin < PHW) {
+        // the WHOLE bin under the lane mask: loads hoisted above it were split off their pair partners
+        if (b + 1 < NB || bin < PHW) {
+          float acc = 0.f;
+          if constexpr (TAPS == 1 && sizeof(T) == 4) {
+            static_assert(NS == 4, "ds_read_b64 tap pairs: 2 x 2 samples");
+            const unsigned wb = lds_addr(wbase);
+            f32x2_t v[NS][2];
+            asm volatile(
+                "ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1]),
+                  "=&v"(v[3][0]), "=&v"(v[3][1])
+                : "v"(wb + 4u * (unsigned)off[b][0][0]), "v"(wb + 4u * (unsigned)off[b][0][1]),
+                  "v"(wb + 4u * (unsigned)off[b][1][0]), "v"(wb + 4u * (unsigned)off[b][1][1]),
+                  "v"(wb + 4u * (unsigned)off[b][2][0]), "v"(wb + 4u * (unsigned)off[b][2][1]),
+                  "v"(wb + 4u * (unsigned)off[b][3][0]), "v"(wb + 4u * (unsigned)off[b][3][1])
+                : "memory");
+#pragma unroll
+            for (int iy = 0; iy < SRT; ++iy) {
+#pragma unroll
+              for (int ix = 0; ix < SRT; ++ix) {
+                const f32x2_t a0 = v[iy * SRT + ix][0], a1 = v[iy * SRT + ix][1];
+                const float t0 = __builtin_fmaf(fx[b][ix][0], a0.y, mul_legacy(fx[b][ix][1], a0.x));   // x edge: 0 * (pixel W-2) = 0
+                const float t1 = __builtin_fmaf(fx[b][ix][0], a1.y, mul_legacy(fx[b][ix][1], a1.x));
+                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+              }
+            }
+          } else if constexpr (TAPS == 1 && sizeof(T) == 2) {
+            static_assert(NS == 4, "ds_read_b32 tap pairs: 2 x 2 samples");
+            const unsigned wb = lds_addr(wbase);
+            unsigned v[NS][2];
+            asm volatile(
+                "ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+                "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1]),
+                  "=&v"(v[3][0]), "=&v"(v[3][1])
+                : "v"(wb + 2u * (unsigned)off[b][0][0]), "v"(wb + 2u * (unsigned)off[b][0][1]),
+                  "v"(wb + 2u * (unsigned)off[b][1][0]), "v"(wb + 2u * (unsigned)off[b][1][1]),
+                  "v"(wb + 2u * (unsigned)off[b][2][0]), "v"(wb + 2u * (unsigned)off[b][2][1]),
+                  "v"(wb + 2u * (unsigned)off[b][3][0]), "v"(wb + 2u * (unsigned)off[b][3][1])
+                : "memory");
+#pragma unroll
+            for (int iy = 0; iy < SRT; ++iy) {
+#pragma unroll
+              for (int ix = 0; ix < SRT; ++ix) {
+                float a0[2], a1[2];
+                unpack_word<T>(v[iy * SRT + ix][0], a0);
+                unpack_word<T>(v[iy * SRT + ix][1], a1);
+                const float t0 = __builtin_fmaf(fx[b][ix][0], a0[1], mul_legacy(fx[b][ix][1], a0[0]));
+                const float t1 = __builtin_fmaf(fx[b][ix][0], a1[1], mul_legacy(fx[b][ix][1], a1[0]));
+                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int iy = 0; iy < SRT; ++iy) {
+#pragma unroll
+              for (int ix = 0; ix < SRT; ++ix) {
+                const T* q0 = wbase + off[b][iy * SRT + ix][0];
+                const T* q1 = wbase + off[b][iy * SRT + ix][1];
+                const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), mul_legacy(fx[b][ix][1], ld(q0)));   // x edge: 0 * (pixel W-2) = 0
+                const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), mul_legacy(fx[b][ix][1], ld(q1)));
+                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+              }
+            }
+          }
           const float r = kPow2 ? acc * inv_count : acc / (float)NS;
-          if constexpr (kStaged) stage[staged * PHW + bin] = r;
+          if constexpr (kStaged) lds_store_f32_opaque(stage_addr + 4u * (unsigned)(staged * PHW + bin), r);
           else st(out + (cg + ch) * PHW + bin, r);   // 16-bit outputs: sub-dword LDS writes cost more than the stores save (measured)
         }
       }
@@ -693,31 +792,7 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   if (kStaged && staged) flush(cc - staged, staged);
 }
 
-// A RoI the shared-staging kernel (roi_align_plane.hip) serves is not this kernel's: key >= 0 names its level, and the
-// level is active iff the pre-pass's window-pixel sums say so — the very rule and integers the other kernel uses.
-struct PlaneSkip {
-  const int* key;        // nullptr: no shared-staging launch ran
-  const int* blocksum;
-  PlanePlan plan;
-};
-
-__device__ __forceinline__ bool served_by_plane_kernel(const PlaneSkip& ps, const MsLevels& lv, int k) {
-  if (ps.key == nullptr) return false;
-  const int kv = __builtin_amdgcn_readfirstlane(ps.key[k]);
-  if (kv < 0) return false;
-  const int l = (kv >> 12) & 15;
-  const int lane = threadIdx.x & 63;
-  int v = lane < kPlanePreBlocks ? ps.blocksum[lane * kMaxLevels + l] : 0;
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  bool active = false;
-#pragma unroll
-  for (int i = 0; i < kMaxLevels; ++i)   // constant indices: a run-time index would put the by-value structs into scratch
-    if (i == l) active = plane_level_active(v, ps.plan.lv[i], ps.plan.gain_x16, ps.plan.N, lv.H[i], lv.W[i]);
-  return active;
-}
-
-template <typename T, typename R, int PHT, int PWT, int SRT>
+template <typename T, typename R, int PHT, int PWT, int SRT, int TAPS>
 __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
@@ -774,15 +849,15 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
       }
   }
   if (dw.nrg <= 1)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 1, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 2)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 3)   // 28 sampled rows of <= 5 pieces: three DMA instructions per channel, not four
-    roi_align_dma_passes<T, PHT, PWT, SRT, 3>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 3, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 4)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 4, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else
-    roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 8, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
@@ -801,29 +876,114 @@ __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* 
                                               k, c0, chunk);
 }
 
-// XCD-aware work placement.  Workgroup b is observed to run on XCD b % 8 (a speed assumption
-// only — nothing depends on it for correctness).  Each XCD gets a CONTIGUOUS range of RoIs and
-// walks it channel-chunk by channel-chunk, so at any moment an XCD's private 4 MiB L2 is asked
-// for one thin channel slice of the feature maps (which fits) by ALL of its RoIs, and the
-// overlap between neighbouring RoI windows turns into L2 hits instead of HBM re-reads.
-__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, int& k,
-                                          int& chunk_idx, int wpb = kThreads / 64) {
+// XCD-aware work placement.  Workgroup b is observed to run on XCD b % 8 (a speed assumption only — nothing depends on
+// it for correctness).  A unit is (RoI, channel chunk); two placements:
+//   pinned (nchunks a multiple of 8): XCD x owns the channel chunks {x, x + 8, ...} of EVERY RoI and walks the RoIs in
+//     `perm` order (roi_fwd_order: image, level, window rows — neighbours in that order overlap in the map and run at
+//     about the same time).  A byte of a feature map is then wanted by ONE private 4 MiB L2 only, and the slice that L2 is
+//     asked for at any moment is a channel chunk of a row band of one plane — the overlap between RoI windows turns into
+//     L2 hits instead of a second / third fetch by another XCD (the RoIPool forward does the same, roi_pool.hip).
+//   ranges (any chunk count): XCD x gets a contiguous range of RoIs and walks it chunk by chunk.
+struct UnitMap {
+  const int* perm;  // nullptr: identity
+  int pinned;
+};
+
+__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const UnitMap& um, int& k, int& chunk_idx,
+                                          int wpb = kThreads / 64) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   const int xcd = blockIdx.x & 7;
   const int64_t j = blockIdx.x >> 3;
+  const int64_t local = j * wpb + wave;
+  if (um.pinned) {
+    const int slot = (int)(local / K);
+    chunk_idx = xcd + 8 * slot;
+    if (chunk_idx >= nchunks) return false;
+    const int64_t kk = local - (int64_t)slot * K;
+    k = um.perm ? __builtin_amdgcn_readfirstlane(um.perm[kk]) : (int)kk;
+    return true;
+  }
   const int64_t kbase = K >> 3, krem = K & 7;
   const int64_t Kx = kbase + (xcd < krem ? 1 : 0);
   const int64_t kstart = xcd * kbase + (xcd < krem ? xcd : krem);
-  const int64_t local = j * wpb + wave;
   if (local >= Kx * nchunks) return false;
   chunk_idx = (int)(local / Kx);
-  k = (int)(kstart + (local - (int64_t)chunk_idx * Kx));
+  const int64_t kk = kstart + (local - (int64_t)chunk_idx * Kx);
+  k = um.perm ? __builtin_amdgcn_readfirstlane(um.perm[kk]) : (int)kk;
   return true;
 }
 
-inline unsigned wave_unit_grid(int64_t K, int nchunks, int wpb = kThreads / 64) {
-  const int64_t per_xcd = ceil_div(ceil_div(K, 8) * nchunks, wpb);
+inline bool unit_map_can_pin(int nchunks) { return nchunks >= 8 && nchunks % 8 == 0; }
+
+inline unsigned wave_unit_grid(int64_t K, int nchunks, bool pinned = false, int wpb = kThreads / 64) {
+  const int64_t per_xcd = pinned ? ceil_div(K * (nchunks / 8), wpb) : ceil_div(ceil_div(K, 8) * nchunks, wpb);
   return (unsigned)(8 * per_xcd);
+}
+
+// Launch order of the RoIs (forward, pinned placement): a one-workgroup counting sort by (image, level, window-top band).
+// Only the ORDER in which units start depends on it — never a result.  Buckets: N * L * bands <= kOrderBuckets.
+constexpr int kOrderThreads = 1024;
+constexpr int kOrderBuckets = 4096;
+constexpr int64_t kOrderMaxRois = 1 << 16;   // beyond that one workgroup is the wrong shape: identity order
+
+template <typename R>
+__global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, const R* __restrict__ rois, int K, int N,
+                                                                int multiscale, int bands, int* __restrict__ perm) {
+  __shared__ int hist[kOrderBuckets];
+  __shared__ int wsum[kOrderThreads / 64];
+  const int tid = threadIdx.x;
+  const int L = multiscale ? lv.n_levels : 1;
+  const int nb = N * L * bands;
+  for (int i = tid; i < nb; i += kOrderThreads) hist[i] = 0;
+  __syncthreads();
+  auto key_of = [&](int k) {
+    const R* r = rois + (int64_t)k * 5;
+    int l = 0;
+    if (multiscale) l = fpn_level<R>(r, lv);
+    int Hl = lv.H[0];
+    float sc = lv.scale[0];
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)   // constant indices: a run-time index would put the by-value struct into scratch
+      if (i == l) {
+        Hl = lv.H[i];
+        sc = lv.scale[i];
+      }
+    const float bf = (float)ld(r);
+    const int b = (bf == bf) ? min(max((int)bf, 0), N - 1) : 0;
+    const float y = (float)ld(r + 2) * sc;
+    int band = (y == y) ? (int)(fminf(fmaxf(y, 0.f), (float)(Hl - 1)) * (float)bands / (float)Hl) : 0;
+    band = min(max(band, 0), bands - 1);
+    return (b * L + l) * bands + band;
+  };
+  for (int k = tid; k < K; k += kOrderThreads) atomicAdd(&hist[key_of(k)], 1);
+  __syncthreads();
+  // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, wave totals
+  int c[4], tsum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid * 4 + i;
+    c[i] = idx < nb ? hist[idx] : 0;
+    tsum += c[i];
+  }
+  int incl = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += o;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+  int run = wbase + incl - tsum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid * 4 + i;
+    if (idx < nb) hist[idx] = run;
+    run += c[i];
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += kOrderThreads) perm[atomicAdd(&hist[key_of(k)], 1)] = k;
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -835,54 +995,39 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restri
   __shared__ WaveShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0}, k, ci)) return;
   const int c0 = ci * chunk;
   roi_align_wave_dispatch<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
                                                aligned, k, c0, chunk, declined);
 }
 
-template <typename T, int PHT, int PWT, int SRT>
+template <typename T, int PHT, int PWT, int SRT, int TAPS>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restrict__ input,
                                                               const T* __restrict__ rois, T* __restrict__ output,
                                                               int C, int H, int W, float spatial_scale, int aligned,
                                                               int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
-                                                              const int* __restrict__ plane_key, const int* __restrict__ plane_blocksum,
-                                                              PlaneLevel plane_level, int plane_gain_x16, int plane_N) {
+                                                              UnitMap um) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
-  if (plane_key != nullptr && __builtin_amdgcn_readfirstlane(plane_key[k]) >= 0) {  // single level: level 0 of the plan
-    const int lane = threadIdx.x & 63;
-    int v = lane < kPlanePreBlocks ? plane_blocksum[lane * kMaxLevels] : 0;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if (plane_level_active(v, plane_level, plane_gain_x16, plane_N, H, W)) {
-      if (ci == 0 && lane == 0) declined[k] = 0;
-      return;
-    }
-  }
-  roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
-                                              chunk, declined);
+  if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
+  roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT, TAPS>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
+                                                    chunk, declined);
 }
 
 // Multi-scale entries: RoIs are float32 image coordinates whatever the feature dtype (roi_common.h).
-template <typename T, int PHT, int PWT, int SRT>
+template <typename T, int PHT, int PWT, int SRT, int TAPS>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const float* __restrict__ rois,
                                                                  T* __restrict__ output, int C, int aligned,
                                                                  int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
-                                                                 PlaneSkip ps) {
+                                                                 UnitMap um) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
-  if (served_by_plane_kernel(ps, lv, k)) {
-    if (ci == 0 && (threadIdx.x & 63) == 0) declined[k] = 0;
-    return;
-  }
+  if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                                  lv.scale[l], aligned, k, ci * chunk, chunk, declined);
+  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT, TAPS>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
+                                                        lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, declined);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -893,20 +1038,45 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, c
   __shared__ WaveShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0}, k, ci)) return;
   const int c0 = ci * chunk;
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
   roi_align_wave_dispatch<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
                                                    lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, c0, chunk, declined);
 }
 
-// Workspace of the forward entries: [declined: K ints, padded to 16 bytes][shared-staging part: plane_workspace_bytes()].
-// A caller that passes only the first part gets the per-RoI kernels alone (the pre-round-3 behaviour).
+// Workspace of the forward entries: [declined: K ints, padded to 16 bytes][perm: K ints].  A caller that passes only the
+// first part gets the identity launch order; no workspace at all: the register-staged wave kernels alone.
 inline size_t fwd_declined_bytes(int64_t K) { return ((size_t)K * sizeof(int) + 15) & ~(size_t)15; }
-inline void* plane_part(void* ws, size_t ws_bytes, int64_t K, int64_t PH, int64_t PW, int64_t sr) {
-  const size_t need = plane_workspace_bytes(K, PH, PW, sr);
-  if (!ws || need == 0 || K >= (1 << 30) || ws_bytes < fwd_declined_bytes(K) + need) return nullptr;
-  return static_cast<char*>(ws) + fwd_declined_bytes(K);
+inline int* perm_part(void* ws, size_t ws_bytes, int64_t K) {
+  if (!ws || K <= 0 || K > kOrderMaxRois || ws_bytes < 2 * fwd_declined_bytes(K)) return nullptr;
+  return reinterpret_cast<int*>(static_cast<char*>(ws) + fwd_declined_bytes(K));
+}
+
+// Process-wide switches of the forward (tvmi_set_option): measured defaults, the other settings stay reachable for the
+// variant table of DESIGN.md §4.1 and for tests that force every route.
+struct FwdOptions {
+  int pin_chunks = 1;   // "roi_align.pin_chunks": channel chunks pinned to XCDs when the chunk count allows it
+  int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
+  int taps = 0;         // "roi_align.tap_reads": 0 ds_read2_b32 pairs, 1 ds_read_b64 pairs (fp32 DMA kernels)
+  int bands = 16;       // "roi_align.order_bands": window-top bands per (image, level) in the order key
+};
+FwdOptions g_fwd_opt;
+
+// Decides placement and order for one launch; launches the order pre-pass when it is used.
+template <typename R>
+UnitMap plan_units(const MsLevels& lv, const R* rois, int64_t N, int64_t K, int nchunks, int multiscale, bool have_declined,
+                   int* perm, hipStream_t stream) {
+  UnitMap um{nullptr, 0};
+  if (!have_declined || !g_fwd_opt.pin_chunks || !unit_map_can_pin(nchunks)) return um;
+  um.pinned = 1;
+  const int64_t L = multiscale ? lv.n_levels : 1;
+  if (g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets) {
+    const int bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * L)));
+    roi_fwd_order<R><<<dim3(1), dim3(kOrderThreads), 0, stream>>>(lv, rois, (int)K, (int)N, multiscale, bands, perm);
+    um.perm = perm;
+  }
+  return um;
 }
 
 int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, const int64_t* widths, const double* scales,
@@ -934,7 +1104,7 @@ constexpr int kMopChunk = 64;   // channels per unit of the launch that mops up 
 template <typename T>
 int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int* declined, void* plane_ws, hipStream_t stream) {
+               int* declined, int* perm, hipStream_t stream) {
   const T* in = static_cast<const T*>(input);
   const T* r = static_cast<const T*>(rois);
   T* out = static_cast<T*>(output);
@@ -947,34 +1117,26 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
     const float fs = (float)scale;
     const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
     const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
-    const dim3 grid(wave_unit_grid(K, nchunks)), mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
-    // shared staging of the map (roi_align_plane.hip) for the RoIs / shapes it serves; this launcher keeps the rest
-    const int* pkey = nullptr;
-    const int* pblocksum = nullptr;
-    PlanePlan plan;
-    plan.lv[0] = PlaneLevel{0, 1, 1, 1, 1, 1, 1, 0, 0};
-    plan.gain_x16 = 0;
-    plan.N = (int)N;
-    if (declined && plane_ws) {
+    const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
+    UnitMap um{nullptr, 0};
+    if (fast_shape && declined) {
       MsLevels one;
       const void* ptrs[1] = {input};
       const int64_t hs[1] = {H}, ws_[1] = {W};
       const double sc[1] = {scale};
       fill_levels(one, ptrs, hs, ws_, sc, 1, 0, 0, 1.0, 0.0, 0.0);
-      plan = make_plane_plan(one, N, C, K, (int)sizeof(T), PH, PW, sr);
-      if (plan.total_blocks > 0) {
-        const PlaneBuffers pb = plane_buffers(plane_ws, K);
-        const int st = launch_plane<T, T>(one, plan, rois, output, C, K, PH, aligned, /*multiscale=*/0, pb, stream);
-        if (st != 0) return st;
-        pkey = pb.key;
-        pblocksum = pb.blocksum;
-      }
+      um = plan_units<T>(one, r, N, K, nchunks, /*multiscale=*/0, true, perm, stream);
     }
+    const dim3 dma_grid(wave_unit_grid(K, nchunks, um.pinned != 0)), grid(wave_unit_grid(K, nchunks)),
+        mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
+    const bool b64 = g_fwd_opt.taps == 1;
+#define TVMI_FWD_DMA(PHT, PWT, SRT, TAPS)                                                                           \
+  roi_align_fwd_dma<T, PHT, PWT, SRT, TAPS><<<dma_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, aligned, \
+                                                                            nchunks, kUnitChunk, nunits, declined, um)
 #define TVMI_FWD(PHT, PWT, SRT)                                                                                   \
   if (declined) {                                                                                                 \
-    roi_align_fwd_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, aligned, \
-                                                                    nchunks, kUnitChunk, nunits, declined, pkey,  \
-                                                                    pblocksum, plan.lv[0], plan.gain_x16, plan.N); \
+    if (b64) TVMI_FWD_DMA(PHT, PWT, SRT, 1);                                               \
+    else TVMI_FWD_DMA(PHT, PWT, SRT, 0);                                                                          \
     roi_align_fwd_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH, \
                                                                          (int)PW, fs, (int)sr, aligned, mop_nchunks, \
                                                                          kMopChunk, mop_nunits, declined);        \
@@ -991,6 +1153,7 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
                                                                  (int)sr, aligned, nchunks, kUnitChunk, nunits, nullptr);
     }
 #undef TVMI_FWD
+#undef TVMI_FWD_DMA
   }
   TVMI_RETURN_LAUNCH_STATUS("tvmi_roi_align_forward");
 }
@@ -1012,20 +1175,6 @@ struct NhwcShared {
   T t[64 * (4 / (int)sizeof(T)) * (PHT * PWT)];
 };
 
-// one 32-bit word of channels -> CPL floats
-template <typename T>
-__device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)sizeof(T)]) {
-  if constexpr (std::is_same<T, float>::value) {
-    v[0] = __builtin_bit_cast(float, w);
-  } else if constexpr (std::is_same<T, __half>::value) {
-    v[0] = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu)));
-    v[1] = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
-  } else {  // bfloat16: the upper half of an fp32
-    v[0] = __builtin_bit_cast(float, w << 16);
-    v[1] = __builtin_bit_cast(float, w & 0xffff0000u);
-  }
-}
-
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const float* __restrict__ rois,
                                                                T* __restrict__ output, int C, int aligned,
@@ -1038,7 +1187,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int k, gi;
-  if (!wave_unit(nunits / ngroups, ngroups, k, gi)) return;
+  if (!wave_unit(nunits / ngroups, ngroups, UnitMap{nullptr, 0}, k, gi)) return;
   const int c0 = gi * GC;
   // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
   const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
@@ -1164,30 +1313,24 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
 
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH,
-                  int64_t PW, int64_t sr, int aligned, int* declined, void* plane_ws, hipStream_t stream) {
+                  int64_t PW, int64_t sr, int aligned, int* declined, int* perm, hipStream_t stream) {
   const float* r = static_cast<const float*>(rois);
   T* out = static_cast<T*>(output);
   const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
   const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
-  const dim3 grid(wave_unit_grid(K, nchunks)), mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
-  // shared staging of the maps (roi_align_plane.hip) first; the wave kernel below keeps what that one does not serve
-  PlaneSkip ps;
-  ps.key = nullptr;
-  ps.blocksum = nullptr;
-  if (declined && plane_ws) {
-    ps.plan = make_plane_plan(lv, N, C, K, (int)sizeof(T), PH, PW, sr);
-    if (ps.plan.total_blocks > 0) {
-      const PlaneBuffers pb = plane_buffers(plane_ws, K);
-      const int st = launch_plane<T, float>(lv, ps.plan, rois, output, C, K, PH, aligned, /*multiscale=*/1, pb, stream);
-      if (st != 0) return st;
-      ps.key = pb.key;
-      ps.blocksum = pb.blocksum;
-    }
-  }
+  const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
+  UnitMap um{nullptr, 0};
+  if (fast_shape && declined) um = plan_units<float>(lv, r, N, K, nchunks, /*multiscale=*/1, true, perm, stream);
+  const dim3 dma_grid(wave_unit_grid(K, nchunks, um.pinned != 0)), grid(wave_unit_grid(K, nchunks)),
+      mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
+  const bool b64 = g_fwd_opt.taps == 1;
+#define TVMI_MS_DMA(PHT, PWT, SRT, TAPS)                                                                            \
+  roi_align_fwd_ms_dma<T, PHT, PWT, SRT, TAPS><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
+                                                                               nunits, declined, um)
 #define TVMI_MS(PHT, PWT, SRT)                                                                                      \
   if (declined) {                                                                                                   \
-    roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
-                                                                       nunits, declined, ps);                       \
+    if (b64) TVMI_MS_DMA(PHT, PWT, SRT, 1);                                                  \
+    else TVMI_MS_DMA(PHT, PWT, SRT, 0);                                                                             \
     roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
                                                                             aligned, mop_nchunks, kMopChunk, mop_nunits, \
                                                                             declined);                              \
@@ -1203,19 +1346,53 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
                                                                   nchunks, kUnitChunk, nunits, nullptr);
   }
 #undef TVMI_MS
+#undef TVMI_MS_DMA
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward");
 }
 
 }  // namespace
+
+int set_roi_option(const char* name, int64_t value) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "roi_align.pin_chunks") g_fwd_opt.pin_chunks = value != 0;
+  else if (n == "roi_align.order") g_fwd_opt.order = value != 0;
+  else if (n == "roi_align.tap_reads") g_fwd_opt.taps = value == 1 ? 1 : 0;
+  else if (n == "roi_align.order_bands") g_fwd_opt.bands = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
+  else return -1;
+  return 0;
+}
+
+int get_roi_option(const char* name, int64_t* value) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "roi_align.pin_chunks") *value = g_fwd_opt.pin_chunks;
+  else if (n == "roi_align.order") *value = g_fwd_opt.order;
+  else if (n == "roi_align.tap_reads") *value = g_fwd_opt.taps;
+  else if (n == "roi_align.order_bands") *value = g_fwd_opt.bands;
+  else return -1;
+  return 0;
+}
+
 }  // namespace tvmi
 
 extern "C" size_t tvmi_roi_align_forward_workspace_bytes(int64_t K, int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio) {
   if (K <= 0) return 0;
-  return tvmi::fwd_declined_bytes(K) + tvmi::plane_workspace_bytes(K, pooled_h, pooled_w, sampling_ratio);
+  (void)pooled_h; (void)pooled_w; (void)sampling_ratio;
+  return 2 * tvmi::fwd_declined_bytes(K);   // [declined][perm]
+}
+
+extern "C" int tvmi_get_option(const char* name, int64_t* value) {
+  if (name && value) {
+    if (tvmi::get_roi_option(name, value) == 0) return 0;
+    if (tvmi::get_nms_option(name, value) == 0) return 0;
+    if (tvmi::get_dcn_option(name, value) == 0) return 0;
+  }
+  return tvmi::set_error((int)hipErrorInvalidValue, "tvmi_get_option: unknown option");
 }
 
 extern "C" int tvmi_set_option(const char* name, int64_t value) {
-  if (tvmi::set_plane_option(name, value) == 0) return 0;
+  if (tvmi::set_roi_option(name, value) == 0) return 0;
   if (tvmi::set_nms_option(name, value) == 0) return 0;
   if (tvmi::set_dcn_option(name, value) == 0) return 0;
   return tvmi::set_error((int)hipErrorInvalidValue, "tvmi_set_option: unknown option");
@@ -1228,7 +1405,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
                                       void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
   int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
-  void* plane_ws = tvmi::plane_part(workspace, workspace_bytes, K, pooled_h, pooled_w, sampling_ratio);
+  int* perm = tvmi::perm_part(workspace, workspace_bytes, K);
   TVMI_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0, "roi_align: negative size");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(input && rois && output, "roi_align: null pointer");
@@ -1238,7 +1415,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
   TVMI_DISPATCH_FLOAT(dt, "roi_align_forward",
                       return tvmi::launch_fwd<scalar_t>(input, rois, output, N, C, H, W, K, pooled_h,
                                                         pooled_w, spatial_scale, sampling_ratio,
-                                                        aligned, declined, plane_ws, s));
+                                                        aligned, declined, perm, s));
   return 0;
 }
 
@@ -1263,15 +1440,15 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
   tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
-  void* plane_ws = tvmi::plane_part(workspace, workspace_bytes, K, pooled_h, pooled_w, sampling_ratio);
+  int* perm = tvmi::perm_part(workspace, workspace_bytes, K);
   switch (dt) {
     case TVMI_F32:
-      return tvmi::launch_ms_fwd<float>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, plane_ws, s);
+      return tvmi::launch_ms_fwd<float>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s);
     case TVMI_F16:
-      return tvmi::launch_ms_fwd<__half>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, plane_ws, s);
+      return tvmi::launch_ms_fwd<__half>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s);
     default:
       return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined,
-                                                 plane_ws, s);
+                                                 perm, s);
   }
 }
 

@@ -72,19 +72,17 @@ __device__ __forceinline__ bool axis_sample(int dim, A start, A bin, int grid, i
 // (0, 1) — the same value, and lo + 1 is always inside the map.
 __device__ __forceinline__ bool axis_sample_shifted(int dim, float start, float bin, int grid, int p, int i, int& lo,
                                                     float& l, float& h) {
-  int hi;
-  const bool v = axis_sample<float>(dim, start, bin, grid, p, i, lo, hi, l, h);
-  if (!v) {
-    lo = 0;
-    l = h = 0.f;
-    return false;
-  }
-  if (lo > dim - 2) {  // lo == dim-1: value is in[dim-1]
-    lo = dim - 2;
-    l = 1.f;
-    h = 0.f;
-  }
-  return true;
+  // branch-free on purpose: written with early returns / conditional stores through the references, the compiler kept
+  // {l, h} in a SCRATCH pair addressed by a run-time offset, and the scratch loads' vmcnt dependency then forced a
+  // `s_waitcnt vmcnt(0)` into the DMA kernels' double-buffered channel loop (guarded by tests/test_isa_guards.py)
+  int lo_, hi_;
+  float l_, h_;
+  const bool v = axis_sample<float>(dim, start, bin, grid, p, i, lo_, hi_, l_, h_);
+  const bool edge = lo_ > dim - 2;  // lo == dim-1: value is in[dim-1]
+  lo = v ? (edge ? dim - 2 : lo_) : 0;
+  l = v ? (edge ? 1.f : l_) : 0.f;
+  h = v ? (edge ? 0.f : h_) : 0.f;
+  return v;
 }
 
 // v_mul_legacy_f32 (0 * x = 0 for every x, NaN and Inf included) as the LLVM intrinsic itself — clang 22 has no builtin
@@ -120,53 +118,10 @@ __device__ __forceinline__ int fpn_level(const R* roi, const MsLevels& lv) {
   return min(max(l, 0), lv.n_levels - 1);
 }
 
-// ---------------------------------------------------------------------------------------
-// Shared-staging forward (roi_align_plane.hip): plan of which levels are served by staging the MAP (whole planes or
-// half-overlapping row bands) instead of every RoI's window, computed on the host from the level shapes alone.
-constexpr int kPlaneThreads = 512;              // 8 waves per workgroup, two workgroups per CU
-constexpr int kPlaneImageBytes = 74 * 1024;     // staged band of one workgroup: [16-byte zero cell][band] per channel
-constexpr int kPlaneListCap = 1024;             // RoIs of one (image, level, band) listed in LDS (4 KB next to the band)
-constexpr int kPlanePreThreads = 1024;          // pre-pass block
-constexpr int kPlanePreBlocks = 64;             // pre-pass grid cap = number of per-block window-pixel sums
-
-constexpr int plane_lanes_per_roi(int PH, int PW, int SR) { return (PH + PW) * SR <= 32 ? 32 : 64; }
-
-struct PlaneLevel {
-  int enabled;
-  int B, S, nbands;       // band rows, band stride (rows), bands per plane (1: the whole plane)
-  int cg, ngroups;        // channels per workgroup, channel groups
-  int nsplit;             // workgroups that share one staged band's RoI list (entry e goes to split e % nsplit)
-  int block_base, nblocks;
-};
-
-struct PlanePlan {
-  PlaneLevel lv[kMaxLevels];
-  int total_blocks;
-  int N;
-  int gain_x16;
-};
-
-struct PlaneBuffers {
-  int* key;        // [K]  (image << 16 | level << 12 | band) of a RoI the shared-staging kernel may serve, else -1
-  int* blocksum;   // [kPlanePreBlocks][kMaxLevels] window pixels the eligible RoIs of a level would stage one by one
-  float2* axis;    // [K][LP] {low index or -1, fraction} of every axis sample
-};
-
-// The device-side rule both forward kernels apply to the same integers: a level is served by staging the map when the
-// RoIs' own windows add up to more than the map (x overlap of the bands), weighted by `gain` — short row fragments cost
-// the texture path ~2.4 accesses per useful 64 bytes, full rows one.
-__host__ __device__ inline bool plane_level_active(int window_px, const PlaneLevel& pl, int gain_x16, int N, int H, int W) {
-  const long long map_px = (long long)N * H * W * (pl.nbands > 1 ? 2 : 1);
-  return pl.enabled != 0 && (long long)window_px * gain_x16 >= map_px * 16;
-}
-
-PlanePlan make_plane_plan(const MsLevels& lv, int64_t N, int64_t C, int64_t K, int esize, int64_t PH, int64_t PW, int64_t sr);
-size_t plane_workspace_bytes(int64_t K, int64_t PH, int64_t PW, int64_t sr);
-PlaneBuffers plane_buffers(void* ws, int64_t K);
-template <typename T, typename R>
-int launch_plane(const MsLevels& lv, const PlanePlan& plan, const void* rois, void* output, int64_t C, int64_t K, int64_t PH,
-                 int aligned, int multiscale, const PlaneBuffers& pb, hipStream_t s);
-int set_plane_option(const char* name, int64_t value);
+int set_roi_option(const char* name, int64_t value);  // roi_align.hip
+int get_roi_option(const char* name, int64_t* value);
+int get_nms_option(const char* name, int64_t* value);
+int get_dcn_option(const char* name, int64_t* value);
 int set_nms_option(const char* name, int64_t value);  // nms.hip
 int set_dcn_option(const char* name, int64_t value);  // deform_conv2d.hip
 

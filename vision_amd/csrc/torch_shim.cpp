@@ -1068,6 +1068,12 @@ int64_t tvmi_abi_version() {
   TORCH_CHECK(tvmi_version() == TVMI_ABI_VERSION, "libtvmi_kernels.so has ABI ", tvmi_version(), ", the glue was built for ", TVMI_ABI_VERSION);
   return tvmi_version();
 }
+int64_t tvmi_get_option_op(const std::string& name) {
+  int64_t v = 0;
+  check_status(tvmi_get_option(name.c_str(), &v), "get_option");
+  return v;
+}
+
 bool tvmi_set_option_op(const std::string& name, int64_t value) {
   check_status(tvmi_set_option(name.c_str(), value), "set_option");
   return true;
@@ -1110,6 +1116,7 @@ TORCH_LIBRARY_FRAGMENT(torchvision, m) {
 // loops in the reference); they live in their own namespace.
 TORCH_LIBRARY(tvmi, m) {
   m.def("abi_version", &tvmi_abi_version);
+  m.def("get_option", &tvmi_get_option_op);
   m.def("set_option", &tvmi_set_option_op);   // process-wide kernel switches (include/tvmi.h: tvmi_set_option)
   // opt-in: our resize kernels on the CUDA key of aten::upsample_* (returns the previous state)
   m.def("override_aten_upsample", &upsample_override::set);
