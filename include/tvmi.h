@@ -45,8 +45,6 @@ int tvmi_version(void);
  *   "roi_align.order"            1 (default) / 0: with pinned chunks, RoIs start in (image, level, window-top band) order
  *                                (a one-workgroup counting sort in front of the launch; needs the forward workspace)
  *   "roi_align.order_bands"      bands per (image, level) in that order key (default 16, 1..64)
- *   "roi_align.tap_reads"        0 / 1: a bilinear tap pair leaves LDS as one ds_read2_b32 (two ds_read_u16 for 16-bit maps) /
- *                                as ONE ds_read_b64 (ds_read_b32) at element alignment
  *   "dcn.channels_last_gather"   1 (default) / 0: the 16-bit MFMA deform_conv2d kernel samples a [B, H*W, C] copy of the input
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)

@@ -4,9 +4,9 @@
   ranges          pin_chunks 0             -> every XCD walks a contiguous RoI range chunk by chunk (the round-1..3 placement)
   pinned          pin_chunks 1, order 0    -> channel chunks pinned to XCDs, identity RoI order
   pinned+order    pin_chunks 1, order 1    -> + the (image, level, window-top band) launch order of roi_fwd_order
-  ... each with tap_reads 0 (ds_read2_b32 pairs) and 1 (one ds_read_b64 / ds_read_b32 per pair at 4- / 2-byte alignment)
+  ... with 1 / 16 / 64 window-top bands in the order key
 
-Placement and order only change WHEN a unit runs, tap_reads only how two adjacent floats leave LDS: all routes must agree
+Placement and order only change WHEN a unit runs: all routes must agree
 BIT FOR BIT with each other and with the oracle at 1e-4 (fp32).  Channel counts are chosen so that the pinned placement is
 really taken (a multiple of 8 chunks of 32 channels) and, in other tests, really refused.  Also pinned here: what a NaN / Inf
 pixel does next to a zero-weight tap."""
@@ -25,12 +25,11 @@ DEV = "cuda"
 TOL = 1e-4
 
 ROUTES = {
-    "ranges": {"roi_align.pin_chunks": 0, "roi_align.order": 0, "roi_align.tap_reads": 0},
-    "pinned": {"roi_align.pin_chunks": 1, "roi_align.order": 0, "roi_align.tap_reads": 0},
-    "pinned+order": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.tap_reads": 0},
-    "pinned+order1band": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.tap_reads": 0, "roi_align.order_bands": 1},
-    "ranges+wide": {"roi_align.pin_chunks": 0, "roi_align.order": 0, "roi_align.tap_reads": 1},
-    "pinned+order+wide": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.tap_reads": 1, "roi_align.order_bands": 64},
+    "ranges": {"roi_align.pin_chunks": 0, "roi_align.order": 0},
+    "pinned": {"roi_align.pin_chunks": 1, "roi_align.order": 0},
+    "pinned+order": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 16},
+    "pinned+order1band": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 1},
+    "pinned+order64bands": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 64},
 }
 
 
@@ -41,7 +40,7 @@ class route:
         self.opts = ROUTES[name]
 
     def __enter__(self):
-        self.saved = {k: int(torch.ops.tvmi.get_option(k)) for k in ("roi_align.pin_chunks", "roi_align.order", "roi_align.tap_reads", "roi_align.order_bands")}
+        self.saved = {k: int(torch.ops.tvmi.get_option(k)) for k in ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands")}
         for k, v in self.opts.items():
             assert torch.ops.tvmi.set_option(k, v)
 
@@ -106,7 +105,7 @@ def test_multiscale_all_routes_agree_with_the_reference(P, aligned, C):
         sel = torch.nonzero(levels == lvl)[:, 0]
         assert sel.numel() > 0
         ref = _ref(feats[str(lvl)], r5[sel], scales[lvl], P, aligned)
-        np.testing.assert_allclose(outs["pinned+order+wide"][sel].numpy(), ref, rtol=0, atol=TOL, err_msg=f"level {lvl}")
+        np.testing.assert_allclose(outs["pinned+order64bands"][sel].numpy(), ref, rtol=0, atol=TOL, err_msg=f"level {lvl}")
 
 
 def test_launch_order_is_a_permutation_and_survives_bad_rois():
@@ -126,7 +125,7 @@ def test_launch_order_is_a_permutation_and_survives_bad_rois():
     rois = rois.to(DEV)
     scales = [1.0, 0.5, 0.25, 0.125]
     res = {}
-    for name in ("ranges", "pinned+order", "pinned+order1band", "pinned+order+wide"):
+    for name in ROUTES:
         with route(name), torch.no_grad():
             res[name] = torch.ops.tvmi.multiscale_roi_align(flist, rois, scales, 7, 7, 2, False, 0, 3, 56.0, 2.0, 1e-6).cpu()
     fin = torch.isfinite(res["ranges"])
@@ -168,7 +167,7 @@ def test_schema_op_all_routes_on_awkward_maps(tv, H, W):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 5e-3)])
 def test_routes_16bit(tv, dtype, tol):
-    """fp16 / bf16 maps (8 elements per 16-byte piece; tap pairs as two ds_read_u16 or ONE 2-byte-aligned ds_read_b32), single
+    """fp16 / bf16 maps (8 elements per 16-byte piece), single
     level with 16-bit RoIs and multi-scale with fp32 RoIs: every route equal to the range placement bit for bit, and within
     the reference's 16-bit bar of fp32."""
     g = gen(77)
@@ -181,7 +180,7 @@ def test_routes_16bit(tv, dtype, tol):
             res[name] = tv.roi_align(x.to(DEV), rois.to(DEV), 1 / 16, 7, 7, 2, False).cpu()
         assert res[name].dtype == dtype and torch.equal(res[name], res["ranges"]), name
     ref = _ref(x.float(), rois.float(), 1 / 16, 7)
-    np.testing.assert_allclose(res["pinned+order+wide"].float().numpy(), ref, rtol=tol, atol=tol)
+    np.testing.assert_allclose(res["pinned+order64bands"].float().numpy(), ref, rtol=tol, atol=tol)
     feats = [torch.rand(N, 256, 400 // s, 672 // s, generator=g).to(dtype).to(DEV) for s in (4, 8, 16, 32)]
     boxes = torch.cat([torch.cat([torch.full((200, 1), float(i)), random_boxes(200, 672, 400, 8, 300, g)], 1) for i in range(N)]).to(DEV)
     res = {}
@@ -214,7 +213,7 @@ def test_nonfinite_pixels_next_to_zero_weight_taps(tv):
     # bins whose samples all sit on the last column / row are finite in the reference (it reads pixel dim-1 only)
     assert np.isfinite(ref[0, :, :, 6]).any() or np.isfinite(ref[0, :, 6, :]).any()
     results = {}
-    for name in ("ranges", "pinned+order+wide"):      # the per-RoI LDS-DMA kernel + its mop-up (RoI 1 has skipped samples), both tap read forms
+    for name in ("ranges", "pinned+order64bands"):      # the per-RoI LDS-DMA kernel + its mop-up (RoI 1 has skipped samples)
         with route(name):
             results[name] = tv.roi_align(xb.to(DEV), rois.to(DEV), 1.0, 7, 7, 2, False).cpu().numpy()
     # the channels_last kernel (reached through the multi-scale op; one level)

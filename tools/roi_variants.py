@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the multi-scale RoIAlign forward of BASELINE config 2 under the launch routes of the LDS-DMA kernels
-(tvmi_set_option: roi_align.pin_chunks / order / order_bands / tap_reads) for 7x7 / 14x14, fp32 / bf16, NCHW; plus the
+(tvmi_set_option: roi_align.pin_chunks / order / order_bands) for 7x7 / 14x14, fp32 / bf16, NCHW; plus the
 channels_last kernel.  4 rotated input sets, HIP events, every route timed `reps` times interleaved (min and median kept).
 usage: roi_variants.py out.json [route,route,...]"""
 import json
@@ -37,24 +37,20 @@ def tm(fn, n=24, warm=4):
     return e0.elapsed_time(e1) / n
 
 
-KEYS = ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands", "roi_align.tap_reads")
+KEYS = ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands")
 SAVED = {k: int(torch.ops.tvmi.get_option(k)) for k in KEYS}
 
 
-def R(pin, order, bands, taps):
-    return dict(zip(KEYS, (pin, order, bands, taps)))
+def R(pin, order, bands):
+    return dict(zip(KEYS, (pin, order, bands)))
 
 
 ROUTES = {
-    "ranges": R(0, 0, 16, 0),
-    "pinned": R(1, 0, 16, 0),
-    "pinned+order1": R(1, 1, 1, 0),
-    "pinned+order4": R(1, 1, 4, 0),
-    "pinned+order16": R(1, 1, 16, 0),
-    "pinned+order64": R(1, 1, 64, 0),
-    "ranges+wide": R(0, 0, 16, 1),
-    "pinned+wide": R(1, 0, 16, 1),
-    "pinned+order16+wide": R(1, 1, 16, 1),
+    "ranges": R(0, 0, 16),
+    "pinned": R(1, 0, 16),
+    "pinned+order1": R(1, 1, 1),
+    "pinned+order16": R(1, 1, 16),
+    "pinned+order64": R(1, 1, 64),
 }
 out = {}
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ROUTES)

@@ -498,8 +498,16 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // sits on the last row/column (where the reference uses x_high = x_low with weight 0) is
 // re-expressed on the pair (dim-2, dim-1) with factors (0, 1) — the same value, never an
 // out-of-row read; the window is shifted left when it would run past the row end.
+// n / d for 0 <= n < 1024 and 1 <= d <= 64 as a multiply-shift: m = ceil(65536 / d) (v_rcp_f32 is exact for powers of two — the
+// only d with an integral 65536 / d — and its 1-ulp error is far below the 1/64 that separates any other quotient from an integer),
+// and n * m >> 16 = floor(n / d) because n * (m - 65536 / d) / 65536 < 1 / d.  The unit set-up divides by two wave-uniform
+// run-time values (pieces per row, rows per DMA instruction) seven times per lane: 2 reciprocals instead of 7 u32 divisions.
+__device__ __forceinline__ unsigned small_div_magic(int d) { return (unsigned)ceilf(65536.f * __builtin_amdgcn_rcpf((float)d)); }
+__device__ __forceinline__ int small_div(int n, unsigned m) { return (int)(((unsigned)n * m) >> 16); }
+
 struct DmaWindow {
   int state, y0, x0, wh, nq, lpr, rpi, nrg;
+  unsigned m_lpr, m_rpi;   // small_div_magic of lpr / rpi
   int sparse;  // 1: the LDS image holds only the SAMPLED rows — slot 2s / 2s+1 = low / high tap row of y-sample s
 };
 
@@ -511,6 +519,7 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   DmaWindow w;
   w.state = 2;
   w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = w.sparse = 0;
+  w.m_lpr = w.m_rpi = 0;
   if (H < 2 || W < EPP) return w;
   int lo = 0, hi = 0, lo2 = 0;
   float l, h;
@@ -545,7 +554,9 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   if (w.x0 < 0) return w;               // map narrower than the window image
   w.lpr = w.nq | 1;
   if (w.lpr > 64) return w;
-  w.rpi = 64 / w.lpr;
+  w.m_lpr = small_div_magic(w.lpr);
+  w.rpi = small_div(64, w.m_lpr);
+  w.m_rpi = small_div_magic(w.rpi);
   // A window taller than 2 rows per y-sample contains rows no sample touches (bins > 2 px): stage only the
   // sampled rows.  The kernel is bound by the bytes that cross L2 -> L1, and this drops ~1/3 of them on the
   // FPN workload (and pulls RoIs that were too tall for 8 DMA blocks per channel back onto this path).
@@ -553,13 +564,14 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
     w.sparse = 1;
     w.wh = 2 * ny;
   }
-  w.nrg = (w.wh + w.rpi - 1) / w.rpi;
+  w.nrg = small_div(w.wh + w.rpi - 1, w.m_rpi);
   // 1 = DMA path (<= 8 DMA instructions per channel), 2 = register-staged / global-gather path
   w.state = w.nrg <= 2 * kDmaPerPass ? 1 : 2;
   return w;
 }
 
 constexpr int kDmaBlkBytes = kDmaBlk * 4;  // 1040
+constexpr int kMopHeader = 4;              // worklist of declined RoIs: [count, -, -, -][RoI indices ...]
 
 template <typename T, int NRG>
 __device__ __forceinline__ void dma_issue_pass(const T* __restrict__ in_pass, int64_t plane_sz, int gc,
@@ -586,8 +598,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(lds_ptr_t)const_cast<void*>(p);
 }
+template <int IMM = 0>
 __device__ __forceinline__ void lds_store_f32_opaque(unsigned addr, float v) {
-  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
 }
 __device__ __forceinline__ f32x4_t lds_load_f32x4_opaque(unsigned addr) {
   f32x4_t v;
@@ -614,12 +627,10 @@ __device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)size
   }
 }
 
-// TAPS = how a lane fetches the two horizontally adjacent floats of a bilinear tap pair from the window image:
-//   0  plain C++ loads, the whole bin computed under the lane mask so that the pair stays ONE ds_read2_b32
-//   1  (fp32) ONE ds_read_b64 per pair at 4-byte alignment — half the LDS cycles of a ds_read2_b32 when conflict-free
-//      (MI355X_MICROARCH.md, LDS table); the 2 * NS reads of a channel are issued back to back and retired by one wait;
-//      (fp16 / bf16) ONE ds_read_b32 per pair at 2-byte alignment instead of two ds_read_u16
-template <typename T, int PHT, int PWT, int SRT, int NRG, int TAPS>
+// (Measured and removed, round 4: a tap pair as ONE ds_read_b64 at 4-byte alignment — or one 2-byte-aligned ds_read_b32 for
+// the 16-bit types — is correct on gfx950 but 2.6x slower for the whole launch, 0.68 vs 0.26 ms: misaligned LDS reads are
+// replayed; profiles/r04_roi_variants_v1.json.)
+template <typename T, int PHT, int PWT, int SRT, int NRG>
 __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __restrict__ in0, T* __restrict__ out,
                                                      int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
                                                      const RoiGeom<float>& g,
@@ -630,14 +641,14 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   constexpr int NB = (PHW + 63) / 64;
   constexpr int NS = SRT * SRT;
   constexpr int EPP = 16 / (int)sizeof(T);
-  constexpr int BLK = kDmaBlkBytes / (int)sizeof(T);  // elements per DMA block incl. skew
   constexpr bool kDouble = NRG <= kDmaPerPass;        // 8 row groups use both buffers as one
   constexpr int G = kDouble ? kDmaPerPass / NRG : 1;
   constexpr bool kPow2 = (NS & (NS - 1)) == 0;
   const float inv_count = 1.f / (float)NS;
   const int lane = threadIdx.x & 63;
-  const int rsub = min(lane / dw.lpr, dw.rpi - 1);
-  const int q = min(lane - (lane / dw.lpr) * dw.lpr, dw.nq - 1);
+  const int lrow = small_div(lane, dw.m_lpr);
+  const int rsub = min(lrow, dw.rpi - 1);
+  const int q = min(lane - lrow * dw.lpr, dw.nq - 1);
   const int gx = dw.x0 + EPP * q;
   char* const bytes = reinterpret_cast<char*>(s.buf);
   int goff[NRG];
@@ -677,105 +688,71 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
         st(out + (int64_t)first_ch * PHW + i, lds_load_f32_opaque(stage_addr + 4u * (unsigned)i));
     }
   };
-  const int npass = (cc + G - 1) / G;
-  if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
-  for (int p = 0; p < npass; ++p) {
-    const int cg = p * G;
-    const int gc = min(G, cc - cg);
-    const T* cur;
-    if (kDouble) {
-      if (p + 1 < npass) {
-        dma_issue_pass<T, NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
-                               bytes + ((p + 1) & 1) * (kDmaBuf * 4));
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NRG) : "memory");  // everything older than the DMAs just issued has landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      cur = reinterpret_cast<const T*>(bytes + (p & 1) * (kDmaBuf * 4));
-    } else {
-      dma_issue_pass<T, NRG>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, bytes);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      cur = reinterpret_cast<const T*>(bytes);
-    }
+  // Tap-pair LDS addresses.  With ONE channel per pass (NRG >= 3) and one bin per lane (7 x 7) the byte address of every
+  // pair is a per-unit constant for each of the two buffers: both sets are formed once (16 VGPRs) and the channel loop
+  // carries no address arithmetic at all; otherwise the wave-uniform (buffer, channel) base is added per pair.
+  constexpr bool kPreAddr = NB == 1 && G == 1;
+  constexpr int NBUF = kDouble ? 2 : 1;
+  typedef const __attribute__((address_space(3))) T* lds_cptr_t;
+  unsigned tap[kPreAddr ? NBUF : 1][NB][NS][2];
+  if constexpr (kPreAddr) {
+    const unsigned base = lds_addr(bytes);
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          tap[u][b][i][0] = base + (unsigned)(u * kDmaBuf * 4) + (unsigned)sizeof(T) * (unsigned)off[b][i][0];
+          tap[u][b][i][1] = base + (unsigned)(u * kDmaBuf * 4) + (unsigned)sizeof(T) * (unsigned)off[b][i][1];
+        }
+  }
+  const unsigned st_lane = stage_addr + 4u * (unsigned)lane;   // this lane's slot of channel 0 in the stage block (bin b: + 256 b)
+  // one pass = gc channels of buffer `buf` (compile-time in the pre-addressed form)
+  auto run_channels = [&](auto buf_tag, int cg, int gc, unsigned dyn_base) {
+    constexpr int BUF = decltype(buf_tag)::value;
     for (int ch = 0; ch < gc; ++ch) {
-      const T* wbase = cur + ch * (NRG * BLK);
+      const unsigned chan = dyn_base + (unsigned)(ch * (NRG * kDmaBlkBytes));   // wave-uniform; unused when pre-addressed
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int bin = lane + 64 * b;
         // the WHOLE bin under the lane mask: loads hoisted above it were split off their pair partners
         if (b + 1 < NB || bin < PHW) {
           float acc = 0.f;
-          if constexpr (TAPS == 1 && sizeof(T) == 4) {
-            static_assert(NS == 4, "ds_read_b64 tap pairs: 2 x 2 samples");
-            const unsigned wb = lds_addr(wbase);
-            f32x2_t v[NS][2];
-            asm volatile(
-                "ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
-                "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1]),
-                  "=&v"(v[3][0]), "=&v"(v[3][1])
-                : "v"(wb + 4u * (unsigned)off[b][0][0]), "v"(wb + 4u * (unsigned)off[b][0][1]),
-                  "v"(wb + 4u * (unsigned)off[b][1][0]), "v"(wb + 4u * (unsigned)off[b][1][1]),
-                  "v"(wb + 4u * (unsigned)off[b][2][0]), "v"(wb + 4u * (unsigned)off[b][2][1]),
-                  "v"(wb + 4u * (unsigned)off[b][3][0]), "v"(wb + 4u * (unsigned)off[b][3][1])
-                : "memory");
 #pragma unroll
-            for (int iy = 0; iy < SRT; ++iy) {
+          for (int iy = 0; iy < SRT; ++iy) {
 #pragma unroll
-              for (int ix = 0; ix < SRT; ++ix) {
-                const f32x2_t a0 = v[iy * SRT + ix][0], a1 = v[iy * SRT + ix][1];
-                const float t0 = __builtin_fmaf(fx[b][ix][0], a0.y, mul_legacy(fx[b][ix][1], a0.x));   // x edge: 0 * (pixel W-2) = 0
-                const float t1 = __builtin_fmaf(fx[b][ix][0], a1.y, mul_legacy(fx[b][ix][1], a1.x));
-                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
+            for (int ix = 0; ix < SRT; ++ix) {
+              const int i = iy * SRT + ix;
+              // integer -> LDS pointer -> generic pointer: the address-space inference turns the loads back into ds_reads
+              const T *q0, *q1;
+              if constexpr (kPreAddr) {
+                q0 = (const T*)reinterpret_cast<lds_cptr_t>((uintptr_t)tap[BUF][b][i][0]);
+                q1 = (const T*)reinterpret_cast<lds_cptr_t>((uintptr_t)tap[BUF][b][i][1]);
+              } else {
+                const T* wbase = reinterpret_cast<const T*>(bytes + chan);
+                q0 = wbase + off[b][i][0];
+                q1 = wbase + off[b][i][1];
               }
-            }
-          } else if constexpr (TAPS == 1 && sizeof(T) == 2) {
-            static_assert(NS == 4, "ds_read_b32 tap pairs: 2 x 2 samples");
-            const unsigned wb = lds_addr(wbase);
-            unsigned v[NS][2];
-            asm volatile(
-                "ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
-                "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[2][0]), "=&v"(v[2][1]),
-                  "=&v"(v[3][0]), "=&v"(v[3][1])
-                : "v"(wb + 2u * (unsigned)off[b][0][0]), "v"(wb + 2u * (unsigned)off[b][0][1]),
-                  "v"(wb + 2u * (unsigned)off[b][1][0]), "v"(wb + 2u * (unsigned)off[b][1][1]),
-                  "v"(wb + 2u * (unsigned)off[b][2][0]), "v"(wb + 2u * (unsigned)off[b][2][1]),
-                  "v"(wb + 2u * (unsigned)off[b][3][0]), "v"(wb + 2u * (unsigned)off[b][3][1])
-                : "memory");
-#pragma unroll
-            for (int iy = 0; iy < SRT; ++iy) {
-#pragma unroll
-              for (int ix = 0; ix < SRT; ++ix) {
-                float a0[2], a1[2];
-                unpack_word<T>(v[iy * SRT + ix][0], a0);
-                unpack_word<T>(v[iy * SRT + ix][1], a1);
-                const float t0 = __builtin_fmaf(fx[b][ix][0], a0[1], mul_legacy(fx[b][ix][1], a0[0]));
-                const float t1 = __builtin_fmaf(fx[b][ix][0], a1[1], mul_legacy(fx[b][ix][1], a1[0]));
-                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int iy = 0; iy < SRT; ++iy) {
-#pragma unroll
-              for (int ix = 0; ix < SRT; ++ix) {
-                const T* q0 = wbase + off[b][iy * SRT + ix][0];
-                const T* q1 = wbase + off[b][iy * SRT + ix][1];
-                const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), mul_legacy(fx[b][ix][1], ld(q0)));   // x edge: 0 * (pixel W-2) = 0
-                const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), mul_legacy(fx[b][ix][1], ld(q1)));
-                acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-                acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
-              }
+              const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), mul_legacy(fx[b][ix][1], ld(q0)));   // x edge: 0 * (pixel W-2) = 0
+              const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), mul_legacy(fx[b][ix][1], ld(q1)));
+              acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
+              acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
             }
           }
           const float r = kPow2 ? acc * inv_count : acc / (float)NS;
-          if constexpr (kStaged) lds_store_f32_opaque(stage_addr + 4u * (unsigned)(staged * PHW + bin), r);
-          else st(out + (cg + ch) * PHW + bin, r);   // 16-bit outputs: sub-dword LDS writes cost more than the stores save (measured)
+          if constexpr (kStaged) {
+            const unsigned sa = st_lane + (unsigned)(staged * (PHW * 4));
+            if (b == 0) lds_store_f32_opaque<0>(sa, r);
+            else if (b == 1) lds_store_f32_opaque<256>(sa, r);
+            else if (b == 2) lds_store_f32_opaque<512>(sa, r);
+            else lds_store_f32_opaque<768>(sa, r);
+          } else {
+            st(out + (cg + ch) * PHW + bin, r);   // 16-bit outputs: sub-dword LDS writes cost more than the stores save (measured)
+          }
+          // 14 x 14: one bin's 16 taps at a time — with the four bins of a lane interleaved the kernel needs > 128 VGPRs and
+          // loses the fourth wave per SIMD the LDS footprint allows
+          if constexpr (NB > 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (kStaged) {
@@ -785,6 +762,31 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
         }
       }
     }
+  };
+  const int npass = (cc + G - 1) / G;
+  if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
+  for (int p = 0; p < npass; ++p) {
+    const int cg = p * G;
+    const int gc = min(G, cc - cg);
+    if (kDouble) {
+      if (p + 1 < npass) {
+        dma_issue_pass<T, NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
+                               bytes + ((p + 1) & 1) * (kDmaBuf * 4));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NRG) : "memory");  // everything older than the DMAs just issued has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if constexpr (kPreAddr) {
+        if (p & 1) run_channels(std::integral_constant<int, NBUF - 1>{}, cg, gc, 0u);
+        else run_channels(std::integral_constant<int, 0>{}, cg, gc, 0u);
+      } else {
+        run_channels(std::integral_constant<int, 0>{}, cg, gc, (unsigned)((p & 1) * (kDmaBuf * 4)));
+      }
+    } else {
+      dma_issue_pass<T, NRG>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, bytes);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      run_channels(std::integral_constant<int, 0>{}, cg, gc, 0u);
+    }
     // the ds_reads above are complete (their results were consumed) before the next DMAs may
     // overwrite this buffer
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -792,7 +794,7 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   if (kStaged && staged) flush(cc - staged, staged);
 }
 
-template <typename T, typename R, int PHT, int PWT, int SRT, int TAPS>
+template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
@@ -809,8 +811,10 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
   const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
   const int64_t plane_sz = (int64_t)H * W;
   const DmaWindow dw = dma_window<PHT, PWT, SRT, EPP>(g, H, W);
-  if (c0 == 0 && lane == 0) declined[k] = dw.state == 2;  // tells the fallback launch what is left
-  if (dw.state == 2) return;
+  if (dw.state == 2) {  // left to the mop-up launch: one worklist entry per RoI (the wave of channel chunk 0 reports it)
+    if (c0 == 0 && lane == 0) declined[kMopHeader + atomicAdd(declined, 1)] = k;
+    return;
+  }
   if (dw.state == 0) {
     for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
     return;
@@ -833,8 +837,9 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
       fy[b][i][1] = h;
       const int r = dw.sparse ? 2 * (ph * SRT + i) : (vy ? lo - dw.y0 : 0);
       const int r1 = dw.sparse ? r + 1 : r + (hi - lo);   // bottom edge: the high tap row IS the low one, like the reference
-      rlo[i][0] = (r / dw.rpi) * BLK + (r % dw.rpi) * rstride;
-      rlo[i][1] = (r1 / dw.rpi) * BLK + (r1 % dw.rpi) * rstride;
+      const int g0 = small_div(r, dw.m_rpi), g1 = small_div(r1, dw.m_rpi);
+      rlo[i][0] = g0 * BLK + (r - g0 * dw.rpi) * rstride;
+      rlo[i][1] = g1 * BLK + (r1 - g1 * dw.rpi) * rstride;
       const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
       fx[b][i][0] = l;
       fx[b][i][1] = h;
@@ -849,26 +854,23 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
       }
   }
   if (dw.nrg <= 1)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 1, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 2)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 2, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 3)   // 28 sampled rows of <= 5 pieces: three DMA instructions per channel, not four
-    roi_align_dma_passes<T, PHT, PWT, SRT, 3, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 3>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else if (dw.nrg <= 4)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 4, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else
-    roi_align_dma_passes<T, PHT, PWT, SRT, 8, TAPS>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* __restrict__ input,
                                                         const R* __restrict__ rois, T* __restrict__ output, int C,
                                                         int H, int W, int PH_, int PW_, float spatial_scale, int sr_,
-                                                        int aligned, int k, int c0, int chunk,
-                                                        const int* __restrict__ declined) {
+                                                        int aligned, int k, int c0, int chunk) {
   if constexpr (PHT > 0 && PWT > 0 && SRT > 0) {
-    // when the DMA launch ran first, this launch only mops up what it declined
-    if (declined && declined[k] == 0) return;
     roi_align_fwd_wave_fast<T, R, PHT, PWT, SRT>(s, input, rois, output, C, H, W, spatial_scale, aligned, k, c0, chunk);
   }
   else
@@ -921,41 +923,78 @@ inline unsigned wave_unit_grid(int64_t K, int nchunks, bool pinned = false, int 
 }
 
 // Launch order of the RoIs (forward, pinned placement): a one-workgroup counting sort by (image, level, window-top band).
-// Only the ORDER in which units start depends on it — never a result.  Buckets: N * L * bands <= kOrderBuckets.
+// Only the ORDER in which units start depends on it — never a result — so the key uses the hardware's approximate
+// log2 / reciprocal (the kernels that compute results evaluate the reference's level formula exactly, roi_common.h).
+// Keys and in-bucket ranks stay in registers between the histogram and the scatter (kOrderPerThread RoIs per thread up to
+// 4096 RoIs; beyond that the key is re-evaluated).  Also clears the mop-up worklist counter of the launch that follows.
+// Buckets: N * L * bands <= kOrderBuckets.
 constexpr int kOrderThreads = 1024;
 constexpr int kOrderBuckets = 4096;
+constexpr int kOrderPerThread = 4;
 constexpr int64_t kOrderMaxRois = 1 << 16;   // beyond that one workgroup is the wrong shape: identity order
 
 template <typename R>
 __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, const R* __restrict__ rois, int K, int N,
-                                                                int multiscale, int bands, int* __restrict__ perm) {
+                                                                int multiscale, int bands, int* __restrict__ perm,
+                                                                int* __restrict__ mop_counter) {
   __shared__ int hist[kOrderBuckets];
   __shared__ int wsum[kOrderThreads / 64];
+  __shared__ float band_scale[kMaxLevels];   // window-top row (level pixels) -> band index
+  __shared__ float lvl_scale[kMaxLevels];
   const int tid = threadIdx.x;
   const int L = multiscale ? lv.n_levels : 1;
   const int nb = N * L * bands;
   for (int i = tid; i < nb; i += kOrderThreads) hist[i] = 0;
-  __syncthreads();
-  auto key_of = [&](int k) {
-    const R* r = rois + (int64_t)k * 5;
-    int l = 0;
-    if (multiscale) l = fpn_level<R>(r, lv);
-    int Hl = lv.H[0];
+  if (tid < kMaxLevels) {
     float sc = lv.scale[0];
+    int Hl = lv.H[0];
 #pragma unroll
     for (int i = 1; i < kMaxLevels; ++i)   // constant indices: a run-time index would put the by-value struct into scratch
-      if (i == l) {
-        Hl = lv.H[i];
+      if (i == tid) {
         sc = lv.scale[i];
+        Hl = lv.H[i];
       }
-    const float bf = (float)ld(r);
+    lvl_scale[tid] = sc;
+    band_scale[tid] = sc * (float)bands * __builtin_amdgcn_rcpf((float)max(Hl, 1));
+  }
+  if (tid == 0 && mop_counter) *mop_counter = 0;
+  __syncthreads();
+  const float inv_s0 = __builtin_amdgcn_rcpf(lv.s0);
+  auto key_of = [&](float bf, float x1, float y1, float x2, float y2) {
+    int l = 0;
+    if (multiscale) {
+      // floor(lvl0 + log2(sqrt(area) / s0) + eps), approximately: v_log_f32 of the area, halved
+      float t = floorf(lv.lvl0 + 0.5f * __builtin_amdgcn_logf((x2 - x1) * (y2 - y1) * inv_s0 * inv_s0) + lv.eps);
+      t = fminf(fmaxf(t, (float)lv.k_min), (float)lv.k_max);
+      l = (t == t) ? min(max((int)t - lv.k_min, 0), L - 1) : 0;
+    }
     const int b = (bf == bf) ? min(max((int)bf, 0), N - 1) : 0;
-    const float y = (float)ld(r + 2) * sc;
-    int band = (y == y) ? (int)(fminf(fmaxf(y, 0.f), (float)(Hl - 1)) * (float)bands / (float)Hl) : 0;
-    band = min(max(band, 0), bands - 1);
+    const float yb = y1 * band_scale[l];
+    const int band = (yb == yb) ? min(max((int)yb, 0), bands - 1) : 0;
     return (b * L + l) * bands + band;
   };
-  for (int k = tid; k < K; k += kOrderThreads) atomicAdd(&hist[key_of(k)], 1);
+  auto load_key = [&](int k) {
+    const R* r = rois + (int64_t)k * 5;
+    return key_of((float)ld(r), (float)ld(r + 1), (float)ld(r + 2), (float)ld(r + 3), (float)ld(r + 4));
+  };
+  const bool in_regs = K <= kOrderThreads * kOrderPerThread;
+  int key[kOrderPerThread], rank[kOrderPerThread];
+  if (in_regs) {
+    float v[kOrderPerThread][5];
+#pragma unroll
+    for (int j = 0; j < kOrderPerThread; ++j) {       // all loads of the thread in flight together
+      const int k = min(tid + j * kOrderThreads, K - 1);
+#pragma unroll
+      for (int e = 0; e < 5; ++e) v[j][e] = (float)ld(rois + (int64_t)k * 5 + e);
+    }
+#pragma unroll
+    for (int j = 0; j < kOrderPerThread; ++j) {
+      key[j] = key_of(v[j][0], v[j][1], v[j][2], v[j][3], v[j][4]);
+      rank[j] = (tid + j * kOrderThreads < K) ? atomicAdd(&hist[key[j]], 1) : 0;
+    }
+  } else {
+    for (int k = tid; k < K; k += kOrderThreads) atomicAdd(&hist[load_key(k)], 1);
+  }
   __syncthreads();
   // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, wave totals
   int c[4], tsum = 0;
@@ -974,7 +1013,13 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
   if ((tid & 63) == 63) wsum[tid >> 6] = incl;
   __syncthreads();
   int wbase = 0;
-  for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+  {
+    const int w = tid >> 6;
+    int part = (tid & 63) < w ? wsum[tid & 15] : 0;   // the totals of the waves in front: a butterfly instead of a serial walk
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
+    wbase = part;
+  }
   int run = wbase + incl - tsum;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -983,7 +1028,27 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
     run += c[i];
   }
   __syncthreads();
-  for (int k = tid; k < K; k += kOrderThreads) perm[atomicAdd(&hist[key_of(k)], 1)] = k;
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < kOrderPerThread; ++j) {
+      const int k = tid + j * kOrderThreads;
+      if (k < K) perm[hist[key[j]] + rank[j]] = k;
+    }
+  } else {
+    for (int k = tid; k < K; k += kOrderThreads) perm[atomicAdd(&hist[load_key(k)], 1)] = k;
+  }
+}
+
+// Mop-up launch: a FIXED small grid whose waves walk the worklist the DMA launch filled (RoI x channel chunk units).
+// With an empty list — the usual case — every wave reads one word and leaves.
+constexpr int kMopBlocks = 512;
+__device__ __forceinline__ bool mop_unit(const int* __restrict__ mop, int nchunks, int64_t& u, int& k, int& ci) {
+  const int n = __builtin_amdgcn_readfirstlane(mop[0]);
+  if (u >= (int64_t)n * nchunks) return false;
+  const int e = (int)(u / nchunks);
+  ci = (int)(u - (int64_t)e * nchunks);
+  k = __builtin_amdgcn_readfirstlane(mop[kMopHeader + e]);
+  return true;
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -991,66 +1056,81 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restri
                                                                T* __restrict__ output, int C, int H, int W, int PH_,
                                                                int PW_, float spatial_scale, int sr_, int aligned,
                                                                int nchunks, int chunk, int64_t nunits,
-                                                               const int* __restrict__ declined) {
+                                                               const int* __restrict__ mop) {
   __shared__ WaveShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
+  if (mop) {   // mop-up form: fixed grid, the waves stride over the worklist
+    for (int64_t u = (int64_t)blockIdx.x * (kThreads / 64) + wave; mop_unit(mop, nchunks, u, k, ci); u += (int64_t)gridDim.x * (kThreads / 64))
+      roi_align_wave_dispatch<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
+                                                   aligned, k, ci * chunk, chunk);
+    return;
+  }
   if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0}, k, ci)) return;
-  const int c0 = ci * chunk;
   roi_align_wave_dispatch<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
-                                               aligned, k, c0, chunk, declined);
+                                               aligned, k, ci * chunk, chunk);
 }
 
-template <typename T, int PHT, int PWT, int SRT, int TAPS>
+template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restrict__ input,
                                                               const T* __restrict__ rois, T* __restrict__ output,
                                                               int C, int H, int W, float spatial_scale, int aligned,
-                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
+                                                              int nchunks, int chunk, int64_t nunits, int* __restrict__ mop,
                                                               UnitMap um) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
-  roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT, TAPS>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
-                                                    chunk, declined);
+  roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
+                                              chunk, mop);
 }
 
 // Multi-scale entries: RoIs are float32 image coordinates whatever the feature dtype (roi_common.h).
-template <typename T, int PHT, int PWT, int SRT, int TAPS>
+template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, const float* __restrict__ rois,
                                                                  T* __restrict__ output, int C, int aligned,
-                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ declined,
+                                                                 int nchunks, int chunk, int64_t nunits, int* __restrict__ mop,
                                                                  UnitMap um) {
   __shared__ DmaShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT, TAPS>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
-                                                        lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, declined);
+  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
+                                                  lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, const float* __restrict__ rois,
                                                                   T* __restrict__ output, int C, int PH_, int PW_,
                                                                   int sr_, int aligned, int nchunks, int chunk,
-                                                                  int64_t nunits, const int* __restrict__ declined) {
+                                                                  int64_t nunits, const int* __restrict__ mop) {
   __shared__ WaveShared s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
+  if (mop) {
+    for (int64_t u = (int64_t)blockIdx.x * (kThreads / 64) + wave; mop_unit(mop, nchunks, u, k, ci); u += (int64_t)gridDim.x * (kThreads / 64)) {
+      const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+      roi_align_wave_dispatch<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
+                                                       lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, ci * chunk, chunk);
+    }
+    return;
+  }
   if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0}, k, ci)) return;
-  const int c0 = ci * chunk;
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
   roi_align_wave_dispatch<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
-                                                   lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, c0, chunk, declined);
+                                                   lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, ci * chunk, chunk);
 }
 
-// Workspace of the forward entries: [declined: K ints, padded to 16 bytes][perm: K ints].  A caller that passes only the
-// first part gets the identity launch order; no workspace at all: the register-staged wave kernels alone.
-inline size_t fwd_declined_bytes(int64_t K) { return ((size_t)K * sizeof(int) + 15) & ~(size_t)15; }
+// Workspace of the forward entries: [mop-up worklist: kMopHeader + K ints, padded to 16 bytes][perm: K ints].  A caller
+// that passes only the first part gets the identity launch order; no workspace at all: the register-staged wave kernels alone.
+inline size_t fwd_mop_bytes(int64_t K) { return ((size_t)(K + kMopHeader) * sizeof(int) + 15) & ~(size_t)15; }
+inline int* mop_part(void* ws, size_t ws_bytes, int64_t K) {
+  return (ws && K > 0 && K < (1 << 30) && ws_bytes >= fwd_mop_bytes(K)) ? static_cast<int*>(ws) : nullptr;
+}
 inline int* perm_part(void* ws, size_t ws_bytes, int64_t K) {
-  if (!ws || K <= 0 || K > kOrderMaxRois || ws_bytes < 2 * fwd_declined_bytes(K)) return nullptr;
-  return reinterpret_cast<int*>(static_cast<char*>(ws) + fwd_declined_bytes(K));
+  if (!ws || K <= 0 || K > kOrderMaxRois || ws_bytes < fwd_mop_bytes(K) + (size_t)K * sizeof(int)) return nullptr;
+  return reinterpret_cast<int*>(static_cast<char*>(ws) + fwd_mop_bytes(K));
 }
 
 // Process-wide switches of the forward (tvmi_set_option): measured defaults, the other settings stay reachable for the
@@ -1058,26 +1138,9 @@ inline int* perm_part(void* ws, size_t ws_bytes, int64_t K) {
 struct FwdOptions {
   int pin_chunks = 1;   // "roi_align.pin_chunks": channel chunks pinned to XCDs when the chunk count allows it
   int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
-  int taps = 0;         // "roi_align.tap_reads": 0 ds_read2_b32 pairs, 1 ds_read_b64 pairs (fp32 DMA kernels)
   int bands = 16;       // "roi_align.order_bands": window-top bands per (image, level) in the order key
 };
 FwdOptions g_fwd_opt;
-
-// Decides placement and order for one launch; launches the order pre-pass when it is used.
-template <typename R>
-UnitMap plan_units(const MsLevels& lv, const R* rois, int64_t N, int64_t K, int nchunks, int multiscale, bool have_declined,
-                   int* perm, hipStream_t stream) {
-  UnitMap um{nullptr, 0};
-  if (!have_declined || !g_fwd_opt.pin_chunks || !unit_map_can_pin(nchunks)) return um;
-  um.pinned = 1;
-  const int64_t L = multiscale ? lv.n_levels : 1;
-  if (g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets) {
-    const int bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * L)));
-    roi_fwd_order<R><<<dim3(1), dim3(kOrderThreads), 0, stream>>>(lv, rois, (int)K, (int)N, multiscale, bands, perm);
-    um.perm = perm;
-  }
-  return um;
-}
 
 int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, const int64_t* widths, const double* scales,
                 int64_t n_levels, int64_t k_min, int64_t k_max, double s0, double lvl0, double eps) {
@@ -1097,6 +1160,22 @@ int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, c
   return 0;
 }
 
+// Decides placement and order for one launch of the DMA kernels and clears the mop-up worklist counter — in the order
+// pre-pass when that runs, with a 4-byte memset otherwise.
+template <typename R>
+int plan_units(UnitMap& um, const MsLevels& lv, const R* rois, int64_t N, int64_t K, int nchunks, int multiscale, int* mop,
+               int* perm, hipStream_t stream) {
+  um = UnitMap{nullptr, 0};
+  um.pinned = (g_fwd_opt.pin_chunks && unit_map_can_pin(nchunks)) ? 1 : 0;
+  const int64_t L = multiscale ? lv.n_levels : 1;
+  if (um.pinned && g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets) {
+    const int bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * L)));
+    roi_fwd_order<R><<<dim3(1), dim3(kOrderThreads), 0, stream>>>(lv, rois, (int)K, (int)N, multiscale, bands, perm, mop);
+    um.perm = perm;
+    return 0;
+  }
+  return (int)hipMemsetAsync(mop, 0, sizeof(int), stream);
+}
 
 constexpr int kUnitChunk = 32;  // channels per wave unit
 constexpr int kMopChunk = 64;   // channels per unit of the launch that mops up what the DMA kernel declined (almost always empty)
@@ -1104,7 +1183,7 @@ constexpr int kMopChunk = 64;   // channels per unit of the launch that mops up 
 template <typename T>
 int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int64_t C, int64_t H,
                int64_t W, int64_t K, int64_t PH, int64_t PW, double scale, int64_t sr, int aligned,
-               int* declined, int* perm, hipStream_t stream) {
+               int* mop, int* perm, hipStream_t stream) {
   const T* in = static_cast<const T*>(input);
   const T* r = static_cast<const T*>(rois);
   T* out = static_cast<T*>(output);
@@ -1119,27 +1198,26 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
     const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
     const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
     UnitMap um{nullptr, 0};
-    if (fast_shape && declined) {
+    if (fast_shape && mop) {
       MsLevels one;
       const void* ptrs[1] = {input};
       const int64_t hs[1] = {H}, ws_[1] = {W};
       const double sc[1] = {scale};
       fill_levels(one, ptrs, hs, ws_, sc, 1, 0, 0, 1.0, 0.0, 0.0);
-      um = plan_units<T>(one, r, N, K, nchunks, /*multiscale=*/0, true, perm, stream);
+      const int st = plan_units<T>(um, one, r, N, K, nchunks, /*multiscale=*/0, mop, perm, stream);
+      if (st != 0) return set_error(st, "tvmi_roi_align_forward: clearing the worklist failed");
     }
     const dim3 dma_grid(wave_unit_grid(K, nchunks, um.pinned != 0)), grid(wave_unit_grid(K, nchunks)),
-        mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
-    const bool b64 = g_fwd_opt.taps == 1;
-#define TVMI_FWD_DMA(PHT, PWT, SRT, TAPS)                                                                           \
-  roi_align_fwd_dma<T, PHT, PWT, SRT, TAPS><<<dma_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, aligned, \
-                                                                            nchunks, kUnitChunk, nunits, declined, um)
+        mop_grid((unsigned)std::min<int64_t>(kMopBlocks, ceil_div(mop_nunits, kThreads / 64))), block(kThreads);
+#define TVMI_FWD_DMA(PHT, PWT, SRT)                                                                                 \
+  roi_align_fwd_dma<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, fs, aligned, \
+                                                                            nchunks, kUnitChunk, nunits, mop, um)
 #define TVMI_FWD(PHT, PWT, SRT)                                                                                   \
-  if (declined) {                                                                                                 \
-    if (b64) TVMI_FWD_DMA(PHT, PWT, SRT, 1);                                               \
-    else TVMI_FWD_DMA(PHT, PWT, SRT, 0);                                                                          \
+  if (mop) {                                                                                                 \
+    TVMI_FWD_DMA(PHT, PWT, SRT);                                                                                  \
     roi_align_fwd_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH, \
                                                                          (int)PW, fs, (int)sr, aligned, mop_nchunks, \
-                                                                         kMopChunk, mop_nunits, declined);        \
+                                                                         kMopChunk, mop_nunits, mop);             \
   } else                                                                                                          \
     roi_align_fwd_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(in, r, out, (int)C, (int)H, (int)W, (int)PH,  \
                                                                      (int)PW, fs, (int)sr, aligned, nchunks,      \
@@ -1313,27 +1391,28 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
 
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH,
-                  int64_t PW, int64_t sr, int aligned, int* declined, int* perm, hipStream_t stream) {
+                  int64_t PW, int64_t sr, int aligned, int* mop, int* perm, hipStream_t stream) {
   const float* r = static_cast<const float*>(rois);
   T* out = static_cast<T*>(output);
   const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
   const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
   const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
   UnitMap um{nullptr, 0};
-  if (fast_shape && declined) um = plan_units<float>(lv, r, N, K, nchunks, /*multiscale=*/1, true, perm, stream);
+  if (fast_shape && mop) {
+    const int st = plan_units<float>(um, lv, r, N, K, nchunks, /*multiscale=*/1, mop, perm, stream);
+    if (st != 0) return set_error(st, "tvmi_multiscale_roi_align_forward: clearing the worklist failed");
+  }
   const dim3 dma_grid(wave_unit_grid(K, nchunks, um.pinned != 0)), grid(wave_unit_grid(K, nchunks)),
-      mop_grid(wave_unit_grid(K, mop_nchunks)), block(kThreads);
-  const bool b64 = g_fwd_opt.taps == 1;
-#define TVMI_MS_DMA(PHT, PWT, SRT, TAPS)                                                                            \
-  roi_align_fwd_ms_dma<T, PHT, PWT, SRT, TAPS><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
-                                                                               nunits, declined, um)
+      mop_grid((unsigned)std::min<int64_t>(kMopBlocks, ceil_div(mop_nunits, kThreads / 64))), block(kThreads);
+#define TVMI_MS_DMA(PHT, PWT, SRT)                                                                                  \
+  roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
+                                                                               nunits, mop, um)
 #define TVMI_MS(PHT, PWT, SRT)                                                                                      \
-  if (declined) {                                                                                                   \
-    if (b64) TVMI_MS_DMA(PHT, PWT, SRT, 1);                                                  \
-    else TVMI_MS_DMA(PHT, PWT, SRT, 0);                                                                             \
+  if (mop) {                                                                                                   \
+    TVMI_MS_DMA(PHT, PWT, SRT);                                                                                     \
     roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
                                                                             aligned, mop_nchunks, kMopChunk, mop_nunits, \
-                                                                            declined);                              \
+                                                                            mop);                                   \
   } else                                                                                                            \
     roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
                                                                         aligned, nchunks, kUnitChunk, nunits, nullptr)
@@ -1357,7 +1436,6 @@ int set_roi_option(const char* name, int64_t value) {
   const std::string n(name);
   if (n == "roi_align.pin_chunks") g_fwd_opt.pin_chunks = value != 0;
   else if (n == "roi_align.order") g_fwd_opt.order = value != 0;
-  else if (n == "roi_align.tap_reads") g_fwd_opt.taps = value == 1 ? 1 : 0;
   else if (n == "roi_align.order_bands") g_fwd_opt.bands = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
   else return -1;
   return 0;
@@ -1368,7 +1446,6 @@ int get_roi_option(const char* name, int64_t* value) {
   const std::string n(name);
   if (n == "roi_align.pin_chunks") *value = g_fwd_opt.pin_chunks;
   else if (n == "roi_align.order") *value = g_fwd_opt.order;
-  else if (n == "roi_align.tap_reads") *value = g_fwd_opt.taps;
   else if (n == "roi_align.order_bands") *value = g_fwd_opt.bands;
   else return -1;
   return 0;
@@ -1379,7 +1456,7 @@ int get_roi_option(const char* name, int64_t* value) {
 extern "C" size_t tvmi_roi_align_forward_workspace_bytes(int64_t K, int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio) {
   if (K <= 0) return 0;
   (void)pooled_h; (void)pooled_w; (void)sampling_ratio;
-  return 2 * tvmi::fwd_declined_bytes(K);   // [declined][perm]
+  return tvmi::fwd_mop_bytes(K) + (size_t)K * sizeof(int);   // [mop-up worklist][launch order]
 }
 
 extern "C" int tvmi_get_option(const char* name, int64_t* value) {
@@ -1404,7 +1481,7 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
                                       double spatial_scale, int64_t sampling_ratio, int aligned,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "roi_align: pooled size must be positive");
-  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
+  int* declined = tvmi::mop_part(workspace, workspace_bytes, K);
   int* perm = tvmi::perm_part(workspace, workspace_bytes, K);
   TVMI_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0, "roi_align: negative size");
   if (K * C * pooled_h * pooled_w == 0) return 0;
@@ -1439,7 +1516,7 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
   tvmi::MsLevels lv;
   tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* declined = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && K < (1 << 30)) ? static_cast<int*>(workspace) : nullptr;
+  int* declined = tvmi::mop_part(workspace, workspace_bytes, K);
   int* perm = tvmi::perm_part(workspace, workspace_bytes, K);
   switch (dt) {
     case TVMI_F32:
