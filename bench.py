@@ -90,8 +90,8 @@ def algorithmic_bytes(feats, n_boxes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="run the NMS + packing chain of a step on a second HIP stream under the "
                     "RoIAlign launch (measured: -4 %% at best, +25 %% on a noisy box; the default is one stream)")
@@ -99,6 +99,7 @@ def main():
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
     ap.add_argument("--no-e2e", action="store_true", help="skip the config-5 block (Mask R-CNN img/s) of the contract line")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 and 4: NMS 100k, deform_conv2d)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, rank plumbing and the all-gather only; measures nothing")
     ap.add_argument("--graph", action="store_true", help="replay the per-rank chain from a captured hipGraph (measured: no gain "
                     "over eager sync-free launches on this stack, so off by default)")
@@ -159,14 +160,15 @@ def main():
             side.wait_stream(cur)
         with torch.cuda.stream(side):
             keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
-            # padded top-MAX_DETS detections per image, fixed shape, ONE launch, keep length read on the device
-            dets, counts = sharding.pack_kept_detections(d["all_boxes"], d["all_scores"], img_idx, keep, BATCH, MAX_DETS, num_keep=num)
+            # padded top-MAX_DETS detections per image + the count of every image, written as the collective payload itself:
+            # fixed shape, ONE launch, keep length read on the device — nothing is assembled between the NMS and the all-gather
+            payload = sharding.pack_kept_payload(d["all_boxes"], d["all_scores"], img_idx, keep, num, BATCH, MAX_DETS)
         pooled = pool(d["feats"], d["boxes"], image_shapes)                                 # [4000, 256, 7, 7], 1 launch
         if side is not cur:
             cur.wait_stream(side)
-            for t in (keep, num, dets, counts):
+            for t in (keep, num, payload):
                 t.record_stream(cur)     # produced on the side stream, consumed (all-gather, parity check) on this one
-        return pooled, num, dets, counts, keep
+        return pooled, num, payload, keep
 
     graph, static_out = None, None
     if args.graph:
@@ -198,10 +200,10 @@ def main():
                 i = counter["i"] % N_SETS
                 counter["i"] += 1
                 graph[i].replay()
-                pooled, num, dets, counts, _ = static_out[i]
+                pooled, num, payload, _ = static_out[i]
             else:
-                pooled, num, dets, counts, _ = device_step()
-            gd, gc = sharding.all_gather_detections(dets, counts)   # the one collective (no-op at world 1)
+                pooled, num, payload, _ = device_step()
+            gd, gc = sharding.all_gather_payload(payload, MAX_DETS)   # the one collective (views only at world 1)
         return pooled, num, gd, gc
 
     def sync():
@@ -212,11 +214,17 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # the contract region: EXACTLY K steps between two (barrier + synchronize); an event after every step (no sync, ~1 us of
+    # host time each) gives the per-step spread of the same run
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -322,6 +330,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_stats": ({"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4),
+                               "p90": round(per_step[int(len(per_step) * 0.9)], 4), "max": round(per_step[-1], 4),
+                               "how": "HIP events between consecutive steps of the timed region (rank 0)"} if per_step else None),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -360,12 +371,12 @@ def main():
     }
 
     parity_ok = True
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:      # also under N > 1: the line of every run carries its own baseline and parity check
         base, ref_pooled, ref_keeps = cpu_baseline(feats, boxes, scores)
         result["cpu_baseline"] = base
         # parity of THIS run's outputs against what the CPU baseline just computed on the same inputs (input set 0)
         with torch.no_grad():
-            pooled, num, _, _, keep = device_step(0)
+            pooled, num, _, keep = device_step(0)
         torch.cuda.synchronize()
         err = float((pooled.cpu() - ref_pooled).abs().max())
         keep = keep[: int(num)].cpu()
@@ -376,6 +387,14 @@ def main():
         parity_ok = err <= 1e-4 and same
         result["parity"] = {"roi_align_max_abs_err": err, "roi_align_tolerance": 1e-4, "nms_index_sets_equal": bool(same),
                             "checked_against": base["kind"], "ok": bool(parity_ok)}
+    if rank == 0 and not args.no_configs:
+        for d in sets[1:]:
+            d.clear()                           # the rotated config-2 sets (1.1 GB) are not needed any more
+        torch.cuda.empty_cache()
+        try:
+            result["configs"] = other_configs(device)
+        except Exception as exc:  # pragma: no cover - depends on the box
+            result["configs"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()          # the config-5 processes form their own group
@@ -389,6 +408,87 @@ def main():
         sys.exit("bench.py: outputs differ from the CPU reference (see the parity block)")
     if args.e2e and rank == 0 and world == 1:
         print(json.dumps(e2e_config5()), flush=True)
+
+
+FP32_PEAK_TF = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+BF16_PEAK_TF = 2500.0    # dense bf16 / fp16 MFMA peak
+
+
+def other_configs(device):
+    """BASELINE configs 3 and 4 inside the contract line: ms = MEDIAN of per-call HIP-event times over
+    >= 20 calls, inputs rotated over independent sets; every entry carries the fraction of the SURVEY.md section-8d bound.
+      nms / batched_nms : 100,000 boxes (80 classes), IoU 0.5, sparse (1000 px canvas) and dense (200 px) variants; wall
+                          time of torchvision::nms incl. the score sort and the output-size sync; bound =
+                          max(pairs * 20 flop / 157.3 TF, mask bytes / 8 TB/s)
+      deform_conv2d     : 2x256x100x136, k3, 256 -> 256: groups=1 fp32 / bf16 against the dense MFMA peak of the dtype,
+                          groups=256 (depthwise) against HBM on its compulsory bytes"""
+    import vision_amd
+
+    tv = torch.ops.torchvision
+
+    def med(fn, n=24, warm=3):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        ts = []
+        for i in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn(i)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ts.sort()
+        return ts[len(ts) // 2], ts[0]
+
+    out = {"timing": "median (and min) of 24 per-call HIP-event times, 3 rotated input sets"}
+    n, nsets = 100_000, 3
+    pairs = n * (n - 1) / 2
+    for canvas, tag in ((1000, "sparse"), (200, "dense")):
+        data = []
+        for i in range(nsets):
+            g = torch.Generator().manual_seed(7 + 13 * i)
+            xy = torch.rand(n, 2, generator=g) * torch.tensor([max(canvas - 64.0, 1.0)] * 2)
+            wh = 1 + torch.rand(n, 2, generator=g) * 100
+            b = torch.cat([xy, torch.minimum(xy + wh, torch.tensor([float(canvas)] * 2))], 1).to(device)
+            data.append((b, torch.rand(n, generator=g).to(device), torch.randint(0, 80, (n,), generator=g).to(device)))
+        kept = int(tv.nms(data[0][0], data[0][1], NMS_THR).numel())
+        ms, mn = med(lambda i: tv.nms(data[i % nsets][0], data[i % nsets][1], NMS_THR))
+        # bound: every pair tested once (20 flop) or the upper-triangular 64-bit mask written and read once
+        mask_bytes = 2 * (n * ((n + 63) // 64) * 8) / 2
+        bound_ms = max(pairs * 20 / (FP32_PEAK_TF * 1e12), mask_bytes / (HBM_PEAK_GBS * 1e9)) * 1e3
+        out[f"nms_100k_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "kept": kept, "Gpairs_per_s": round(pairs / ms / 1e6, 1),
+                                  "bound_ms": round(bound_ms, 4), "frac_of_bound": round(bound_ms / ms, 4),
+                                  "bound": "all N(N-1)/2 pair tests at 20 flop on the 157.3 TF fp32 vector peak (rows of boxes that are "
+                                           "already suppressed are skipped, so the dense variant tests fewer pairs than the bound assumes)"}
+        keptb = int(vision_amd.batched_nms(*data[0], NMS_THR).numel())
+        ms, mn = med(lambda i: vision_amd.batched_nms(*data[i % nsets], NMS_THR))
+        pairs_b = pairs / 80          # same-class pairs only (80 uniform classes)
+        bound_b = max(pairs_b * 20 / (FP32_PEAK_TF * 1e12), (2 * n * 4 + n * 16) / (HBM_PEAK_GBS * 1e9)) * 1e3
+        out[f"batched_nms_100k_x80_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "kept": keptb, "bound_ms": round(bound_b, 5),
+                                              "frac_of_bound": round(bound_b / ms, 4)}
+        del data
+    B, C, H, W = 2, 256, 100, 136
+    cfg4 = []
+    for i in range(nsets):
+        g = torch.Generator().manual_seed(100 + i)
+        cfg4.append(dict(x=torch.randn(B, C, H, W, generator=g).to(device), off=torch.randn(B, 18, H, W, generator=g).to(device),
+                         w1=(torch.randn(256, C, 3, 3, generator=g) * 0.01).to(device),
+                         wd=(torch.randn(256, 1, 3, 3, generator=g) * 0.01).to(device), bias=torch.randn(256, generator=g).to(device)))
+    flops = 2.0 * B * 256 * C * 9 * H * W
+    ms, mn = med(lambda i: vision_amd.deform_conv2d(cfg4[i % nsets]["x"], cfg4[i % nsets]["off"], cfg4[i % nsets]["w1"], cfg4[i % nsets]["bias"], padding=1))
+    out["deform_conv2d_g1_fp32"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "TFLOPs": round(flops / ms / 1e9, 1),
+                                    "frac_of_mfma_peak": round(flops / ms / 1e9 / FP32_PEAK_TF, 4), "peak_TFLOPs": FP32_PEAK_TF}
+    h = [{k: v.to(torch.bfloat16) for k, v in d.items()} for d in cfg4]
+    ms, mn = med(lambda i: vision_amd.deform_conv2d(h[i % nsets]["x"], h[i % nsets]["off"], h[i % nsets]["w1"], h[i % nsets]["bias"], padding=1))
+    out["deform_conv2d_g1_bf16"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "TFLOPs": round(flops / ms / 1e9, 1),
+                                    "frac_of_mfma_peak": round(flops / ms / 1e9 / BF16_PEAK_TF, 4), "peak_TFLOPs": BF16_PEAK_TF,
+                                    "note": "incl. the channels-last re-layout pre-passes of the call"}
+    ms, mn = med(lambda i: vision_amd.deform_conv2d(cfg4[i % nsets]["x"], cfg4[i % nsets]["off"], cfg4[i % nsets]["wd"], cfg4[i % nsets]["bias"], padding=1))
+    dw_bytes = (2 * B * C * H * W + B * 18 * H * W + 256 * 9 + 256) * 4      # in + out + offsets + weights + bias
+    out["deform_conv2d_g256_fp32"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "compulsory_MB": round(dw_bytes / 1e6, 1),
+                                      "GBs": round(dw_bytes / ms / 1e6, 1), "frac_of_hbm_peak": round(dw_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def _free_port():
@@ -416,10 +516,11 @@ def dry_run(rank, world, args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    dets = torch.full((BATCH, MAX_DETS, sharding.DET_FIELDS), float(rank))
-    counts = torch.full((BATCH,), rank + 1, dtype=torch.int32)
-    gd, gc = sharding.all_gather_detections(dets, counts)
-    ok = gd.shape[0] == BATCH * world and gc.tolist() == [r + 1 for r in range(world) for _ in range(BATCH)]
+    # the payload form of the timed path (sharding.pack_kept_payload writes it on the GPU): detections + the count in-row
+    payload = torch.full((BATCH, MAX_DETS * sharding.DET_FIELDS + 1), float(rank))
+    payload[:, -1] = float(rank + 1)
+    gd, gc = sharding.all_gather_payload(payload, MAX_DETS)
+    ok = gd.shape[0] == BATCH * world and gc.tolist() == [float(r + 1) for r in range(world) for _ in range(BATCH)]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

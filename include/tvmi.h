@@ -326,6 +326,13 @@ int tvmi_pack_detections_devcount(const float* boxes, const float* scores, const
                                   const int64_t* image_idx, const int64_t* keep, int64_t keep_capacity,
                                   const int64_t* num_keep_dev, int64_t num_images, int64_t max_dets, float* dets,
                                   int32_t* counts, void* stream);
+/* The same launch writing the COLLECTIVE PAYLOAD itself: row b of `payload` ([num_images, row_stride] floats, row_stride >=
+ * max_dets * 6 + 1) = the max_dets x 6 detection block of image b followed by its count as a float — what
+ * vision_amd/sharding.py all-gathers (replaces the pickled all_gather_object of references/detection/utils.py:70-83) with no
+ * assembly launches between the NMS and the collective.  `counts` (int32) is optional (NULL: not written). */
+int tvmi_pack_detections_payload(const float* boxes, const float* scores, const int64_t* labels, const int64_t* image_idx,
+                                 const int64_t* keep, int64_t keep_capacity, const int64_t* num_keep_dev, int64_t num_images,
+                                 int64_t max_dets, float* payload, int64_t row_stride, int32_t* counts, void* stream);
 
 /* convert_boxes_to_roi_format (torchvision/ops/_utils.py:18-25) in one launch: per-image box
  * lists [n_i,4] (dtype dt, contiguous) -> rois [sum n_i, 5] = (image index, x1, y1, x2, y2).

@@ -99,3 +99,37 @@ def test_bench_gpus_n_launches_n_ranks_itself():
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     p = _bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "refusing" in p.stderr
+
+
+def test_bench_dry_run_with_four_ranks():
+    """the launcher / rank plumbing / collective beyond two ranks (gloo, CPU)."""
+    import json
+
+    p = _bench("--gpus", "4", "--dry-run", "--steps", "2", "--warmup", "1", timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["gather_ok"] is True and line["gathered_images"] == 16
+
+
+def _payload_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, D = 3, 5
+        payload = torch.full((B, D * sharding.DET_FIELDS + 1), float(rank))
+        payload[:, -1] = torch.arange(B, dtype=torch.float32) + rank      # counts ride in the last column
+        gd, gc = sharding.all_gather_payload(payload, D)
+        ok = gd.shape == (world * B, D, sharding.DET_FIELDS) and gc.tolist() == [float(i + r) for r in range(world) for i in range(B)]
+        ok = ok and all(float(gd[r * B:(r + 1) * B].min()) == float(r) == float(gd[r * B:(r + 1) * B].max()) for r in range(world))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_rank_all_gather_of_the_in_place_payload():
+    world, port = 3, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_payload_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True, 2: True}

@@ -41,6 +41,11 @@ def test_one_rank_rccl_group_all_gathers_the_detection_payload():
         torch.cuda.synchronize()
         assert gd.data_ptr() != dets.data_ptr(), "the collective was short-circuited"
         assert torch.equal(gd, dets) and torch.equal(gc, counts) and gd.shape == (B, 100, 6)
+        # the lean form bench.py uses: the packing launch writes the payload, the collective returns views of the gathered buffer
+        payload = sharding.pack_kept_payload(boxes, scores, img, keep, num, B, 100)
+        pd, pc = sharding.all_gather_payload(payload, 100, always_collective=True)
+        torch.cuda.synchronize()
+        assert pd.data_ptr() != payload.data_ptr() and torch.equal(pd, dets) and torch.equal(pc.round().to(torch.int32), counts)
         # and a plain all_reduce, so that a second RCCL kernel has run on this communicator
         t = torch.ones(8, device=dev)
         dist.all_reduce(t)

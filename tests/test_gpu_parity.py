@@ -1453,3 +1453,26 @@ def test_multiscale_roi_align_16bit_features_keep_fp32_boxes():
         with torch.no_grad(), torch.autocast("cuda", dtype=dt):
             out2 = pool({k: v.to(dt).to(DEV) for k, v in feats.items()}, [b.to(DEV) for b in boxes], [(800, 1344)] * B)
         assert torch.equal(out, out2)
+
+
+def test_pack_kept_payload_is_the_padded_payload_in_place():
+    """`tvmi_pack_detections_payload`: the [B, D*6+1] collective payload written by the packing launch
+    itself equals what all_gather_detections used to assemble from (dets, counts) with six torch launches; the split is views."""
+    from vision_amd import sharding
+
+    g = gen(321)
+    B, n, D = 3, 900, 40
+    boxes = random_boxes(n, 300, 300, 10, 80, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    labels = torch.randint(1, 91, (n,), generator=g).to(DEV)
+    img = torch.randint(0, B, (n,), generator=g).to(DEV)
+    kp, num = vision_amd.boxes.batched_nms_padded(boxes, scores, img, 0.5, B)
+    want_d, want_c = sharding.pack_kept_detections(boxes, scores, img, kp, B, D, labels=labels, num_keep=num)
+    payload = sharding.pack_kept_payload(boxes, scores, img, kp, num, B, D, labels=labels)
+    assert tuple(payload.shape) == (B, D * 6 + 1) and payload.dtype == torch.float32
+    d, c = sharding.split_payload(payload, D)
+    assert d.data_ptr() == payload.data_ptr() and torch.equal(d, want_d) and torch.equal(c.round().to(torch.int32), want_c)
+    gd, gc = sharding.all_gather_payload(payload, D)          # no process group: views of the same payload
+    assert gd.data_ptr() == payload.data_ptr() and torch.equal(gd, want_d)
+    out = sharding.unpack_detections(gd, gc)
+    assert [o["boxes"].shape[0] for o in out] == want_c.tolist()

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, const int64_t* __restrict__ labels,
     const int64_t* __restrict__ image_idx, const int64_t* __restrict__ keep, int64_t num_keep,
     const int64_t* __restrict__ num_keep_dev, int num_images, int max_dets, float* __restrict__ dets,
-    int32_t* __restrict__ counts) {
+    int32_t* __restrict__ counts, int64_t row_stride, int count_in_row) {
   // the keep list may come straight from an NMS launch on the same stream: its length then lives on the device.
   // A negative length is the sync-free NMS's error sentinel (a segment above its size limit, an id outside the
   // promised range): the keep list is then unspecified, and the sentinel is passed on as counts[b] = -1 (zero
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const int b = blockIdx.x;
-  float* my = dets + (int64_t)b * max_dets * 6;
+  float* my = dets + (int64_t)b * row_stride;   // row_stride = max_dets * 6 for the plain [B, D, 6] layout
   for (int i = tid; i < max_dets * 6; i += kPackThreads) my[i] = 0.f;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(kPackThreads) void pack_detections_kernel(
     // the keep list is in score order: once this image holds max_dets detections nothing later can enter its payload
     if (s_cnt >= max_dets) break;
   }
-  if (tid == 0) counts[b] = poisoned ? -1 : min(s_cnt, max_dets);
+  if (tid == 0) {
+    const int n = poisoned ? -1 : min(s_cnt, max_dets);
+    if (counts) counts[b] = n;
+    if (count_in_row) my[(int64_t)max_dets * 6] = (float)n;   // collective payload: the count rides in the row
+  }
 }
 
 
@@ -268,7 +272,7 @@ extern "C" int tvmi_pack_detections(const float* boxes, const float* scores, con
   TVMI_CHECK_ARG(dets && counts && (num_keep == 0 || (boxes && scores && image_idx && keep)),
                  "pack_detections: null pointer");
   tvmi::pack_detections_kernel<<<dim3((unsigned)num_images), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
-      boxes, scores, labels, image_idx, keep, num_keep, nullptr, (int)num_images, (int)max_dets, dets, counts);
+      boxes, scores, labels, image_idx, keep, num_keep, nullptr, (int)num_images, (int)max_dets, dets, counts, max_dets * 6, 0);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections");
 }
 
@@ -282,8 +286,25 @@ extern "C" int tvmi_pack_detections_devcount(const float* boxes, const float* sc
   TVMI_CHECK_ARG(dets && counts && num_keep_dev && (keep_capacity == 0 || (boxes && scores && image_idx && keep)),
                  "pack_detections: null pointer");
   tvmi::pack_detections_kernel<<<dim3((unsigned)num_images), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
-      boxes, scores, labels, image_idx, keep, keep_capacity, num_keep_dev, (int)num_images, (int)max_dets, dets, counts);
+      boxes, scores, labels, image_idx, keep, keep_capacity, num_keep_dev, (int)num_images, (int)max_dets, dets, counts,
+      max_dets * 6, 0);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections_devcount");
+}
+
+extern "C" int tvmi_pack_detections_payload(const float* boxes, const float* scores, const int64_t* labels,
+                                            const int64_t* image_idx, const int64_t* keep, int64_t keep_capacity,
+                                            const int64_t* num_keep_dev, int64_t num_images, int64_t max_dets,
+                                            float* payload, int64_t row_stride, int32_t* counts, void* stream) {
+  TVMI_CHECK_ARG(num_images >= 0 && max_dets >= 0 && keep_capacity >= 0, "pack_detections: negative size");
+  if (num_images == 0) return 0;
+  TVMI_CHECK_ARG(num_images <= 65535, "pack_detections: at most 65535 images per call");
+  TVMI_CHECK_ARG(row_stride >= max_dets * 6 + 1, "pack_detections_payload: a row holds max_dets * 6 floats and the count");
+  TVMI_CHECK_ARG(payload && num_keep_dev && (keep_capacity == 0 || (boxes && scores && image_idx && keep)),
+                 "pack_detections: null pointer");
+  tvmi::pack_detections_kernel<<<dim3((unsigned)num_images), dim3(tvmi::kPackThreads), 0, static_cast<hipStream_t>(stream)>>>(
+      boxes, scores, labels, image_idx, keep, keep_capacity, num_keep_dev, (int)num_images, (int)max_dets, payload, counts,
+      row_stride, 1);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_pack_detections_payload");
 }
 
 extern "C" int tvmi_detection_candidates(const float* class_logits, const float* box_regression, const float* proposals,

@@ -957,6 +957,34 @@ std::tuple<at::Tensor, at::Tensor> pack_detections_devcount(const at::Tensor& bo
   return std::make_tuple(dets, counts);
 }
 
+// The collective payload written in place: [B, max_dets * 6 + 1] floats, the count of an image in the last column.
+at::Tensor pack_detections_payload(const at::Tensor& boxes, const at::Tensor& scores, const c10::optional<at::Tensor>& labels,
+                                   const at::Tensor& image_idx, const at::Tensor& keep, const at::Tensor& num_keep,
+                                   int64_t num_images, int64_t max_dets) {
+  TORCH_CHECK(boxes.is_cuda() && scores.is_cuda() && image_idx.is_cuda() && keep.is_cuda() && num_keep.is_cuda(),
+              "pack_detections: CUDA tensors expected");
+  TORCH_CHECK(boxes.dim() == 2 && boxes.size(1) == 4 && scores.dim() == 1 && scores.size(0) == boxes.size(0) &&
+                  image_idx.dim() == 1 && image_idx.size(0) == boxes.size(0) && keep.dim() == 1 && num_keep.numel() == 1 &&
+                  num_keep.scalar_type() == at::kLong,
+              "pack_detections: boxes [N,4], scores [N], image_idx [N], keep [M], num_keep [1] int64 expected");
+  c10::DeviceGuard guard(boxes.device());
+  at::Tensor b = boxes.to(at::kFloat).contiguous(), s = scores.to(at::kFloat).contiguous();
+  at::Tensor ii = image_idx.to(at::kLong).contiguous(), k = keep.to(at::kLong).contiguous();
+  at::Tensor lab;
+  const int64_t* lab_ptr = nullptr;
+  if (labels.has_value() && labels->defined()) {
+    lab = labels->to(at::kLong).contiguous();
+    lab_ptr = lab.const_data_ptr<int64_t>();
+  }
+  at::Tensor payload = at::empty({num_images, max_dets * 6 + 1}, b.options());
+  check_status(tvmi_pack_detections_payload(b.const_data_ptr<float>(), s.const_data_ptr<float>(), lab_ptr,
+                                            ii.const_data_ptr<int64_t>(), k.const_data_ptr<int64_t>(), k.size(0),
+                                            num_keep.const_data_ptr<int64_t>(), num_images, max_dets,
+                                            payload.mutable_data_ptr<float>(), max_dets * 6 + 1, nullptr, current_stream(boxes)),
+               "pack_detections_payload");
+  return payload;
+}
+
 // ---- convert_boxes_to_roi_format (ops/_utils.py:18-25) in one launch
 at::Tensor boxes_to_rois(at::TensorList boxes) {
   TORCH_CHECK(boxes.size() >= 1 && boxes.size() <= 64, "boxes_to_rois: 1..64 box lists supported");
@@ -1128,6 +1156,9 @@ TORCH_LIBRARY(tvmi, m) {
   m.def("nms_segmented_padded(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold, int num_segments=-1) -> (Tensor, Tensor)");
   m.def(
       "pack_detections_devcount(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, Tensor num_keep, int num_images, int max_dets) -> (Tensor, Tensor)");
+  // the same launch writing the all-gather payload [B, max_dets * 6 + 1] in place (the count in the last column)
+  m.def(
+      "pack_detections_payload(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, Tensor num_keep, int num_images, int max_dets) -> Tensor");
   // aten::upsample_* arithmetic on our kernels (mode 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic;
   // scale_* <= 0 means "not given")
   m.def(
@@ -1173,6 +1204,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("nms_segmented", &nms_segmented);
   m.impl("nms_segmented_padded", &nms_segmented_padded);
   m.impl("pack_detections_devcount", &pack_detections_devcount);
+  m.impl("pack_detections_payload", &pack_detections_payload);
   m.impl("interpolate2d", &interpolate2d);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
   m.impl("multiscale_roi_align_backward", &multiscale_roi_align_backward);

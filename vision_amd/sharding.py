@@ -89,6 +89,31 @@ def pack_kept_detections(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep:
     return pack_detections(per_b, per_s, per_l, max_dets)
 
 
+def pack_kept_payload(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep: Tensor, num_keep: Tensor, num_images: int,
+                      max_dets: int, labels: Tensor = None) -> Tensor:
+    """The hot-path form of pack_kept_detections for N > 1: ONE launch writes the collective payload itself —
+    `[num_images, max_dets * 6 + 1]` fp32, row b = the padded detections of image b followed by its count — so nothing is
+    assembled between the NMS and `all_gather_payload` (~6 tiny torch launches per step before)."""
+    return torch.ops.tvmi.pack_detections_payload(boxes, scores, labels, image_idx, keep, num_keep, int(num_images), int(max_dets))
+
+
+def split_payload(payload: Tensor, max_dets: int) -> Tuple[Tensor, Tensor]:
+    """(`dets` [B, max_dets, 6], `counts` [B] float32) VIEWS of a payload — no launch, no copy."""
+    return payload[:, : max_dets * DET_FIELDS].unflatten(1, (max_dets, DET_FIELDS)), payload[:, max_dets * DET_FIELDS]
+
+
+def all_gather_payload(payload: Tensor, max_dets: int, group=None, always_collective: bool = False) -> Tuple[Tensor, Tensor]:
+    """The one collective of the path on a payload written by `pack_kept_payload`: one `all_gather_into_tensor`, then views
+    of the gathered buffer (`dets` [world*B, D, 6], `counts` [world*B] as float32 — `unpack_detections` rounds them on the
+    host).  A world of one returns views of its own payload."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or always_collective):
+        world = dist.get_world_size(group)
+        gathered = torch.empty((world * payload.shape[0], payload.shape[1]), dtype=payload.dtype, device=payload.device)
+        dist.all_gather_into_tensor(gathered, payload, group=group)
+        payload = gathered
+    return split_payload(payload, max_dets)
+
+
 def all_gather_detections(dets: Tensor, counts: Tensor, group=None, always_collective: bool = False) -> Tuple[Tensor, Tensor]:
     """All-gather equally shaped per-rank (`dets` [B_local, D, 6], `counts` [B_local]) into
     ([world*B_local, D, 6], [world*B_local]) in rank order.  Counts ride in the same buffer as
@@ -112,6 +137,7 @@ def all_gather_detections(dets: Tensor, counts: Tensor, group=None, always_colle
 def unpack_detections(dets: Tensor, counts: Tensor) -> List[dict]:
     out = []
     for d, n in zip(dets, counts.tolist()):
+        n = int(round(n))      # counts gathered inside the float payload arrive as float32
         if n < 0:
             raise RuntimeError("detection payload carries the sync-free NMS error sentinel (count -1): a segment exceeded the "
                                "size limit of the no-sync path or an id was outside the promised range; use batched_nms()")
