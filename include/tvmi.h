@@ -50,12 +50,17 @@ int tvmi_version(void);
  *                                (default 24576; 0 = never)
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)
  *   "nms.replan_max"             re-plans per call (default 3)
- *   "nms.device_handoff"         1 (default) / 0: resolver <-> push hand-offs of the large path through memory words (agent-scope
- *                                atomics, no fences) instead of stream events; one call per device at a time, never under capture.
- *                                Needs the call's three streams to run concurrently: switched off automatically when
- *                                rocprofv3 collects counters (it runs one kernel at a time and says so in the environment:
- *                                ROCPROF_COUNTER_COLLECTION); set it to 0 under any other tool that serialises kernels —
- *                                a poll that cannot be satisfied traps after about a second
+ *   "nms.device_handoff"         1 (default) / 0: resolver <-> push hand-offs of the large path of tvmi_nms_blocking through memory
+ *                                words (agent-scope atomics, no fences) instead of stream events; one call per device at a time,
+ *                                never under capture, never in tvmi_nms (which may not synchronise).  Needs the call's three
+ *                                streams to run concurrently: not taken when the environment says kernels are serialised
+ *                                (ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS / ROCP_METRICS / ROCP_INPUT, HIP_LAUNCH_BLOCKING,
+ *                                AMD_SERIALIZE_KERNEL).  Anything else that keeps the launches from running side by side is caught
+ *                                on the device: a poll gives up after about a second, the call is re-run with stream events —
+ *                                a slower correct answer — and the process stops using the hand-offs (reads back as 0) until the
+ *                                option is set to 1 again
+ *   "nms.handoff_lose_flag"      test hook, 0 (default) / 1: the resolver of the first chunk does not announce itself, so the
+ *                                recovery path above runs for real
  *   "nms.mask_lds_bytes"         dynamic LDS per mask workgroup of the large path (all chunks but the first) — an
  *                                occupancy cap that keeps wave slots free for the sweep's 16-wave workgroup
  *                                (default 36000 = four workgroups per CU; 0 = no cap) */

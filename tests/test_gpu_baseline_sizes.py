@@ -143,7 +143,7 @@ def test_config2_multiscale_roi_align_full_fwd_bwd(P):
     assert ob.dtype == torch.bfloat16
     rb = rois.clone()
     for lvl in range(4):
-        sel = torch.nonzero(levels == lvl)[:, 0][:200]     # 200 RoIs per level keep the CPU side short
+        sel = torch.nonzero(levels == lvl)[:, 0]           # all 4000 RoIs, like the fp32 path
         ref = _cpu_roi_align(feats[lvl].to(torch.bfloat16).float(), rb[sel], pool.scales[lvl], P)
         np.testing.assert_allclose(ob[sel.to(DEV)].float().cpu().numpy(), ref, rtol=5e-3, atol=5e-3, err_msg=f"bf16 level {lvl}")
 
@@ -219,6 +219,36 @@ def test_config2_roi_align_backward_16bit_values(tv, dtype):
         ref16 = _cpu_roi_align_backward(grad[sel].float().contiguous(), r16.float(), pool.scales[lvl], P, shape)
         np.testing.assert_allclose(got.float().cpu().numpy(), ref16, rtol=5e-3, atol=5e-3 * max(1.0, float(np.abs(ref16).max())),
                                    err_msg=f"per-level backward level {lvl}")
+
+
+@pytest.mark.parametrize("groups", [1, 256])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_config4_deform_conv2d_backward_full_size(tv, groups, dtype):
+    """`_deform_conv2d_backward` at config-4 size (2x256x100x136, k3, 256 -> 256, mask on) against the
+    reference CPU kernel (cpu/deform_conv2d_kernel.cpp:1153-1226) — all five gradients.  fp32: sums of up to 2304 (g=1) /
+    27,200 (weights: over the pixels) products in another order, bar 1e-4 relative to the gradient's own scale.  bf16: the
+    reference computes the 16-bit backward in the 16-bit type; ours is compared with the fp32 reference on the rounded
+    tensors at the 16-bit bar of the forward test (1e-2 of the gradient's scale)."""
+    g = gen(620 + groups)
+    B, C, H, W, OC = 2, 256, 100, 136, 256
+    x = torch.randn(B, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(OC, C // groups, 3, 3, generator=g) * (0.01 if groups == 1 else 0.2)).to(dtype)
+    off = torch.randn(B, 18, H, W, generator=g).to(dtype)
+    m = torch.rand(B, 9, H, W, generator=g).to(dtype)
+    b = torch.randn(OC, generator=g).to(dtype)
+    gr = torch.randn(B, OC, H, W, generator=g).to(dtype)
+    if not O.load_reference():
+        pytest.skip("needs the reference CPU kernels (oracle/_ref): the C restatement has no deform_conv2d backward")
+    got = tv._deform_conv2d_backward(gr.to(DEV), x.to(DEV), w.to(DEV), off.to(DEV), m.to(DEV), b.to(DEV), 1, 1, 1, 1, 1, 1, groups, 1, True)
+    if True:
+        ref = torch.ops.torchvision._deform_conv2d_backward(gr.float(), x.float(), w.float(), off.float(), m.float(), b.float(),
+                                                            1, 1, 1, 1, 1, 1, groups, 1, True)
+        ref = [r.numpy() for r in ref]
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    for name, a, r in zip(("grad_input", "grad_weight", "grad_offset", "grad_mask", "grad_bias"), got, ref):
+        assert a.dtype == dtype, name
+        scale = max(1.0, float(np.abs(r).max()))
+        np.testing.assert_allclose(a.float().cpu().numpy(), r, rtol=tol, atol=tol * scale, err_msg=f"{name} groups={groups}")
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["bf16", "fp16"])

@@ -30,8 +30,13 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
     evaluated on the shifted boxes `boxes + idxs * (boxes.max() + 1)` (fp32 rounding of the shifted
     coordinates moves IoUs at the threshold edge, so the kept set can differ from the per-category
     loop's — tests/test_gpu_parity.py pins a case), above it on the unshifted boxes (the loop's
-    arithmetic).  The one thing not reproduced is the trick's cross-category suppression when boxes
-    have coordinates below -1 (shifted categories then overlap in the reference).
+    arithmetic).  The trick's one side effect is reproduced too: with a coordinate below -1 the shifted
+    categories overlap (max - min > max + 1) and the reference suppresses ACROSS categories — the same
+    launch that takes the maximum takes the minimum (`aminmax`), and such an input is answered by the
+    reference's own formulation, one global-order `nms()` of the shifted boxes (a second pass: the flag is
+    read after the segmented result's size synchronisation, so the usual input pays one small
+    device-to-host read, no extra launch).  16-bit boxes shift in their own dtype like the reference
+    (`idxs.to(boxes)`; a product beyond the fp16 range is inf there as well).
     `num_segments` (extension, optional): a promise that 0 <= idxs < num_segments, which lets
     N <= 4096 run as a single launch.  CPU tensors (tests only) follow the reference's switch."""
     if boxes.is_cuda:
@@ -39,9 +44,13 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
         if boxes.numel() == 0:
             return torch.empty((0,), dtype=torch.int64, device=boxes.device)
         if boxes.numel() <= 100_000:   # ops/boxes.py:83: the reference's coordinate-trick regime on device tensors
-            max_coordinate = boxes.max()
+            min_coordinate, max_coordinate = torch.aminmax(boxes)
             offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
-            boxes = boxes + offsets[:, None]
+            shifted = boxes + offsets[:, None]
+            keep = torch.ops.tvmi.nms_segmented(shifted, scores, idxs, iou_threshold, int(num_segments))
+            if bool(min_coordinate < -1):      # shifted categories overlap: the reference's nms() sees cross-category pairs
+                keep = torch.ops.torchvision.nms(shifted, scores, iou_threshold)
+            return keep
         return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold, int(num_segments))
     if boxes.numel() > 4000:
         return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)

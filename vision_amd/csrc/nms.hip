@@ -398,15 +398,25 @@ __global__ __launch_bounds__(256) void nms_colreduce(const u64* __restrict__ mas
 // writer's stores and atomics are acknowledged before the word that announces them is written (the idiom nms_small_seg_sweep's
 // ticket already uses).  The mask tiles a push kernel reads were written by a mask kernel that completed before the resolver
 // started (stream event), and nobody reads a tile before it is written, so no stale copy of one can sit in any L2.
-// A poll that outlives its bound (seconds: only a broken launch order can do that) traps instead of hanging the queue.
+// A poll that outlives its bound (about a second: the launches it waits for are not running beside it — a tool that
+// serialises kernels, a debugger, a co-tenant that keeps the resolver off the CUs) GIVES UP: it raises the call's `failed`
+// word (one more SweepSync behind the per-chunk ones) and goes on with whatever is in memory; every later poll of the call
+// sees the word and returns at once, so the launch chain drains in bounded time.  The host reads the word when the call has
+// finished (tvmi_nms_blocking synchronises anyway) and re-runs the call in the stream-event form: a slower correct answer
+// instead of a GPU fault (VERDICT r03 item 4 — this used to be __builtin_trap()).
 struct SweepSync {  // one per chunk, zeroed with removed[] at the start of a level
   int flag, near_done, pad[2];
 };
-__device__ __forceinline__ void poll_until_equal(const int* p, int want) {
+__device__ __forceinline__ void poll_until_equal(const int* p, int want, int* failed) {
   int polls = 0;
   while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
     __builtin_amdgcn_s_sleep(4);
-    if (++polls > (1 << 20)) __builtin_trap();   // >= 1 s of polling: the launch order is broken (see kernels_are_serialised)
+    ++polls;
+    if ((polls & 1023) == 0 && __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (polls > (1 << 20)) {
+      __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
   }
 }
 __device__ __forceinline__ void signal_after_my_stores(int* p) {  // one thread, after the workgroup's barrier
@@ -419,12 +429,12 @@ __device__ __forceinline__ void signal_after_my_stores(int* p) {  // one thread,
 // nms_colreduce launch right behind it on the same stream, whose workgroups report to the chunk's far counter.
 constexpr int kPushGroups = 128;
 __global__ __launch_bounds__(256) void nms_push(const u64* __restrict__ mask, const u64* keepbits, u64* __restrict__ removed, int CB,
-                                                int b0, int b1, int b2, SweepSync* sync) {
+                                                int b0, int b1, int b2, SweepSync* sync, int* failed) {
   __shared__ u64 s_kb[kWide];
   __builtin_amdgcn_s_setprio(2);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (threadIdx.x == 0) poll_until_equal(&sync->flag, 1);
+  if (threadIdx.x == 0) poll_until_equal(&sync->flag, 1, failed);
   __syncthreads();
   // this kernel started before the resolver wrote them: agent-scope loads (the far push, a later launch, reads them plainly)
   if ((int)threadIdx.x < b1 - b0) s_kb[threadIdx.x] = __hip_atomic_load(&keepbits[b0 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -460,7 +470,8 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
                                                                    const u64* __restrict__ removed,
                                                                    u64* __restrict__ keepbits, int n, int CB, int b0, int b1,
                                                                    int64_t* __restrict__ keep_out,
-                                                                   int64_t* __restrict__ num_keep, SweepSync* sync, int chunk) {
+                                                                   int64_t* __restrict__ num_keep, SweepSync* sync, int chunk,
+                                                                   int* failed, int lose_flag) {
   __shared__ u64 s_keep[kWide];
   __shared__ u64 s_jac[2][kSuper];
   __shared__ int s_changed[3];
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
   if (sync) {  // device hand-offs: removed[b0..b1) is complete once the push kernels of the two previous chunks have reported
     if (threadIdx.x == 0) {
       // (the far push of chunk - 2 precedes the near push of chunk - 1 on their in-order stream: one poll covers both)
-      if (chunk >= 1) poll_until_equal(&sync[chunk - 1].near_done, kPushGroups);
+      if (chunk >= 1) poll_until_equal(&sync[chunk - 1].near_done, kPushGroups, failed);
     }
     __syncthreads();
   }
@@ -575,7 +586,9 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_resolve_wide(const u64* __
   if (sync) {  // the keep bits of the chunk are acknowledged stores: release the push kernel before the index list is emitted
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) signal_after_my_stores(&sync[chunk].flag);
+    // lose_flag: test hook ("nms.handoff_lose_flag"): chunk 0 never announces itself, as if this workgroup had not run
+    // beside the push kernel — the recovery path (poll gives up, host re-runs with stream events) is then exercised for real
+    if (threadIdx.x == 0 && !(lose_flag && chunk == 0)) signal_after_my_stores(&sync[chunk].flag);
   }
   // append the kept original indices in score order
   if (threadIdx.x == 0) {
@@ -722,6 +735,8 @@ __global__ __launch_bounds__(256) void nms_compact_order(const u64* __restrict__
   if ((surv >> lane) & 1ull) order_out[offsets[w] + __popcll(surv & ((1ull << lane) - 1ull))] = order[(int64_t)(pb + w) * 64 + lane];
 }
 
+__global__ void nms_report_failed(const int* __restrict__ failed, int* __restrict__ host_word) { *host_word = *failed; }
+
 // Fork / join helpers of the large-problem path.  The mask kernel (throughput-bound, fills the chip) is launched in
 // chunks of kWide row blocks on one internal stream; the sweep of chunk c (latency-bound: one resolve workgroup plus
 // the near push) runs on a second, higher-priority stream as soon as chunk c of the mask is complete — i.e. UNDER the
@@ -797,12 +812,24 @@ struct HandoffClaim {
 HandoffClaim g_handoff_claim[64];
 // A profiler that collects hardware counters per dispatch runs ONE kernel at a time (rocprofv3 --pmc: measured — the polling
 // push kernel then waits for a resolver that is never started).  rocprofv3 announces that mode to the process it launches.
+// HIP_LAUNCH_BLOCKING / AMD_SERIALIZE_KERNEL serialise every launch of the process, and the older rocprof generations announce
+// counter collection through ROCP_* variables.  What none of these catch (a debugger, a co-tenant that starves the resolver) is
+// caught on the device: a poll gives up after about a second, the call is re-run in the stream-event form and the process
+// stops using the hand-offs (g_handoff_broken).
+inline bool env_nonzero(const char* name) {
+  const char* v = std::getenv(name);
+  return v != nullptr && v[0] != '\0' && !(v[0] == '0' && v[1] == '\0');
+}
 inline bool kernels_are_serialised() {
-  static const bool yes = std::getenv("ROCPROF_COUNTER_COLLECTION") != nullptr || std::getenv("ROCPROF_COUNTERS") != nullptr;
+  static const bool yes = std::getenv("ROCPROF_COUNTER_COLLECTION") != nullptr || std::getenv("ROCPROF_COUNTERS") != nullptr ||
+                          std::getenv("ROCP_METRICS") != nullptr || std::getenv("ROCP_INPUT") != nullptr ||
+                          env_nonzero("HIP_LAUNCH_BLOCKING") || env_nonzero("AMD_SERIALIZE_KERNEL") ||
+                          env_nonzero("CUDA_LAUNCH_BLOCKING") || env_nonzero("TVMI_TOOL_SERIALIZED_PROFILER");
   return yes;
 }
+std::atomic<bool> g_handoff_broken{false};   // a poll of this process has timed out once: stream events from now on
 inline bool claim_handoff(int dev) {
-  if (dev < 0 || dev >= 64 || kernels_are_serialised()) return false;
+  if (dev < 0 || dev >= 64 || kernels_are_serialised() || g_handoff_broken.load(std::memory_order_relaxed)) return false;
   HandoffClaim& h = g_handoff_claim[dev];
   std::lock_guard<std::mutex> lock(h.mu);
   if (h.enqueuing) return false;
@@ -825,7 +852,7 @@ inline void release_handoff(int dev, hipStream_t stream) {
 // their survivors (0 = never); "nms.replan_divisor" — the first 1/divisor of the row chunks is swept before the re-plan;
 // "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
 std::atomic<int64_t> g_replan_min_boxes{24576};
-std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000}, g_device_handoff{1};
+std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000}, g_device_handoff{1}, g_handoff_lose_flag{0};
 
 // Workspace of the large path: mask tiles | removed[CB] | keepbits[CB] | survivor offsets[CB] (int) | two score-order
 // buffers of n indices (re-planning ping-pongs between them).
@@ -834,11 +861,12 @@ struct LargeWorkspace {
   SweepSync* sync;   // one per chunk, directly behind keepbits[] (cleared with them)
   int* offsets;
   int64_t* order_buf[2];
+  int* failed;       // raised by a hand-off poll that gave up (sticky for the whole call: outside the per-level clears)
 };
 inline size_t large_state_bytes(size_t n) {
   const size_t CB = ceil_div(n, (size_t)64);
   return 2 * CB * sizeof(u64) + ceil_div(CB, (size_t)kWide) * sizeof(SweepSync) + ceil_div(CB, (size_t)2) * 2 * sizeof(int) +
-         2 * n * sizeof(int64_t);
+         2 * n * sizeof(int64_t) + 16;
 }
 inline size_t sweep_state_bytes(size_t CB) { return 2 * CB * sizeof(u64) + ceil_div(CB, (size_t)kWide) * sizeof(SweepSync); }
 inline LargeWorkspace carve(void* workspace, size_t n) {
@@ -851,13 +879,15 @@ inline LargeWorkspace carve(void* workspace, size_t n) {
   w.offsets = reinterpret_cast<int*>(w.sync + ceil_div(CB, (size_t)kWide));
   w.order_buf[0] = reinterpret_cast<int64_t*>(w.offsets + ceil_div(CB, (size_t)2) * 2);
   w.order_buf[1] = w.order_buf[0] + n;
+  w.failed = reinterpret_cast<int*>(w.order_buf[1] + n);
   return w;
 }
 
 template <typename T>
 int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, double thr, void* workspace,
-           int64_t* keep_out, int64_t* num_keep, hipStream_t stream, bool may_sync) {
+           int64_t* keep_out, int64_t* num_keep, hipStream_t stream, bool may_sync, bool allow_handoff = true) {
   const T* d = static_cast<const T*>(dets);
+  const int64_t n_call = n;   // a hand-off that gave up re-runs the call from here
   const ThrBand band = thr_band(thr);
   if (ceil_div(n, 64) <= kSmallCB) {  // latency-bound sizes: one mask launch, the whole sweep is one more
     const int CB = (int)ceil_div(n, 64);
@@ -871,6 +901,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
   u64 *mask = ws.mask, *removed = ws.removed, *keepbits = ws.keepbits;
   const size_t state_bytes = sweep_state_bytes((size_t)ceil_div(n, 64));   // removed[] + keepbits[] + the hand-off words
   hipError_t e = hipMemsetAsync(num_keep, 0, sizeof(int64_t), stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ws.failed, 0, sizeof(int), stream);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
   static SweepStreams no_streams;  // never ensure()d: only names the members below when the device query failed
   SweepStreams* ssp = g_sweep_streams.current();
@@ -903,6 +934,15 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     }
   } claim_release{claimed, claim_dev, stream};
   bool side_streams_open = false;  // a re-plan leaves the three side streams forked, idle and ahead of `stream`
+  // Everything the side streams did is ordered before what the caller enqueues next: the sweep stream has waited for every
+  // mask chunk, so joining it and the far stream joins all three.  BOTH on every way out: with device hand-offs
+  // the far stream is released by the resolver's flag, which is raised BEFORE the resolver appends to keep_out / num_keep.
+  auto join_side_streams = [&]() {
+    bool j = hipEventRecord(ss.join, ss.sweep_stream) == hipSuccess && hipStreamWaitEvent(stream, ss.join, 0) == hipSuccess;
+    j = (hipEventRecord(ss.join_far, ss.far_stream) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess) && j;
+    side_streams_open = false;
+    return j;
+  };
   while (true) {
     const int CB = (int)ceil_div(n, 64);
     if (CB <= kSmallCB) {  // what survived a re-plan fits the one-workgroup sweep: append to the list (streams are idle)
@@ -915,7 +955,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     bool forked = side_streams_open;
     if (!forked) {
       e = hipMemsetAsync(removed, 0, state_bytes, stream);
-      if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");
+      if (e != hipSuccess) return set_error((int)e, "tvmi_nms: memset");   // (the side streams are not forked here)
       forked = ssp && ss.ensure(nchunks) && hipEventRecord(ss.fork, stream) == hipSuccess &&
                hipStreamWaitEvent(ss.mask_stream, ss.fork, 0) == hipSuccess &&
                hipStreamWaitEvent(ss.sweep_stream, ss.fork, 0) == hipSuccess &&
@@ -924,7 +964,9 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     hipStream_t ms = forked ? ss.mask_stream : stream, sw = forked ? ss.sweep_stream : stream, fs = forked ? ss.far_stream : stream;
     // device-side hand-offs need the three streams to really run concurrently: not under capture (a graph may serialise
     // its branches — may_sync is false there anyway only for tvmi_nms, so ask), and not without the side streams
-    if (!claim_tried && forked && !capturing && g_device_handoff.load(std::memory_order_relaxed) != 0) {
+    // ... and only where the call may synchronise at its end to learn whether a poll gave up (tvmi_nms_blocking)
+    if (!claim_tried && forked && !capturing && may_sync && allow_handoff && ss.host_count &&
+        g_device_handoff.load(std::memory_order_relaxed) != 0) {
       claim_tried = true;
       (void)hipGetDevice(&claim_dev);
       claimed = claim_handoff(claim_dev);
@@ -953,7 +995,8 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     auto resolve = [&](int c) {
       const int b0 = c * kWide, b1 = std::min(CB, b0 + kWide);
       nms_resolve_wide<<<dim3(1), dim3(kSuper * kWave), 0, sw>>>(mask, cur, removed, keepbits, (int)n, CB, b0, b1, keep_out,
-                                                                 num_keep, handoff ? ws.sync : nullptr, c);
+                                                                 num_keep, handoff ? ws.sync : nullptr, c, ws.failed,
+                                                                 handoff ? g_handoff_lose_flag.load(std::memory_order_relaxed) : 0);
     };
     if (forked) {
       // PUSH pipeline on three streams.  Chunk c: its mask tiles (mask stream), then — sweep stream, the serial link —
@@ -977,7 +1020,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
           // every chunk (58 us per chunk for 33 us of resolve).  Every wait targets work that was enqueued earlier, so
           // any interleaving of the three queues — even a single shared one — makes progress.
           resolve(c);
-          if (b1 < CB) nms_push<<<dim3(kPushGroups), dim3(256), 0, fs>>>(mask, keepbits, removed, CB, b0, b1, b2, ws.sync + c);
+          if (b1 < CB) nms_push<<<dim3(kPushGroups), dim3(256), 0, fs>>>(mask, keepbits, removed, CB, b0, b1, b2, ws.sync + c, ws.failed);
           // the FAR push needs no counter: the far stream is in order, so the near push of chunk c + 1 — whose counter the
           // resolver of chunk c + 2 polls — cannot even start before this launch has finished
           push(fs, b0, b1, b2, CB);
@@ -1001,10 +1044,7 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
       }
     }
     if (!ok || limit >= nchunks) {
-      if (forked) {  // the sweep stream has waited for every mask chunk: joining it and the far stream joins all three
-        ok = ok && hipEventRecord(ss.join, sw) == hipSuccess && hipStreamWaitEvent(stream, ss.join, 0) == hipSuccess;
-        ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
-      }
+      if (forked) ok = join_side_streams() && ok;
       break;
     }
     // Every kept row of blocks < pb has been pushed to every column once the far stream is through: compact the rest
@@ -1018,21 +1058,37 @@ int launch(const void* dets, const int64_t* order, const int64_t* seg, int64_t n
     nms_compact_order<<<dim3((unsigned)ceil_div(CB - pb, 4)), dim3(256), 0, fs>>>(removed, cur, (int)n, CB, pb, ws.offsets, next);
     e = hipMemsetAsync(removed, 0, state_bytes, fs);
     if (e == hipSuccess) e = hipStreamSynchronize(fs);
-    if (e != hipSuccess) return set_error((int)e, "tvmi_nms: synchronising for the survivor count");
+    if (e != hipSuccess) {
+      (void)join_side_streams();   // work may still be queued on the side streams while the caller frees the workspace
+      return set_error((int)e, "tvmi_nms: synchronising for the survivor count");
+    }
     side_streams_open = true;
     const int survivors = *static_cast<volatile int*>(ss.host_count);
     cur = next;
     n = survivors;
     --replans_left;
     if (survivors <= 0) {  // nothing left: close the fork
-      ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
+      ok = join_side_streams() && ok;
       break;
     }
-    if (ceil_div(n, 64) <= kSmallCB) {  // the one-workgroup sweep runs on the caller's stream: it follows the far stream
-      ok = ok && hipEventRecord(ss.join_far, fs) == hipSuccess && hipStreamWaitEvent(stream, ss.join_far, 0) == hipSuccess;
+    if (ceil_div(n, 64) <= kSmallCB) {  // the one-workgroup sweep runs on the caller's stream: it follows BOTH side streams
+      ok = join_side_streams() && ok;   // (it appends to keep_out / num_keep, which the last resolver writes after its flag)
     }
   }
   if (!ok) return set_error((int)hipErrorUnknown, "tvmi_nms: stream fork / join failed");
+  if (claimed) {
+    // Did a hand-off poll give up?  The call may synchronise (its caller reads num_keep next): read the word through the
+    // pinned host slot; if it is raised the result is unspecified — re-run the whole call in the stream-event form.
+    nms_report_failed<<<dim3(1), dim3(1), 0, stream>>>(ws.failed, ss.host_count + 1);
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return set_error((int)e, "tvmi_nms: synchronising for the hand-off status");
+    if (static_cast<volatile int*>(ss.host_count)[1] != 0) {
+      g_handoff_broken.store(true, std::memory_order_relaxed);
+      release_handoff(claim_dev, stream);
+      claimed = false;
+      return launch<T>(dets, order, seg, n_call, thr, workspace, keep_out, num_keep, stream, may_sync, /*allow_handoff=*/false);
+    }
+  }
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms");
 }
 
@@ -1629,6 +1685,11 @@ int set_nms_option(const char* name, int64_t value) {
   }
   if (std::strcmp(name, "nms.device_handoff") == 0) {
     g_device_handoff.store(value != 0, std::memory_order_relaxed);
+    if (value != 0) g_handoff_broken.store(false, std::memory_order_relaxed);   // switching it on again re-arms it after a give-up
+    return 0;
+  }
+  if (std::strcmp(name, "nms.handoff_lose_flag") == 0) {
+    g_handoff_lose_flag.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
   if (std::strcmp(name, "nms.mask_lds_bytes") == 0) {
@@ -1645,7 +1706,9 @@ int set_nms_option(const char* name, int64_t value) {
 int get_nms_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "nms.replan_min_boxes") == 0) *value = (int64_t)g_replan_min_boxes.load(std::memory_order_relaxed);
   else if (std::strcmp(name, "nms.replan_divisor") == 0) *value = g_replan_divisor.load(std::memory_order_relaxed);
-  else if (std::strcmp(name, "nms.device_handoff") == 0) *value = g_device_handoff.load(std::memory_order_relaxed) ? 1 : 0;
+  else if (std::strcmp(name, "nms.device_handoff") == 0)
+    *value = (g_device_handoff.load(std::memory_order_relaxed) && !g_handoff_broken.load(std::memory_order_relaxed)) ? 1 : 0;
+  else if (std::strcmp(name, "nms.handoff_lose_flag") == 0) *value = g_handoff_lose_flag.load(std::memory_order_relaxed);
   else if (std::strcmp(name, "nms.mask_lds_bytes") == 0) *value = g_mask_lds_bytes.load(std::memory_order_relaxed);
   else if (std::strcmp(name, "nms.replan_max") == 0) *value = g_replan_max.load(std::memory_order_relaxed);
   else return -1;
