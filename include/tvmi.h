@@ -31,6 +31,15 @@ typedef enum tvmi_dtype {
   TVMI_BF16 = 3
 } tvmi_dtype;
 
+/* integer element types of the quantized entries (the reference dispatches AT_INTEGRAL_TYPES, quantized/cpu/qroi_align_kernel.cpp:252) */
+typedef enum {
+  TVMI_U8 = 0,
+  TVMI_I8 = 1,
+  TVMI_I16 = 2,
+  TVMI_I32 = 3,
+  TVMI_I64 = 4
+} tvmi_int_dtype;
+
 /* Library / ABI version (major*10000 + minor*100 + patch).  300 = round 3: the RoI backward entries OVERWRITE grad_input
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
@@ -435,6 +444,17 @@ int tvmi_normalize_resize_batch(const void* const* images, const int64_t* height
  */
 int tvmi_paste_masks(const void* masks, const float* boxes, void* output, tvmi_dtype dt, int64_t N, int64_t M,
                      int64_t im_h, int64_t im_w, int64_t padding, void* stream);
+
+/* ------------------------------------------------------------------ quantized ------
+ * torchvision::qroi_align (quantized/cpu/qroi_align_kernel.cpp:22-178, CPU-only in the reference): `input` [1, C, H, W] and
+ * `rois` [K, 5] are integer tensors of type `dt` with explicit (scale, zero point); bilinear sums on the raw integers,
+ * dequantised once, averaged, re-quantised with round-half-even and saturated to `dt`; batch index 0 for every RoI.
+ * Bit-identical to the reference kernel.  (torchvision::qnms needs no entry of its own: its arithmetic is tvmi_nms_blocking on
+ * the boxes widened to float32 — quantized/cpu/qnms_kernel.cpp:60-120 — see the dispatcher glue.) */
+int tvmi_qroi_align_forward(const void* input, const void* rois, void* output, tvmi_int_dtype dt, int64_t C, int64_t H, int64_t W,
+                            int64_t K, int64_t pooled_h, int64_t pooled_w, double input_scale, int64_t input_zero_point,
+                            double rois_scale, int64_t rois_zero_point, double spatial_scale, int64_t sampling_ratio, int aligned,
+                            void* stream);
 
 #ifdef __cplusplus
 }

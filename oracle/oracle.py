@@ -361,3 +361,91 @@ def transform_images(images, min_size, max_size, mean, std, size_divisible=32, f
     for i, r in enumerate(resized):
         out[i, :, : r.shape[1], : r.shape[2]] = r
     return out, sizes
+
+
+def qnms(dets, scores, iou_threshold):
+    """torchvision::qnms (quantized/cpu/qnms_kernel.cpp:22-120): integer boxes / scores; the boxes are evaluated as float32
+    with the arithmetic of cpu/nms_kernel.cpp (the scale cancels), in the stable descending order of the integer scores."""
+    d = np.asarray(dets).astype(np.float32)
+    order = np.argsort(-np.asarray(scores).astype(np.int64), kind="stable").astype(np.int64)
+    n = d.shape[0]
+    areas = (d[:, 2] - d[:, 0]) * (d[:, 3] - d[:, 1])
+    sup = np.zeros(n, dtype=bool)
+    keep = []
+    f = np.float32
+    for _i in range(n):
+        i = order[_i]
+        if sup[i]:
+            continue
+        keep.append(i)
+        js = order[_i + 1:]
+        js = js[~sup[js]]
+        xx1 = np.maximum(d[i, 0], d[js, 0])
+        yy1 = np.maximum(d[i, 1], d[js, 1])
+        xx2 = np.minimum(d[i, 2], d[js, 2])
+        yy2 = np.minimum(d[i, 3], d[js, 3])
+        inter = np.maximum(f(0), xx2 - xx1) * np.maximum(f(0), yy2 - yy1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[js] - inter)
+        sup[js[ovr.astype(np.float64) > iou_threshold]] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def qroi_align(x, rois, input_scale, input_zero_point, rois_scale, rois_zero_point, spatial_scale, ph, pw, sampling_ratio, aligned):
+    """torchvision::qroi_align (quantized/cpu/qroi_align_kernel.cpp:22-178), op by op in float32: RoIs dequantised on load,
+    bilinear sums on the raw integers, one dequantisation, average, round-half-even re-quantisation, saturation.  Pure-python
+    loops: small cases only."""
+    f = np.float32
+    x = np.asarray(x)
+    rois = np.asarray(rois)
+    _, C, H, W = x.shape
+    K = rois.shape[0]
+    info = np.iinfo(x.dtype)
+    out = np.zeros((K, C, ph, pw), dtype=x.dtype)
+    isc, rsc, ssc = f(input_scale), f(rois_scale), f(spatial_scale)
+    off = f(0.5) if aligned else f(0.0)
+    for k in range(K):
+        sw, sh, ew, eh = [(f(rois[k, j]) - f(rois_zero_point)) * rsc * ssc - off for j in (1, 2, 3, 4)]
+        rw, rh = ew - sw, eh - sh
+        if not aligned:
+            rw, rh = max(rw, f(1)), max(rh, f(1))
+        bh, bw = rh / f(ph), rw / f(pw)
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / f(ph)))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / f(pw)))
+        count = f(max(gh * gw, 1))
+
+        def axis(dim, start, binsz, grid, p, i):
+            c = start + f(p) * binsz + f(i + 0.5) * binsz / f(grid)
+            if c < -1.0 or c > dim:
+                return None
+            c = max(c, f(0))
+            lo = int(c)
+            if lo >= dim - 1:
+                hi = lo = dim - 1
+                c = f(lo)
+            else:
+                hi = lo + 1
+            l_ = c - f(lo)
+            return lo, hi, l_, f(1) - l_
+        for c in range(C):
+            plane = x[0, c].astype(np.float32)
+            for p in range(ph):
+                for q in range(pw):
+                    val, sum_w = f(0), f(0)
+                    for iy in range(gh):
+                        ay = axis(H, sh, bh, gh, p, iy)
+                        for ix in range(gw):
+                            ax = axis(W, sw, bw, gw, q, ix)
+                            if ay is None or ax is None:
+                                continue
+                            ylo, yhi, ly, hy = ay
+                            xlo, xhi, lx, hx = ax
+                            w1, w2, w3, w4 = hy * hx, hy * lx, ly * hx, ly * lx
+                            val = f(val + f(f(f(w1 * plane[ylo, xlo] + w2 * plane[ylo, xhi]) + w3 * plane[yhi, xlo]) + w4 * plane[yhi, xhi]))
+                            sum_w = f(sum_w + f(f(f(w1 + w2) + w3) + w4))
+                    val = f(isc * f(val - f(f(input_zero_point) * sum_w)))
+                    val = f(val / count)
+                    inv = f(f(1.0) / isc)
+                    qv = int(f(f(input_zero_point) + f(np.rint(f(val * inv)))))
+                    out[k, c, p, q] = min(max(qv, info.min), info.max)
+    return out

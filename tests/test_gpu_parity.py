@@ -1487,10 +1487,25 @@ def test_batched_nms_mirrors_the_coordinate_trick_with_negative_boxes(n, ncat):
     suppresses ACROSS categories (ops/boxes.py:93-109).  The mirror must return the reference's index list there too:
     expected = the reference formulation itself on the CPU (shifted boxes -> the reference CPU nms kernel / its C restatement)."""
     g = gen(4000 + n)
-    boxes = random_boxes(n, 160, 160, 4, 90, g) - 70.0          # coordinates in [-70, 90]: min < -1, max + 1 = 91 < extent
+    boxes = random_boxes(n, 160, 160, 4, 90, g) - 70.0          # coordinates in [-70, 90]: min < -1
     boxes[: n // 3] += 70.0                                     # a third stays non-negative
     scores = torch.rand(n, generator=g)
     idxs = torch.randint(0, ncat, (n,), generator=g)
+    # planted cross-category pairs: box 0 pins the maximum at 95 (shift per category = 96); A in category c with all
+    # coordinates >= 30, B = A - 96 (+ jitter) in category c + 1 with a lower score: after the shifts B lies on A
+    boxes[0] = torch.tensor([60.0, 60.0, 95.0, 95.0])
+    npairs = 40
+    for k in range(npairs):
+        a, bidx = 1 + 2 * k, 2 + 2 * k
+        xy = 30.0 + torch.rand(2, generator=g) * 20.0
+        wh = 20.0 + torch.rand(2, generator=g) * 20.0
+        boxes[a] = torch.cat([xy, xy + wh])
+        boxes[bidx] = boxes[a] - 96.0 + (torch.rand(4, generator=g) - 0.5)
+        c = int(torch.randint(0, ncat - 1, (1,), generator=g))
+        idxs[a], idxs[bidx] = c, c + 1
+        scores[a], scores[bidx] = 0.99 - 0.001 * k, 0.5 - 0.001 * k
+    boxes.clamp_(max=95.0)
+    assert float(boxes.max()) == 95.0 and float(boxes.min()) < -1.0
     shifted = boxes + (idxs.to(boxes) * (boxes.max() + 1))[:, None]
     want = O.nms(shifted.numpy(), scores.numpy(), 0.5)
     per_cat = O.nms(boxes.numpy(), scores.numpy(), 0.5, idxs.numpy())
@@ -1575,3 +1590,40 @@ def test_nms_large_path_under_serialising_environment(var):
     env = dict(os.environ, **{var: "3" if var == "AMD_SERIALIZE_KERNEL" else "1"})
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64])
+def test_qnms_and_qroi_align_device_kernels(tv, dtype):
+    """SURVEY.md section 8f-4 (the last item): torchvision::qnms / torchvision::qroi_align on device tensors — CPU-only ops in the
+    reference (quantized/cpu/qnms_kernel.cpp, qroi_align_kernel.cpp), integer tensors with explicit (scale, zero point).  Bit-exact
+    against the reference CPU kernels (oracle/_ref) or, without them, the numpy restatement on a smaller case."""
+    g = gen(90)
+    info = torch.iinfo(dtype)
+    have_ref = O.load_reference()
+    n = 3000 if have_ref else 400
+    b = torch.randint(0, min(info.max, 120) - 40, (n, 2), generator=g)
+    boxes = torch.cat([b, b + torch.randint(1, 40, (n, 2), generator=g)], 1).to(dtype)
+    scores = torch.randint(max(info.min, -100), min(info.max, 127), (n,), generator=g).to(dtype)
+    for thr in (0.3, 0.5):
+        want = tv.qnms(boxes, scores, thr).numpy() if have_ref else O.qnms(boxes.numpy(), scores.numpy(), thr)
+        got = tv.qnms(boxes.to(DEV), scores.to(DEV), thr)
+        assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want), (dtype, thr)
+    assert tv.qnms(boxes[:0].to(DEV), scores[:0].to(DEV), 0.5).numel() == 0
+    with pytest.raises(RuntimeError, match="same type"):
+        tv.qnms(boxes.to(DEV), scores.to(torch.int64 if dtype != torch.int64 else torch.int32).to(DEV), 0.5)
+    K, C, H, W = (200, 16, 40, 56) if have_ref else (6, 2, 11, 13)
+    lo, hi = max(info.min, -100), min(info.max, 200)
+    x = torch.randint(lo, hi + 1, (1, C, H, W), generator=g).to(dtype)
+    x1 = torch.randint(0, 2 * W, (K,), generator=g)
+    y1 = torch.randint(0, 2 * H, (K,), generator=g)
+    rois = torch.stack([torch.zeros(K, dtype=torch.int64), x1, y1, x1 + torch.randint(0, 2 * W, (K,), generator=g),
+                        y1 + torch.randint(0, 2 * H, (K,), generator=g)], 1).clamp(max=min(info.max, 120)).to(dtype)
+    zp = 3 if info.min < 0 else 120
+    for (P, sr, aligned, scale) in ((7, 2, False, 1.0), (3, 0, True, 0.5), (5, 3, False, 0.25)):
+        args = (0.07, zp, 0.5, 0, scale, P, P + 1, sr, aligned)
+        want = tv.qroi_align(x, rois, *args).numpy() if have_ref else O.qroi_align(x.numpy(), rois.numpy(), *args)
+        got = tv.qroi_align(x.to(DEV), rois.to(DEV), *args)
+        assert got.dtype == dtype and tuple(got.shape) == (K, C, P, P + 1)
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"{dtype} P={P} sr={sr} aligned={aligned}")
+    with pytest.raises(RuntimeError, match="one image per batch"):
+        tv.qroi_align(torch.cat([x, x]).to(DEV), rois.to(DEV), 0.07, zp, 0.5, 0, 1.0, 3, 3, 2, False)

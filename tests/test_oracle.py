@@ -198,3 +198,36 @@ def test_transform_images_golden():
         assert [tuple(s) for s in G[f"xform_{tag}_sizes"]] == sizes
         assert out.shape == G[f"xform_{tag}_out"].shape
         np.testing.assert_allclose(out, G[f"xform_{tag}_out"], rtol=0, atol=2e-5)
+
+
+def _quantized_case(dtype, g, K=30, C=5, H=19, W=23):
+    info = torch.iinfo(dtype)
+    lo, hi = max(info.min, -100), min(info.max, 200)
+    x = torch.randint(lo, hi + 1, (1, C, H, W), generator=g).to(dtype)
+    # RoIs in quantised image coordinates (rois_scale 0.5 -> coordinates 0 .. 2*extent), a few hanging outside / degenerate
+    x1 = torch.randint(0, 2 * W, (K,), generator=g)
+    y1 = torch.randint(0, 2 * H, (K,), generator=g)
+    x2 = x1 + torch.randint(0, 2 * W, (K,), generator=g)
+    y2 = y1 + torch.randint(0, 2 * H, (K,), generator=g)
+    rois = torch.stack([torch.zeros(K, dtype=torch.int64), x1, y1, x2, y2], 1).clamp(max=min(info.max, 120)).to(dtype)
+    return x, rois
+
+
+def test_quantized_restatements_vs_reference(need_ref, tv):
+    """oracle.qnms / oracle.qroi_align (numpy, op by op in float32) pinned to the reference's CPU kernels
+    (quantized/cpu/qnms_kernel.cpp, qroi_align_kernel.cpp — part of oracle/_ref) bit for bit."""
+    g = gen(33)
+    for dtype in (torch.uint8, torch.int8, torch.int16, torch.int32):
+        info = torch.iinfo(dtype)
+        n = 300
+        b = torch.randint(0, min(info.max, 100) - 40, (n, 2), generator=g)
+        boxes = torch.cat([b, b + torch.randint(1, 40, (n, 2), generator=g)], 1).to(dtype)
+        scores = torch.randint(max(info.min, -50), min(info.max, 120), (n,), generator=g).to(dtype)     # many ties: stable order matters
+        for thr in (0.3, 0.5, 0.75):
+            assert np.array_equal(O.qnms(boxes.numpy(), scores.numpy(), thr), tv.qnms(boxes, scores, thr).numpy()), (dtype, thr)
+        x, rois = _quantized_case(dtype, g, K=8, C=2, H=11, W=13)
+        zp = 3 if info.min < 0 else 120
+        for (sr, aligned, scale) in ((2, False, 1.0), (0, True, 0.5), (3, False, 0.25)):
+            ref = tv.qroi_align(x, rois, 0.07, zp, 0.5, 0, scale, 3, 4, sr, aligned).numpy()
+            got = O.qroi_align(x.numpy(), rois.numpy(), 0.07, zp, 0.5, 0, scale, 3, 4, sr, aligned)
+            np.testing.assert_array_equal(got, ref, err_msg=f"{dtype} sr={sr} aligned={aligned}")

@@ -208,3 +208,49 @@ def test_reference_retinanet_and_maskrcnn_run_on_our_kernels(tmp_path):
         """
     )
     _run(code, tmp_path)
+
+
+@pytest.mark.gpu
+def test_fuse_detection_model_gives_the_reference_detections(tmp_path):
+    """`vision_amd.fuse_detection_model(model)`: the product API that swaps the fused pieces into a
+    reference detection model.  Faster R-CNN, Mask R-CNN and RetinaNet (ResNet50-FPN, random init, box / score threshold 0 so
+    that the post-processing is busy): the fused model must return the reference model's detections on the same images — same
+    count, same labels in the same order, scores / boxes / masks within the rounding the first op (fused normalise + resize vs
+    F.interpolate) carries through a random-init network — and must leave another model of the same class untouched."""
+    code = _prelude(tmp_path) + textwrap.dedent(
+        """
+        import vision_amd
+        from torchvision.models import detection as D
+
+        dev = "cuda"
+        g = torch.Generator().manual_seed(0)
+        imgs = [torch.rand(3, 256, 320, generator=g).to(dev), torch.rand(3, 224, 288, generator=g).to(dev)]
+        kw = dict(weights=None, weights_backbone=None, min_size=256, max_size=320)
+        models = {
+            "fasterrcnn": lambda: D.fasterrcnn_resnet50_fpn(box_score_thresh=0.0, rpn_post_nms_top_n_test=200, box_detections_per_img=30, **kw),
+            "maskrcnn": lambda: D.maskrcnn_resnet50_fpn(box_score_thresh=0.0, rpn_post_nms_top_n_test=200, box_detections_per_img=20, **kw),
+            "retinanet": lambda: D.retinanet_resnet50_fpn(score_thresh=0.0, detections_per_img=50, topk_candidates=200, **kw),
+        }
+        for name, ctor in models.items():
+            torch.manual_seed(0)
+            model = ctor().eval().to(dev)
+            with torch.no_grad():
+                ref = model(imgs)
+            other = ctor().eval()
+            before = (type(other.transform).forward, getattr(other, "roi_heads", other).postprocess_detections.__func__)
+            assert vision_amd.fuse_detection_model(model) is model
+            with torch.no_grad():
+                fus = model(imgs)
+            assert before == (type(other.transform).forward, getattr(other, "roi_heads", other).postprocess_detections.__func__), "class-level state was patched"
+            assert len(ref) == len(fus) == 2
+            for a, b in zip(ref, fus):
+                assert a["boxes"].shape == b["boxes"].shape and a["boxes"].shape[0] > 0, (name, a["boxes"].shape, b["boxes"].shape)
+                assert torch.equal(a["labels"], b["labels"]), name
+                assert float((a["scores"] - b["scores"]).abs().max()) < 2e-4, name
+                assert float((a["boxes"] - b["boxes"]).abs().max()) < 0.25, name
+                if "masks" in a:
+                    assert a["masks"].shape == b["masks"].shape and float((a["masks"] - b["masks"]).abs().max()) < 5e-3, name
+        print("OVERLAY_OK", torchvision.__file__)
+        """
+    )
+    _run(code, tmp_path)

@@ -87,29 +87,8 @@ def main():
     has_masks = args.model == "maskrcnn"
 
     def apply_fused():
-        import torchvision.models.detection.transform as T
-        from torchvision.models.detection.image_list import ImageList
-
-        names = ["0", "1", "2", "3"]
-        tr = model.transform
-        if args.model != "retinanet":
-            model.roi_heads.box_roi_pool = vision_amd.MultiScaleRoIAlign(names, 7, 2)
-            if has_masks:
-                model.roi_heads.mask_roi_pool = vision_amd.MultiScaleRoIAlign(names, 14, 2)
-            rh, rpn = model.roi_heads, model.rpn
-            rh.postprocess_detections = lambda logits, reg, props, shapes: vision_amd.postprocess_detections(
-                logits, reg, props, shapes, bbox_reg_weights=rh.box_coder.weights, score_thresh=rh.score_thresh,
-                nms_thresh=rh.nms_thresh, detections_per_img=rh.detections_per_img)
-            rpn.filter_proposals = lambda props, obj, shapes, per_level: vision_amd.filter_proposals(
-                props, obj, shapes, per_level, pre_nms_top_n=rpn.pre_nms_top_n(), post_nms_top_n=rpn.post_nms_top_n(),
-                nms_thresh=rpn.nms_thresh, score_thresh=rpn.score_thresh, min_size=rpn.min_size)
-            T.paste_masks_in_image = vision_amd.paste_masks_in_image
-
-        def fused_transform(images, targets=None):
-            tensors, sizes = vision_amd.transform_images(images, tr.min_size, tr.max_size, tr.image_mean, tr.image_std,
-                                                         tr.size_divisible)
-            return ImageList(tensors, [tuple(s) for s in sizes]), targets
-        tr.forward = fused_transform
+        # the product API (vision_amd/integration.py): pools, post-processing, proposal filtering, transform, mask pasting
+        integration.fuse_detection_model(model)
 
     if args.variant == "fused":
         apply_fused()

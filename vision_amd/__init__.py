@@ -65,7 +65,8 @@ from .deform_conv import DeformConv2d, deform_conv2d  # noqa: E402,F401
 from .poolers import LevelMapper, MultiScaleRoIAlign  # noqa: E402,F401
 from .resize import interpolate, resize  # noqa: E402,F401
 from .masks import expand_boxes, expand_masks, paste_masks_in_image  # noqa: E402,F401
-from .detection_post import filter_proposals, postprocess_detections  # noqa: E402,F401
+from .detection_post import filter_proposals, postprocess_detections, retinanet_postprocess_detections  # noqa: E402,F401
+from .integration import fuse_detection_model  # noqa: E402,F401
 from .transform import resize_boxes, resize_keypoints, resized_size, transform_images  # noqa: E402,F401
 from .transform import transform as transform_with_targets  # noqa: E402,F401
 from . import sharding  # noqa: E402,F401

@@ -164,6 +164,17 @@ at::Tensor nms_segmented(const at::Tensor& dets, const at::Tensor& scores, const
   return std::get<0>(r).narrow(0, 0, num_keep);
 }
 
+// ---- qnms (quantized/cpu/qnms_kernel.cpp:22-146; CPU-only in the reference): integer boxes / scores.  The reference evaluates
+// the boxes as float32 with the arithmetic of cpu/nms_kernel.cpp (the quantisation scale cancels in the IoU) in the stable
+// descending order of the INTEGER scores — i.e. our nms on the widened boxes with aten's stable sort of the integer scores.
+at::Tensor qnms_forward(const at::Tensor& dets, const at::Tensor& scores, double iou_threshold) {
+  TORCH_CHECK(dets.is_cuda(), "dets must be a CUDA tensor");
+  TORCH_CHECK(scores.is_cuda(), "scores must be a CUDA tensor");
+  TORCH_CHECK(dets.scalar_type() == scores.scalar_type(), "dets should have the same type as scores");
+  TORCH_CHECK(c10::isIntegralType(dets.scalar_type(), /*includeBool=*/false), "qnms: integer tensors expected (the reference dispatches AT_INTEGRAL_TYPES)");
+  return nms_segmented(dets.to(at::kFloat), scores, c10::nullopt, iou_threshold, -1);
+}
+
 // no host synchronisation: (keep [n] whose first num[0] entries are valid, num [1] int64 on the device)
 std::tuple<at::Tensor, at::Tensor> nms_segmented_padded(const at::Tensor& dets, const at::Tensor& scores,
                                                         const c10::optional<at::Tensor>& seg, double iou_threshold,
@@ -985,6 +996,36 @@ at::Tensor pack_detections_payload(const at::Tensor& boxes, const at::Tensor& sc
   return payload;
 }
 
+// ---- qroi_align (quantized/cpu/qroi_align_kernel.cpp:182-231: checks and messages; :22-178: arithmetic)
+at::Tensor qroi_align_forward(const at::Tensor& input, const at::Tensor& rois, double input_scale, int64_t input_zero_point,
+                              double rois_scale, int64_t rois_zero_point, double spatial_scale, c10::SymInt pooled_height,
+                              c10::SymInt pooled_width, int64_t sampling_ratio, bool aligned) {
+  TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+  TORCH_CHECK(rois.is_cuda(), "rois must be a CUDA tensor");
+  TORCH_CHECK(rois.dim() == 2 && rois.size(1) == 5, "rois must have shape as Tensor[K, 5]");
+  TORCH_CHECK(input.dim() == 4 && input.size(0) == 1, "Only one image per batch is allowed in qroi_align.");
+  TORCH_CHECK(input.scalar_type() == rois.scalar_type(), "input should have the same type as rois");
+  tvmi_int_dtype dt;
+  switch (input.scalar_type()) {
+    case at::kByte: dt = TVMI_U8; break;
+    case at::kChar: dt = TVMI_I8; break;
+    case at::kShort: dt = TVMI_I16; break;
+    case at::kInt: dt = TVMI_I32; break;
+    case at::kLong: dt = TVMI_I64; break;
+    default: TORCH_CHECK(false, "qroi_align: integer tensors expected (the reference dispatches AT_INTEGRAL_TYPES)");
+  }
+  c10::DeviceGuard guard(input.device());
+  const int64_t ph = pooled_height.expect_int(), pw = pooled_width.expect_int();
+  at::Tensor in = input.contiguous(), r = rois.contiguous();
+  at::Tensor out = at::empty({rois.size(0), input.size(1), ph, pw}, input.options());
+  if (out.numel() == 0) return out;
+  check_status(tvmi_qroi_align_forward(in.const_data_ptr(), r.const_data_ptr(), out.mutable_data_ptr(), dt, input.size(1), input.size(2),
+                                       input.size(3), rois.size(0), ph, pw, input_scale, input_zero_point, rois_scale,
+                                       rois_zero_point, spatial_scale, sampling_ratio, aligned ? 1 : 0, current_stream(input)),
+               "qroi_align");
+  return out;
+}
+
 // ---- convert_boxes_to_roi_format (ops/_utils.py:18-25) in one launch
 at::Tensor boxes_to_rois(at::TensorList boxes) {
   TORCH_CHECK(boxes.size() >= 1 && boxes.size() <= 64, "boxes_to_rois: 1..64 box lists supported");
@@ -1198,6 +1239,8 @@ TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
   m.impl("_ps_roi_pool_backward", &ps_roi_pool_backward);
   m.impl("deform_conv2d", &deform_conv2d_forward);
   m.impl("_deform_conv2d_backward", &deform_conv2d_backward);
+  m.impl("qnms", &qnms_forward);
+  m.impl("qroi_align", &qroi_align_forward);
 }
 
 TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {

@@ -98,3 +98,52 @@ def postprocess_detections(class_logits: Tensor, box_regression: Tensor, proposa
     keep = torch.ops.tvmi.nms_segmented(b, s, img * C + labels, float(nms_thresh), B * C)
     dets, counts = torch.ops.tvmi.pack_detections(b, s, labels, img, keep, B, int(detections_per_img))
     return (dets, counts) if padded else _split(dets, counts, True)
+
+
+def retinanet_postprocess_detections(cls_logits: Sequence[Tensor], bbox_regression: Sequence[Tensor], anchors: Sequence[Sequence[Tensor]],
+                                     image_shapes: Sequence[Tuple[int, int]], *, score_thresh: float = 0.05,
+                                     topk_candidates: int = 1000, nms_thresh: float = 0.5, detections_per_img: int = 300,
+                                     padded: bool = False):
+    """`RetinaNet.postprocess_detections` (torchvision/models/detection/retinanet.py:509-571), batched over the images of a step.
+    `cls_logits[l]` [B, A_l, K] and `bbox_regression[l]` [B, A_l, 4] per pyramid level (what the reference's forward splits the
+    head outputs into, :624-636), `anchors[i][l]` [A_l, 4] per image and level.  The reference loops images x levels (sigmoid,
+    threshold, top-k, decode, clip: ~12 launches each) and calls batched_nms per image; here: per level ONE sigmoid + top-k over
+    the batch (library plumbing), ONE gather / decode / clip kernel for all survivors (`tvmi::rpn_candidates`: BoxCoder weights
+    (1, 1, 1, 1) and the clip of `det_utils.BoxCoder`, the same as the RPN's), one `nonzero`, ONE class-segmented NMS over all
+    images and one packing launch.  Returns the reference's list of {boxes, scores, labels} dicts (or the padded payload)."""
+    _load()
+    _need_cuda(cls_logits[0], "retinanet_postprocess_detections")
+    B, K = cls_logits[0].shape[0], cls_logits[0].shape[-1]
+    dev = cls_logits[0].device
+    cand_logit, cand_anchor, cand_delta, cand_label, cand_ok, per_level = [], [], [], [], [], []
+    for lvl, (logits, deltas) in enumerate(zip(cls_logits, bbox_regression)):
+        flat = logits.detach().reshape(B, -1)                         # [B, A_l * K], (anchor, class) fastest = class
+        scores = torch.sigmoid(flat)
+        k = min(int(topk_candidates), flat.shape[1])                  # det_utils._topk_min
+        masked = torch.where(scores > score_thresh, scores, scores.new_full((), -1.0))
+        vals, idx = masked.topk(k, dim=1)
+        a_idx = torch.div(idx, K, rounding_mode="floor")
+        anc = torch.stack([anchors[i][lvl] for i in range(B)])        # [B, A_l, 4]
+        gi = a_idx[..., None].expand(-1, -1, 4)
+        cand_logit.append(flat.gather(1, idx))
+        cand_anchor.append(anc.gather(1, gi))
+        cand_delta.append(deltas.detach().gather(1, gi))
+        cand_label.append(idx - a_idx * K)
+        cand_ok.append(vals > score_thresh)
+        per_level.append(k)
+    logit, anc, dlt = torch.cat(cand_logit, 1), torch.cat(cand_anchor, 1).contiguous(), torch.cat(cand_delta, 1).contiguous()
+    labels, ok = torch.cat(cand_label, 1), torch.cat(cand_ok, 1)
+    T = logit.shape[1]
+    top_idx = torch.arange(T, device=dev, dtype=torch.int64).expand(B, T).contiguous()
+    offsets = torch.tensor([0] + per_level[:-1], dtype=torch.int64).cumsum(0).to(dev)
+    boxes, scores, _, _ = torch.ops.tvmi.rpn_candidates(logit.contiguous(), anc, dlt, top_idx, offsets, _image_hw(image_shapes, dev),
+                                                        BBOX_XFORM_CLIP, 0.0, -1.0)
+    sel = ok.reshape(-1).nonzero()[:, 0]
+    img = sel // T
+    b, sc, lab = boxes.reshape(-1, 4)[sel], scores.reshape(-1)[sel], labels.reshape(-1)[sel]
+    keep = torch.ops.tvmi.nms_segmented(b, sc, img * K + lab, float(nms_thresh), B * K)
+    dets, counts = torch.ops.tvmi.pack_detections(b, sc, lab, img, keep, B, int(detections_per_img))
+    if padded:
+        return dets, counts
+    bl, sl, ll = _split(dets, counts, True)
+    return [{"boxes": x, "scores": y, "labels": z} for x, y, z in zip(bl, sl, ll)]
