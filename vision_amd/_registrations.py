@@ -189,6 +189,26 @@ def _fake_boxes_to_rois(boxes):
     return boxes[0].new_empty((sum(b.shape[0] for b in boxes), 5))
 
 
+def _fake_qnms(dets, scores, iou_threshold):
+    # torchvision/_meta_registrations.py:177-188
+    torch._check(dets.dim() == 2, lambda: f"boxes should be a 2d tensor, got {dets.dim()}D")
+    torch._check(dets.size(1) == 4, lambda: f"boxes should have 4 elements in dimension 1, got {dets.size(1)}")
+    torch._check(scores.dim() == 1, lambda: f"scores should be a 1d tensor, got {scores.dim()}")
+    torch._check(dets.size(0) == scores.size(0),
+                 lambda: f"boxes and scores should have same number of elements in dimension 0, got {dets.size(0)} and {scores.size(0)}")
+    ctx = torch.library.get_ctx()
+    return dets.new_empty(ctx.new_dynamic_size(), dtype=torch.long)
+
+
+def _fake_qroi_align(input, rois, input_scale, input_zero_point, rois_scale, rois_zero_point, spatial_scale, pooled_height,
+                     pooled_width, sampling_ratio, aligned):
+    # torchvision/_meta_registrations.py:191-215
+    torch._check(rois.size(1) == 5, lambda: "rois must have shape as Tensor[K, 5]")
+    torch._check(input.dtype == rois.dtype,
+                 lambda: f"Expected tensor for input to have the same type as tensor for rois; but type {input.dtype} does not equal {rois.dtype}")
+    return input.new_empty((rois.size(0), input.size(1), pooled_height, pooled_width))
+
+
 _FAKES = {
     "tvmi::boxes_to_rois": _fake_boxes_to_rois,
     "tvmi::sort_scores_desc": lambda scores: scores.new_empty(scores.shape, dtype=torch.int64),
@@ -216,6 +236,8 @@ _FAKES = {
     "torchvision::deform_conv2d": _fake_deform_conv2d,
     "torchvision::_deform_conv2d_backward": _fake_deform_conv2d_bwd,
     "torchvision::box_iou_rotated": _fake_box_iou_rotated,
+    "torchvision::qnms": _fake_qnms,
+    "torchvision::qroi_align": _fake_qroi_align,
 }
 
 

@@ -15,6 +15,8 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
     """Greedy NMS; int64 indices of kept boxes in decreasing score order
     (torchvision.ops.nms, ops/boxes.py:20-54)."""
     assert_has_ops()
+    if boxes.is_quantized:      # ops/boxes.py:48-53: quantized boxes / scores -> qnms on their integer representation
+        return torch.ops.torchvision.qnms(boxes.int_repr(), scores.int_repr(), iou_threshold)
     return torch.ops.torchvision.nms(boxes, scores, iou_threshold)
 
 

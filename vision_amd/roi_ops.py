@@ -51,7 +51,14 @@ def roi_align(input: Tensor, boxes: BoxesArg, output_size, spatial_scale: float 
     ops/roi_align.py:204-285)."""
     assert_has_ops()
     oh, ow = _pair(output_size)
-    return torch.ops.torchvision.roi_align(input, _rois(boxes), spatial_scale, oh, ow, sampling_ratio, aligned)
+    rois = _rois(boxes)
+    if input.is_quantized:      # ops/roi_align.py:251-274: per-tensor quantized input and rois -> qroi_align on the integer data
+        if not rois.is_quantized:
+            raise ValueError("If input is quantized, rois must also be quantized.")
+        out_int = torch.ops.torchvision.qroi_align(input.int_repr(), rois.int_repr(), input.q_scale(), input.q_zero_point(),
+                                                   rois.q_scale(), rois.q_zero_point(), spatial_scale, oh, ow, sampling_ratio, aligned)
+        return torch._make_per_tensor_quantized_tensor(out_int, scale=input.q_scale(), zero_point=input.q_zero_point())
+    return torch.ops.torchvision.roi_align(input, rois, spatial_scale, oh, ow, sampling_ratio, aligned)
 
 
 def roi_pool(input: Tensor, boxes: BoxesArg, output_size, spatial_scale: float = 1.0) -> Tensor:
