@@ -549,17 +549,19 @@ def config5_block(rank, local_rank, world):
         out = json.loads(line[-1]) if line else {"error": (p.stderr or p.stdout)[-600:]}
     except Exception as exc:  # pragma: no cover - depends on the box
         out = {"error": f"{type(exc).__name__}: {exc}"}
-    # RetinaNet-R50-FPN of the reference on this library (north_star names it): unchanged python, per-level top-k +
-    # batched_nms (models/detection/retinanet.py:509-571) landing in our NMS kernels; img/s only, same images
+    # RetinaNet-R50-FPN of the reference on this library (north_star names it): unchanged python (per-level top-k +
+    # batched_nms, models/detection/retinanet.py:509-571, landing in our NMS kernels), then vision_amd.fuse_detection_model
     try:
-        cmd_r = [sys.executable, os.path.join(ROOT, "tools", "e2e_maskrcnn.py"), "--model", "retinanet", "--variant", "reference",
+        cmd_r = [sys.executable, os.path.join(ROOT, "tools", "e2e_maskrcnn.py"), "--model", "retinanet", "--variant", "both",
                  "--score-thresh", "0.0", "--steps", "4", "--warmup", "2"]
         env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
         p = subprocess.run(cmd_r, capture_output=True, text=True, timeout=300, env=env)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if line:
             r = json.loads(line[-1])
-            out["retinanet_reference_python_img_s"] = r.get("value")
+            out["retinanet_reference_python_img_s"] = r.get("reference_python_img_s", r.get("value"))
+            out["retinanet_fused_img_s"] = r.get("fused_img_s")          # vision_amd.fuse_detection_model: fused post-processing + transform
+            out["retinanet_same_detections_both_ways"] = r.get("same_detections_both_ways")
             out["retinanet_detections_per_image"] = r.get("detections_per_image")
         elif rank == 0:
             out["retinanet_error"] = (p.stderr or p.stdout)[-400:]

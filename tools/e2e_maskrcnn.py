@@ -39,7 +39,7 @@ def main():
                          "ways in one process and compare")
     ap.add_argument("--model", default="maskrcnn", choices=["maskrcnn", "fasterrcnn", "retinanet"],
                     help="detection model of the reference (all ResNet50-FPN, random init); the fused variant swaps what the "
-                         "model has: RetinaNet keeps its own post-processing (retinanet.py:509-571: per-level top-k + batched_nms, "
+                         "model has: RetinaNet gets vision_amd.retinanet_postprocess_detections (retinanet.py:509-571: per-level top-k + batched_nms, "
                          "which lands in our NMS kernels unchanged) and only gets the fused image transform")
     ap.add_argument("--batch", type=int, default=2, help="images per GPU and step")
     ap.add_argument("--steps", type=int, default=8)
@@ -97,7 +97,10 @@ def main():
     batches = [[torch.rand(3, 800, 1333, generator=g).to(device) for _ in range(args.batch)] for _ in range(2)]
 
     def compare(ref, fus):
-        """same detections in the same order; values differ by fp32 rounding carried through a random-init network"""
+        """same detections in the same order; values differ by fp32 rounding carried through a random-init network.  Where the
+        scores TIE (a random-init RetinaNet: sigmoid collapses many logits onto one float) the order among equal scores is
+        torch.topk's choice and differs between the per-image 1-D calls of the reference and the batched call — there the
+        detections are compared as a multiset, leaving out the ties that straddle the detections_per_img cut."""
         rep, ok = [], True
         for a, b in zip(ref, fus):
             n = min(len(a["scores"]), len(b["scores"]))
@@ -106,11 +109,22 @@ def main():
             ds = float((a["scores"][:n] - b["scores"][:n]).abs().max()) if n else 0.0
             db = float((a["boxes"][:n] - b["boxes"][:n]).abs().max()) if n else 0.0
             dm = float((a["masks"][:n] - b["masks"][:n]).abs().max()) if (n and has_masks) else 0.0
-            rep.append({"detections": [len(a["scores"]), len(b["scores"])], "labels_equal": lab, "max_score_diff": ds,
-                        "max_box_diff_px": db, "max_mask_diff": dm})
+            entry = {"detections": [len(a["scores"]), len(b["scores"])], "labels_equal": lab, "max_score_diff": ds,
+                     "max_box_diff_px": db, "max_mask_diff": dm}
+            good = same_n and lab and ds < 2e-4 and db < 0.25 and dm < 5e-3
+            if not good and same_n and ds < 2e-4 and n and not has_masks:
+                cut = float(torch.minimum(a["scores"][:n].min(), b["scores"][:n].min())) + 1e-6
+
+                def bag(o):
+                    keep = o["scores"] > cut
+                    return sorted((int(l), round(float(x[0]), 1), round(float(x[1]), 1), round(float(x[2]), 1), round(float(x[3]), 1))
+                                  for l, x in zip(o["labels"][keep].tolist(), o["boxes"][keep].tolist()))
+                ba, bb = bag(a), bag(b)
+                entry["order_differs_only_among_tied_scores"] = good = len(ba) == len(bb) and ba == bb
+            rep.append(entry)
             # the two pipelines differ by the rounding of their first op (fused normalise + resize vs F.interpolate) carried through
             # a random-init 50-layer network: 5e-5 .. 6e-5 in the scores and 0.003 .. 0.06 px in the boxes across GPU-box visits
-            ok = ok and same_n and lab and ds < 2e-4 and db < 0.25 and dm < 5e-3
+            ok = ok and good
         return rep, ok
 
     if args.variant == "check":
