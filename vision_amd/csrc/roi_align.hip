@@ -477,13 +477,17 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
 // image is [channel][row][wpad] with wpad = 64 / rows-per-instruction, so a lane's slot is a
 // pure function of its lane id, and lanes past the window edge fetch the clamped edge element
 // (the very element the reference multiplies its zero weight with).
-constexpr int kDmaPerPass = 4;                   // DMA instructions (x 1 KiB) per pass and buffer
+// DMA instructions (x 1 KiB) per pass and buffer.  (Measured, round 4: three blocks per buffer at 7 x 7 — 7.8 KB of LDS per
+// wave, FIVE workgroups = 20 waves per CU, windows of 4 .. 6 row groups single-buffered — is 2 % SLOWER than four blocks and four
+// workgroups, 0.228 vs 0.224 ms box-normalised: the kernel does not want occupancy, it wants its prefetch depth.)
+constexpr int dma_per_pass(int /*pht*/) { return 4; }
 constexpr int kDmaBlk = 260;                     // LDS floats per DMA instruction block (256 + 4 skew, 16-B aligned)
-constexpr int kDmaBuf = kDmaPerPass * kDmaBlk;   // floats per buffer
+constexpr int dma_buf_floats(int pht) { return dma_per_pass(pht) * kDmaBlk; }   // floats per buffer
 
 constexpr int kDmaStage = 400;   // floats: finished [channel][bin] rows of a wave, parked until they leave as 16-byte stores
+template <int PHT>
 struct DmaShared {
-  __attribute__((aligned(16))) float buf[2 * kDmaBuf];
+  __attribute__((aligned(16))) float buf[2 * dma_buf_floats(PHT)];
   __attribute__((aligned(16))) float stage[kDmaStage];
 };
 
@@ -566,14 +570,14 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   }
   w.nrg = small_div(w.wh + w.rpi - 1, w.m_rpi);
   // 1 = DMA path (<= 8 DMA instructions per channel), 2 = register-staged / global-gather path
-  w.state = w.nrg <= 2 * kDmaPerPass ? 1 : 2;
+  w.state = w.nrg <= 2 * dma_per_pass(PHT) ? 1 : 2;
   return w;
 }
 
 constexpr int kDmaBlkBytes = kDmaBlk * 4;  // 1040
 constexpr int kMopHeader = 4;              // worklist of declined RoIs: [count, -, -, -][RoI indices ...]
 
-template <typename T, int NRG>
+template <typename T, int NRG, int kDmaPerPass>
 __device__ __forceinline__ void dma_issue_pass(const T* __restrict__ in_pass, int64_t plane_sz, int gc,
                                                const int (&goff)[NRG], char* __restrict__ dst) {
   constexpr int G = NRG <= kDmaPerPass ? kDmaPerPass / NRG : 1;
@@ -631,7 +635,7 @@ __device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)size
 // the 16-bit types — is correct on gfx950 but 2.6x slower for the whole launch, 0.68 vs 0.26 ms: misaligned LDS reads are
 // replayed; profiles/r04_roi_variants_v1.json.)
 template <typename T, int PHT, int PWT, int SRT, int NRG>
-__device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __restrict__ in0, T* __restrict__ out,
+__device__ __forceinline__ void roi_align_dma_passes(DmaShared<PHT>& s, const T* __restrict__ in0, T* __restrict__ out,
                                                      int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
                                                      const RoiGeom<float>& g,
                                                      const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
@@ -641,7 +645,9 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
   constexpr int NB = (PHW + 63) / 64;
   constexpr int NS = SRT * SRT;
   constexpr int EPP = 16 / (int)sizeof(T);
-  constexpr bool kDouble = NRG <= kDmaPerPass;        // 8 row groups use both buffers as one
+  constexpr int kDmaPerPass = dma_per_pass(PHT), kDmaBuf = dma_buf_floats(PHT);
+  static_assert(NRG <= 2 * kDmaPerPass, "row groups beyond both buffers");
+  constexpr bool kDouble = NRG <= kDmaPerPass;        // more row groups use both buffers as one
   constexpr int G = kDouble ? kDmaPerPass / NRG : 1;
   constexpr bool kPow2 = (NS & (NS - 1)) == 0;
   const float inv_count = 1.f / (float)NS;
@@ -764,13 +770,13 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
     }
   };
   const int npass = (cc + G - 1) / G;
-  if (kDouble) dma_issue_pass<T, NRG>(in0, plane_sz, min(G, cc), goff, bytes);
+  if (kDouble) dma_issue_pass<T, NRG, kDmaPerPass>(in0, plane_sz, min(G, cc), goff, bytes);
   for (int p = 0; p < npass; ++p) {
     const int cg = p * G;
     const int gc = min(G, cc - cg);
     if (kDouble) {
       if (p + 1 < npass) {
-        dma_issue_pass<T, NRG>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
+        dma_issue_pass<T, NRG, kDmaPerPass>(in0 + (int64_t)(cg + G) * plane_sz, plane_sz, min(G, cc - cg - G), goff,
                                bytes + ((p + 1) & 1) * (kDmaBuf * 4));
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * NRG) : "memory");  // everything older than the DMAs just issued has landed
       } else {
@@ -783,7 +789,7 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
         run_channels(std::integral_constant<int, 0>{}, cg, gc, (unsigned)((p & 1) * (kDmaBuf * 4)));
       }
     } else {
-      dma_issue_pass<T, NRG>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, bytes);
+      dma_issue_pass<T, NRG, kDmaPerPass>(in0 + (int64_t)cg * plane_sz, plane_sz, gc, goff, bytes);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       run_channels(std::integral_constant<int, 0>{}, cg, gc, 0u);
     }
@@ -795,7 +801,7 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared& s, const T* __re
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
-__device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __restrict__ input,
+__device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared<PHT>& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
                                                        int c0, int chunk, int* __restrict__ declined) {
@@ -862,7 +868,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared& s, const T* __
   else if (dw.nrg <= 4)
     roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else
-    roi_align_dma_passes<T, PHT, PWT, SRT, 8>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2 * dma_per_pass(PHT)>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restric
                                                               int C, int H, int W, float spatial_scale, int aligned,
                                                               int nchunks, int chunk, int64_t nunits, int* __restrict__ mop,
                                                               UnitMap um) {
-  __shared__ DmaShared s[kThreads / 64];
+  __shared__ DmaShared<PHT> s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
                                                                  T* __restrict__ output, int C, int aligned,
                                                                  int nchunks, int chunk, int64_t nunits, int* __restrict__ mop,
                                                                  UnitMap um) {
-  __shared__ DmaShared s[kThreads / 64];
+  __shared__ DmaShared<PHT> s[kThreads / 64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
