@@ -1441,7 +1441,6 @@ int plan_units(UnitMap& um, const MsLevels& lv, const R* rois, int64_t N, int64_
                int* perm, hipStream_t stream) {
   um = UnitMap{nullptr, 0, 0};
   um.pinned = (g_fwd_opt.pin_chunks && unit_map_can_pin(nchunks)) ? 1 : 0;
-  um.packed = g_fwd_opt.packed;
   const int64_t L = multiscale ? lv.n_levels : 1;
   if (um.pinned && g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets) {
     const int bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * L)));
