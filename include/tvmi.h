@@ -54,9 +54,6 @@ int tvmi_version(void);
  *   "roi_align.order"            1 (default) / 0: with pinned chunks, RoIs start in (image, level, window-top band) order
  *                                (a one-workgroup counting sort in front of the launch; needs the forward workspace)
  *   "roi_align.order_bands"      bands per (image, level) in that order key (default 16, 1..64)
- *   "roi_align.packed"           1 (default) / 0: the lanes of an LDS-DMA instruction carry a flat (channel, window row, piece)
- *                                packing — several channels per instruction for small windows — instead of whole row groups of
- *                                one channel per instruction
  *   "dcn.channels_last_gather"   1 (default) / 0: the 16-bit MFMA deform_conv2d kernel samples a [B, H*W, C] copy of the input
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)

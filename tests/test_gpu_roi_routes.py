@@ -5,8 +5,6 @@
   pinned          pin_chunks 1, order 0    -> channel chunks pinned to XCDs, identity RoI order
   pinned+order    pin_chunks 1, order 1    -> + the (image, level, window-top band) launch order of roi_fwd_order
   ... with 1 / 16 / 64 window-top bands in the order key
-  ...+packed      packed 1                 -> the DMA instructions carry a flat (channel, row, piece) packing instead of whole row
-                                              groups of one channel (other LDS image, other pass structure, same arithmetic)
 
 Placement and order only change WHEN a unit runs: all routes must agree
 BIT FOR BIT with each other and with the oracle at 1e-4 (fp32).  Channel counts are chosen so that the pinned placement is
@@ -27,13 +25,11 @@ DEV = "cuda"
 TOL = 1e-4
 
 ROUTES = {
-    "ranges": {"roi_align.pin_chunks": 0, "roi_align.order": 0, "roi_align.packed": 0},
-    "pinned": {"roi_align.pin_chunks": 1, "roi_align.order": 0, "roi_align.packed": 0},
-    "pinned+order": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 16, "roi_align.packed": 0},
-    "pinned+order1band": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 1, "roi_align.packed": 0},
-    "pinned+order64bands": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 64, "roi_align.packed": 0},
-    "ranges+packed": {"roi_align.pin_chunks": 0, "roi_align.order": 0, "roi_align.packed": 1},
-    "pinned+order+packed": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 16, "roi_align.packed": 1},
+    "ranges": {"roi_align.pin_chunks": 0, "roi_align.order": 0},
+    "pinned": {"roi_align.pin_chunks": 1, "roi_align.order": 0},
+    "pinned+order": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 16},
+    "pinned+order1band": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 1},
+    "pinned+order64bands": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 64},
 }
 
 
@@ -44,7 +40,7 @@ class route:
         self.opts = ROUTES[name]
 
     def __enter__(self):
-        self.saved = {k: int(torch.ops.tvmi.get_option(k)) for k in ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands", "roi_align.packed")}
+        self.saved = {k: int(torch.ops.tvmi.get_option(k)) for k in ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands")}
         for k, v in self.opts.items():
             assert torch.ops.tvmi.set_option(k, v)
 
@@ -217,7 +213,7 @@ def test_nonfinite_pixels_next_to_zero_weight_taps(tv):
     # bins whose samples all sit on the last column / row are finite in the reference (it reads pixel dim-1 only)
     assert np.isfinite(ref[0, :, :, 6]).any() or np.isfinite(ref[0, :, 6, :]).any()
     results = {}
-    for name in ("ranges", "pinned+order64bands", "pinned+order+packed"):      # the per-RoI LDS-DMA kernel + its mop-up (RoI 1 has skipped samples)
+    for name in ("ranges", "pinned+order64bands"):      # the per-RoI LDS-DMA kernel + its mop-up (RoI 1 has skipped samples)
         with route(name):
             results[name] = tv.roi_align(xb.to(DEV), rois.to(DEV), 1.0, 7, 7, 2, False).cpu().numpy()
     # the channels_last kernel (reached through the multi-scale op; one level)

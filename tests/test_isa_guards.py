@@ -89,7 +89,7 @@ def test_occupancy_assumptions_of_the_hot_kernels(tmp_path):
     for r in dma.values():
         assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 96 and 0 < r["lds"] <= 40 * 1024, r
         assert 4 * r["lds"] <= 160 * 1024
-    big = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi14ELi14ELi2E" in k}     # fp32
+    big = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi14ELi14ELi2E" in k}
     assert len(big) == 1 and all(v["vgpr"] <= 128 and v["spill"] == 0 and v["scratch"] == 0 for v in big.values()), big
     assert re.search(r"s_waitcnt vmcnt\(3\)", text) and re.search(r"s_waitcnt vmcnt\(4\)", text)
     _, dcn = _kernel_resources(os.path.join(CSRC, "deform_conv2d.hip"), tmp_path)
@@ -129,9 +129,9 @@ def test_roi_align_dma_loop_keeps_its_prefetch_in_flight(tmp_path):
     for name, body in dma.items():
         assert "scratch_" not in body, name
         n0 = len(re.findall(r"s_waitcnt vmcnt\(0\)", body))
-        assert n0 <= 10, (name, n0)     # 5 + 2 written ones (row-group / packed form) + the RoI loads of the 16-bit single-level entry + the worklist atomics
+        assert n0 <= 7, (name, n0)      # 5 written ones + the RoI loads of the 16-bit single-level entry + the worklist atomic
         assert not re.search(r"s_waitcnt vmcnt\(0\) lgkmcnt", body), name     # a compiler-made combined wait inside the channel loop
         if "IfLi7ELi7E" in name:     # row-group forms 1, 2, 3 x 2 buffers, 4 x 2 buffers, 8: 7 loop bodies of 8 pair reads, no address VALU
-            assert len(re.findall(r"ds_read2_b32", body)) == (7 + 2) * 8, name     # + the packed form's two pass loops
+            assert len(re.findall(r"ds_read2_b32", body)) == 7 * 8, name
         if "IfLi14ELi14E" in name:
-            assert len(re.findall(r"ds_read2_b32", body)) == (5 + 2) * 8 * 4, name
+            assert len(re.findall(r"ds_read2_b32", body)) == 5 * 8 * 4, name

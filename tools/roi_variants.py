@@ -37,12 +37,12 @@ def tm(fn, n=24, warm=4):
     return e0.elapsed_time(e1) / n
 
 
-KEYS = ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands", "roi_align.packed")
+KEYS = ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands")
 SAVED = {k: int(torch.ops.tvmi.get_option(k)) for k in KEYS}
 
 
-def R(pin, order, bands, packed=0):
-    return dict(zip(KEYS, (pin, order, bands, packed)))
+def R(pin, order, bands):
+    return dict(zip(KEYS, (pin, order, bands)))
 
 
 ROUTES = {
@@ -51,8 +51,6 @@ ROUTES = {
     "pinned+order1": R(1, 1, 1),
     "pinned+order16": R(1, 1, 16),
     "pinned+order64": R(1, 1, 64),
-    "ranges+packed": R(0, 0, 16, 1),
-    "pinned+order16+packed": R(1, 1, 16, 1),
 }
 out = {}
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(ROUTES)

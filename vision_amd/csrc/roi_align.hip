@@ -511,7 +511,6 @@ __device__ __forceinline__ int small_div(int n, unsigned m) { return (int)(((uns
 
 struct DmaWindow {
   int state, y0, x0, wh, nq, lpr, rpi, nrg;
-  int geom_ok;   // y0 / x0 / wh / nq / lpr are valid (state 2 may still be set by the row-group limit)
   unsigned m_lpr, m_rpi;   // small_div_magic of lpr / rpi
   int sparse;  // 1: the LDS image holds only the SAMPLED rows — slot 2s / 2s+1 = low / high tap row of y-sample s
 };
@@ -525,7 +524,6 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
   w.state = 2;
   w.y0 = w.x0 = w.wh = w.nq = w.lpr = w.rpi = w.nrg = w.sparse = 0;
   w.m_lpr = w.m_rpi = 0;
-  w.geom_ok = 0;
   if (H < 2 || W < EPP) return w;
   int lo = 0, hi = 0, lo2 = 0;
   float l, h;
@@ -571,7 +569,6 @@ __device__ __forceinline__ DmaWindow dma_window(const RoiGeom<float>& g, int H, 
     w.wh = 2 * ny;
   }
   w.nrg = small_div(w.wh + w.rpi - 1, w.m_rpi);
-  w.geom_ok = 1;
   // 1 = DMA path (<= 8 DMA instructions per channel), 2 = register-staged / global-gather path
   w.state = w.nrg <= 2 * dma_per_pass(PHT) ? 1 : 2;
   return w;
@@ -803,261 +800,6 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared<PHT>& s, const T*
   if (kStaged && staged) flush(cc - staged, staged);
 }
 
-// ---------------------------------------------------------------------------------------
-// PACKED staging ("roi_align.packed"): the same LDS-DMA idea with the 64 lanes of a DMA instruction assigned to a FLAT
-// index over (channel of the pass, window row, piece) instead of "rpi whole rows of ONE channel per instruction".  Every lane
-// of a global_load_lds carries its own 64-bit address, so one instruction can fetch pieces of several channel planes; the LDS
-// image of a pass is simply [channel][row][lpr pieces] contiguous (block stride exactly 1 KiB, rows may straddle instruction
-// blocks).  A window of n1 = rows x lpr lanes per channel puts P = floor(256 / n1) channels into the M = ceil(P n1 / 64) <= 4
-// instructions of a pass: the FPN workload's 2.05 DMA instructions per RoI-channel become 1.75, and — what the kernel is
-// actually short of (it wants prefetch depth, not occupancy) — a small window has up to 8x more channels in
-// flight per wave.  Windows of 257 .. 512 lanes take both buffers as one (P = 1, M <= 8), larger ones go to the mop-up launch.
-struct PackedWindow {
-  int state, y0, x0, wh, nq, lpr, sparse;
-  int n1, P, M;
-  unsigned m_lpr;
-  float inv_n1;
-};
-
-template <int PHT, int PWT, int SRT, int EPP>
-__device__ __forceinline__ PackedWindow packed_window(const RoiGeom<float>& g, int H, int W, int cc) {
-  const DmaWindow d = dma_window<PHT, PWT, SRT, EPP>(g, H, W);
-  PackedWindow w;
-  w.state = d.state;
-  w.y0 = d.y0;
-  w.x0 = d.x0;
-  w.wh = d.wh;
-  w.nq = d.nq;
-  w.lpr = d.lpr;
-  w.sparse = d.sparse;
-  w.m_lpr = d.m_lpr;
-  w.n1 = w.P = w.M = 0;
-  w.inv_n1 = 0.f;
-  if (d.state == 0 || d.geom_ok == 0) return w;   // all outputs zero, or declined before the geometry was complete
-  w.n1 = d.wh * d.lpr;
-  w.inv_n1 = __builtin_amdgcn_rcpf((float)w.n1);
-  if (w.n1 > 8 * 64) {
-    w.state = 2;                                 // more than both buffers: mop-up launch
-    return w;
-  }
-  w.state = 1;                                   // (the row-group form's own limit of 8 groups does not apply here)
-  if (w.n1 <= 4 * 64) {
-    w.P = min((int)(256.5f * w.inv_n1), cc);     // floor(256 / n1): 256.5 / n1 is >= 0.5 / n1 away from the next integer
-    w.P = max(w.P, 1);
-    w.M = (w.P * w.n1 + 63) >> 6;
-  } else {
-    w.P = 1;
-    w.M = (w.n1 + 63) >> 6;
-  }
-  return w;
-}
-
-template <typename T, int PHT, int PWT, int SRT>
-__device__ __forceinline__ void roi_align_packed_passes(DmaShared<PHT>& s, const T* __restrict__ in0, T* __restrict__ out,
-                                                        int64_t plane_sz, int cc, int H, int W, const PackedWindow& pw_,
-                                                        const RoiGeom<float>& g,
-                                                        const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
-                                                        const float (&fy)[(PHT * PWT + 63) / 64][SRT][2],
-                                                        const float (&fx)[(PHT * PWT + 63) / 64][SRT][2]) {
-  constexpr int PHW = PHT * PWT;
-  constexpr int NB = (PHW + 63) / 64;
-  constexpr int NS = SRT * SRT;
-  constexpr int EPP = 16 / (int)sizeof(T);
-  constexpr int kBufBytes = 4 * 1024;            // one buffer = four 1-KiB instruction blocks, no skew
-  constexpr bool kPow2 = (NS & (NS - 1)) == 0;
-  const float inv_count = 1.f / (float)NS;
-  const int lane = threadIdx.x & 63;
-  const int P = pw_.P, M = pw_.M, n1 = pw_.n1;
-  const bool dbl = n1 <= 4 * 64;                 // wave-uniform
-  char* const bytes = reinterpret_cast<char*>(s.buf);
-  // ---- per-lane source of every instruction of a pass: flat = 64 m + lane -> (channel of the pass, row, piece)
-  int64_t eoff[8];                               // element offset from the pass's first channel plane
-  int chan_of[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    eoff[m] = 0;
-    chan_of[m] = 0;
-    if (m >= M) continue;                                            // wave-uniform
-    const int flat = min(64 * m + lane, P * n1 - 1);                 // lanes past the pass re-fetch its last piece (same slot value)
-    const int cp = (int)(((float)flat + 0.5f) * pw_.inv_n1);         // flat / n1: (flat + 0.5) / n1 is >= 0.5 / n1 away from an integer
-    const int rem = flat - cp * n1;
-    const int row = small_div(rem, pw_.m_lpr);
-    const int q = min(rem - row * pw_.lpr, pw_.nq - 1);              // the pad piece of an odd pitch duplicates the last real one
-    int y = pw_.y0 + row;
-    if (pw_.sparse) {
-      int lo, hi;
-      float l, h;
-      axis_sample<float>(H, g.start_h, g.bin_h, SRT, (row >> 1) / SRT, (row >> 1) % SRT, lo, hi, l, h);
-      y = (row & 1) ? hi : lo;
-    }
-    chan_of[m] = cp;
-    eoff[m] = (int64_t)cp * plane_sz + (int64_t)(min(y, H - 1) * W + pw_.x0 + EPP * q);
-  }
-  // returns the number of instructions issued (wave-uniform): M, or fewer for the partial last pass of a chunk — its missing
-  // channels must not touch memory past the tensor, so their lanes are masked and instructions without a live lane are not issued
-  auto issue = [&](const T* in_pass, int gc, char* dst) {
-    const bool full = gc >= P;
-    const int mi = full ? M : (gc * n1 + 63) >> 6;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < mi) {
-        if (full || chan_of[m] < gc)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(in_pass + eoff[m]), (lds_ptr_t)(dst + m * 1024), 16, 0, 0);
-      }
-    }
-    return mi;
-  };
-  auto wait_all_but = [&](int keep) {            // s_waitcnt takes an immediate: the four counts a pass can have
-    if (keep >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (keep == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  };
-  constexpr bool kStaged = sizeof(T) == 4;
-  constexpr int SC = (kDmaStage * 4 / (int)sizeof(T)) / PHW >= 8 ? 8 : ((kDmaStage * 4 / (int)sizeof(T)) / PHW >= 2 ? 2 : 1);
-  constexpr int kGroupVec = SC * PHW * (int)sizeof(T) / 16;
-  const unsigned stage_addr = lds_addr(s.stage);
-  const bool vec_ok = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-  int staged = 0;
-  auto flush = [&](int first_ch, int nch) {
-    if (nch == SC && vec_ok) {
-      f32x4_t* dst = reinterpret_cast<f32x4_t*>(out + (int64_t)first_ch * PHW);
-#pragma unroll
-      for (int i = 0; i < (kGroupVec + 63) / 64; ++i) {
-        const int v = lane + 64 * i;
-        if (v < kGroupVec) __builtin_nontemporal_store(lds_load_f32x4_opaque(stage_addr + 16u * (unsigned)v), dst + v);
-      }
-    } else {
-      for (int i = lane; i < nch * PHW; i += 64)
-        st(out + (int64_t)first_ch * PHW + i, lds_load_f32_opaque(stage_addr + 4u * (unsigned)i));
-    }
-  };
-  const unsigned st_lane = stage_addr + 4u * (unsigned)lane;
-  const unsigned chan_bytes = (unsigned)(n1 * 16);                    // LDS bytes of one channel's window image
-  auto run_channels = [&](int cg, int gc, unsigned buf_base) {
-    for (int ch = 0; ch < gc; ++ch) {
-      const T* wbase = reinterpret_cast<const T*>(bytes + buf_base + (unsigned)ch * chan_bytes);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int bin = lane + 64 * b;
-        if (b + 1 < NB || bin < PHW) {
-          float acc = 0.f;
-#pragma unroll
-          for (int iy = 0; iy < SRT; ++iy) {
-#pragma unroll
-            for (int ix = 0; ix < SRT; ++ix) {
-              const int i = iy * SRT + ix;
-              const T* q0 = wbase + off[b][i][0];
-              const T* q1 = wbase + off[b][i][1];
-              const float t0 = __builtin_fmaf(fx[b][ix][0], ld(q0 + 1), mul_legacy(fx[b][ix][1], ld(q0)));   // x edge: 0 * (pixel W-2) = 0
-              const float t1 = __builtin_fmaf(fx[b][ix][0], ld(q1 + 1), mul_legacy(fx[b][ix][1], ld(q1)));
-              acc = __builtin_fmaf(fy[b][iy][1], t0, acc);
-              acc = __builtin_fmaf(fy[b][iy][0], t1, acc);
-            }
-          }
-          const float r = kPow2 ? acc * inv_count : acc / (float)NS;
-          if constexpr (kStaged) {
-            const unsigned sa = st_lane + (unsigned)(staged * (PHW * 4));
-            if (b == 0) lds_store_f32_opaque<0>(sa, r);
-            else if (b == 1) lds_store_f32_opaque<256>(sa, r);
-            else if (b == 2) lds_store_f32_opaque<512>(sa, r);
-            else lds_store_f32_opaque<768>(sa, r);
-          } else {
-            st(out + (cg + ch) * PHW + bin, r);
-          }
-          if constexpr (NB > 1) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if constexpr (kStaged) {
-        if (++staged == SC) {
-          flush(cg + ch + 1 - SC, SC);
-          staged = 0;
-        }
-      }
-    }
-  };
-  const int npass = (cc + P - 1) / P;
-  if (dbl) issue(in0, min(P, cc), bytes);
-  for (int p = 0; p < npass; ++p) {
-    const int cg = p * P;
-    const int gc = min(P, cc - cg);
-    if (dbl) {
-      if (p + 1 < npass) {
-        const int mi = issue(in0 + (int64_t)(cg + P) * plane_sz, min(P, cc - cg - P), bytes + ((p + 1) & 1) * kBufBytes);
-        wait_all_but(mi);   // everything older than the instructions just issued has landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      run_channels(cg, gc, (unsigned)((p & 1) * kBufBytes));
-    } else {
-      issue(in0 + (int64_t)cg * plane_sz, gc, bytes);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      run_channels(cg, gc, 0u);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of this buffer are complete before the next DMAs overwrite it
-  }
-  if (kStaged && staged) flush(cc - staged, staged);
-}
-
-template <typename T, typename R, int PHT, int PWT, int SRT>
-__device__ __forceinline__ void roi_align_fwd_wave_packed(DmaShared<PHT>& s, const T* __restrict__ input,
-                                                          const R* __restrict__ rois, T* __restrict__ output,
-                                                          int C, int H, int W, float spatial_scale, int aligned, int k,
-                                                          int c0, int chunk, int* __restrict__ declined) {
-  constexpr int PHW = PHT * PWT;
-  constexpr int NB = (PHW + 63) / 64;
-  constexpr int NS = SRT * SRT;
-  constexpr int EPP = 16 / (int)sizeof(T);
-  const int lane = threadIdx.x & 63;
-  const int cc = min(chunk, C - c0);
-  const RoiGeom<float> g = roi_geom<R, float>(rois + (int64_t)k * 5, spatial_scale, PHT, PWT, SRT, aligned != 0);
-  T* out = output + ((int64_t)k * C + c0) * PHW;
-  const T* in0 = input + ((int64_t)g.batch * C + c0) * H * W;
-  const int64_t plane_sz = (int64_t)H * W;
-  const PackedWindow w = packed_window<PHT, PWT, SRT, EPP>(g, H, W, cc);
-  if (w.state == 2) {
-    if (c0 == 0 && lane == 0) declined[kMopHeader + atomicAdd(declined, 1)] = k;
-    return;
-  }
-  if (w.state == 0) {
-    for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
-    return;
-  }
-  int off[NB][NS][2];
-  float fy[NB][SRT][2], fx[NB][SRT][2];
-  const int rstride = EPP * w.lpr;
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int bin = min(lane + 64 * b, PHW - 1);
-    const int ph = bin / PWT, pw = bin - ph * PWT;
-    int rlo[SRT][2], xlo[SRT];
-#pragma unroll
-    for (int i = 0; i < SRT; ++i) {
-      int lo, hi;
-      float l, h;
-      const bool vy = axis_sample<float>(H, g.start_h, g.bin_h, SRT, ph, i, lo, hi, l, h);
-      fy[b][i][0] = l;
-      fy[b][i][1] = h;
-      const int r = w.sparse ? 2 * (ph * SRT + i) : (vy ? lo - w.y0 : 0);
-      const int r1 = w.sparse ? r + 1 : r + (hi - lo);
-      rlo[i][0] = r * rstride;
-      rlo[i][1] = r1 * rstride;
-      const bool vx = axis_sample_shifted(W, g.start_w, g.bin_w, SRT, pw, i, lo, l, h);
-      fx[b][i][0] = l;
-      fx[b][i][1] = h;
-      xlo[i] = vx ? lo - w.x0 : 0;
-    }
-#pragma unroll
-    for (int iy = 0; iy < SRT; ++iy)
-#pragma unroll
-      for (int ix = 0; ix < SRT; ++ix) {
-        off[b][iy * SRT + ix][0] = rlo[iy][0] + xlo[ix];
-        off[b][iy * SRT + ix][1] = rlo[iy][1] + xlo[ix];
-      }
-  }
-  roi_align_packed_passes<T, PHT, PWT, SRT>(s, in0, out, plane_sz, cc, H, W, w, g, off, fy, fx);
-}
-
 template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared<PHT>& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
@@ -1153,7 +895,6 @@ __device__ __forceinline__ void roi_align_wave_dispatch(WaveShared& s, const T* 
 struct UnitMap {
   const int* perm;  // nullptr: identity
   int pinned;
-  int packed;       // staging form of the DMA kernels: 0 row groups of one channel per instruction, 1 flat (channel, row, piece) packing
 };
 
 __device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const UnitMap& um, int& k, int& chunk_idx,
@@ -1331,7 +1072,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restri
                                                    aligned, k, ci * chunk, chunk);
     return;
   }
-  if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0, 0}, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0}, k, ci)) return;
   roi_align_wave_dispatch<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, PH_, PW_, spatial_scale, sr_,
                                                aligned, k, ci * chunk, chunk);
 }
@@ -1346,12 +1087,8 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_dma(const T* __restric
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
-  if (um.packed)
-    roi_align_fwd_wave_packed<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
-                                                   chunk, mop);
-  else
-    roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
-                                                chunk, mop);
+  roi_align_fwd_wave_dma<T, T, PHT, PWT, SRT>(s[wave], input, rois, output, C, H, W, spatial_scale, aligned, k, ci * chunk,
+                                              chunk, mop);
 }
 
 // Multi-scale entries: RoIs are float32 image coordinates whatever the feature dtype (roi_common.h).
@@ -1365,12 +1102,8 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  if (um.packed)
-    roi_align_fwd_wave_packed<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
-                                                       lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
-  else
-    roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
-                                                    lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
+  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
+                                                  lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -1389,7 +1122,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, c
     }
     return;
   }
-  if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0, 0}, k, ci)) return;
+  if (!wave_unit(nunits / nchunks, nchunks, UnitMap{nullptr, 0}, k, ci)) return;
   const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
   roi_align_wave_dispatch<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
                                                    lv.W[l], PH_, PW_, lv.scale[l], sr_, aligned, k, ci * chunk, chunk);
@@ -1412,7 +1145,6 @@ struct FwdOptions {
   int pin_chunks = 1;   // "roi_align.pin_chunks": channel chunks pinned to XCDs when the chunk count allows it
   int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
   int bands = 16;       // "roi_align.order_bands": window-top bands per (image, level) in the order key
-  int packed = 1;       // "roi_align.packed": flat (channel, row, piece) packing of the DMA instructions
 };
 FwdOptions g_fwd_opt;
 
@@ -1439,7 +1171,7 @@ int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, c
 template <typename R>
 int plan_units(UnitMap& um, const MsLevels& lv, const R* rois, int64_t N, int64_t K, int nchunks, int multiscale, int* mop,
                int* perm, hipStream_t stream) {
-  um = UnitMap{nullptr, 0, 0};
+  um = UnitMap{nullptr, 0};
   um.pinned = (g_fwd_opt.pin_chunks && unit_map_can_pin(nchunks)) ? 1 : 0;
   const int64_t L = multiscale ? lv.n_levels : 1;
   if (um.pinned && g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets) {
@@ -1471,7 +1203,7 @@ int launch_fwd(const void* input, const void* rois, void* output, int64_t N, int
     const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
     const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
     const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
-    UnitMap um{nullptr, 0, 0};
+    UnitMap um{nullptr, 0};
     if (fast_shape && mop) {
       MsLevels one;
       const void* ptrs[1] = {input};
@@ -1539,7 +1271,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int k, gi;
-  if (!wave_unit(nunits / ngroups, ngroups, UnitMap{nullptr, 0, 0}, k, gi)) return;
+  if (!wave_unit(nunits / ngroups, ngroups, UnitMap{nullptr, 0}, k, gi)) return;
   const int c0 = gi * GC;
   // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
   const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
@@ -1671,7 +1403,7 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
   const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
   const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
   const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
-  UnitMap um{nullptr, 0, 0};
+  UnitMap um{nullptr, 0};
   if (fast_shape && mop) {
     const int st = plan_units<float>(um, lv, r, N, K, nchunks, /*multiscale=*/1, mop, perm, stream);
     if (st != 0) return set_error(st, "tvmi_multiscale_roi_align_forward: clearing the worklist failed");
@@ -1711,7 +1443,6 @@ int set_roi_option(const char* name, int64_t value) {
   if (n == "roi_align.pin_chunks") g_fwd_opt.pin_chunks = value != 0;
   else if (n == "roi_align.order") g_fwd_opt.order = value != 0;
   else if (n == "roi_align.order_bands") g_fwd_opt.bands = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
-  else if (n == "roi_align.packed") g_fwd_opt.packed = value != 0;
   else return -1;
   return 0;
 }
@@ -1722,7 +1453,6 @@ int get_roi_option(const char* name, int64_t* value) {
   if (n == "roi_align.pin_chunks") *value = g_fwd_opt.pin_chunks;
   else if (n == "roi_align.order") *value = g_fwd_opt.order;
   else if (n == "roi_align.order_bands") *value = g_fwd_opt.bands;
-  else if (n == "roi_align.packed") *value = g_fwd_opt.packed;
   else return -1;
   return 0;
 }
