@@ -7,6 +7,9 @@ if os.environ.get("TVMI_TOOL_SERIALIZED_PROFILER"):
     # rocprofv3 --pmc runs ONE kernel at a time: the polling push kernel of the large-NMS hand-offs would wait for a resolver
     # that cannot start.  Counter passes use the stream-event form of the same pipeline.
     torch.ops.tvmi.set_option("nms.device_handoff", 0)
+for kv in filter(None, os.environ.get("TVMI_SET_OPTIONS", "").split(",")):     # e.g. TVMI_SET_OPTIONS=roi_align.order=0,nms.device_handoff=0
+    name, val = kv.split("=")
+    torch.ops.tvmi.set_option(name, int(val))
 which = sys.argv[1] if len(sys.argv) > 1 else "roi7"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")

@@ -481,6 +481,13 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
 // wave, FIVE workgroups = 20 waves per CU, windows of 4 .. 6 row groups single-buffered — is 2 % SLOWER than four blocks and four
 // workgroups, 0.228 vs 0.224 ms box-normalised: the kernel does not want occupancy, it wants its prefetch depth.)
 constexpr int dma_per_pass(int /*pht*/) { return 4; }
+// (Measured and removed, round 4: "packed" staging — the 64 lanes of a DMA instruction assigned to a flat (channel of the pass,
+// window row, piece) index, so that a small window puts several channels into one instruction and a pass always fills its four
+// blocks: 2.05 -> 1.75 DMA instructions per RoI-channel on the FPN workload, up to 8x more channels in flight per wave.  Correct
+// (every route test green) and 12 % SLOWER, 0.248 vs 0.221 ms (fp32 7 x 7; bf16 0.199 vs 0.176): an instruction whose lanes span
+// several channel planes touches as many cache lines as the instructions it replaces — the texture path is paid per line, not
+// per instruction — and the per-lane 64-bit plane offsets plus the per-channel tap address arithmetic come on top.
+// profiles/r04_roi_variants_packed.json.)
 constexpr int kDmaBlk = 260;                     // LDS floats per DMA instruction block (256 + 4 skew, 16-B aligned)
 constexpr int dma_buf_floats(int pht) { return dma_per_pass(pht) * kDmaBlk; }   // floats per buffer
 
