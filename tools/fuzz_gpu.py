@@ -19,6 +19,7 @@ while time.time() - t0 < 60:
         k1 = ri(3, 50); b[1::k1, 2] = b[1::k1, 0] - 1.0
         if ri(0, 1): b[2::ri(5, 60)] *= 2.0 ** -38
         if ri(0, 1): b[3::ri(5, 60)] *= 2.0 ** 33
+    if ri(0, 4) == 0: b -= canvas * 0.6                  # coordinates below -1: the coordinate trick of batched_nms suppresses across categories
     s = torch.rand(n, generator=g)
     if ri(0, 2) == 0: s = (s * ri(2, 50)).floor() / 16
     idx = torch.randint(0, S, (n,), generator=g)
@@ -37,7 +38,10 @@ while time.time() - t0 < 60:
         gotb = vision_amd.batched_nms(b.to(dev), s.to(dev), idx.to(dev), thr, num_segments=hint).cpu().numpy()   # the reference's switch of arithmetic
         assert np.array_equal(gotb, O.batched_nms(b, s, idx, thr)), ("batched", n, S, hint, thr)
     # ---- RoIAlign forward NCHW vs channels_last vs oracle, backward vs oracle
-    N, C, H, W = ri(1, 3), ri(1, 70), ri(2, 60), ri(4, 70)
+    N, C, H, W = ri(1, 3), [ri(1, 70), ri(1, 70), 256, 512][ri(0, 3)], ri(2, 60), ri(4, 70)
+    # launch routes of the LDS-DMA forward (C = 256 / 512: channel chunks pinned to XCDs, launch order from the pre-pass)
+    torch.ops.tvmi.set_option("roi_align.pin_chunks", ri(0, 1)); torch.ops.tvmi.set_option("roi_align.order", ri(0, 1))
+    torch.ops.tvmi.set_option("roi_align.order_bands", [1, 16, 64][ri(0, 2)])
     x = torch.rand(N, C, H, W, generator=g)
     k = ri(1, 60); scale = [1.0, 0.5, 0.25][ri(0, 2)]
     bx = torch.rand(k, 2, generator=g) * torch.tensor([W / scale, H / scale]) * 1.1 - 0.05 * W / scale

@@ -11,8 +11,8 @@ export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 echo "== host: $(nproc) cpus; $(rocminfo 2>/dev/null | grep -m1 gfx9)"> $OUT/env.txt
 python -c "import torch; print(torch.__version__, torch.version.hip, torch.cuda.get_device_name(0), torch.cuda.device_count())" >> $OUT/env.txt 2>&1
-timeout 600 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/prof -o bench -- python $ROOTDIR/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOTDIR/$OUT/prof.log 2>&1
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/prof -o bench -- python $ROOTDIR/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-configs > $ROOTDIR/$OUT/prof.log 2>&1
 cd $ROOTDIR
 timeout 600 python tools/gpu_matrix.py $OUT/matrix.json > $OUT/matrix.log 2>&1; tail -3 $OUT/matrix.log
 cd /tmp
