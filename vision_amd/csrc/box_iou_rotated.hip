@@ -7,27 +7,19 @@
 // (:102-103).  The double-precision promotions of the reference (angle, EPS comparisons,
 // centre shift, area/2.0) are kept.
 //
-// Layout: an 8x8 thread tile (one wave) per workgroup; the 8 row boxes and 8 column boxes of the tile are staged once in
-// LDS, each lane then works on its own pair.  The reference's three 24-entry work arrays (candidate points, the points in
-// scan order, their squared distances) are indexed at run time by the Graham scan — as private arrays they live in SCRATCH
-// (global memory, ~0.5 us per dependent access; round 3: 0.167 ms at 2000 x 2000).  Here they are lane-interleaved LDS arrays
-// (element i of lane l at [i][l]: conflict-free, ~64-cycle accesses), 120 floats per lane = 30 KB per workgroup (fp64: 60 KB);
-// same algorithm, same operations, same order — only where the arrays live changed.  Pairs whose circumscribed circles do not
-// touch skip the polygon clipping altogether (the IoU is exactly 0 there: no candidate point can exist).
+// Layout: a 16x16 thread tile per workgroup; the 16 row boxes and 16 column boxes of the
+// tile are staged once in LDS, each lane then works on its own pair with the 24-point
+// scratch arrays held per lane.  Pairs whose circumscribed circles do not touch skip the
+// polygon clipping altogether (the IoU is exactly 0 there: no candidate point can exist).
+// (Measured, round 4: the three 24-entry work arrays as lane-interleaved LDS arrays instead of private (scratch) arrays — no
+// scratch, 75 VGPRs, but 30 KB of LDS per 64-lane workgroup = 5 waves per CU: 0.403 ms instead of 0.166 ms at 2000 x 2000.
+// The scratch accesses of this kernel are L1 / L2 hits hidden by 32 resident waves per CU; the arrays stay private.)
 #include "tvmi_common.h"
 
 namespace tvmi {
 namespace {
 
-constexpr int kTile = 8;
-constexpr int kLanes = kTile * kTile;   // 64: one wave per workgroup
-
-// lane-interleaved LDS array: element i of this lane
-template <typename V>
-struct LaneArr {
-  V* p;   // already offset by the lane
-  __device__ __forceinline__ V& operator[](int i) const { return p[i * kLanes]; }
-};
+constexpr int kTile = 16;
 
 template <typename T>
 struct P2 {
@@ -65,18 +57,15 @@ __device__ __forceinline__ void corners(T cx, T cy, T w, T h, T angle, P2<T> (&p
 
 // :89-171 — candidate vertices of the intersection polygon
 template <typename T>
-__device__ __forceinline__ int candidates(const P2<T> (&a)[4], const P2<T> (&b)[4], const LaneArr<P2<T>>& out) {
+__device__ int candidates(const P2<T> (&a)[4], const P2<T> (&b)[4], P2<T> (&out)[24]) {
   P2<T> ea[4], eb[4];
-#pragma unroll
   for (int i = 0; i < 4; ++i) {
     ea[i] = sub(a[(i + 1) & 3], a[i]);
     eb[i] = sub(b[(i + 1) & 3], b[i]);
   }
   const double EPS = 1e-5;
   int n = 0;
-#pragma unroll
   for (int i = 0; i < 4; ++i) {
-#pragma unroll
     for (int j = 0; j < 4; ++j) {
       const T det = cross2(eb[j], ea[i]);
       if (fabs((double)det) <= 1e-14) continue;  // parallel edges
@@ -84,20 +73,19 @@ __device__ __forceinline__ int candidates(const P2<T> (&a)[4], const P2<T> (&b)[
       const T t1 = cross2(eb[j], d) / det;
       const T t2 = cross2(ea[i], d) / det;
       if ((double)t1 > -EPS && (double)t1 < 1.0f + EPS && (double)t2 > -EPS && (double)t2 < 1.0f + EPS) {
-        out[n] = P2<T>{a[i].x + ea[i].x * t1, a[i].y + ea[i].y * t1};
+        out[n].x = a[i].x + ea[i].x * t1;
+        out[n].y = a[i].y + ea[i].y * t1;
         ++n;
       }
     }
   }
   // corners of `a` inside `b`, then corners of `b` inside `a` (projection test)
-#pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const P2<T>(&q)[4] = pass == 0 ? a : b;
     const P2<T>(&r)[4] = pass == 0 ? b : a;
     const P2<T>& AB = pass == 0 ? eb[0] : ea[0];
     const P2<T>& DA = pass == 0 ? eb[3] : ea[3];
     const T ABAB = dot2(AB, AB), ADAD = dot2(DA, DA);
-#pragma unroll
     for (int i = 0; i < 4; ++i) {
       const P2<T> AP = sub(q[i], r[0]);
       const T pAB = dot2(AP, AB);
@@ -113,48 +101,37 @@ __device__ __forceinline__ int candidates(const P2<T> (&a)[4], const P2<T> (&b)[
 
 // :173-305 (device branch) — Graham scan on points shifted to the lowest-leftmost one
 template <typename T>
-__device__ __forceinline__ int hull(const LaneArr<P2<T>>& p, int n, const LaneArr<P2<T>>& q, const LaneArr<T>& dist) {
+__device__ int hull(const P2<T> (&p)[24], int n, P2<T> (&q)[24]) {
   int t = 0;
-  P2<T> start = p[0];
-  for (int i = 1; i < n; ++i) {
-    const P2<T> pi = p[i];
-    if (pi.y < start.y || (pi.y == start.y && pi.x < start.x)) {
-      t = i;
-      start = pi;
-    }
-  }
+  for (int i = 1; i < n; ++i)
+    if (p[i].y < p[t].y || (p[i].y == p[t].y && p[i].x < p[t].x)) t = i;
+  const P2<T> start = p[t];
   for (int i = 0; i < n; ++i) q[i] = sub(p[i], start);
   {
     const P2<T> tmp = q[0];
     q[0] = q[t];
     q[t] = tmp;
   }
-  for (int i = 0; i < n; ++i) {
-    const P2<T> qi = q[i];
-    dist[i] = dot2(qi, qi);
-  }
+  T dist[24];
+  for (int i = 0; i < n; ++i) dist[i] = dot2(q[i], q[i]);
   for (int i = 1; i < n - 1; ++i) {
-    P2<T> qi = q[i];      // the running minimum of position i stays in registers across the inner loop
-    T di = dist[i];
     for (int j = i + 1; j < n; ++j) {
-      const P2<T> qj = q[j];
-      const T dj = dist[j];
-      const T cp = cross2(qi, qj);
-      if (((double)cp < -1e-6) || (fabs((double)cp) < 1e-6 && di > dj)) {
-        q[j] = qi;
-        dist[j] = di;
-        qi = qj;
-        di = dj;
+      const T cp = cross2(q[i], q[j]);
+      if (((double)cp < -1e-6) || (fabs((double)cp) < 1e-6 && dist[i] > dist[j])) {
+        const P2<T> tq = q[i];
+        q[i] = q[j];
+        q[j] = tq;
+        const T td = dist[i];
+        dist[i] = dist[j];
+        dist[j] = td;
       }
     }
-    q[i] = qi;
-    dist[i] = di;
   }
   int k = 1;
   for (; k < n; ++k)
     if ((double)dist[k] > 1e-8) break;
   if (k == n) {
-    q[0] = start;
+    q[0] = p[t];
     return 1;
   }
   q[1] = q[k];
@@ -173,8 +150,7 @@ __device__ __forceinline__ int hull(const LaneArr<P2<T>>& p, int n, const LaneAr
 }
 
 template <typename T>
-__device__ __forceinline__ float pair_iou(const T* b1, const T* b2, const LaneArr<P2<T>>& cand, const LaneArr<P2<T>>& ord,
-                                          const LaneArr<T>& dist) {
+__device__ float pair_iou(const T* b1, const T* b2) {
   const double sx = ((double)b1[0] + (double)b2[0]) / 2.0;
   const double sy = ((double)b1[1] + (double)b2[1]) / 2.0;
   const T x1 = (T)((double)b1[0] - sx), y1 = (T)((double)b1[1] - sy);
@@ -190,17 +166,16 @@ __device__ __forceinline__ float pair_iou(const T* b1, const T* b2, const LaneAr
     const double rr = (r1 + r2) * 1.001 + 1e-3;
     if (dx * dx + dy * dy > rr * rr && b1[2] >= 0 && b1[3] >= 0 && b2[2] >= 0 && b2[3] >= 0) return 0.f;
   }
-  P2<T> pa[4], pb[4];
+  P2<T> pa[4], pb[4], cand[24], ord[24];
   corners<T>(x1, y1, b1[2], b1[3], b1[4], pa);
   corners<T>(x2, y2, b2[2], b2[3], b2[4], pb);
   const int n = candidates<T>(pa, pb, cand);
   T inter = 0;
   if (n > 2) {
-    const int m = hull<T>(cand, n, ord, dist);
+    const int m = hull<T>(cand, n, ord);
     if (m > 2) {
       T area = 0;
-      const P2<T> o0 = ord[0];
-      for (int i = 1; i < m - 1; ++i) area += fabs(cross2(sub(ord[i], o0), sub(ord[i + 1], o0)));
+      for (int i = 1; i < m - 1; ++i) area += fabs(cross2(sub(ord[i], ord[0]), sub(ord[i + 1], ord[0])));
       inter = (T)((double)area / 2.0);
     }
   }
@@ -215,21 +190,20 @@ __global__ __launch_bounds__(kTile* kTile) void box_iou_rotated_kernel(const T* 
                                                                        float* __restrict__ out, int N, int M) {
   __shared__ T s1[kTile][5];
   __shared__ T s2[kTile][5];
-  __shared__ P2<T> s_cand[24][kLanes], s_ord[24][kLanes];
-  __shared__ T s_dist[24][kLanes];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int tid = ty * kTile + tx;
   const int row0 = blockIdx.y * kTile, col0 = blockIdx.x * kTile;
   if (tid < kTile * 5) {
     const int r = tid / 5, c = tid - r * 5;
     s1[r][c] = row0 + r < N ? boxes1[(int64_t)(row0 + r) * 5 + c] : (T)0;
+  } else if (tid >= 128 && tid < 128 + kTile * 5) {
+    const int t2 = tid - 128;
+    const int r = t2 / 5, c = t2 - r * 5;
     s2[r][c] = col0 + r < M ? boxes2[(int64_t)(col0 + r) * 5 + c] : (T)0;
   }
   __syncthreads();
   const int i = row0 + ty, j = col0 + tx;
-  if (i < N && j < M)
-    out[(int64_t)i * M + j] = pair_iou<T>(s1[ty], s2[tx], LaneArr<P2<T>>{&s_cand[0][tid]}, LaneArr<P2<T>>{&s_ord[0][tid]},
-                                          LaneArr<T>{&s_dist[0][tid]});
+  if (i < N && j < M) out[(int64_t)i * M + j] = pair_iou<T>(s1[ty], s2[tx]);
 }
 
 }  // namespace
