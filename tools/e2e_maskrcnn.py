@@ -48,6 +48,8 @@ def main():
                     help="box_score_thresh; random-init class scores are ~1/91, so 0.0 keeps the post-processing busy "
                          "(100 detections per image) and the default 0.05 of the reference keeps none")
     ap.add_argument("--no-aten-override", action="store_true")
+    ap.add_argument("--channels-last", action="store_true", help="run the model (backbone / FPN / heads) in torch.channels_last: the FPN "
+                    "maps then reach MultiScaleRoIAlign as NHWC tensors and the 7x7 pooling takes the native channels_last kernel")
     args = ap.parse_args()
 
     rank, local_rank, world = (int(os.environ.get(k, "0")) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
@@ -84,6 +86,8 @@ def main():
         ctor = D.maskrcnn_resnet50_fpn if args.model == "maskrcnn" else D.fasterrcnn_resnet50_fpn
         model = ctor(weights=None, weights_backbone=None, box_score_thresh=args.score_thresh)
     model = model.eval().to(device)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
     has_masks = args.model == "maskrcnn"
 
     def apply_fused():
@@ -178,6 +182,7 @@ def main():
             "detections_per_image": [int(o["boxes"].shape[0]) for o in out],
             "mask_shape": list(out[0]["masks"].shape) if has_masks else None,
             "aten_upsample_override": not args.no_aten_override,
+            "channels_last": bool(args.channels_last),
             "aten_upsample_calls_per_step": (int(torch.ops.tvmi.aten_upsample_calls()) - calls0) / max(args.steps, 1),
             "reference_python": torchvision.__file__,
             "data": "synthetic", "weights": "random init (seed 0)", "dtype": "f32",
