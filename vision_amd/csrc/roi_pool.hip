@@ -294,6 +294,10 @@ __global__ __launch_bounds__(kPoolThreads) void roi_pool_fwd_cols(const T* __res
     if (folds && c0 + cc + g2 < C) {
       // write-once streams (2 x 200 MB at the measured shape) must not evict the feature planes from L2.  The seven
       // stores of a lane are 28 bytes apart; together the wave fills G x 196 contiguous bytes.
+      // (Measured, round 4: parking a pass's [channel][bin] results in LDS and storing them as 16-byte pieces — 2 + 2 store
+      // instructions per pass instead of 7 + 7, what gained the RoIAlign forward 5 % — made THIS kernel 20 % slower, 0.565 vs
+      // 0.469 ms: two more wave barriers and an LDS round trip per 8-channel pass, 29 KB of LDS per workgroup.
+      // profiles/r04_matrix_roipool_staged_stores.json)
       const int64_t o0 = out0 + (int64_t)(cc + g2) * kBins + pw2;
 #pragma unroll
       for (int ph = 0; ph < PH; ++ph) {
