@@ -54,26 +54,53 @@ struct Tap {
 
 template <typename A>
 __device__ __forceinline__ void make_tap(Tap<A>& t, int H, int W, A h, A w, A mask) {
-  t.m = mask;
-  if (h <= (A)-1 || (A)H <= h || w <= (A)-1 || (A)W <= w) {
-    t.o1 = t.o2 = t.o3 = t.o4 = 0;
-    t.w1 = t.w2 = t.w3 = t.w4 = (A)0;
-    return;
-  }
-  const int hl = (int)floor(h), wl = (int)floor(w);
+  // branch-free on purpose (round 4): with an early return for the out-of-image case the compiler kept the Tap of the fused
+  // kernels in SCRATCH (conditional stores through the reference) and re-loaded it inside the slab loop
+  const bool inside = !(h <= (A)-1 || (A)H <= h || w <= (A)-1 || (A)W <= w);
+  const A hc = inside ? h : (A)0, wc = inside ? w : (A)0;
+  const int hl = (int)floor(hc), wl = (int)floor(wc);
   const int hh_ = hl + 1, wh_ = wl + 1;
-  const A lh = h - (A)hl, lw = w - (A)wl;
+  const A lh = hc - (A)hl, lw = wc - (A)wl;
   const A hh = (A)1 - lh, hw = (A)1 - lw;
   const bool v_hl = hl >= 0, v_wl = wl >= 0, v_hh = hh_ <= H - 1, v_wh = wh_ <= W - 1;
   const int chl = v_hl ? hl : 0, cwl = v_wl ? wl : 0, chh = v_hh ? hh_ : H - 1, cwh = v_wh ? wh_ : W - 1;
-  t.o1 = chl * W + cwl;
-  t.o2 = chl * W + cwh;
-  t.o3 = chh * W + cwl;
-  t.o4 = chh * W + cwh;
-  t.w1 = (v_hl && v_wl) ? hh * hw : (A)0;
-  t.w2 = (v_hl && v_wh) ? hh * lw : (A)0;
-  t.w3 = (v_hh && v_wl) ? lh * hw : (A)0;
-  t.w4 = (v_hh && v_wh) ? lh * lw : (A)0;
+  t.m = mask;
+  t.o1 = inside ? chl * W + cwl : 0;
+  t.o2 = inside ? chl * W + cwh : 0;
+  t.o3 = inside ? chh * W + cwl : 0;
+  t.o4 = inside ? chh * W + cwh : 0;
+  t.w1 = (inside && v_hl && v_wl) ? hh * hw : (A)0;
+  t.w2 = (inside && v_hl && v_wh) ? hh * lw : (A)0;
+  t.w3 = (inside && v_hh && v_wl) ? lh * hw : (A)0;
+  t.w4 = (inside && v_hh && v_wh) ? lh * lw : (A)0;
+}
+
+// The raw (offset_h, offset_w, mask) of one tap of one pixel, and the Tap they give: split so that the fused kernels can
+// fetch the raw values of the NEXT offset-group segment while the current one is consumed (load_tap below does both at
+// once: a dependent global-load round trip in front of the first gathers of every segment, nine times per tile at config 4).
+template <typename A>
+struct TapRaw {
+  A off_h, off_w, m;
+};
+template <typename T, typename A>
+__device__ __forceinline__ TapRaw<A> load_tap_raw(const DcnParams& p, const T* __restrict__ offset, const T* __restrict__ mask,
+                                                  int b, int og, int tap, int oy, int ox) {
+  const int64_t plane = (int64_t)p.oh * p.ow;
+  const int64_t pix = (int64_t)oy * p.ow + ox;
+  const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * p.kh * p.kw) * plane;
+  TapRaw<A> r;
+  r.off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
+  r.off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
+  r.m = (A)1;
+  if (p.use_mask) r.m = ld(mask + ((int64_t)(b * p.ogroups + og) * p.kh * p.kw + tap) * plane + pix);
+  return r;
+}
+template <typename A>
+__device__ __forceinline__ void tap_from_raw(Tap<A>& t, const DcnParams& p, const TapRaw<A>& r, int tap, int oy, int ox) {
+  const int i = tap / p.kw, j = tap - i * p.kw;
+  const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + r.off_h;
+  const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + r.off_w;
+  make_tap<A>(t, p.H, p.W, y, x, r.m);
 }
 
 template <typename T, typename A>
@@ -247,13 +274,24 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
   // Slab iteration space: tap (outer) x offset-group segment x ic0 (inner).
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
   bool have = KK > 0 && p.ICg > 0;
+  // raw offsets / mask of the segment AFTER the current one, fetched when the current one begins (a whole segment ahead)
+  TapRaw<float> raw_next{0.f, 0.f, 1.f};
+  auto fetch_raw = [&](int tap, int ic) {
+    if (pix_ok) raw_next = load_tap_raw<float, float>(p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
+  };
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
     if (pix_ok) {
-      load_tap<float, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+      tap_from_raw<float>(tap_cur, p, raw_next, tap, poy, pox);
       plan = make_pair_plan(tap_cur, p.W);
     }
+    int t2 = tap, i2 = s_seg_end;
+    if (i2 >= p.ICg) {
+      i2 = 0;
+      t2 = tap + 1;
+    }
+    if (t2 < KK) fetch_raw(t2, i2);
   };
   auto issue_loads = [&](int tap, int ic0, int kmax) {
 #pragma unroll
@@ -299,6 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
 
   int buf = 0;
   if (have) {
+    fetch_raw(0, 0);
     begin_segment(0, 0);
     issue_loads(0, 0, min(kBK, s_seg_end));
   }
@@ -341,6 +380,14 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
 
   // epilogue: D[row][col], col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (oc)
   const int l31 = lane & 31, kq = lane >> 5;
+  // the bias of this lane's 16 MI output rows as ONE batch of independent loads (clamped row index).  Round 3 loaded
+  // `bias[oc]` inside the guarded store: 32 dependent load -> wait -> store round trips at the end of every tile.
+  float brow[MI][16];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      brow[mi][r] = bias[g * p.OCg + min(oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq, p.OCg - 1)];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
@@ -354,7 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-        if (oc < p.OCg) obase[(int64_t)oc * p.oh * p.ow] = acc[mi][ni][r] + bias[g * p.OCg + oc];
+        if (oc < p.OCg) obase[(int64_t)oc * p.oh * p.ow] = acc[mi][ni][r] + brow[mi][r];
       }
     }
   }
@@ -384,6 +431,11 @@ __device__ __forceinline__ f32x16v mfma16(uint4 a, uint4 b, f32x16v c) {
 
 template <typename T>
 __device__ __forceinline__ unsigned short to16(float v) {
+  // the value is an fp32 RESULT (mask x bilinear sum, rounded to fp32) that is then rounded to 16 bits: keep the backend from
+  // folding the last multiply into v_fma_mixlo_f16, which rounds the exact product ONCE — the planar and the channels-last
+  // kernel must produce the same bits (test_deform_conv2d_channels_last_gather_is_bit_identical), and round 4's branch-free
+  // make_tap made that fold possible in one of them
+  asm volatile("" : "+v"(v));
   if constexpr (std::is_same<T, __half>::value) return __half_as_ushort(__float2half(v));
   else {
     const __hip_bfloat16 b = __float2bfloat16(v);
@@ -470,13 +522,24 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
 
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
   bool have = KK > 0 && p.ICg > 0;
+  // raw offsets / mask of the segment AFTER the current one, fetched when the current one begins (a whole segment ahead)
+  TapRaw<float> raw_next{0.f, 0.f, 1.f};
+  auto fetch_raw = [&](int tap, int ic) {
+    if (pix_ok) raw_next = load_tap_raw<T, float>(p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
+  };
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
     if (pix_ok) {
-      load_tap<T, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+      tap_from_raw<float>(tap_cur, p, raw_next, tap, poy, pox);
       plan = make_pair_plan(tap_cur, p.W);
     }
+    int t2 = tap, i2 = s_seg_end;
+    if (i2 >= p.ICg) {
+      i2 = 0;
+      t2 = tap + 1;
+    }
+    if (t2 < KK) fetch_raw(t2, i2);
   };
   auto issue_loads = [&](int tap, int ic0, int kmax) {
 #pragma unroll
@@ -535,6 +598,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
   int buf = 0;
   int cur_len = 0, cur_base = 0;
   if (have) {
+    fetch_raw(0, 0);
     begin_segment(0, 0);
     cur_len = slab_len(0);
     cur_base = 0;
@@ -588,6 +652,12 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
 
   // epilogue: D[row][col], col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (oc)
   const int l31 = lane & 31, kq = lane >> 5;
+  float brow[MI][16];   // one batch of independent bias loads (see the fp32 kernel's epilogue)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      brow[mi][r] = ld(bias + g * p.OCg + min(oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq, p.OCg - 1));
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
@@ -601,7 +671,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + ld(bias + g * p.OCg + oc));
+        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + brow[mi][r]);
       }
     }
   }
@@ -712,10 +782,23 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
 
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
   bool have = KK > 0 && p.ICg > 0;
+  // raw offsets / mask of the segment AFTER the current one, fetched when the current one begins (a whole segment ahead)
+  TapRaw<float> raw_next{0.f, 0.f, 1.f};
+  auto fetch_raw = [&](int tap, int ic) {
+    if (pix_ok) raw_next = load_tap_raw<T, float>(p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
+  };
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
-    if (pix_ok) load_tap<T, float>(tap_cur, p, offset, mask, pb, og, tap, poy, pox);
+    if (pix_ok) {
+      tap_from_raw<float>(tap_cur, p, raw_next, tap, poy, pox);
+    }
+    int t2 = tap, i2 = s_seg_end;
+    if (i2 >= p.ICg) {
+      i2 = 0;
+      t2 = tap + 1;
+    }
+    if (t2 < KK) fetch_raw(t2, i2);
   };
   auto issue_loads = [&](int tap, int ic0, int kmax) {   // kmax: channels of the slab (a multiple of 8)
 #pragma unroll
@@ -773,6 +856,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
 
   int buf = 0;
   if (have) {
+    fetch_raw(0, 0);
     begin_segment(0, 0);
     issue_loads(0, 0, min(kClBK, s_seg_end));
   }
@@ -811,6 +895,12 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
   }
 
   const int l31 = lane & 31, kq = lane >> 5;
+  float brow[MI][16];   // one batch of independent bias loads (see the fp32 kernel's epilogue)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      brow[mi][r] = ld(bias + g * p.OCg + min(oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq, p.OCg - 1));
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
@@ -824,7 +914,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + ld(bias + g * p.OCg + oc));
+        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + brow[mi][r]);
       }
     }
   }
