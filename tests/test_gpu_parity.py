@@ -1286,14 +1286,20 @@ def test_deform_conv2d_channels_last_gather_is_bit_identical():
                     opt("dcn.channels_last_gather", 0)
                     want = vision_amd.deform_conv2d(x, off, w, bias, stride=stride, padding=dil, dilation=dil, mask=m)
                     opt("dcn.channels_last_gather", 1)
-                    got = vision_amd.deform_conv2d(x, off, w, bias, stride=stride, padding=dil, dilation=dil, mask=m)
-                    if (C // ogroups) % 16 == 0 or C % 8 != 0:
-                        assert torch.equal(got, want), (dt, C, OC, groups, ogroups, m is not None)
-                    else:   # same products, another grouping of the fp32 additions, then one rounding to 16 bits
-                        err = (got.float() - want.float()).abs().max().item()
-                        assert err <= 2.0 ** (-7 if dt == torch.bfloat16 else -10) * want.float().abs().max().item(), (dt, C, err)
+                    # round 4: the pipelined kernel (1: 8 waves, 2: 4 waves; 0: the round-3 kernel) and the XCD tile dealing
+                    for variant, xcd in ((1, 1), (1, 0), (2, 1), (0, 1)):
+                        opt("dcn.cl_variant", variant)
+                        opt("dcn.xcd_tiles", xcd)
+                        got = vision_amd.deform_conv2d(x, off, w, bias, stride=stride, padding=dil, dilation=dil, mask=m)
+                        if (C // ogroups) % 16 == 0 or C % 8 != 0:
+                            assert torch.equal(got, want), (dt, C, OC, groups, ogroups, m is not None, variant, xcd)
+                        else:   # same products, another grouping of the fp32 additions, then one rounding to 16 bits
+                            err = (got.float() - want.float()).abs().max().item()
+                            assert err <= 2.0 ** (-7 if dt == torch.bfloat16 else -10) * want.float().abs().max().item(), (dt, C, err)
     finally:
         opt("dcn.channels_last_gather", 1)
+        opt("dcn.cl_variant", 1)
+        opt("dcn.xcd_tiles", 1)
 
 
 def test_large_score_sort_equals_stable_descending_sort():

@@ -61,6 +61,8 @@ def _kernel_resources(src, tmp_path):
     out = tmp_path / (os.path.basename(src) + ".s")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
            f"-I{os.path.join(ROOT, 'include')}", "-S", "--cuda-device-only", src, "-o", str(out)]
+    if src.endswith("deform_conv2d.hip"):
+        cmd.insert(1, "-fno-slp-vectorize")   # as in the Makefile
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     text = out.read_text()
     res = {}

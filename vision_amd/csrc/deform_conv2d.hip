@@ -41,7 +41,20 @@ struct DcnParams {
   int use_mask;
   int ICg, OCg;          // channels per weight group
   int cpog;              // channels per offset group
+  int xcd_tiles;         // option "dcn.xcd_tiles": pixel tiles dealt to the XCDs in contiguous ranges (see tile_of_block)
 };
+
+// Workgroup b of a launch runs on XCD b % 8 (private 4 MB L2).  Pixel tiles are dealt in CONTIGUOUS ranges — XCD x owns tiles
+// [start(x), start(x) + count(x)) — so that the taps of neighbouring tiles meet in one L2 instead of every L2 pulling the
+// whole input.  A bijection of [0, ntile) for any ntile; only used when the grid is one-dimensional (y = z = 1).
+__device__ __forceinline__ int tile_of_block(const DcnParams& p) {
+  int tile = blockIdx.x;
+  if (p.xcd_tiles && gridDim.y * gridDim.z == 1) {
+    const int ntile = gridDim.x, x = tile & 7, j = tile >> 3, base = ntile >> 3, rem = ntile & 7;
+    tile = x * base + min(x, rem) + j;
+  }
+  return tile;
+}
 
 // One sampling location: 4 corner offsets (clamped to a valid address) and 4 weights
 // (zeroed for corners outside the image), per cpu/deform_conv2d_kernel.cpp:95-132.
@@ -78,29 +91,36 @@ __device__ __forceinline__ void make_tap(Tap<A>& t, int H, int W, A h, A w, A ma
 // The raw (offset_h, offset_w, mask) of one tap of one pixel, and the Tap they give: split so that the fused kernels can
 // fetch the raw values of the NEXT offset-group segment while the current one is consumed (load_tap below does both at
 // once: a dependent global-load round trip in front of the first gathers of every segment, nine times per tile at config 4).
-template <typename A>
+// (the raw values stay in the tensor's type until they are used: converting a 16-bit value at load time is a use, and the
+// wait it needs would sit right behind the load)
+template <typename T>
 struct TapRaw {
-  A off_h, off_w, m;
+  T off_h, off_w, m;
 };
-template <typename T, typename A>
-__device__ __forceinline__ TapRaw<A> load_tap_raw(const DcnParams& p, const T* __restrict__ offset, const T* __restrict__ mask,
-                                                  int b, int og, int tap, int oy, int ox) {
+template <typename T>
+__device__ __forceinline__ TapRaw<T> tap_raw_identity() {
+  TapRaw<T> r;
+  st(&r.off_h, 0.f);
+  st(&r.off_w, 0.f);
+  st(&r.m, 1.f);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void load_tap_raw(TapRaw<T>& r, const DcnParams& p, const T* __restrict__ offset,
+                                             const T* __restrict__ mask, int b, int og, int tap, int oy, int ox) {
   const int64_t plane = (int64_t)p.oh * p.ow;
   const int64_t pix = (int64_t)oy * p.ow + ox;
   const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * p.kh * p.kw) * plane;
-  TapRaw<A> r;
-  r.off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
-  r.off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
-  r.m = (A)1;
-  if (p.use_mask) r.m = ld(mask + ((int64_t)(b * p.ogroups + og) * p.kh * p.kw + tap) * plane + pix);
-  return r;
+  r.off_h = optr[(int64_t)(2 * tap) * plane + pix];
+  r.off_w = optr[(int64_t)(2 * tap + 1) * plane + pix];
+  if (p.use_mask) r.m = mask[((int64_t)(b * p.ogroups + og) * p.kh * p.kw + tap) * plane + pix];
 }
-template <typename A>
-__device__ __forceinline__ void tap_from_raw(Tap<A>& t, const DcnParams& p, const TapRaw<A>& r, int tap, int oy, int ox) {
+template <typename T, typename A>
+__device__ __forceinline__ void tap_from_raw(Tap<A>& t, const DcnParams& p, const TapRaw<T>& r, int tap, int oy, int ox) {
   const int i = tap / p.kw, j = tap - i * p.kw;
-  const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + r.off_h;
-  const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + r.off_w;
-  make_tap<A>(t, p.H, p.W, y, x, r.m);
+  const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + (A)ld(&r.off_h);
+  const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + (A)ld(&r.off_w);
+  make_tap<A>(t, p.H, p.W, y, x, (A)ld(&r.m));
 }
 
 template <typename T, typename A>
@@ -187,6 +207,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ inpu
   }
 }
 
+std::atomic<int> g_xcd_tiles{1};   // option "dcn.xcd_tiles": contiguous pixel-tile ranges per XCD (tile_of_block)
+std::atomic<int> g_cl_variant{1};  // option "dcn.cl_variant": 0 = the round-3 channels-last kernel, 1 = the pipelined one, 2 = its 4-wave tile
 std::atomic<int> g_cl_gather{1};  // option "dcn.channels_last_gather": the 16-bit MFMA kernel samples a [B, H*W, C] copy
 
 // ------------------------------------------------------------------ fused MFMA forward (fp32)
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
   const int g = blockIdx.z;
   const int oc0 = blockIdx.y * BM;  // within group
   const int64_t npix = (int64_t)p.B * p.oh * p.ow;
-  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+  const int64_t pix0 = (int64_t)tile_of_block(p) * BN;
   const int KK = p.kh * p.kw;
   const int64_t in_plane = (int64_t)p.H * p.W;
 
@@ -275,15 +297,15 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_f32(const float* __
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
   bool have = KK > 0 && p.ICg > 0;
   // raw offsets / mask of the segment AFTER the current one, fetched when the current one begins (a whole segment ahead)
-  TapRaw<float> raw_next{0.f, 0.f, 1.f};
+  TapRaw<float> raw_next = tap_raw_identity<float>();
   auto fetch_raw = [&](int tap, int ic) {
-    if (pix_ok) raw_next = load_tap_raw<float, float>(p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
+    if (pix_ok) load_tap_raw<float>(raw_next, p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
   };
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
     if (pix_ok) {
-      tap_from_raw<float>(tap_cur, p, raw_next, tap, poy, pox);
+      tap_from_raw<float, float>(tap_cur, p, raw_next, tap, poy, pox);
       plan = make_pair_plan(tap_cur, p.W);
     }
     int t2 = tap, i2 = s_seg_end;
@@ -442,6 +464,12 @@ __device__ __forceinline__ unsigned short to16(float v) {
     return *reinterpret_cast<const unsigned short*>(&b);
   }
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ f32x2 unpack16x2(unsigned u) {   // the two 16-bit values of a dword, as fp32
+  if constexpr (std::is_same<T, __half>::value) return f32x2{__half2float(__ushort_as_half((unsigned short)(u & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(u >> 16)))};
+  else return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
 template <typename T>
 __device__ __forceinline__ float from16bits(unsigned short h) {
   if constexpr (std::is_same<T, __half>::value) return __half2float(__ushort_as_half(h));
@@ -486,7 +514,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
   const int g = blockIdx.z;
   const int oc0 = blockIdx.y * BM;
   const int64_t npix = (int64_t)p.B * p.oh * p.ow;
-  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+  const int64_t pix0 = (int64_t)tile_of_block(p) * BN;
   const int KK = p.kh * p.kw;
   const int64_t in_plane = (int64_t)p.H * p.W;
   const int nslab = ICg_pad / 16;
@@ -523,15 +551,15 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16(const T* __restr
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
   bool have = KK > 0 && p.ICg > 0;
   // raw offsets / mask of the segment AFTER the current one, fetched when the current one begins (a whole segment ahead)
-  TapRaw<float> raw_next{0.f, 0.f, 1.f};
+  TapRaw<T> raw_next = tap_raw_identity<T>();
   auto fetch_raw = [&](int tap, int ic) {
-    if (pix_ok) raw_next = load_tap_raw<T, float>(p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
+    if (pix_ok) load_tap_raw<T>(raw_next, p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
   };
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
     if (pix_ok) {
-      tap_from_raw<float>(tap_cur, p, raw_next, tap, poy, pox);
+      tap_from_raw<T, float>(tap_cur, p, raw_next, tap, poy, pox);
       plan = make_pair_plan(tap_cur, p.W);
     }
     int t2 = tap, i2 = s_seg_end;
@@ -750,7 +778,7 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
   const int g = blockIdx.z;
   const int oc0 = blockIdx.y * BM;
   const int64_t npix = (int64_t)p.B * p.oh * p.ow;
-  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+  const int64_t pix0 = (int64_t)tile_of_block(p) * BN;
   const int KK = p.kh * p.kw;
   const int noct = p.ICg / 8;
 
@@ -783,15 +811,15 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
   int s_tap = 0, s_ic = 0, s_seg_end = 0;
   bool have = KK > 0 && p.ICg > 0;
   // raw offsets / mask of the segment AFTER the current one, fetched when the current one begins (a whole segment ahead)
-  TapRaw<float> raw_next{0.f, 0.f, 1.f};
+  TapRaw<T> raw_next = tap_raw_identity<T>();
   auto fetch_raw = [&](int tap, int ic) {
-    if (pix_ok) raw_next = load_tap_raw<T, float>(p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
+    if (pix_ok) load_tap_raw<T>(raw_next, p, offset, mask, pb, (g * p.ICg + ic) / p.cpog, tap, poy, pox);
   };
   auto begin_segment = [&](int tap, int ic) {
     const int og = (g * p.ICg + ic) / p.cpog;
     s_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
     if (pix_ok) {
-      tap_from_raw<float>(tap_cur, p, raw_next, tap, poy, pox);
+      tap_from_raw<T, float>(tap_cur, p, raw_next, tap, poy, pox);
     }
     int t2 = tap, i2 = s_seg_end;
     if (i2 >= p.ICg) {
@@ -895,6 +923,308 @@ __global__ __launch_bounds__(64 * WM * WN) void dcn_fwd_mfma_16_cl(const T* __re
   }
 
   const int l31 = lane & 31, kq = lane >> 5;
+  float brow[MI][16];   // one batch of independent bias loads (see the fp32 kernel's epilogue)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      brow[mi][r] = ld(bias + g * p.OCg + min(oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq, p.OCg - 1));
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int64_t pix = pix0 + (wn * NI + ni) * 32 + l31;
+    if (pix >= npix) continue;
+    const int ox = (int)(pix % p.ow);
+    const int oy = (int)((pix / p.ow) % p.oh);
+    const int b = (int)(pix / ((int64_t)p.ow * p.oh));
+    T* obase = out + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * p.oh * p.ow + (int64_t)oy * p.ow + ox;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = oc0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (oc < p.OCg) st(obase + (int64_t)oc * p.oh * p.ow, acc[mi][ni][r] + brow[mi][r]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ round 4: the channels-last kernel, pipelined
+// Same tile, arithmetic and LDS layout as dcn_fwd_mfma_16_cl above, two changes that the counters of round 3 asked for
+// (the kernel was neither MFMA- nor HBM-bound: ~1600 cycles per 32-channel slab against 256 cycles of MFMA work):
+//  * the loads of D slabs are in flight, not one: D register stages (4 corner octets + the weight pieces + the 5 tap
+//    weights of the slab they belong to), the loop unrolled D times so that every stage index is static and the compiler's
+//    counted `s_waitcnt vmcnt(N)` leaves the D-1 newer stages in flight.  Every load is unconditional (addresses clamped,
+//    values zeroed at commit) and the slab iterator SATURATES at the last slab (D-1 redundant re-loads per tile) — a
+//    conditional load would make the counted wait conservative;
+//  * producer lanes are (pixel, octet) with the OCTET fastest: kOct neighbouring lanes read one 16*kOct-byte run of a
+//    pixel's channel vector, so a gather instruction touches 64/kOct cache lines instead of 64 (the texture path is paid
+//    per line: profiles/r04_pmc_sq_roi7_summary.txt).
+// The workgroup -> pixel-tile map deals CONTIGUOUS tile ranges to the 8 XCDs (workgroup b runs on XCD b % 8), so that the
+// taps of neighbouring tiles meet in one private L2.
+template <typename T, int WM, int WN, int MI, int NI, int BK, int D, int WPE>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void dcn_fwd_mfma_16_clp(const T* __restrict__ input_cl, const T* __restrict__ wt8,
+                                                                    const T* __restrict__ offset, const T* __restrict__ mask,
+                                                                    const T* __restrict__ bias, T* __restrict__ out, DcnParams p,
+                                                                    int OCg_pad) {
+  constexpr int kOct = BK / 8, kPitch = BK + 8;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+  constexpr int NITEM = BN * kOct;                  // producer items (pixel, octet) of a slab
+  constexpr int PI = (NITEM + NT - 1) / NT;
+  constexpr int AQ = BM * kOct;                     // 16-byte pieces of the A slab
+  constexpr int AV = (AQ + NT - 1) / NT;
+  static_assert(D >= 2 && D <= 4, "pipeline depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned short dcn16_clp_lds[];
+  unsigned short(*As)[BM][kPitch] = reinterpret_cast<unsigned short(*)[BM][kPitch]>(dcn16_clp_lds);
+  unsigned short(*Bs)[BN][kPitch] = reinterpret_cast<unsigned short(*)[BN][kPitch]>(dcn16_clp_lds + 2 * BM * kPitch);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = blockIdx.z;
+  const int oc0 = blockIdx.y * BM;
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  const int64_t pix0 = (int64_t)tile_of_block(p) * BN;
+  const int KK = p.kh * p.kw;
+  const int noct = p.ICg / 8;
+
+  // producer items of this thread
+  int pn[PI], poct[PI], pb[PI], poy[PI], pox[PI];
+  bool item_ok[PI], pix_ok[PI];
+  const T* in_b[PI];
+#pragma unroll
+  for (int r = 0; r < PI; ++r) {
+    const int item = tid + r * NT;
+    item_ok[r] = item < NITEM;
+    pn[r] = item_ok[r] ? item / kOct : 0;
+    poct[r] = item % kOct;
+    const int64_t my_pix = pix0 + pn[r];
+    pix_ok[r] = item_ok[r] && my_pix < npix;
+    pb[r] = poy[r] = pox[r] = 0;
+    if (pix_ok[r]) {
+      pox[r] = (int)(my_pix % p.ow);
+      poy[r] = (int)((my_pix / p.ow) % p.oh);
+      pb[r] = (int)(my_pix / ((int64_t)p.ow * p.oh));
+    }
+    in_b[r] = input_cl + (int64_t)pb[r] * p.H * p.W * p.C + (int64_t)g * p.ICg;
+  }
+  // this thread's pieces of the A slab
+  int a_m[AV], a_oct[AV];
+  bool a_ok[AV];
+#pragma unroll
+  for (int e = 0; e < AV; ++e) {
+    const int piece = tid + e * NT;
+    a_ok[e] = piece < AQ && oc0 + piece % BM < OCg_pad;
+    a_m[e] = a_ok[e] ? piece % BM : 0;
+    a_oct[e] = a_ok[e] ? piece / BM : 0;
+  }
+
+  f32x16v acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  struct Stage {
+    uint4 cv[PI][4];   // the four corner octets of the items
+    uint4 av[AV];      // the weight pieces
+    // the weights and the mask of the slab's tap, as genuine PAIRS: a scalar broadcast by op_sel makes v_pk_mul_f32 name the
+    // odd neighbour register as well, and when that neighbour holds a still-pending load (the next segment's raw offsets)
+    // the slab loop waits for vmcnt(0) on a value it never reads
+    f32x2 w1[PI], w2[PI], w3[PI], w4[PI], wm[PI];
+    int kmax;          // channels of the slab (a multiple of 8)
+  };
+  Stage stg[D];
+
+  Tap<float> tap_cur[PI];
+  TapRaw<T> raw_next[PI];
+#pragma unroll
+  for (int r = 0; r < PI; ++r) {
+    tap_cur[r].o1 = tap_cur[r].o2 = tap_cur[r].o3 = tap_cur[r].o4 = 0;
+    tap_cur[r].w1 = tap_cur[r].w2 = tap_cur[r].w3 = tap_cur[r].w4 = 0.f;
+    tap_cur[r].m = 0.f;
+    raw_next[r] = tap_raw_identity<T>();
+  }
+
+  // slab iterator of the ISSUE side: tap (outer) x offset-group segment x ic0 (inner); saturates at the last slab
+  int i_tap = 0, i_ic = 0, i_seg_end = 0;
+  bool i_have = KK > 0 && p.ICg > 0;
+  int total = 0;
+  {
+    int per_tap = 0;
+    for (int ic = 0; ic < p.ICg;) {
+      const int og = (g * p.ICg + ic) / p.cpog;
+      const int end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
+      per_tap += (end - ic + BK - 1) / BK;
+      ic = end;
+    }
+    total = per_tap * KK;
+  }
+  // addresses: a UNIFORM base (the group's channel run of the slab) + a 32-bit per-lane byte offset (pixel corner, octet),
+  // re-formed per segment only — the launcher sends inputs of 4 GiB and more to the round-3 kernel
+  auto corner_off = [&](int r, int o) { return (unsigned)((((int64_t)pb[r] * p.H * p.W + o) * p.C + 8 * poct[r]) * 2); };
+  unsigned coff[PI][4];   // of the current segment's tap (lanes without a pixel: corner 0 of image 0)
+#pragma unroll
+  for (int r = 0; r < PI; ++r) coff[r][0] = coff[r][1] = coff[r][2] = coff[r][3] = corner_off(r, 0);
+  unsigned a_off[AV];
+#pragma unroll
+  for (int e = 0; e < AV; ++e) a_off[e] = (unsigned)((a_oct[e] * OCg_pad + a_m[e]) * 16);
+  auto fetch_raw = [&](int tap, int ic) {
+#pragma unroll
+    for (int r = 0; r < PI; ++r)
+      if (pix_ok[r]) load_tap_raw<T>(raw_next[r], p, offset, mask, pb[r], (g * p.ICg + ic) / p.cpog, tap, poy[r], pox[r]);
+  };
+  auto begin_segment = [&](int tap, int ic) {
+    const int og = (g * p.ICg + ic) / p.cpog;
+    i_seg_end = min(p.ICg, (og + 1) * p.cpog - g * p.ICg);
+#pragma unroll
+    for (int r = 0; r < PI; ++r)
+      if (pix_ok[r]) {
+        tap_from_raw<T, float>(tap_cur[r], p, raw_next[r], tap, poy[r], pox[r]);
+        coff[r][0] = corner_off(r, tap_cur[r].o1);
+        coff[r][1] = corner_off(r, tap_cur[r].o2);
+        coff[r][2] = corner_off(r, tap_cur[r].o3);
+        coff[r][3] = corner_off(r, tap_cur[r].o4);
+      }
+    int t2 = tap, i2 = i_seg_end;
+    if (i2 >= p.ICg) {
+      i2 = 0;
+      t2 = tap + 1;
+    }
+    if (t2 < KK) fetch_raw(t2, i2);
+  };
+  auto issue = [&](Stage& sg) {
+    const int kmax = min(BK, i_seg_end - i_ic);
+    sg.kmax = kmax;
+    const char* gbase = reinterpret_cast<const char*>(input_cl + (int64_t)g * p.ICg + i_ic);
+    const char* wbase = reinterpret_cast<const char*>(wt8 + ((((int64_t)g * KK + i_tap) * noct + i_ic / 8) * OCg_pad + oc0) * 8);
+    const bool whole = kmax == BK;   // uniform; both arms issue the same loads (the counted waits stay exact)
+#pragma unroll
+    for (int r = 0; r < PI; ++r) {
+      if (whole) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg.cv[r][k] = *reinterpret_cast<const uint4*>(gbase + coff[r][k]);
+      } else {
+        const unsigned back = 8 * poct[r] < kmax ? 0u : 16u * poct[r];   // a partial slab: octets past its end read octet 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sg.cv[r][k] = *reinterpret_cast<const uint4*>(gbase + (coff[r][k] - back));
+      }
+      sg.w1[r] = f32x2{tap_cur[r].w1, tap_cur[r].w1};
+      sg.w2[r] = f32x2{tap_cur[r].w2, tap_cur[r].w2};
+      sg.w3[r] = f32x2{tap_cur[r].w3, tap_cur[r].w3};
+      sg.w4[r] = f32x2{tap_cur[r].w4, tap_cur[r].w4};
+      sg.wm[r] = f32x2{tap_cur[r].m, tap_cur[r].m};
+    }
+    if (whole) {
+#pragma unroll
+      for (int e = 0; e < AV; ++e) sg.av[e] = *reinterpret_cast<const uint4*>(wbase + a_off[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < AV; ++e) {
+        const unsigned back = 8 * a_oct[e] < kmax ? 0u : (unsigned)(a_oct[e] * OCg_pad * 16);
+        sg.av[e] = *reinterpret_cast<const uint4*>(wbase + (a_off[e] - back));
+      }
+    }
+    if (i_have) {
+      int n_tap = i_tap, n_ic = i_ic + BK;
+      bool n_have = true;
+      if (n_ic >= i_seg_end) {
+        n_ic = i_seg_end;
+        if (n_ic >= p.ICg) {
+          n_ic = 0;
+          n_tap = i_tap + 1;
+          if (n_tap >= KK) n_have = false;
+        }
+        if (n_have) begin_segment(n_tap, n_ic);
+      }
+      if (n_have) {
+        i_tap = n_tap;
+        i_ic = n_ic;
+      }
+      i_have = n_have;
+    }
+  };
+  // mask x bilinear sum of one dword's two channels, as packed fp32 (v_pk_mul_f32 / v_pk_add_f32: the same roundings, in the same
+  // order, as the scalar expression of the other kernels — the commit is VALU-bound: 4 cycles per wave64 instruction)
+  auto blend2 = [&](f32x2 w1, f32x2 w2, f32x2 w3, f32x2 w4, f32x2 m, unsigned u1, unsigned u2, unsigned u3, unsigned u4) {
+    const f32x2 r = m * (w1 * unpack16x2<T>(u1) + w2 * unpack16x2<T>(u2) + w3 * unpack16x2<T>(u3) + w4 * unpack16x2<T>(u4));
+    return (unsigned)to16<T>(r.x) | ((unsigned)to16<T>(r.y) << 16);
+  };
+  auto commit = [&](const Stage& sg, int buf) {
+    const bool whole = sg.kmax == BK;   // uniform: a whole slab needs no zero-fill (columns of pixels past the end are never stored)
+#pragma unroll
+    for (int r = 0; r < PI; ++r) {
+      if (!item_ok[r]) continue;
+      const unsigned* c0 = reinterpret_cast<const unsigned*>(&sg.cv[r][0]);
+      const unsigned* c1 = reinterpret_cast<const unsigned*>(&sg.cv[r][1]);
+      const unsigned* c2 = reinterpret_cast<const unsigned*>(&sg.cv[r][2]);
+      const unsigned* c3 = reinterpret_cast<const unsigned*>(&sg.cv[r][3]);
+      unsigned packed[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) packed[d] = blend2(sg.w1[r], sg.w2[r], sg.w3[r], sg.w4[r], sg.wm[r], c0[d], c1[d], c2[d], c3[d]);
+      if (!whole) {
+        if (!(8 * poct[r] < sg.kmax)) packed[0] = packed[1] = packed[2] = packed[3] = 0u;
+      }
+      *reinterpret_cast<uint4*>(&Bs[buf][pn[r]][8 * poct[r]]) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int piece = tid + e * NT;
+      if (piece >= AQ) continue;
+      unsigned short* dst = &As[buf][piece % BM][8 * (piece / BM)];
+      if (whole) {   // (rows past OCg are zero in the re-laid-out weights)
+        *reinterpret_cast<uint4*>(dst) = sg.av[e];
+      } else {
+        const bool zero = !(8 * (piece / BM) < sg.kmax);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(zero ? 0u : sg.av[e].x, zero ? 0u : sg.av[e].y, zero ? 0u : sg.av[e].z, zero ? 0u : sg.av[e].w);
+      }
+    }
+  };
+  const int kq = lane >> 5, l31 = lane & 31;
+  auto multiply = [&](int buf) {
+#pragma unroll
+    for (int step = 0; step < BK / 16; ++step) {
+      uint4 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const uint4*>(&As[buf][(wm * MI + mi) * 32 + l31][16 * step + kq * 8]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const uint4*>(&Bs[buf][(wn * NI + ni) * 32 + l31][16 * step + kq * 8]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16<T>(a[mi], b[ni], acc[mi][ni]);
+    }
+  };
+
+  if (total > 0) {
+    fetch_raw(0, 0);
+    begin_segment(0, 0);
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u) issue(stg[u]);
+    int buf = 0;
+    const int full = total / D * D;
+    for (int s = 0; s < full; s += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        issue(stg[(u + D - 1) % D]);
+        commit(stg[u], buf);
+        __syncthreads();
+        multiply(buf);
+        buf ^= 1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u) {
+      if (full + u < total) {
+        commit(stg[u], buf);
+        __syncthreads();
+        multiply(buf);
+        buf ^= 1;
+      }
+    }
+  }
+
   float brow[MI][16];   // one batch of independent bias loads (see the fp32 kernel's epilogue)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -1260,6 +1590,7 @@ int fill_params(DcnParams& p, int64_t B, int64_t C, int64_t H, int64_t W, int64_
   p.ICg = (int)(C / groups);
   p.OCg = (int)(OC / groups);
   p.cpog = (int)(C / ogroups);
+  p.xcd_tiles = g_xcd_tiles.load(std::memory_order_relaxed);
   TVMI_CHECK_ARG(p.oh > 0 && p.ow > 0, "deform_conv2d: calculated output size too small");
   TVMI_CHECK_ARG(H * W < (1ll << 31), "deform_conv2d: plane too large");
   return 0;
@@ -1298,6 +1629,27 @@ int launch_cl16(const T* input_cl, const T* wt8, const T* offset, const T* mask,
       input_cl, wt8, offset, mask, bias, out, p, OCg_pad);
   return 0;
 }
+template <typename T, int WM, int WN, int MI, int NI, int BK, int D, int WPE = 1>
+int launch_clp16(const T* input_cl, const T* wt8, const T* offset, const T* mask, const T* bias, T* out, const DcnParams& p,
+                 int OCg_pad, hipStream_t s) {
+  constexpr int NT = 64 * WM * WN, BM = 32 * MI * WM, BN = 32 * NI * WN;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(unsigned short);
+  auto kern = dcn_fwd_mfma_16_clp<T, WM, WN, MI, NI, BK, D, WPE>;
+  if (lds > 64 * 1024) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error((int)hipErrorInvalidValue, "deform_conv2d: cannot reserve the LDS slabs");
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  kern<<<dim3((unsigned)ceil_div(npix, BN), (unsigned)ceil_div(p.OCg, BM), (unsigned)p.groups), dim3(NT), lds, s>>>(
+      input_cl, wt8, offset, mask, bias, out, p, OCg_pad);
+  return 0;
+}
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 1 << 20)); }
 
 }  // namespace
@@ -1307,12 +1659,28 @@ int set_dcn_option(const char* name, int64_t value) {
     g_cl_gather.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "dcn.cl_variant") == 0) {
+    g_cl_variant.store((int)value, std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
+    g_xcd_tiles.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
   return -1;
 }
 
 int get_dcn_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "dcn.channels_last_gather") == 0) {
     *value = g_cl_gather.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.cl_variant") == 0) {
+    *value = g_cl_variant.load(std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
+    *value = g_xcd_tiles.load(std::memory_order_relaxed);
     return 0;
   }
   return -1;
@@ -1369,6 +1737,7 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     // per tile instead of 4 (more waves per SIMD to hide the gather latency behind)
     const int64_t ntiles = ceil_div(npix, p.OCg > 128 ? 64 : (p.OCg > 64 ? 128 : 256)) * ceil_div(p.OCg, p.OCg > 128 ? 256 : (p.OCg > 64 ? 128 : 64)) * p.groups;
     const bool eight = ntiles < 3 * 768;
+    // (round 4: a 256 x 128 tile was measured as well — 0.435 ms against 0.413 at config 4, profiles/r04_dcn_variants.json)
     if (p.OCg > 128) {
       if (eight) TVMI_DCN(4, 2, 2, 1); else TVMI_DCN(4, 1, 2, 2);
     } else if (p.OCg > 64) {
@@ -1387,6 +1756,7 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     if (g_cl_gather.load(std::memory_order_relaxed) && can_gather_channels_last(p, dt) && workspace_bytes >= cl_at + cl_bytes) {
       void* in_cl = static_cast<char*>(workspace) + cl_at;
       const int64_t w8total = (int64_t)p.groups * kh * kw * p.ICg * OCg_pad;   // <= wtotal
+#define TVMI_CLARGS(scalar_t) icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s
 #define TVMI_DCN16_CL(scalar_t)                                                                                        \
   do {                                                                                                                 \
     dcn_weight_relayout8<scalar_t><<<grid1d(w8total), dim3(256), 0, s>>>((const scalar_t*)weight, (scalar_t*)workspace, p, OCg_pad); \
@@ -1394,6 +1764,14 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
         (const scalar_t*)input, (scalar_t*)in_cl, (int)C, (int)(H * W));                                               \
     const scalar_t* icl = (const scalar_t*)in_cl;                                                                      \
     const scalar_t* w8 = (const scalar_t*)workspace;                                                                   \
+    const int variant = cl_bytes < ((size_t)1 << 32) ? g_cl_variant.load(std::memory_order_relaxed) : 0;  /* 32-bit lane offsets */ \
+    /* measured at config 4 (profiles/r04_dcn_variants.json): 256 x 128 tile, 8 waves of 64 x 64 — 0.098 ms against 0.125 ms   \
+       for the round-3 kernel; 4 waves 0.104; 256 x 64 tiles 0.151; three stages 0.102.  OC = 128: 128 x 128 tile 0.096        \
+       against 0.137 (round 3) and 0.150 (128 x 256 tile: 107 workgroups) */                                                 \
+    if (p.OCg > 128 && variant == 1) st = launch_clp16<scalar_t, 4, 2, 2, 2, 32, 2>(TVMI_CLARGS(scalar_t));            \
+    else if (p.OCg > 128 && variant == 2) st = launch_clp16<scalar_t, 4, 1, 2, 2, 32, 2>(TVMI_CLARGS(scalar_t));       \
+    else if (p.OCg > 64 && p.OCg <= 128 && variant > 0) st = launch_clp16<scalar_t, 2, 4, 2, 1, 32, 2>(TVMI_CLARGS(scalar_t)); \
+    else                                                                                                               \
     if (p.OCg > 128) st = launch_cl16<scalar_t, 4, 2, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
     else if (p.OCg > 64) st = launch_cl16<scalar_t, 2, 4, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
     else st = launch_cl16<scalar_t, 1, 8, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
