@@ -1115,6 +1115,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
       sg.w3[r] = f32x2{tap_cur[r].w3, tap_cur[r].w3};
       sg.w4[r] = f32x2{tap_cur[r].w4, tap_cur[r].w4};
       sg.wm[r] = f32x2{tap_cur[r].m, tap_cur[r].m};
+      // (opaque, or the backend folds the pairs back into op_sel broadcasts of one register)
+      asm volatile("" : "+v"(sg.w1[r]), "+v"(sg.w2[r]), "+v"(sg.w3[r]), "+v"(sg.w4[r]), "+v"(sg.wm[r]));
     }
     if (whole) {
 #pragma unroll
@@ -1155,7 +1157,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
     const bool whole = sg.kmax == BK;   // uniform: a whole slab needs no zero-fill (columns of pixels past the end are never stored)
 #pragma unroll
     for (int r = 0; r < PI; ++r) {
-      if (!item_ok[r]) continue;
+      if constexpr (NITEM != PI * NT) {   // (no exec-mask branch otherwise: the blend shares a basic block with the MFMAs)
+        if (!item_ok[r]) continue;
+      }
       const unsigned* c0 = reinterpret_cast<const unsigned*>(&sg.cv[r][0]);
       const unsigned* c1 = reinterpret_cast<const unsigned*>(&sg.cv[r][1]);
       const unsigned* c2 = reinterpret_cast<const unsigned*>(&sg.cv[r][2]);
@@ -1171,7 +1175,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
 #pragma unroll
     for (int e = 0; e < AV; ++e) {
       const int piece = tid + e * NT;
-      if (piece >= AQ) continue;
+      if constexpr (AQ != AV * NT) {
+        if (piece >= AQ) continue;
+      }
       unsigned short* dst = &As[buf][piece % BM][8 * (piece / BM)];
       if (whole) {   // (rows past OCg are zero in the re-laid-out weights)
         *reinterpret_cast<uint4*>(dst) = sg.av[e];
@@ -1197,32 +1203,34 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
     }
   };
 
+  // One barrier per slab.  Between two barriers a wave multiplies slab s (LDS buffer s & 1) AND blends slab s + 1 into the
+  // other buffer — one basic block, so the matrix pipe runs under the blend's VALU work instead of after it (the counters of
+  // the first pipelined version: VALU 43 %, MFMA 17 %, nothing else above 50 % — the phases of the 8 lock-stepped waves did not
+  // overlap; profiles/r04_pmc_sq_dcn_bf16_clp_summary.txt).
   if (total > 0) {
     fetch_raw(0, 0);
     begin_segment(0, 0);
 #pragma unroll
-    for (int u = 0; u < D - 1; ++u) issue(stg[u]);
+    for (int u = 0; u < D; ++u) issue(stg[u]);
     int buf = 0;
-    const int full = total / D * D;
+    commit(stg[0], 0);
+    auto step = [&](Stage& refill, const Stage& next) {
+      __syncthreads();
+      issue(refill);            // its slab went to LDS in the previous step
+      multiply(buf);
+      commit(next, buf ^ 1);
+      buf ^= 1;
+    };
+    const int steps = total - 1, full = steps / D * D;
     for (int s = 0; s < full; s += D) {
 #pragma unroll
-      for (int u = 0; u < D; ++u) {
-        issue(stg[(u + D - 1) % D]);
-        commit(stg[u], buf);
-        __syncthreads();
-        multiply(buf);
-        buf ^= 1;
-      }
+      for (int u = 0; u < D; ++u) step(stg[u], stg[(u + 1) % D]);
     }
 #pragma unroll
-    for (int u = 0; u < D - 1; ++u) {
-      if (full + u < total) {
-        commit(stg[u], buf);
-        __syncthreads();
-        multiply(buf);
-        buf ^= 1;
-      }
-    }
+    for (int u = 0; u < D - 1; ++u)
+      if (full + u < steps) step(stg[u], stg[(u + 1) % D]);
+    __syncthreads();
+    multiply(buf);
   }
 
   float brow[MI][16];   // one batch of independent bias loads (see the fp32 kernel's epilogue)
