@@ -44,7 +44,7 @@ typedef enum {
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
  * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
-#define TVMI_ABI_VERSION 302
+#define TVMI_ABI_VERSION 303
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
@@ -55,6 +55,8 @@ int tvmi_version(void);
  *                                (a one-workgroup counting sort in front of the launch; needs the forward workspace)
  *   "roi_align.order_bands"      bands per (image, level) in that order key (default 16, 1..64)
  *   "dcn.channels_last_gather"   1 (default) / 0: the 16-bit MFMA deform_conv2d kernel samples a [B, H*W, C] copy of the input
+ *   "dcn.bwd_mfma"               1 (default) / 0: tvmi_deform_conv2d_backward contracts on the matrix cores where the shapes allow
+ *                                (0 = the direct kernels for every problem)
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)
@@ -319,6 +321,26 @@ int tvmi_deformable_col2im_coord(const void* columns, const void* input, const v
                                  int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t stride_h,
                                  int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w,
                                  int64_t offset_groups, int use_mask, void* stream);
+/* The whole backward pass in one call, no materialised `columns` and no library GEMM.  Replaces the reference's
+ * backward_gradient_inputs + backward_gradient_parameters (cpu/deform_conv2d_kernel.cpp:554-919, 1153-1226;
+ * cuda/deform_conv2d_kernel.cu:752-1033, 1257-1330: a GEMM per weight group into [C*kh*kw, B*oh*ow], col2im_coord, col2im,
+ * im2col into the same buffer, a second GEMM).  grad_out [B,OC,oh,ow]; grad_input / grad_weight / grad_offset / grad_mask
+ * (ignored unless use_mask) / grad_bias (may be NULL) have the shapes of input / weight / offset / mask / [OC] and are FULLY
+ * overwritten.  fp32 / fp16 / bf16 problems with at least 16 channels per weight group on both sides (and whole 32-channel
+ * blocks per offset group) contract on the fp32 matrix cores inside two fused kernels — sums in fp32, 16-bit results rounded
+ * once; everything else (fp64, depthwise, tiny channel counts) runs direct kernels with the same fusion.  grad_input is
+ * accumulated with float atomics like the reference's (not bit-reproducible run to run).  `workspace`:
+ * tvmi_deform_conv2d_backward_workspace_bytes (re-laid-out weights, the [tap][oc][ic] weight-gradient sums, fp32 sums of
+ * 16-bit problems; 0 for fp64). */
+size_t tvmi_deform_conv2d_backward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC,
+                                                   int64_t kh, int64_t kw, int64_t oh, int64_t ow, int64_t groups,
+                                                   int64_t offset_groups);
+int tvmi_deform_conv2d_backward(const void* grad_out, const void* input, const void* weight, const void* offset,
+                                const void* mask, void* grad_input, void* grad_weight, void* grad_offset, void* grad_mask,
+                                void* grad_bias, tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC,
+                                int64_t kh, int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                                int64_t dil_h, int64_t dil_w, int64_t groups, int64_t offset_groups, int use_mask,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------- detection post-processing --------
  * One launch from the score-ordered keep list of a (batched) NMS to the fixed-shape payload

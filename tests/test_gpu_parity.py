@@ -645,6 +645,110 @@ def test_deform_conv2d_depthwise_kernel(cfg, dtype):
     np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=tol, atol=tol)
 
 
+DCN_BWD_CFGS = [
+    dict(B=2, C=64, OC=96, H=20, W=24, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True),     # matrix cores
+    dict(B=2, C=64, OC=96, H=20, W=24, k=(3, 3), groups=1, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True),     # 32 channels per offset group
+    dict(B=1, C=48, OC=200, H=13, W=17, k=(3, 3), groups=1, og=1, stride=(2, 1), pad=(1, 2), dil=(1, 2), mask=False),   # channel / oc / pixel tails, no mask
+    dict(B=3, C=64, OC=64, H=11, W=9, k=(1, 3), groups=2, og=2, stride=(1, 1), pad=(0, 1), dil=(1, 1), mask=True),      # two weight groups
+    dict(B=1, C=320, OC=272, H=9, W=10, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True),    # two channel chunks, two oc chunks
+    dict(B=3, C=36, OC=40, H=11, W=9, k=(1, 3), groups=2, og=3, stride=(1, 1), pad=(0, 1), dil=(1, 1), mask=True),      # direct: 12 channels per offset group
+    dict(B=2, C=8, OC=8, H=9, W=9, k=(3, 3), groups=8, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False),        # direct: depthwise
+    dict(B=2, C=6, OC=2, H=5, W=4, k=(3, 2), groups=2, og=3, stride=(2, 1), pad=(1, 0), dil=(2, 1), mask=True),         # direct: the reference's test configuration
+    dict(B=1, C=32, OC=32, H=8, W=8, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, zero_off=True),  # y = -1 / x = -1 exactly
+]
+
+
+def _dcn_bwd_inputs(cfg, dtype, seed=31):
+    g = gen(seed)
+    kh, kw = cfg["k"]
+    oh = (cfg["H"] + 2 * cfg["pad"][0] - (cfg["dil"][0] * (kh - 1) + 1)) // cfg["stride"][0] + 1
+    ow = (cfg["W"] + 2 * cfg["pad"][1] - (cfg["dil"][1] * (kw - 1) + 1)) // cfg["stride"][1] + 1
+    x = torch.randn(cfg["B"], cfg["C"], cfg["H"], cfg["W"], generator=g)
+    w = torch.randn(cfg["OC"], cfg["C"] // cfg["groups"], kh, kw, generator=g) * 0.1
+    off = torch.randn(cfg["B"], 2 * cfg["og"] * kh * kw, oh, ow, generator=g) * 2
+    if cfg.get("zero_off"):
+        off = torch.zeros_like(off)
+    m = torch.rand(cfg["B"], cfg["og"] * kh * kw, oh, ow, generator=g)
+    b = torch.randn(cfg["OC"], generator=g)
+    gr = torch.randn(cfg["B"], cfg["OC"], oh, ow, generator=g)
+    args = (*cfg["stride"], *cfg["pad"], *cfg["dil"], cfg["groups"], cfg["og"], cfg["mask"])
+    return [v.to(dtype) for v in (gr, x, w, off, m, b)], args
+
+
+def _dcn_bwd_compare(got, ref, tol, what):
+    for name, a, r in zip(("grad_input", "grad_weight", "grad_offset", "grad_mask", "grad_bias"), got, ref):
+        r = r.double().numpy()
+        scale = max(1.0, float(np.abs(r).max()))
+        np.testing.assert_allclose(a.double().cpu().numpy(), r, rtol=tol, atol=tol * scale, err_msg=f"{name} {what}")
+
+
+@pytest.mark.parametrize("route", ["default", "direct"])
+@pytest.mark.parametrize("cfg", DCN_BWD_CFGS, ids=[str(i) for i in range(len(DCN_BWD_CFGS))])
+def test_deform_conv2d_backward_fused_vs_reference(tv, cfg, route):
+    """`_deform_conv2d_backward` = ONE call of tvmi_deform_conv2d_backward (deform_conv2d_bwd.hip: two fused matrix-core kernels
+    or the direct kernels; no `columns`, no library GEMM) against the reference CPU kernels
+    (cpu/deform_conv2d_kernel.cpp:274-348, 407-551, 1153-1226), all five gradients, on every route: offset groups, weight
+    groups, strides / dilations, channel and pixel tails, no mask, and zero offsets with padding (sampling rows at exactly
+    y = -1, where get_coordinate_weight still sees the row below while the bilinear sample is zero).  fp32 bar 1e-4 of the
+    gradient's scale (sums in another order)."""
+    if not O.load_reference():
+        pytest.skip("needs the reference CPU kernels (oracle/_ref)")
+    ts, args = _dcn_bwd_inputs(cfg, torch.float32)
+    torch.ops.tvmi.set_option("dcn.bwd_mfma", 0 if route == "direct" else 1)
+    try:
+        got = tv._deform_conv2d_backward(*[v.to(DEV) for v in ts], *args)
+    finally:
+        torch.ops.tvmi.set_option("dcn.bwd_mfma", 1)
+    _dcn_bwd_compare(got, tv._deform_conv2d_backward(*ts, *args), TOL, route)
+
+
+@pytest.mark.parametrize("dtype,tol,idx", [(torch.bfloat16, 1.5e-2, 0), (torch.float16, 2e-3, 1), (torch.bfloat16, 1.5e-2, 6), (torch.float64, 1e-10, 7),
+                                           (torch.float64, 1e-10, 0)], ids=["bf16-mfma", "fp16-mfma", "bf16-direct", "fp64-direct", "fp64-large"])
+def test_deform_conv2d_backward_fused_other_dtypes(tv, dtype, tol, idx):
+    """16-bit tensors are read natively, contracted and summed in fp32 and rounded once (the reference keeps `columns` and its
+    atomics in the 16-bit type): compared with the fp32 reference on the rounded tensors, bar = a few 16-bit ulps of the
+    gradient's scale.  fp64 always takes the direct kernels: 1e-10."""
+    if not O.load_reference():
+        pytest.skip("needs the reference CPU kernels (oracle/_ref)")
+    ts, args = _dcn_bwd_inputs(DCN_BWD_CFGS[idx], dtype)
+    got = tv._deform_conv2d_backward(*[v.to(DEV) for v in ts], *args)
+    assert all(a.dtype == dtype for a in got)
+    up = torch.float64 if dtype == torch.float64 else torch.float32
+    _dcn_bwd_compare(got, tv._deform_conv2d_backward(*[v.to(up) for v in ts], *args), tol, str(dtype))
+
+
+def test_deform_conv2d_backward_through_the_c_abi():
+    """tvmi_deform_conv2d_backward through ctypes on raw device pointers: outputs are FULLY overwritten (poisoned first), the
+    workspace query sizes the call, a short workspace is refused."""
+    import ctypes
+
+    if not O.load_reference():
+        pytest.skip("needs the reference CPU kernels (oracle/_ref)")
+    lib = vision_amd._loader.kernels()
+    cfg = DCN_BWD_CFGS[1]
+    ts, args = _dcn_bwd_inputs(cfg, torch.float32)
+    gr, x, w, off, m, b = [v.to(DEV).contiguous() for v in ts]
+    outs = [torch.full_like(v, float("nan")) for v in (x, w, off, m, b)]
+    B, C, H, W = x.shape
+    OC, _, kh, kw = w.shape
+    oh, ow = gr.shape[2:]
+    i64 = ctypes.c_int64
+    lib.tvmi_deform_conv2d_backward_workspace_bytes.restype = ctypes.c_size_t
+    lib.tvmi_deform_conv2d_backward_workspace_bytes.argtypes = [ctypes.c_int] + [i64] * 11
+    nbytes = lib.tvmi_deform_conv2d_backward_workspace_bytes(0, B, C, H, W, OC, kh, kw, oh, ow, cfg["groups"], cfg["og"])
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    lib.tvmi_deform_conv2d_backward.restype = ctypes.c_int
+    lib.tvmi_deform_conv2d_backward.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_int] + [i64] * 15 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    ptrs = [v.data_ptr() for v in (gr, x, w, off, m)] + [v.data_ptr() for v in outs]
+    dims = [B, C, H, W, OC, kh, kw, *cfg["stride"], *cfg["pad"], *cfg["dil"], cfg["groups"], cfg["og"]]
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.tvmi_deform_conv2d_backward(*ptrs, 0, *dims, 1, ws.data_ptr(), nbytes, stream) == 0
+    torch.cuda.synchronize()
+    _dcn_bwd_compare(outs, torch.ops.torchvision._deform_conv2d_backward(*ts, *args), TOL, "ctypes")
+    assert lib.tvmi_deform_conv2d_backward(*ptrs, 0, *dims, 1, ws.data_ptr(), nbytes - 1, stream) != 0
+
+
 def test_deform_conv2d_zero_offset_is_conv_and_batch0(tv):
     g = gen(15)
     x = torch.randn(2, 32, 14, 14, generator=g).to(DEV)

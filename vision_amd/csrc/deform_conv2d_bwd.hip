@@ -1,0 +1,835 @@
+// deform_conv2d_bwd.hip — the backward pass of deform_conv2d for gfx950 (MI355X), fused.
+//
+// Semantics: torchvision/csrc/ops/cpu/deform_conv2d_kernel.cpp
+//   deformable_col2im_kernel :274-348 (grad_input), get_coordinate_weight :407-438 and
+//   deformable_col2im_coord_kernel :440-551 (grad_offset, grad_mask), backward host code :1153-1226;
+//   the device pattern it replaces: cuda/deform_conv2d_kernel.cu:752-1033 (compute_grad_input / compute_grad_offset_and_mask:
+//   one library GEMM `columns = W^T x grad_out` per weight group into a materialised [C*kh*kw, B*oh*ow] buffer — 250 MB at
+//   2x256x100x136, k = 3 — read back by a col2im and a col2im_coord kernel; backward_gradient_parameters: im2col into the
+//   same buffer + a second library GEMM).
+//
+// Here `columns` never exists in memory and no library GEMM is called:
+//   * dcn_bwd_data_mfma   workgroup = 64 output pixels.  For every (tap, 256 input channels) it contracts
+//         gcol[(tap, c), n] = sum_o W[o, c, tap] * grad_out[o, n]      (K = out channels of the weight group)
+//     on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, both operands staged through double-buffered LDS slabs, one barrier
+//     per 16-deep slab) and consumes the 32x32 accumulator blocks WHERE THEY ARE: a lane holds 16 channels of ONE pixel, whose
+//     sampling location it computed once per tap; per value it gathers the 4 corners of the input (for the coordinate /
+//     mask gradients), scatters `mask * bilinear weight * gcol` into grad_input with global float atomics (what the
+//     reference does, cuda/deform_conv2d_kernel.cu:319-389) and adds to its private grad_offset / grad_mask sums, which leave
+//     the wave as one atomic per (tap, pixel, component).
+//   * dcn_bwd_weight_mfma  workgroup = (tap, pixel range, 256 out channels x 128 in channels).  It contracts
+//         grad_weight[o, c, tap] = sum_n grad_out[o, n] * col[(c, tap), n]   (K = output pixels)
+//     with the offset-gather + bilinear "im2col" values of a 16-pixel slab produced straight into LDS (as the forward kernel
+//     does), and adds its partial block to a [tap][o][c] fp32 buffer (coalesced atomics), which a last small kernel
+//     transposes into the weight layout.
+//   * 16-bit tensors are read natively and contracted in fp32 (sums in fp32 buffers, rounded once at the end — the reference
+//     accumulates grad_input in 16-bit atomics); fp64, depthwise and tiny channel counts take the direct kernels below
+//     (same fusion, no matrix cores).
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <type_traits>
+
+#include "dcn_common.h"
+
+namespace tvmi {
+namespace {
+
+std::atomic<int> g_bwd_mfma{1};   // option "dcn.bwd_mfma": 0 sends every problem to the direct kernels
+std::atomic<int> g_bwd_blas{0};   // option "dcn.bwd_blas" (measurement only): the dispatcher glue takes the round-3 route (library GEMMs)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One sampling location as the backward needs it: the 4 corner offsets (clamped to a legal address), the bilinear weights of
+// the forward (zero for corners outside the image and for locations outside (-1, H) x (-1, W): deform_conv2d_kernel.cpp:95-132
+// — the weights col2im scatters with, :334-343), and what get_coordinate_weight (:407-438) uses: the corner validity on its
+// own (NOT gated by the location test: y == -1 exactly has a valid lower row there) and the fractions.
+template <typename A>
+struct BwdTap {
+  int o[4];
+  A bw[4];        // bilinear weights, no mask
+  A m;            // modulation mask (1 when unused)
+  A dy, dx;
+  bool cv[4];     // corner validity of get_coordinate_weight
+};
+
+template <typename A>
+__device__ __forceinline__ void make_bwd_tap(BwdTap<A>& t, int H, int W, A y, A x, A mask) {
+  const bool inside = !(y <= (A)-1 || (A)H <= y || x <= (A)-1 || (A)W <= x);
+  // far-away (or NaN) coordinates: every corner is invalid; keep the int conversion defined
+  const A yc = fmin(fmax(y, (A)-2), (A)H + (A)1), xc = fmin(fmax(x, (A)-2), (A)W + (A)1);
+  const int yl = (int)floor(yc), xl = (int)floor(xc);
+  const int yh = yl + 1, xh = xl + 1;
+  const bool vyl = 0 <= yl && yl < H, vyh = 0 <= yh && yh < H, vxl = 0 <= xl && xl < W, vxh = 0 <= xh && xh < W;
+  const int cyl = min(max(yl, 0), H - 1), cyh = min(max(yh, 0), H - 1), cxl = min(max(xl, 0), W - 1), cxh = min(max(xh, 0), W - 1);
+  t.dy = yc - (A)yl;
+  t.dx = xc - (A)xl;
+  t.m = mask;
+  t.o[0] = cyl * W + cxl;
+  t.o[1] = cyl * W + cxh;
+  t.o[2] = cyh * W + cxl;
+  t.o[3] = cyh * W + cxh;
+  t.cv[0] = vyl && vxl;
+  t.cv[1] = vyl && vxh;
+  t.cv[2] = vyh && vxl;
+  t.cv[3] = vyh && vxh;
+  const A hh = (A)1 - t.dy, hw = (A)1 - t.dx;
+  t.bw[0] = (inside && t.cv[0]) ? hh * hw : (A)0;
+  t.bw[1] = (inside && t.cv[1]) ? hh * t.dx : (A)0;
+  t.bw[2] = (inside && t.cv[2]) ? t.dy * hw : (A)0;
+  t.bw[3] = (inside && t.cv[3]) ? t.dy * t.dx : (A)0;
+}
+
+template <typename T, typename A>
+__device__ __forceinline__ void load_bwd_tap(BwdTap<A>& t, const DcnParams& p, const T* __restrict__ offset,
+                                             const T* __restrict__ mask, int b, int og, int tap, int oy, int ox) {
+  const int i = tap / p.kw, j = tap - i * p.kw;
+  const int64_t plane = (int64_t)p.oh * p.ow;
+  const int64_t pix = (int64_t)oy * p.ow + ox;
+  const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * p.kh * p.kw) * plane;
+  const A off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
+  const A off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
+  A mval = (A)1;
+  if (p.use_mask) mval = ld(mask + ((int64_t)(b * p.ogroups + og) * p.kh * p.kw + tap) * plane + pix);
+  const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + off_h;
+  const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + off_w;
+  make_bwd_tap<A>(t, p.H, p.W, y, x, mval);
+}
+
+// What one gcol value v = columns[(c, tap), n] contributes, given the 4 corner values of input channel c (read at the clamped
+// offsets): the scatter into grad_input (col2im), and the three sums of col2im_coord.
+template <typename A>
+struct CoordSums {
+  A gy, gx, gm;
+};
+template <typename A>
+__device__ __forceinline__ void accumulate_coord(CoordSums<A>& s, const BwdTap<A>& t, A v, A x0, A x1, A x2, A x3, bool use_mask) {
+  const A v_yx = t.cv[0] ? x0 : (A)0, v_yX = t.cv[1] ? x1 : (A)0, v_Yx = t.cv[2] ? x2 : (A)0, v_YX = t.cv[3] ? x3 : (A)0;
+  const A wy = t.dx * (v_YX - v_yX) + ((A)1 - t.dx) * (v_Yx - v_yx);   // get_coordinate_weight, y direction
+  const A wx = t.dy * (v_YX - v_Yx) + ((A)1 - t.dy) * (v_yX - v_yx);   // x direction
+  s.gy += t.m * wy * v;
+  s.gx += t.m * wx * v;
+  if (use_mask) s.gm += v * (t.bw[0] * x0 + t.bw[1] * x1 + t.bw[2] * x2 + t.bw[3] * x3);
+}
+
+// ------------------------------------------------------------------ small kernels around the two contractions
+// weight [OC, ICg, kh, kw] (T) -> wtb [groups][tap][OCg_pad][ICg_pad] fp32 (ic fastest, zero padded): the A operand of
+// the data-gradient contraction, rows = out channels (K), columns = in channels (M)
+template <typename T>
+__global__ void dcn_weight_relayout_bwd(const T* __restrict__ w, float* __restrict__ wtb, DcnParams p, int OCg_pad, int ICg_pad) {
+  const int KK = p.kh * p.kw;
+  const int64_t total = (int64_t)p.groups * KK * OCg_pad * ICg_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ic = (int)(idx % ICg_pad);
+    const int oc = (int)((idx / ICg_pad) % OCg_pad);
+    const int tap = (int)((idx / ((int64_t)ICg_pad * OCg_pad)) % KK);
+    const int g = (int)(idx / ((int64_t)ICg_pad * OCg_pad * KK));
+    float v = 0.f;
+    if (oc < p.OCg && ic < p.ICg) v = ld(w + (((int64_t)(g * p.OCg + oc)) * p.ICg + ic) * KK + tap);
+    wtb[idx] = v;
+  }
+}
+
+// gw_ws [groups][tap][OCg][ICg] fp32 -> grad_weight [OC, ICg, kh, kw] (T)
+template <typename T>
+__global__ void dcn_bwd_weight_finish(const float* __restrict__ ws, T* __restrict__ gw, DcnParams p) {
+  const int KK = p.kh * p.kw;
+  const int64_t total = (int64_t)p.OC * p.ICg * KK;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(idx % KK);
+    const int ic = (int)((idx / KK) % p.ICg);
+    const int ocg = (int)(idx / ((int64_t)KK * p.ICg));   // g * OCg + oc
+    const int g = ocg / p.OCg, oc = ocg - g * p.OCg;
+    st(gw + idx, ws[(((int64_t)g * KK + tap) * p.OCg + oc) * p.ICg + ic]);
+  }
+}
+
+template <typename T>
+__global__ void dcn_round_from_f32(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) st(dst + i, src[i]);
+}
+
+// grad_bias[oc] = sum over images and pixels of grad_out (the reference: grad.sum({0, 2, 3}))
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_bias(const T* __restrict__ gout, T* __restrict__ gbias, int B, int OC, int64_t plane) {
+  using A = typename Acc<T>::type;
+  __shared__ A part[4];
+  const int oc = blockIdx.x;
+  A s = (A)0;
+  for (int b = 0; b < B; ++b) {
+    const T* src = gout + ((int64_t)b * OC + oc) * plane;
+    for (int64_t i = threadIdx.x; i < plane; i += 256) s += ld(src + i);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) st(gbias + oc, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ------------------------------------------------------------------ data gradients on the matrix cores
+constexpr int kBwBK = 16;
+
+// 8 waves: 4 along M (in channels, 64 each = 2 blocks of 32) x 2 along N (pixels, 32 each).  The lane <-> (pixel, channel)
+// map of an accumulator block is the forward kernel's: D[row][col], col = lane & 31 = pixel, row = (r & 3) + 8 (r >> 2) +
+// 4 (lane >> 5) = channel.  GI: fp32 accumulation buffers (the outputs themselves for fp32 tensors).
+template <typename T>
+__global__ __launch_bounds__(512) void dcn_bwd_data_mfma(const T* __restrict__ input, const float* __restrict__ wtb,
+                                                         const T* __restrict__ offset, const T* __restrict__ mask,
+                                                         const T* __restrict__ gout, float* __restrict__ gi,
+                                                         float* __restrict__ goff, float* __restrict__ gmask, DcnParams p,
+                                                         int OCg_pad, int ICg_pad) {
+  constexpr int WM = 4, WN = 2, MI = 2;
+  constexpr int NT = 64 * WM * WN;       // 512
+  constexpr int BM = 32 * MI * WM;       // 256 in channels
+  constexpr int BN = 32 * WN;            // 64 pixels
+  constexpr int AV = kBwBK * BM / 4 / NT;   // float4 pieces of the A slab per thread (2)
+  constexpr int BV = kBwBK * BN / NT;       // B values per thread (2)
+  static_assert(AV * NT * 4 == kBwBK * BM && BV * NT == kBwBK * BN, "slab shapes");
+  __shared__ __attribute__((aligned(16))) float As[2][kBwBK][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kBwBK][BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int kq = lane >> 5, l31 = lane & 31;
+  const int g = blockIdx.z;
+  const int KK = p.kh * p.kw;
+  const int64_t oplane = (int64_t)p.oh * p.ow, iplane = (int64_t)p.H * p.W;
+  const int64_t npix = (int64_t)p.B * oplane;
+  const int64_t pix0 = (int64_t)blockIdx.x * BN;
+
+  // producer side of the B slab: this thread's pixel and its rows of the slab
+  const int pn = tid % BN, ksub = tid / BN;   // 8 row subsets
+  const int64_t prod_pix = pix0 + pn;
+  const bool prod_ok = prod_pix < npix;
+  const int64_t prod_b = prod_ok ? prod_pix / oplane : 0, prod_in = prod_ok ? prod_pix - prod_b * oplane : 0;
+  const T* gout_p = gout + ((int64_t)prod_b * p.OC + (int64_t)g * p.OCg) * oplane + prod_in;
+
+  // consumer side: the pixel of this lane's accumulator column
+  const int64_t my_pix = pix0 + wn * 32 + l31;
+  const bool pix_ok = my_pix < npix;
+  int mb = 0, moy = 0, mox = 0;
+  if (pix_ok) {
+    mox = (int)(my_pix % p.ow);
+    moy = (int)((my_pix / p.ow) % p.oh);
+    mb = (int)(my_pix / oplane);
+  }
+  const int64_t my_in = (int64_t)moy * p.ow + mox;
+
+  const int nks = OCg_pad / kBwBK;                 // slabs per (tap, channel chunk)
+  const int ncc = (p.ICg + BM - 1) / BM;           // channel chunks per tap
+  const int total = KK * ncc * nks;
+
+  f32x16 acc[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+  float4 av[AV];
+  float bv[BV];
+  auto issue = [&](int tap, int c0, int oc0) {
+    const float* wsrc = wtb + (((int64_t)g * KK + tap) * OCg_pad + oc0) * ICg_pad + c0;
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int lin = (tid + e * NT) * 4;
+      const int kk = lin / BM, m = lin - kk * BM;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + m < ICg_pad) v = *reinterpret_cast<const float4*>(wsrc + (int64_t)kk * ICg_pad + m);
+      av[e] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+      const int oc = oc0 + ksub + e * (NT / BN);
+      bv[e] = (prod_ok && oc < p.OCg) ? (float)ld(gout_p + (int64_t)oc * oplane) : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int lin = (tid + e * NT) * 4;
+      const int kk = lin / BM, m = lin - kk * BM;
+      *reinterpret_cast<float4*>(&As[buf][kk][m]) = av[e];
+    }
+#pragma unroll
+    for (int e = 0; e < BV; ++e) Bs[buf][ksub + e * (NT / BN)][pn] = bv[e];
+  };
+
+  // grad_offset / grad_mask sums of this lane's pixel for the current (tap, offset group)
+  BwdTap<float> tp;
+  CoordSums<float> sums{0.f, 0.f, 0.f};
+  int cur_tap = -1, cur_og = -1;
+  auto flush = [&]() {
+    if (cur_tap < 0) return;
+    // the two lane halves hold different channels of the same pixel
+    sums.gy += __shfl_xor(sums.gy, 32);
+    sums.gx += __shfl_xor(sums.gx, 32);
+    sums.gm += __shfl_xor(sums.gm, 32);
+    if (pix_ok && kq == 0) {
+      float* o = goff + ((int64_t)(mb * p.ogroups + cur_og) * 2 * KK + 2 * cur_tap) * oplane + my_in;
+      unsafeAtomicAdd(o, sums.gy);
+      unsafeAtomicAdd(o + oplane, sums.gx);
+      if (p.use_mask) unsafeAtomicAdd(gmask + ((int64_t)(mb * p.ogroups + cur_og) * KK + cur_tap) * oplane + my_in, sums.gm);
+    }
+    sums.gy = sums.gx = sums.gm = 0.f;
+  };
+  auto epilogue = [&](int tap, int c0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ct = c0 + (wm * MI + mi) * 32;   // first channel of the block, inside the weight group
+      if (ct < p.ICg) {                          // (wave-uniform)
+        const int og = (g * p.ICg + ct) / p.cpog;   // one offset group per block: the launcher checks the alignment
+        if (og != cur_og || tap != cur_tap) {       // (wave-uniform)
+          flush();
+          cur_og = og;
+          cur_tap = tap;
+          if (pix_ok) load_bwd_tap<T, float>(tp, p, offset, mask, mb, og, tap, moy, mox);
+        }
+        if (pix_ok) {
+          const int cbase = ct + 4 * kq;
+          const T* in_c = input + ((int64_t)mb * p.C + (int64_t)g * p.ICg) * iplane;
+          float* gi_c = gi + ((int64_t)mb * p.C + (int64_t)g * p.ICg) * iplane;
+          float xv[16][4];
+          // all corner reads of the block first (they only feed the coordinate sums) ...
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = min(cbase + (r & 3) + 8 * (r >> 2), p.ICg - 1);
+            const T* pl = in_c + (int64_t)c * iplane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[r][k] = (float)ld(pl + tp.o[k]);
+          }
+          // ... the scatter, which needs none of them, under their latency ...
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = cbase + (r & 3) + 8 * (r >> 2);
+            if (c < p.ICg) {
+              float* pl = gi_c + (int64_t)c * iplane;
+              const float v = acc[mi][r];
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (tp.bw[k] != 0.f) unsafeAtomicAdd(pl + tp.o[k], tp.m * tp.bw[k] * v);
+            }
+          }
+          // ... then the coordinate / mask sums
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = cbase + (r & 3) + 8 * (r >> 2);
+            if (c < p.ICg) accumulate_coord<float>(sums, tp, acc[mi][r], xv[r][0], xv[r][1], xv[r][2], xv[r][3], p.use_mask != 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    }
+  };
+
+  if (total > 0) {
+    int s_tap = 0, s_cc = 0, s_ks = 0;
+    issue(0, 0, 0);
+    int buf = 0;
+    for (int it = 0; it < total; ++it) {
+      commit(buf);
+      __syncthreads();
+      int n_tap = s_tap, n_cc = s_cc, n_ks = s_ks + 1;
+      if (n_ks == nks) {
+        n_ks = 0;
+        if (++n_cc == ncc) {
+          n_cc = 0;
+          ++n_tap;
+        }
+      }
+      if (it + 1 < total) issue(n_tap, n_cc * BM, n_ks * kBwBK);
+#pragma unroll
+      for (int kk = 0; kk < kBwBK; kk += 2) {
+        float a[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[mi] = As[buf][kk + kq][(wm * MI + mi) * 32 + l31];
+        const float b = Bs[buf][kk + kq][wn * 32 + l31];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b, acc[mi], 0, 0, 0);
+      }
+      if (s_ks == nks - 1) epilogue(s_tap, s_cc * BM);
+      s_tap = n_tap;
+      s_cc = n_cc;
+      s_ks = n_ks;
+      buf ^= 1;
+    }
+    flush();
+  }
+}
+
+// ------------------------------------------------------------------ weight gradient on the matrix cores
+// 8 waves: 4 along M (out channels, 64 each) x 2 along N (in channels, 64 each); K = output pixels in slabs of 16.
+// LDS rows are [row][k] with a pitch of 17 floats: both operands arrive pixel-fastest (grad_out rows from memory, the sampled
+// values per producer pixel) and are read as fragments with the row across the lanes — 17 l mod 64 is a permutation of the banks.
+constexpr int kBwPitch = kBwBK + 1;
+
+template <typename T>
+__global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__ input, const T* __restrict__ offset,
+                                                           const T* __restrict__ mask, const T* __restrict__ gout,
+                                                           float* __restrict__ gw_ws, DcnParams p, int pix_per_wg, int ncc,
+                                                           int nmc) {
+  constexpr int WM = 4, WN = 2, MI = 2, NI = 2;
+  constexpr int NT = 64 * WM * WN;      // 512
+  constexpr int BM = 32 * MI * WM;      // 256 out channels
+  constexpr int BN = 32 * NI * WN;      // 128 in channels
+  constexpr int AV = BM * kBwBK / NT;   // 8 grad_out values per thread and slab
+  constexpr int BV = BN * kBwBK / NT;   // 4 sampled values per thread and slab
+  constexpr int RSUB = NT / kBwBK;      // 32 row subsets among the producers
+  extern __shared__ __attribute__((aligned(16))) float dcn_bww_lds[];
+  float(*As)[BM][kBwPitch] = reinterpret_cast<float(*)[BM][kBwPitch]>(dcn_bww_lds);
+  float(*Bs)[BN][kBwPitch] = reinterpret_cast<float(*)[BN][kBwPitch]>(dcn_bww_lds + 2 * BM * kBwPitch);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int kq = lane >> 5, l31 = lane & 31;
+  const int g = blockIdx.z;
+  const int KK = p.kh * p.kw;
+  // blockIdx.y = (tap, channel chunk, out-channel chunk)
+  const int mc = blockIdx.y % nmc, cc = (blockIdx.y / nmc) % ncc, tap = blockIdx.y / (nmc * ncc);
+  const int o0 = mc * BM, c0 = cc * BN;
+  const int64_t oplane = (int64_t)p.oh * p.ow, iplane = (int64_t)p.H * p.W;
+  const int64_t npix = (int64_t)p.B * oplane;
+  const int64_t n_begin = (int64_t)blockIdx.x * pix_per_wg, n_end = min(npix, n_begin + pix_per_wg);
+  if (n_begin >= n_end) return;
+  const int nslab = (int)((n_end - n_begin + kBwBK - 1) / kBwBK);
+
+  // producer: pixel k of the slab, rows rsub + 32 e.  The producer pixel walks in steps of 16 through (image, y, x);
+  // (pb, poy, pox) always describe pixel `pn` (clamped to the last pixel of the tensor when the range ends inside a slab).
+  const int pk = tid % kBwBK, rsub = tid / kBwBK;
+  int64_t pn = n_begin + pk;
+  int pb, poy, pox;
+  {
+    const int64_t nn = min(pn, npix - 1);
+    pox = (int)(nn % p.ow);
+    poy = (int)((nn / p.ow) % p.oh);
+    pb = (int)(nn / oplane);
+  }
+  auto advance = [&]() {
+    pn += kBwBK;
+    if (pn >= npix) return;   // (stays on a legal pixel; `pn` says that the slab position is past the end)
+    pox += kBwBK;
+    while (pox >= p.ow) {
+      pox -= p.ow;
+      if (++poy == p.oh) {
+        poy = 0;
+        ++pb;
+      }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // the offset group of this thread's first row: its raw (offset_h, offset_w, mask) are fetched one slab AHEAD (a dependent
+  // load in front of the gathers of every slab otherwise); rows in other offset groups load theirs on the spot
+  const int og_first = (g * p.ICg + min(c0 + rsub, p.ICg - 1)) / p.cpog;
+  TapRaw<T> raw = tap_raw_identity<T>();
+  auto fetch_raw = [&]() {
+    if (pn < n_end) load_tap_raw<T>(raw, p, offset, mask, pb, og_first, tap, poy, pox);
+  };
+
+  float ga[AV];       // grad_out values of the next slab
+  float xb[BV][4];    // corner values of the next slab
+  float wgt[BV][4];   // their bilinear weights, zero for rows / pixels that do not exist
+  float wmask[BV];    // the modulation mask of the row's offset group (multiplies the sum, as in the forward: sample_tap)
+  auto issue = [&]() {
+    const bool ok = pn < n_end;
+    const int64_t pin = (int64_t)poy * p.ow + pox;
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int o = o0 + rsub + e * RSUB;
+      ga[e] = (ok && o < p.OCg) ? (float)ld(gout + ((int64_t)pb * p.OC + (int64_t)g * p.OCg + o) * oplane + pin) : 0.f;
+    }
+    Tap<float> t;
+    tap_from_raw<T, float>(t, p, raw, tap, poy, pox);
+    int og_cur = og_first;
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+      const int c = c0 + rsub + e * RSUB;
+      const bool cok = ok && c < p.ICg;
+      const int cl = min(c, p.ICg - 1);
+      const int og = (g * p.ICg + cl) / p.cpog;
+      if (og != og_cur) {
+        load_tap<T, float>(t, p, offset, mask, pb, og, tap, poy, pox);
+        og_cur = og;
+      }
+      const T* pl = input + ((int64_t)pb * p.C + (int64_t)g * p.ICg + cl) * iplane;
+      xb[e][0] = (float)ld(pl + t.o1);
+      xb[e][1] = (float)ld(pl + t.o2);
+      xb[e][2] = (float)ld(pl + t.o3);
+      xb[e][3] = (float)ld(pl + t.o4);
+      wgt[e][0] = cok ? t.w1 : 0.f;
+      wgt[e][1] = cok ? t.w2 : 0.f;
+      wgt[e][2] = cok ? t.w3 : 0.f;
+      wgt[e][3] = cok ? t.w4 : 0.f;
+      wmask[e] = cok ? t.m : 0.f;
+    }
+    advance();
+    fetch_raw();
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < AV; ++e) As[buf][rsub + e * RSUB][pk] = ga[e];
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+      // a row / pixel that does not exist contributes exactly zero (its corner values may be anything, even inf)
+      const bool live = wmask[e] != 0.f || wgt[e][0] != 0.f || wgt[e][1] != 0.f || wgt[e][2] != 0.f || wgt[e][3] != 0.f;
+      const float v = wmask[e] * (wgt[e][0] * xb[e][0] + wgt[e][1] * xb[e][1] + wgt[e][2] * xb[e][2] + wgt[e][3] * xb[e][3]);
+      Bs[buf][rsub + e * RSUB][pk] = live ? v : 0.f;
+    }
+  };
+
+  fetch_raw();
+  issue();
+  int buf = 0;
+  for (int s = 0; s < nslab; ++s) {
+    commit(buf);
+    __syncthreads();
+    if (s + 1 < nslab) issue();
+#pragma unroll
+    for (int kk = 0; kk < kBwBK; kk += 2) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = As[buf][(wm * MI + mi) * 32 + l31][kk + kq];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = Bs[buf][(wn * NI + ni) * 32 + l31][kk + kq];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+
+  // D[row][col]: col = lane & 31 = in channel (adjacent lanes, adjacent addresses), row = out channel
+  float* dst = gw_ws + ((int64_t)g * KK + tap) * p.OCg * p.ICg;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int c = c0 + (wn * NI + ni) * 32 + l31;
+    if (c >= p.ICg) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+        if (o < p.OCg) unsafeAtomicAdd(dst + (int64_t)o * p.ICg + c, acc[mi][ni][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ direct kernels (any dtype; depthwise, tiny channel counts, fp64)
+// One thread per (image, offset group, tap, output pixel): it walks the channels of the offset group, forms
+// gcol = sum_o W[o, c, tap] * grad_out[o, n] on the fly, scatters into grad_input and OWNS its grad_offset / grad_mask
+// elements (plain stores).  GI = the type the sums are kept in (T for fp32 / fp64 tensors, float buffers for 16-bit ones).
+template <typename T, typename GI>
+__global__ __launch_bounds__(256) void dcn_bwd_data_direct(const T* __restrict__ input, const T* __restrict__ weight,
+                                                           const T* __restrict__ offset, const T* __restrict__ mask,
+                                                           const T* __restrict__ gout, GI* __restrict__ gi,
+                                                           GI* __restrict__ goff, GI* __restrict__ gmask, DcnParams p,
+                                                           int64_t total) {
+  using A = typename Acc<T>::type;
+  const int KK = p.kh * p.kw;
+  const int64_t oplane = (int64_t)p.oh * p.ow, iplane = (int64_t)p.H * p.W;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % p.ow);
+    const int oy = (int)((idx / p.ow) % p.oh);
+    const int tap = (int)((idx / oplane) % KK);
+    const int og = (int)((idx / (oplane * KK)) % p.ogroups);
+    const int b = (int)(idx / (oplane * KK * p.ogroups));
+    const int64_t pin = (int64_t)oy * p.ow + ox;
+    BwdTap<A> t;
+    load_bwd_tap<T, A>(t, p, offset, mask, b, og, tap, oy, ox);
+    CoordSums<A> s{(A)0, (A)0, (A)0};
+    for (int cc = 0; cc < p.cpog; ++cc) {
+      const int c = og * p.cpog + cc;
+      const int g = c / p.ICg, ic = c - g * p.ICg;
+      const T* wp = weight + (((int64_t)g * p.OCg) * p.ICg + ic) * KK + tap;
+      const T* gp = gout + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * oplane + pin;
+      A v = (A)0;
+      for (int o = 0; o < p.OCg; ++o) v += ld(wp + (int64_t)o * p.ICg * KK) * ld(gp + (int64_t)o * oplane);
+      const T* pl = input + ((int64_t)b * p.C + c) * iplane;
+      const A x0 = ld(pl + t.o[0]), x1 = ld(pl + t.o[1]), x2 = ld(pl + t.o[2]), x3 = ld(pl + t.o[3]);
+      GI* gpl = gi + ((int64_t)b * p.C + c) * iplane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t.bw[k] != (A)0) atomic_accum(gpl + t.o[k], t.m * t.bw[k] * v);
+      accumulate_coord<A>(s, t, v, x0, x1, x2, x3, p.use_mask != 0);
+    }
+    GI* o = goff + ((int64_t)(b * p.ogroups + og) * 2 * KK + 2 * tap) * oplane + pin;
+    o[0] = (GI)s.gy;
+    o[oplane] = (GI)s.gx;
+    if (p.use_mask) gmask[((int64_t)(b * p.ogroups + og) * KK + tap) * oplane + pin] = (GI)s.gm;
+  }
+}
+
+// One workgroup per (in channel, tap, chunk of kDirOB out channels of the channel's weight group): every thread samples
+// col[(c, tap), n] for its pixels once and multiplies it into the chunk's grad_out values; block reduction; plain stores.
+constexpr int kDirOB = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void dcn_bwd_weight_direct(const T* __restrict__ input, const T* __restrict__ offset,
+                                                             const T* __restrict__ mask, const T* __restrict__ gout,
+                                                             T* __restrict__ gw, DcnParams p) {
+  using A = typename Acc<T>::type;
+  __shared__ A part[4][kDirOB];
+  const int KK = p.kh * p.kw;
+  const int c = blockIdx.x, tap = blockIdx.y, oc0 = blockIdx.z * kDirOB;
+  const int g = c / p.ICg, ic = c - g * p.ICg, og = c / p.cpog;
+  const int64_t oplane = (int64_t)p.oh * p.ow, iplane = (int64_t)p.H * p.W;
+  const int64_t npix = (int64_t)p.B * oplane;
+  A acc[kDirOB];
+#pragma unroll
+  for (int j = 0; j < kDirOB; ++j) acc[j] = (A)0;
+  for (int64_t n = threadIdx.x; n < npix; n += 256) {
+    const int ox = (int)(n % p.ow);
+    const int oy = (int)((n / p.ow) % p.oh);
+    const int b = (int)(n / oplane);
+    Tap<A> t;
+    load_tap<T, A>(t, p, offset, mask, b, og, tap, oy, ox);
+    const A val = sample_tap<T, A>(t, input + ((int64_t)b * p.C + c) * iplane);
+    const T* gp = gout + ((int64_t)b * p.OC + (int64_t)g * p.OCg + oc0) * oplane + (int64_t)oy * p.ow + ox;
+#pragma unroll
+    for (int j = 0; j < kDirOB; ++j)
+      if (oc0 + j < p.OCg) acc[j] += ld(gp + (int64_t)j * oplane) * val;
+  }
+#pragma unroll
+  for (int j = 0; j < kDirOB; ++j) {
+    A s = acc[j];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kDirOB && oc0 + (int)threadIdx.x < p.OCg) {
+    const int j = threadIdx.x;
+    st(gw + (((int64_t)(g * p.OCg + oc0 + j)) * p.ICg + ic) * KK + tap, part[0][j] + part[1][j] + part[2][j] + part[3][j]);
+  }
+}
+
+// the matrix-core kernels: fp32 / fp16 / bf16 tensors with a real contraction on both sides, one offset group per 32-channel
+// accumulator block
+inline bool bwd_mfma_shape(const DcnParams& p, tvmi_dtype dt) {
+  if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16)) return false;
+  if (p.OCg < 16 || p.ICg < 16) return false;
+  return p.ogroups == 1 || (p.cpog % 32 == 0 && p.ICg % 32 == 0);
+}
+
+struct BwdPlan {
+  bool mfma, wide;          // wide: 16-bit tensors (sums live in fp32 buffers of the workspace)
+  int OCg_pad, ICg_pad;
+  size_t at_wtb, at_gw, at_gi, at_goff, at_gmask, bytes;
+};
+inline BwdPlan bwd_plan(const DcnParams& p, tvmi_dtype dt) {
+  BwdPlan q{};
+  const bool shape = bwd_mfma_shape(p, dt);   // the workspace is sized by the shape alone (the option may change between query and call)
+  q.mfma = shape && g_bwd_mfma.load(std::memory_order_relaxed);
+  q.wide = dt == TVMI_F16 || dt == TVMI_BF16;
+  q.OCg_pad = dcn_round_up(p.OCg, kBwBK);
+  q.ICg_pad = dcn_round_up(p.ICg, 32);
+  const int KK = p.kh * p.kw;
+  size_t at = 0;
+  if (shape) {
+    q.at_wtb = at;
+    at += dcn_align256((size_t)p.groups * KK * q.OCg_pad * q.ICg_pad * sizeof(float));
+    q.at_gw = at;
+    at += dcn_align256((size_t)p.OC * p.ICg * KK * sizeof(float));
+  }
+  if (q.wide) {
+    q.at_gi = at;
+    at += dcn_align256((size_t)p.B * p.C * p.H * p.W * sizeof(float));
+    q.at_goff = at;
+    at += dcn_align256((size_t)p.B * 2 * KK * p.ogroups * p.oh * p.ow * sizeof(float));
+    q.at_gmask = at;
+    at += dcn_align256((size_t)p.B * KK * p.ogroups * p.oh * p.ow * sizeof(float));
+  }
+  q.bytes = at;
+  return q;
+}
+
+template <typename T>
+int launch_bwd_weight_mfma(const T* input, const T* offset, const T* mask, const T* gout, float* gw_ws, const DcnParams& p,
+                           hipStream_t s) {
+  constexpr int BM = 256, BN = 128;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * kBwPitch * sizeof(float);
+  auto kern = dcn_bwd_weight_mfma<T>;
+  static bool attr_set[64] = {};  // per instantiation and device; racing threads set the same value
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error((int)hipErrorInvalidValue, "deform_conv2d backward: cannot reserve the LDS slabs");
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const int KK = p.kh * p.kw;
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  const int ncc = (int)ceil_div(p.ICg, BN), nmc = (int)ceil_div(p.OCg, BM);
+  const int64_t per_pixel_range = (int64_t)KK * ncc * nmc * p.groups;
+  // ~3 workgroups per CU in total, pixel ranges of whole slabs, at least 8 slabs each
+  int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(768, per_pixel_range), ceil_div(npix, 8 * kBwBK)));
+  const int64_t pix_per_wg = ceil_div(ceil_div(npix, nchunks), kBwBK) * kBwBK;
+  nchunks = ceil_div(npix, pix_per_wg);
+  if ((int64_t)KK * ncc * nmc > 65535 || p.groups > 65535)
+    return set_error((int)hipErrorInvalidValue, "deform_conv2d backward: too many weight tiles");
+  kern<<<dim3((unsigned)nchunks, (unsigned)(KK * ncc * nmc), (unsigned)p.groups), dim3(512), lds, s>>>(
+      input, offset, mask, gout, gw_ws, p, (int)pix_per_wg, ncc, nmc);
+  return 0;
+}
+
+}  // namespace
+
+int set_dcn_bwd_option(const char* name, int64_t value) {
+  if (std::strcmp(name, "dcn.bwd_mfma") == 0) {
+    g_bwd_mfma.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.bwd_blas") == 0) {
+    g_bwd_blas.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
+  return -1;
+}
+int get_dcn_bwd_option(const char* name, int64_t* value) {
+  if (std::strcmp(name, "dcn.bwd_mfma") == 0) {
+    *value = g_bwd_mfma.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.bwd_blas") == 0) {
+    *value = g_bwd_blas.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  return -1;
+}
+}  // namespace tvmi
+
+using namespace tvmi;
+
+extern "C" size_t tvmi_deform_conv2d_backward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W,
+                                                              int64_t OC, int64_t kh, int64_t kw, int64_t oh, int64_t ow,
+                                                              int64_t groups, int64_t offset_groups) {
+  if (B <= 0 || C <= 0 || OC <= 0 || groups <= 0 || offset_groups <= 0 || kh <= 0 || kw <= 0 || oh <= 0 || ow <= 0) return 0;
+  if (C % groups || OC % groups || C % offset_groups) return 0;
+  DcnParams p{};
+  p.B = (int)B;
+  p.C = (int)C;
+  p.H = (int)H;
+  p.W = (int)W;
+  p.OC = (int)OC;
+  p.kh = (int)kh;
+  p.kw = (int)kw;
+  p.oh = (int)oh;
+  p.ow = (int)ow;
+  p.groups = (int)groups;
+  p.ogroups = (int)offset_groups;
+  p.ICg = (int)(C / groups);
+  p.OCg = (int)(OC / groups);
+  p.cpog = (int)(C / offset_groups);
+  BwdPlan q = bwd_plan(p, dt);
+  return q.bytes;
+}
+
+extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* input, const void* weight, const void* offset,
+                                           const void* mask, void* grad_input, void* grad_weight, void* grad_offset,
+                                           void* grad_mask, void* grad_bias, tvmi_dtype dt, int64_t B, int64_t C, int64_t H,
+                                           int64_t W, int64_t OC, int64_t kh, int64_t kw, int64_t stride_h, int64_t stride_w,
+                                           int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t groups,
+                                           int64_t offset_groups, int use_mask, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  DcnParams p;
+  if (int e = fill_params_common(p, B, C, H, W, OC, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups,
+                                 offset_groups, use_mask))
+    return e;
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64 || dt == TVMI_F16 || dt == TVMI_BF16, "deform_conv2d backward: unsupported dtype");
+  if (B == 0 || C == 0 || OC == 0) return 0;
+  TVMI_CHECK_ARG(grad_out && input && weight && offset && grad_input && grad_weight && grad_offset && (!use_mask || (mask && grad_mask)),
+                 "deform_conv2d backward: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const BwdPlan q = bwd_plan(p, dt);
+  TVMI_CHECK_ARG(q.bytes == 0 || (workspace && workspace_bytes >= q.bytes), "deform_conv2d backward: workspace too small");
+  const size_t esz = dt == TVMI_F64 ? 8 : (dt == TVMI_F32 ? 4 : 2);
+  const int KK = p.kh * p.kw;
+  const int64_t oplane = (int64_t)p.oh * p.ow, npix = B * oplane;
+  const int64_t n_gi = B * C * H * W, n_goff = B * 2 * KK * p.ogroups * oplane, n_gmask = B * KK * p.ogroups * oplane;
+  char* ws = static_cast<char*>(workspace);
+#define TVMI_HIP_OK(expr)                                                                         \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) return set_error((int)e__, "tvmi_deform_conv2d_backward: memset");     \
+  } while (0)
+
+  // where the sums are formed: the outputs themselves, or fp32 buffers for 16-bit tensors
+  void* gi_acc = q.wide ? (void*)(ws + q.at_gi) : grad_input;
+  void* goff_acc = q.wide ? (void*)(ws + q.at_goff) : grad_offset;
+  void* gmask_acc = q.wide ? (void*)(ws + q.at_gmask) : grad_mask;
+  const size_t asz = q.wide ? 4 : esz;
+  TVMI_HIP_OK(hipMemsetAsync(gi_acc, 0, (size_t)n_gi * asz, s));   // the scatter accumulates
+  if (q.mfma) {                                                   // ... and so do the per-wave partial sums of the matrix-core route
+    TVMI_HIP_OK(hipMemsetAsync(goff_acc, 0, (size_t)n_goff * asz, s));
+    if (use_mask) TVMI_HIP_OK(hipMemsetAsync(gmask_acc, 0, (size_t)n_gmask * asz, s));
+    TVMI_HIP_OK(hipMemsetAsync(ws + q.at_gw, 0, (size_t)p.OC * p.ICg * KK * sizeof(float), s));
+  }
+#undef TVMI_HIP_OK
+
+  if (q.mfma) {
+    float* wtb = reinterpret_cast<float*>(ws + q.at_wtb);
+    float* gw_ws = reinterpret_cast<float*>(ws + q.at_gw);
+    const int64_t wtotal = (int64_t)p.groups * KK * q.OCg_pad * q.ICg_pad;
+    int st_ = 0;
+#define TVMI_BWD_MFMA(scalar_t)                                                                                        \
+  do {                                                                                                                 \
+    dcn_weight_relayout_bwd<scalar_t><<<dcn_grid1d(wtotal), dim3(256), 0, s>>>((const scalar_t*)weight, wtb, p, q.OCg_pad, q.ICg_pad); \
+    dcn_bwd_data_mfma<scalar_t><<<dim3((unsigned)ceil_div(npix, 64), 1, (unsigned)p.groups), dim3(512), 0, s>>>(        \
+        (const scalar_t*)input, wtb, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)grad_out,         \
+        (float*)gi_acc, (float*)goff_acc, (float*)gmask_acc, p, q.OCg_pad, q.ICg_pad);                                  \
+    st_ = launch_bwd_weight_mfma<scalar_t>((const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,      \
+                                           (const scalar_t*)grad_out, gw_ws, p, s);                                    \
+    if (st_ == 0)                                                                                                      \
+      dcn_bwd_weight_finish<scalar_t><<<dcn_grid1d((int64_t)p.OC * p.ICg * KK), dim3(256), 0, s>>>(gw_ws, (scalar_t*)grad_weight, p); \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_BWD_MFMA(float);
+    else if (dt == TVMI_F16) TVMI_BWD_MFMA(__half);
+    else TVMI_BWD_MFMA(__hip_bfloat16);
+#undef TVMI_BWD_MFMA
+    if (st_) return st_;
+  } else {
+    const int64_t total = B * p.ogroups * KK * oplane;
+    const dim3 wgrid((unsigned)C, (unsigned)KK, (unsigned)ceil_div(p.OCg, kDirOB));
+    TVMI_CHECK_ARG(KK <= 65535 && ceil_div(p.OCg, kDirOB) <= 65535, "deform_conv2d backward: kernel / group size too large");
+#define TVMI_BWD_DIRECT(scalar_t, acc_t)                                                                               \
+  do {                                                                                                                 \
+    dcn_bwd_data_direct<scalar_t, acc_t><<<dcn_grid1d(total), dim3(256), 0, s>>>(                                       \
+        (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,                \
+        (const scalar_t*)grad_out, (acc_t*)gi_acc, (acc_t*)goff_acc, (acc_t*)gmask_acc, p, total);                      \
+    dcn_bwd_weight_direct<scalar_t><<<wgrid, dim3(256), 0, s>>>((const scalar_t*)input, (const scalar_t*)offset,        \
+                                                                (const scalar_t*)mask, (const scalar_t*)grad_out,       \
+                                                                (scalar_t*)grad_weight, p);                            \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_BWD_DIRECT(float, float);
+    else if (dt == TVMI_F64) TVMI_BWD_DIRECT(double, double);
+    else if (dt == TVMI_F16) TVMI_BWD_DIRECT(__half, float);
+    else TVMI_BWD_DIRECT(__hip_bfloat16, float);
+#undef TVMI_BWD_DIRECT
+  }
+  if (q.wide) {
+#define TVMI_BWD_ROUND(scalar_t)                                                                                        \
+  do {                                                                                                                 \
+    dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_gi), dim3(256), 0, s>>>((const float*)gi_acc, (scalar_t*)grad_input, n_gi); \
+    dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_goff), dim3(256), 0, s>>>((const float*)goff_acc, (scalar_t*)grad_offset, n_goff); \
+    if (use_mask)                                                                                                      \
+      dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_gmask), dim3(256), 0, s>>>((const float*)gmask_acc, (scalar_t*)grad_mask, n_gmask); \
+  } while (0)
+    if (dt == TVMI_F16) TVMI_BWD_ROUND(__half);
+    else TVMI_BWD_ROUND(__hip_bfloat16);
+#undef TVMI_BWD_ROUND
+  }
+  if (grad_bias) {
+    TVMI_DISPATCH_FLOAT(dt, "deform_conv2d_backward",
+                        dcn_bwd_bias<scalar_t><<<dim3((unsigned)OC), dim3(256), 0, s>>>((const scalar_t*)grad_out, (scalar_t*)grad_bias,
+                                                                                        (int)B, (int)OC, oplane));
+  }
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_deform_conv2d_backward");
+}

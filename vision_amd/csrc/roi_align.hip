@@ -1477,6 +1477,7 @@ extern "C" int tvmi_get_option(const char* name, int64_t* value) {
     if (tvmi::get_roi_option(name, value) == 0) return 0;
     if (tvmi::get_nms_option(name, value) == 0) return 0;
     if (tvmi::get_dcn_option(name, value) == 0) return 0;
+    if (tvmi::get_dcn_bwd_option(name, value) == 0) return 0;
   }
   return tvmi::set_error((int)hipErrorInvalidValue, "tvmi_get_option: unknown option");
 }
@@ -1485,6 +1486,7 @@ extern "C" int tvmi_set_option(const char* name, int64_t value) {
   if (tvmi::set_roi_option(name, value) == 0) return 0;
   if (tvmi::set_nms_option(name, value) == 0) return 0;
   if (tvmi::set_dcn_option(name, value) == 0) return 0;
+  if (tvmi::set_dcn_bwd_option(name, value) == 0) return 0;
   return tvmi::set_error((int)hipErrorInvalidValue, "tvmi_set_option: unknown option");
 }
 

@@ -124,5 +124,7 @@ int get_nms_option(const char* name, int64_t* value);
 int get_dcn_option(const char* name, int64_t* value);
 int set_nms_option(const char* name, int64_t value);  // nms.hip
 int set_dcn_option(const char* name, int64_t value);  // deform_conv2d.hip
+int get_dcn_bwd_option(const char* name, int64_t* value);
+int set_dcn_bwd_option(const char* name, int64_t value);  // deform_conv2d_bwd.hip
 
 }  // namespace tvmi

@@ -489,10 +489,10 @@ at::Tensor deform_conv2d_forward(const at::Tensor& input, const at::Tensor& weig
   return out;
 }
 
-// Backward (cuda/deform_conv2d_kernel.cu:752-1033,1257-1330): the gather/scatter kernels are
+// MEASUREMENT ONLY (option "dcn.bwd_blas", off by default): the round-3 backward — the gather/scatter kernels are
 // ours; the two plain GEMMs per weight group go to the BLAS library through ATen.  Images
 // are processed in chunks so that the materialised columns stay below ~1 GiB.
-std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_conv2d_backward(
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_conv2d_backward_blas(
     const at::Tensor& grad, const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
     const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
     int64_t dilation_h, int64_t dilation_w, int64_t n_weight_grps, int64_t n_offset_grps, bool use_mask) {
@@ -547,6 +547,45 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_co
     at::Tensor col_g = columns.view({G, ICg * KK, nb * plane});
     gw.baddbmm_(go_g, col_g.transpose(1, 2));
   }
+  return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
+}
+
+// Backward (cpu/deform_conv2d_kernel.cpp:1153-1226, cuda/deform_conv2d_kernel.cu:752-1033,1257-1330): ONE call into the kernels
+// library — two fused matrix-core kernels (or the direct ones), no materialised `columns`, no library GEMM
+// (deform_conv2d_bwd.hip).
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_conv2d_backward(
+    const at::Tensor& grad, const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
+    const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+    int64_t dilation_h, int64_t dilation_w, int64_t n_weight_grps, int64_t n_offset_grps, bool use_mask) {
+  int64_t blas = 0;
+  if (tvmi_get_option("dcn.bwd_blas", &blas) == 0 && blas)
+    return deform_conv2d_backward_blas(grad, input, weight, offset, mask, bias, stride_h, stride_w, pad_h, pad_w, dilation_h,
+                                       dilation_w, n_weight_grps, n_offset_grps, use_mask);
+  at::Tensor grad_c = grad.contiguous(), input_c = input.contiguous(), offset_c = offset.contiguous();
+  at::Tensor weight_c = weight.contiguous(), mask_c = mask.contiguous(), bias_c = bias.contiguous();
+  const DcnShape s = dcn_check(input_c, weight_c, offset_c, mask_c, bias_c, stride_h, stride_w, pad_h, pad_w,
+                               dilation_h, dilation_w, n_weight_grps, n_offset_grps, use_mask);
+  c10::DeviceGuard guard(input.device());
+  at::globalContext().alertNotDeterministic("deform_conv2d_backward_kernel");
+  // every output is fully overwritten by the call (it zero-fills what it accumulates into)
+  at::Tensor grad_input = at::empty_like(input_c), grad_offset = at::empty_like(offset_c);
+  at::Tensor grad_mask = use_mask ? at::empty_like(mask_c) : at::zeros_like(mask_c);
+  at::Tensor grad_weight = at::empty_like(weight_c);
+  at::Tensor grad_bias = at::ones_like(bias_c);
+  if (s.B == 0 || input_c.numel() == 0 || weight_c.numel() == 0)
+    return std::make_tuple(at::zeros_like(input_c), at::zeros_like(weight_c), at::zeros_like(offset_c), at::zeros_like(mask_c), grad_bias);
+  const tvmi_dtype dt = dtype_of(input_c, "_deform_conv2d_backward");
+  const size_t ws_bytes = tvmi_deform_conv2d_backward_workspace_bytes(dt, s.B, s.C, s.H, s.W, s.OC, s.kh, s.kw, s.oh, s.ow,
+                                                                      n_weight_grps, n_offset_grps);
+  at::Tensor ws = at::empty({(int64_t)ws_bytes}, input_c.options().dtype(at::kByte));
+  check_status(tvmi_deform_conv2d_backward(grad_c.const_data_ptr(), input_c.const_data_ptr(), weight_c.const_data_ptr(),
+                                           offset_c.const_data_ptr(), mask_c.const_data_ptr(), grad_input.mutable_data_ptr(),
+                                           grad_weight.mutable_data_ptr(), grad_offset.mutable_data_ptr(),
+                                           grad_mask.mutable_data_ptr(), grad_bias.mutable_data_ptr(), dt, s.B, s.C, s.H, s.W,
+                                           s.OC, s.kh, s.kw, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                                           n_weight_grps, n_offset_grps, use_mask ? 1 : 0,
+                                           ws_bytes ? ws.mutable_data_ptr() : nullptr, ws_bytes, current_stream(input)),
+               "_deform_conv2d_backward");
   return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
 }
 
