@@ -57,6 +57,8 @@ int tvmi_version(void);
  *   "dcn.channels_last_gather"   1 (default) / 0: the 16-bit MFMA deform_conv2d kernel samples a [B, H*W, C] copy of the input
  *   "dcn.bwd_mfma"               1 (default) / 0: tvmi_deform_conv2d_backward contracts on the matrix cores where the shapes allow
  *                                (0 = the direct kernels for every problem)
+ *   "dcn.bwd_window"             1 (default) / 0: its data-gradient kernel adds the grad_input contributions of a pixel tile in an
+ *                                LDS window and flushes it once per channel chunk (0 = one global atomic per contribution)
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)

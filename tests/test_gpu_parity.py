@@ -655,6 +655,8 @@ DCN_BWD_CFGS = [
     dict(B=2, C=8, OC=8, H=9, W=9, k=(3, 3), groups=8, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False),        # direct: depthwise
     dict(B=2, C=6, OC=2, H=5, W=4, k=(3, 2), groups=2, og=3, stride=(2, 1), pad=(1, 0), dil=(2, 1), mask=True),         # direct: the reference's test configuration
     dict(B=1, C=32, OC=32, H=8, W=8, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, zero_off=True),  # y = -1 / x = -1 exactly
+    dict(B=2, C=64, OC=64, H=30, W=40, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, off_scale=0.5),  # offsets inside the LDS window's reach
+    dict(B=1, C=64, OC=32, H=40, W=40, k=(3, 3), groups=1, og=1, stride=(2, 2), pad=(1, 1), dil=(1, 1), mask=True, off_scale=0.5),  # stride 2: window too large for LDS -> global atomics
 ]
 
 
@@ -665,7 +667,7 @@ def _dcn_bwd_inputs(cfg, dtype, seed=31):
     ow = (cfg["W"] + 2 * cfg["pad"][1] - (cfg["dil"][1] * (kw - 1) + 1)) // cfg["stride"][1] + 1
     x = torch.randn(cfg["B"], cfg["C"], cfg["H"], cfg["W"], generator=g)
     w = torch.randn(cfg["OC"], cfg["C"] // cfg["groups"], kh, kw, generator=g) * 0.1
-    off = torch.randn(cfg["B"], 2 * cfg["og"] * kh * kw, oh, ow, generator=g) * 2
+    off = torch.randn(cfg["B"], 2 * cfg["og"] * kh * kw, oh, ow, generator=g) * cfg.get("off_scale", 2)
     if cfg.get("zero_off"):
         off = torch.zeros_like(off)
     m = torch.rand(cfg["B"], cfg["og"] * kh * kw, oh, ow, generator=g)
@@ -682,7 +684,7 @@ def _dcn_bwd_compare(got, ref, tol, what):
         np.testing.assert_allclose(a.double().cpu().numpy(), r, rtol=tol, atol=tol * scale, err_msg=f"{name} {what}")
 
 
-@pytest.mark.parametrize("route", ["default", "direct"])
+@pytest.mark.parametrize("route", ["default", "global_atomics", "direct"])
 @pytest.mark.parametrize("cfg", DCN_BWD_CFGS, ids=[str(i) for i in range(len(DCN_BWD_CFGS))])
 def test_deform_conv2d_backward_fused_vs_reference(tv, cfg, route):
     """`_deform_conv2d_backward` = ONE call of tvmi_deform_conv2d_backward (deform_conv2d_bwd.hip: two fused matrix-core kernels
@@ -695,10 +697,12 @@ def test_deform_conv2d_backward_fused_vs_reference(tv, cfg, route):
         pytest.skip("needs the reference CPU kernels (oracle/_ref)")
     ts, args = _dcn_bwd_inputs(cfg, torch.float32)
     torch.ops.tvmi.set_option("dcn.bwd_mfma", 0 if route == "direct" else 1)
+    torch.ops.tvmi.set_option("dcn.bwd_window", 0 if route == "global_atomics" else 1)
     try:
         got = tv._deform_conv2d_backward(*[v.to(DEV) for v in ts], *args)
     finally:
         torch.ops.tvmi.set_option("dcn.bwd_mfma", 1)
+        torch.ops.tvmi.set_option("dcn.bwd_window", 1)
     _dcn_bwd_compare(got, tv._deform_conv2d_backward(*ts, *args), TOL, route)
 
 

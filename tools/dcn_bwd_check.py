@@ -18,6 +18,7 @@ CFGS = [
     dict(tag="direct og3 (12/og)", B=3, C=36, OC=40, H=11, W=9, k=(1, 3), groups=2, og=3, stride=(1, 1), pad=(0, 1), dil=(1, 1), mask=True),
     dict(tag="direct depthwise", B=2, C=8, OC=8, H=9, W=9, k=(3, 3), groups=8, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False),
     dict(tag="direct reference-test cfg", B=2, C=6, OC=2, H=5, W=4, k=(3, 2), groups=2, og=3, stride=(2, 1), pad=(1, 0), dil=(2, 1), mask=True),
+    dict(tag="mfma small offsets 64->64 (window only)", B=2, C=64, OC=64, H=30, W=40, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, off_scale=0.5),
     dict(tag="mfma zero offsets (y = -1 rows)", B=1, C=32, OC=32, H=8, W=8, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, zero_off=True),
 ]
 def make(cfg, dtype, seed=31):
@@ -27,7 +28,7 @@ def make(cfg, dtype, seed=31):
     ow = (cfg["W"] + 2 * cfg["pad"][1] - (cfg["dil"][1] * (kw - 1) + 1)) // cfg["stride"][1] + 1
     x = torch.randn(cfg["B"], cfg["C"], cfg["H"], cfg["W"], generator=g)
     w = torch.randn(cfg["OC"], cfg["C"] // cfg["groups"], kh, kw, generator=g) * 0.1
-    off = torch.randn(cfg["B"], 2 * cfg["og"] * kh * kw, oh, ow, generator=g) * 2
+    off = torch.randn(cfg["B"], 2 * cfg["og"] * kh * kw, oh, ow, generator=g) * cfg.get("off_scale", 2)
     if cfg.get("zero_off"): off = torch.zeros_like(off)
     m = torch.rand(cfg["B"], cfg["og"] * kh * kw, oh, ow, generator=g)
     b = torch.randn(cfg["OC"], generator=g)
@@ -58,12 +59,17 @@ def check(tag, cfg, dtype, mfma=1):
 if have_ref:
     for cfg in CFGS:
         check(cfg["tag"] + " fp32", cfg, torch.float32)
+    for cfg in CFGS[:5]:
+        torch.ops.tvmi.set_option("dcn.bwd_window", 0)
+        check(cfg["tag"] + " fp32 global atomics only", cfg, torch.float32)
+        torch.ops.tvmi.set_option("dcn.bwd_window", 1)
     check(CFGS[0]["tag"] + " fp32 forced direct", CFGS[0], torch.float32, mfma=0)
     check(CFGS[1]["tag"] + " fp32 forced direct", CFGS[1], torch.float32, mfma=0)
     check(CFGS[0]["tag"] + " bf16", CFGS[0], torch.bfloat16)
     check(CFGS[1]["tag"] + " fp16", CFGS[1], torch.float16)
     check(CFGS[6]["tag"] + " bf16", CFGS[6], torch.bfloat16)
     check(CFGS[7]["tag"] + " fp64", CFGS[7], torch.float64)
+    check(CFGS[8]["tag"] + " bf16", CFGS[8], torch.bfloat16)
     check(CFGS[0]["tag"] + " fp64", CFGS[0], torch.float64)
 else:
     print("no reference CPU kernels (oracle/_ref): values not checked")
@@ -86,8 +92,9 @@ for groups in (1, 256):
     w = torch.randn(OC, C // groups, 3, 3, generator=g) * (0.01 if groups == 1 else 0.2)
     for dt in (torch.float32, torch.bfloat16):
         ts = [t.to(dev, dt) for t in (gr, x, w, off, m, b)]
-        for route, opts in (("fused", {"dcn.bwd_blas": 0}), ("direct", {"dcn.bwd_blas": 0, "dcn.bwd_mfma": 0}), ("blas_r03", {"dcn.bwd_blas": 1})):
-            if route == "direct" and groups != 1: continue
+        for route, opts in (("fused", {"dcn.bwd_blas": 0}), ("fused_global_atomics", {"dcn.bwd_window": 0}), ("direct", {"dcn.bwd_blas": 0, "dcn.bwd_mfma": 0}), ("blas_r03", {"dcn.bwd_blas": 1})):
+            if route in ("direct", "fused_global_atomics") and groups != 1: continue
+            if route == "direct" and dt != torch.float32: continue
             for k, v in opts.items(): torch.ops.tvmi.set_option(k, v)
             key = f"c4 backward g={groups} {str(dt).split('.')[-1]} {route}"
             try:
@@ -95,5 +102,5 @@ for groups in (1, 256):
             except Exception as e:  # noqa
                 out[key] = {"error": repr(e)[:300]}
             print(key, out[key], flush=True)
-            torch.ops.tvmi.set_option("dcn.bwd_blas", 0); torch.ops.tvmi.set_option("dcn.bwd_mfma", 1)
+            torch.ops.tvmi.set_option("dcn.bwd_blas", 0); torch.ops.tvmi.set_option("dcn.bwd_mfma", 1); torch.ops.tvmi.set_option("dcn.bwd_window", 1)
 if len(sys.argv) > 1: json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -72,6 +72,16 @@ with torch.no_grad():
         off = torch.randn(2, 18, 100, 136, generator=g).to(dev).to(dt)
         for _ in range(reps):
             vision_amd.deform_conv2d(x, off, w, padding=1)
+    elif which in ("dcn_bwd", "dcn_bwd_dw", "dcn_bwd_bf16"):
+        g = torch.Generator().manual_seed(0)
+        groups = 256 if which == "dcn_bwd_dw" else 1
+        dt = torch.bfloat16 if which.endswith("bf16") else torch.float32
+        ts = [torch.randn(2, 256, 100, 136, generator=g), torch.randn(2, 256, 100, 136, generator=g),
+              torch.randn(256, 256 // groups, 3, 3, generator=g) * 0.01, torch.randn(2, 18, 100, 136, generator=g),
+              torch.rand(2, 9, 100, 136, generator=g), torch.randn(256, generator=g)]
+        ts = [t.to(dev).to(dt) for t in ts]
+        for _ in range(reps):
+            torch.ops.torchvision._deform_conv2d_backward(*ts, 1, 1, 1, 1, 1, 1, groups, 1, True)
     elif which == "dcn":
         g = torch.Generator().manual_seed(0)
         x = torch.randn(2, 256, 100, 136, generator=g).to(dev); w = (torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(dev)

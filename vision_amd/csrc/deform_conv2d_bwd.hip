@@ -36,6 +36,7 @@ namespace tvmi {
 namespace {
 
 std::atomic<int> g_bwd_mfma{1};   // option "dcn.bwd_mfma": 0 sends every problem to the direct kernels
+std::atomic<int> g_bwd_window{1}; // option "dcn.bwd_window": 0 = the data-gradient kernel scatters with global atomics only
 std::atomic<int> g_bwd_blas{0};   // option "dcn.bwd_blas" (measurement only): the dispatcher glue takes the round-3 route (library GEMMs)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -358,6 +359,262 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_mfma(const T* __restrict__ i
   }
 }
 
+// ------------------------------------------------------------------ data gradients on the matrix cores, grad_input through an LDS window
+// dcn_bwd_data_mfma above spends ~5 of its 5.5 ms at config 4 in the scatter: 250 M global float atomics whose addresses follow
+// the (random) offsets — one 64-byte granule per lane (profiles/r04_dcn_bwd_*.json: the round-3 route with library GEMMs, the
+// fused kernel and the depthwise direct kernel all land at ~6 ms).  Here the scatter goes to LDS:
+//   workgroup = an 8 x 16 tile of output pixels of one image; channel chunk (64) OUTER, tap inner.  The 36 contributions
+//   (9 taps x 4 corners) a chunk's accumulator blocks make per pixel are added with ds_add_f32 into a window of the input
+//   plane — the tile's footprint plus kWinR pixels of offset reach — kept in LDS per channel of the chunk; after the last tap
+//   the window is flushed ONCE with row-contiguous global atomics (neighbouring tiles overlap in their halos) and zeroed.
+//   A corner outside the window (an offset beyond the reach) falls back to a global atomic: correct for any offset, fast
+//   for |offset| <= kWinR.  grad_offset / grad_mask: as above, one atomic per (tap, chunk, pixel, component) and wave.
+// Lane <-> pixel: accumulator column block wn holds tile rows 2 wn, 2 wn + 1 (16 pixels each).
+constexpr int kWinTH = 8, kWinTW = 16, kWinR = 3, kWinCH = 64;
+
+struct WinGeom {
+  int wh, ww, wsz;   // window rows, columns, elements per channel
+  int ntx, nty;      // tiles per image
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void dcn_bwd_data_mfma_win(const T* __restrict__ input, const float* __restrict__ wtb,
+                                                             const T* __restrict__ offset, const T* __restrict__ mask,
+                                                             const T* __restrict__ gout, float* __restrict__ gi,
+                                                             float* __restrict__ goff, float* __restrict__ gmask, DcnParams p,
+                                                             int OCg_pad, int ICg_pad, WinGeom wg) {
+  constexpr int WM = 2, WN = 4;
+  constexpr int NT = 64 * WM * WN;       // 512
+  constexpr int BM = kWinCH;             // 64 in channels = 2 blocks of 32
+  constexpr int BN = kWinTH * kWinTW;    // 128 pixels = 4 blocks of 32
+  constexpr int AQ = kBwBK * BM / 4;     // 256 float4 pieces of the A slab: threads 0..255 take one each
+  constexpr int BV = kBwBK * BN / NT;    // 4 B values per thread
+  static_assert(BM == 32 * WM && BN == 32 * WN && AQ <= NT && BV * NT == kBwBK * BN, "tile shapes");
+  extern __shared__ __attribute__((aligned(16))) float dcn_bwin_lds[];
+  float(*As)[kBwBK][BM] = reinterpret_cast<float(*)[kBwBK][BM]>(dcn_bwin_lds);
+  float(*Bs)[kBwBK][BN] = reinterpret_cast<float(*)[kBwBK][BN]>(dcn_bwin_lds + 2 * kBwBK * BM);
+  float* win = dcn_bwin_lds + 2 * kBwBK * (BM + BN);   // [kWinCH][wsz]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int kq = lane >> 5, l31 = lane & 31;
+  const int g = blockIdx.z, b = blockIdx.y;
+  const int KK = p.kh * p.kw;
+  const int64_t oplane = (int64_t)p.oh * p.ow, iplane = (int64_t)p.H * p.W;
+  const int ty0 = (blockIdx.x / wg.ntx) * kWinTH, tx0 = (blockIdx.x % wg.ntx) * kWinTW;
+  const int wy0 = ty0 * p.sh - p.ph - kWinR, wx0 = tx0 * p.sw - p.pw - kWinR;   // image coordinates of window element (0, 0)
+
+  // producer side of the B slab
+  const int pn = tid % BN, ksub = tid / BN;   // 4 row subsets
+  const int poy = ty0 + (pn >> 4), pox = tx0 + (pn & 15);
+  const bool prod_ok = poy < p.oh && pox < p.ow;
+  const T* gout_p = gout + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * oplane + (prod_ok ? (int64_t)poy * p.ow + pox : 0);
+
+  // consumer side: the pixel of this lane's accumulator column
+  const int moy = ty0 + 2 * wn + (l31 >> 4), mox = tx0 + (l31 & 15);
+  const bool pix_ok = moy < p.oh && mox < p.ow;
+  const int64_t my_in = pix_ok ? (int64_t)moy * p.ow + mox : 0;
+
+  const int nks = OCg_pad / kBwBK;
+  const int ncc = (p.ICg + BM - 1) / BM;
+  const int total = ncc * KK * nks;
+
+  for (int e = tid; e < kWinCH * wg.wsz; e += NT) win[e] = 0.f;   // (the first barrier of the slab loop orders this)
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+  float bv[BV];
+  const int a_kk = (tid * 4) / BM, a_m = (tid * 4) % BM;   // (threads >= AQ: unused)
+  auto issue = [&](int tap, int c0, int oc0) {
+    if (tid < AQ) {
+      av = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c0 + a_m < ICg_pad)
+        av = *reinterpret_cast<const float4*>(wtb + (((int64_t)g * KK + tap) * OCg_pad + oc0 + a_kk) * ICg_pad + c0 + a_m);
+    }
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+      const int oc = oc0 + ksub + e * (NT / BN);
+      bv[e] = (prod_ok && oc < p.OCg) ? (float)ld(gout_p + (int64_t)oc * oplane) : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    if (tid < AQ) *reinterpret_cast<float4*>(&As[buf][a_kk][a_m]) = av;
+#pragma unroll
+    for (int e = 0; e < BV; ++e) Bs[buf][ksub + e * (NT / BN)][pn] = bv[e];
+  };
+
+  // the raw (offset_h, offset_w, mask) of this lane's pixel for the tap whose slabs are being contracted: fetched when the
+  // tap begins, used in its epilogue
+  TapRaw<T> raw = tap_raw_identity<T>();
+  auto epilogue = [&](int tap, int c0) {
+    const int ct = c0 + wm * 32;   // first channel of this wave's block, inside the weight group
+    if (ct < p.ICg && pix_ok) {
+      const int og = (g * p.ICg + ct) / p.cpog;   // one offset group per block: the launcher checks the alignment
+      BwdTap<float> tp;
+      {
+        const int i = tap / p.kw, j = tap - i * p.kw;
+        const float y = (float)(moy * p.sh - p.ph) + (float)(i * p.dh) + (float)ld(&raw.off_h);
+        const float x = (float)(mox * p.sw - p.pw) + (float)(j * p.dw) + (float)ld(&raw.off_w);
+        make_bwd_tap<float>(tp, p.H, p.W, y, x, (float)ld(&raw.m));
+      }
+      // window offsets of the 4 corners.  Every lane issues every ds_add_f32 (no exec juggling around 64 LDS instructions):
+      // a corner with zero weight or outside the window adds 0.0 to an element of the lane's own (row 0 of the channel: 64
+      // distinct banks); a weighted corner outside the window — an offset beyond the reach — is rare and goes to the cold
+      // loop of global atomics below.
+      int wo[4];
+      float wgt[4];
+      bool inw[4], far_k[4], far = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cy = tp.o[k] / p.W, cx = tp.o[k] - cy * p.W;
+        const int wy = cy - wy0, wx = cx - wx0;
+        const bool in_window = wy >= 0 && wy < wg.wh && wx >= 0 && wx < wg.ww;
+        const bool weighted = tp.bw[k] != 0.f;
+        inw[k] = in_window && weighted;
+        far_k[k] = weighted && !in_window;
+        far = far || far_k[k];
+        wo[k] = inw[k] ? wy * wg.ww + wx : lane;
+        wgt[k] = tp.m * tp.bw[k];
+      }
+      const int cbase = ct + 4 * kq;
+      // 32-bit element offsets from the (image, weight group) base: the launcher sends larger planes to the kernel above
+      const T* in_c = input + ((int64_t)b * p.C + (int64_t)g * p.ICg) * iplane;
+      float* gi_c = gi + ((int64_t)b * p.C + (int64_t)g * p.ICg) * iplane;
+      const int ipl = (int)iplane;
+      CoordSums<float> sums{0.f, 0.f, 0.f};
+      // 8 accumulator rows at a time: corner reads first (they only feed the coordinate sums), the scatter under their
+      // latency, then the sums
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float xv[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = 8 * half + q;
+          const int c = min(cbase + (r & 3) + 8 * (r >> 2), p.ICg - 1);
+          const int coff = c * ipl;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xv[q][k] = (float)ld(in_c + (coff + tp.o[k]));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = 8 * half + q;
+          const int c = cbase + (r & 3) + 8 * (r >> 2);
+          if (c < p.ICg) {
+            float* wrow = win + (c - c0) * wg.wsz;
+            const float v = acc[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_add_f32(wrow + wo[k], inw[k] ? wgt[k] * v : 0.f);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = 8 * half + q;
+          const int c = cbase + (r & 3) + 8 * (r >> 2);
+          if (c < p.ICg) accumulate_coord<float>(sums, tp, acc[r], xv[q][0], xv[q][1], xv[q][2], xv[q][3], p.use_mask != 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (far) {
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+          const int c = cbase + (r & 3) + 8 * (r >> 2);
+          if (c >= p.ICg) continue;
+          float v = 0.f;   // (acc[r] with a run-time r: select, not a scratch array)
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) v = rr == r ? acc[rr] : v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (far_k[k]) unsafeAtomicAdd(gi_c + (c * ipl + tp.o[k]), wgt[k] * v);
+        }
+      }
+      // the two lane halves hold different channels of the same pixel (both halves are active here: pix_ok is per pixel)
+      sums.gy += __shfl_xor(sums.gy, 32);
+      sums.gx += __shfl_xor(sums.gx, 32);
+      sums.gm += __shfl_xor(sums.gm, 32);
+      if (kq == 0) {
+        float* o = goff + ((int64_t)(b * p.ogroups + og) * 2 * KK + 2 * tap) * oplane + my_in;
+        unsafeAtomicAdd(o, sums.gy);
+        unsafeAtomicAdd(o + oplane, sums.gx);
+        if (p.use_mask) unsafeAtomicAdd(gmask + ((int64_t)(b * p.ogroups + og) * KK + tap) * oplane + my_in, sums.gm);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  };
+  auto flush_window = [&](int c0) {
+    for (int ch = wave; ch < kWinCH; ch += NT / 64) {
+      if (c0 + ch >= p.ICg) break;
+      float* wrow = win + ch * wg.wsz;
+      float* gpl = gi + ((int64_t)b * p.C + (int64_t)g * p.ICg + c0 + ch) * iplane;
+      for (int idx = lane; idx < wg.wsz; idx += 64) {
+        const float v = wrow[idx];
+        wrow[idx] = 0.f;
+        const int wy = idx / wg.ww, wx = idx - wy * wg.ww;
+        const int iy = wy0 + wy, ix = wx0 + wx;
+        if (v != 0.f && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) unsafeAtomicAdd(gpl + (int64_t)iy * p.W + ix, v);
+      }
+    }
+  };
+  auto fetch_raw = [&](int tap, int c0) {
+    const int ct = c0 + wm * 32;
+    if (ct < p.ICg && pix_ok) load_tap_raw<T>(raw, p, offset, mask, b, (g * p.ICg + ct) / p.cpog, tap, moy, mox);
+  };
+
+  if (total > 0) {
+    int s_cc = 0, s_tap = 0, s_ks = 0;
+    issue(0, 0, 0);
+    fetch_raw(0, 0);
+    int buf = 0;
+    for (int it = 0; it < total; ++it) {
+      commit(buf);
+      __syncthreads();
+      int n_cc = s_cc, n_tap = s_tap, n_ks = s_ks + 1;
+      if (n_ks == nks) {
+        n_ks = 0;
+        if (++n_tap == KK) {
+          n_tap = 0;
+          ++n_cc;
+        }
+      }
+      if (it + 1 < total) issue(n_tap, n_cc * BM, n_ks * kBwBK);
+#pragma unroll
+      for (int kk = 0; kk < kBwBK; kk += 2) {
+        const float a = As[buf][kk + kq][wm * 32 + l31];
+        const float bb = Bs[buf][kk + kq][wn * 32 + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+      }
+      if (s_ks == nks - 1) {
+        epilogue(s_tap, s_cc * BM);
+        if (it + 1 < total) fetch_raw(n_tap, n_cc * BM);   // (after the epilogue used the current tap's)
+        if (s_tap == KK - 1) {
+          __syncthreads();   // every wave's window adds of this chunk are done
+          flush_window(s_cc * BM);
+        }
+      }
+      s_cc = n_cc;
+      s_tap = n_tap;
+      s_ks = n_ks;
+      buf ^= 1;
+    }
+  }
+}
+
+inline WinGeom win_geom(const DcnParams& p) {
+  WinGeom w{};
+  w.wh = (kWinTH - 1) * p.sh + (p.kh - 1) * p.dh + 2 * kWinR + 2;
+  w.ww = (kWinTW - 1) * p.sw + (p.kw - 1) * p.dw + 2 * kWinR + 2;
+  w.wsz = w.wh * w.ww;
+  w.ntx = (int)ceil_div(p.ow, kWinTW);
+  w.nty = (int)ceil_div(p.oh, kWinTH);
+  return w;
+}
+inline size_t win_lds_bytes(const WinGeom& w) {
+  return ((size_t)2 * kBwBK * (kWinCH + kWinTH * kWinTW) + (size_t)kWinCH * w.wsz) * sizeof(float);
+}
+
 // ------------------------------------------------------------------ weight gradient on the matrix cores
 // 8 waves: 4 along M (out channels, 64 each) x 2 along N (in channels, 64 each); K = output pixels in slabs of 16.
 // LDS rows are [row][k] with a pitch of 17 floats: both operands arrive pixel-fastest (grad_out rows from memory, the sampled
@@ -651,6 +908,35 @@ inline BwdPlan bwd_plan(const DcnParams& p, tvmi_dtype dt) {
   return q;
 }
 
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // per workgroup on gfx950
+
+template <typename T>
+int launch_bwd_data_mfma(const T* input, const float* wtb, const T* offset, const T* mask, const T* gout, float* gi, float* goff,
+                         float* gmask, const DcnParams& p, int OCg_pad, int ICg_pad, hipStream_t s) {
+  const WinGeom w = win_geom(p);
+  const size_t lds = win_lds_bytes(w);
+  const int64_t tiles = (int64_t)w.ntx * w.nty;
+  const bool small = (int64_t)p.ICg * p.H * p.W < (1ll << 31);   // 32-bit element offsets inside an (image, weight group)
+  if (g_bwd_window.load(std::memory_order_relaxed) && small && lds <= kMaxLdsBytes && tiles < (1ll << 31) && p.B <= 65535 && p.groups <= 65535) {
+    auto kern = dcn_bwd_data_mfma_win<T>;
+    static size_t attr_set[64] = {};  // the largest size set so far, per instantiation and device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || attr_set[dev] < lds) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error((int)hipErrorInvalidValue, "deform_conv2d backward: cannot reserve the LDS window");
+      if (dev >= 0 && dev < 64) attr_set[dev] = lds;
+    }
+    kern<<<dim3((unsigned)tiles, (unsigned)p.B, (unsigned)p.groups), dim3(512), lds, s>>>(input, wtb, offset, mask, gout, gi, goff,
+                                                                                         gmask, p, OCg_pad, ICg_pad, w);
+    return 0;
+  }
+  const int64_t npix = (int64_t)p.B * p.oh * p.ow;
+  dcn_bwd_data_mfma<T><<<dim3((unsigned)ceil_div(npix, 64), 1, (unsigned)p.groups), dim3(512), 0, s>>>(
+      input, wtb, offset, mask, gout, gi, goff, gmask, p, OCg_pad, ICg_pad);
+  return 0;
+}
+
 template <typename T>
 int launch_bwd_weight_mfma(const T* input, const T* offset, const T* mask, const T* gout, float* gw_ws, const DcnParams& p,
                            hipStream_t s) {
@@ -691,6 +977,10 @@ int set_dcn_bwd_option(const char* name, int64_t value) {
     g_bwd_blas.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "dcn.bwd_window") == 0) {
+    g_bwd_window.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
   return -1;
 }
 int get_dcn_bwd_option(const char* name, int64_t* value) {
@@ -700,6 +990,10 @@ int get_dcn_bwd_option(const char* name, int64_t* value) {
   }
   if (std::strcmp(name, "dcn.bwd_blas") == 0) {
     *value = g_bwd_blas.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.bwd_window") == 0) {
+    *value = g_bwd_window.load(std::memory_order_relaxed) ? 1 : 0;
     return 0;
   }
   return -1;
@@ -752,7 +1046,7 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
   TVMI_CHECK_ARG(q.bytes == 0 || (workspace && workspace_bytes >= q.bytes), "deform_conv2d backward: workspace too small");
   const size_t esz = dt == TVMI_F64 ? 8 : (dt == TVMI_F32 ? 4 : 2);
   const int KK = p.kh * p.kw;
-  const int64_t oplane = (int64_t)p.oh * p.ow, npix = B * oplane;
+  const int64_t oplane = (int64_t)p.oh * p.ow;
   const int64_t n_gi = B * C * H * W, n_goff = B * 2 * KK * p.ogroups * oplane, n_gmask = B * KK * p.ogroups * oplane;
   char* ws = static_cast<char*>(workspace);
 #define TVMI_HIP_OK(expr)                                                                         \
@@ -782,10 +1076,10 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
 #define TVMI_BWD_MFMA(scalar_t)                                                                                        \
   do {                                                                                                                 \
     dcn_weight_relayout_bwd<scalar_t><<<dcn_grid1d(wtotal), dim3(256), 0, s>>>((const scalar_t*)weight, wtb, p, q.OCg_pad, q.ICg_pad); \
-    dcn_bwd_data_mfma<scalar_t><<<dim3((unsigned)ceil_div(npix, 64), 1, (unsigned)p.groups), dim3(512), 0, s>>>(        \
-        (const scalar_t*)input, wtb, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)grad_out,         \
-        (float*)gi_acc, (float*)goff_acc, (float*)gmask_acc, p, q.OCg_pad, q.ICg_pad);                                  \
-    st_ = launch_bwd_weight_mfma<scalar_t>((const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,      \
+    st_ = launch_bwd_data_mfma<scalar_t>((const scalar_t*)input, wtb, (const scalar_t*)offset, (const scalar_t*)mask,   \
+                                         (const scalar_t*)grad_out, (float*)gi_acc, (float*)goff_acc, (float*)gmask_acc, \
+                                         p, q.OCg_pad, q.ICg_pad, s);                                                  \
+    if (st_ == 0) st_ = launch_bwd_weight_mfma<scalar_t>((const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,      \
                                            (const scalar_t*)grad_out, gw_ws, p, s);                                    \
     if (st_ == 0)                                                                                                      \
       dcn_bwd_weight_finish<scalar_t><<<dcn_grid1d((int64_t)p.OC * p.ICg * KK), dim3(256), 0, s>>>(gw_ws, (scalar_t*)grad_weight, p); \
