@@ -59,6 +59,8 @@ int tvmi_version(void);
  *                                (0 = the direct kernels for every problem)
  *   "dcn.bwd_window"             1 (default) / 0: its data-gradient kernel adds the grad_input contributions of a pixel tile in an
  *                                LDS window and flushes it once per channel chunk (0 = one global atomic per contribution)
+ *   "dcn.bwd_owner"              1 (default) / 0: 3 x 3 problems with whole 64-channel chunks take the owner form of that kernel
+ *                                (lane = channel, plain LDS read-add-write instead of LDS atomics, nine taps' accumulators resident)
  *   "nms.replan_min_boxes"       tvmi_nms_blocking re-plans problems of at least this many boxes on their survivors
  *                                (default 24576; 0 = never)
  *   "nms.replan_divisor"         share of the row chunks swept before a re-plan (default 16 = the first sixteenth)

@@ -657,6 +657,8 @@ DCN_BWD_CFGS = [
     dict(B=1, C=32, OC=32, H=8, W=8, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, zero_off=True),  # y = -1 / x = -1 exactly
     dict(B=2, C=64, OC=64, H=30, W=40, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, off_scale=0.5),  # offsets inside the LDS window's reach
     dict(B=1, C=64, OC=32, H=40, W=40, k=(3, 3), groups=1, og=1, stride=(2, 2), pad=(1, 1), dil=(1, 1), mask=True, off_scale=0.5),  # stride 2: window too large for LDS -> global atomics
+    dict(B=1, C=64, OC=32, H=8, W=8, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, zero_off=True),   # owner form, y = -1 / x = -1 exactly
+    dict(B=2, C=128, OC=64, H=17, W=21, k=(3, 3), groups=2, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False, off_scale=4),  # owner form: two weight groups, most offsets beyond the window's reach
 ]
 
 
@@ -684,7 +686,7 @@ def _dcn_bwd_compare(got, ref, tol, what):
         np.testing.assert_allclose(a.double().cpu().numpy(), r, rtol=tol, atol=tol * scale, err_msg=f"{name} {what}")
 
 
-@pytest.mark.parametrize("route", ["default", "global_atomics", "direct"])
+@pytest.mark.parametrize("route", ["default", "window", "global_atomics", "direct"])
 @pytest.mark.parametrize("cfg", DCN_BWD_CFGS, ids=[str(i) for i in range(len(DCN_BWD_CFGS))])
 def test_deform_conv2d_backward_fused_vs_reference(tv, cfg, route):
     """`_deform_conv2d_backward` = ONE call of tvmi_deform_conv2d_backward (deform_conv2d_bwd.hip: two fused matrix-core kernels
@@ -696,12 +698,15 @@ def test_deform_conv2d_backward_fused_vs_reference(tv, cfg, route):
     if not O.load_reference():
         pytest.skip("needs the reference CPU kernels (oracle/_ref)")
     ts, args = _dcn_bwd_inputs(cfg, torch.float32)
+    # default: the owner form of the data-gradient kernel where the shape allows (3 x 3, 64-channel chunks), else the window kernel
     torch.ops.tvmi.set_option("dcn.bwd_mfma", 0 if route == "direct" else 1)
+    torch.ops.tvmi.set_option("dcn.bwd_owner", 0 if route in ("window", "global_atomics") else 1)
     torch.ops.tvmi.set_option("dcn.bwd_window", 0 if route == "global_atomics" else 1)
     try:
         got = tv._deform_conv2d_backward(*[v.to(DEV) for v in ts], *args)
     finally:
         torch.ops.tvmi.set_option("dcn.bwd_mfma", 1)
+        torch.ops.tvmi.set_option("dcn.bwd_owner", 1)
         torch.ops.tvmi.set_option("dcn.bwd_window", 1)
     _dcn_bwd_compare(got, tv._deform_conv2d_backward(*ts, *args), TOL, route)
 

@@ -60,9 +60,12 @@ if have_ref:
     for cfg in CFGS:
         check(cfg["tag"] + " fp32", cfg, torch.float32)
     for cfg in CFGS[:5]:
+        torch.ops.tvmi.set_option("dcn.bwd_owner", 0)
+        check(cfg["tag"] + " fp32 window kernel (LDS atomics)", cfg, torch.float32)
         torch.ops.tvmi.set_option("dcn.bwd_window", 0)
         check(cfg["tag"] + " fp32 global atomics only", cfg, torch.float32)
         torch.ops.tvmi.set_option("dcn.bwd_window", 1)
+        torch.ops.tvmi.set_option("dcn.bwd_owner", 1)
     check(CFGS[0]["tag"] + " fp32 forced direct", CFGS[0], torch.float32, mfma=0)
     check(CFGS[1]["tag"] + " fp32 forced direct", CFGS[1], torch.float32, mfma=0)
     check(CFGS[0]["tag"] + " bf16", CFGS[0], torch.bfloat16)
@@ -92,8 +95,9 @@ for groups in (1, 256):
     w = torch.randn(OC, C // groups, 3, 3, generator=g) * (0.01 if groups == 1 else 0.2)
     for dt in (torch.float32, torch.bfloat16):
         ts = [t.to(dev, dt) for t in (gr, x, w, off, m, b)]
-        for route, opts in (("fused", {"dcn.bwd_blas": 0}), ("fused_global_atomics", {"dcn.bwd_window": 0}), ("direct", {"dcn.bwd_blas": 0, "dcn.bwd_mfma": 0}), ("blas_r03", {"dcn.bwd_blas": 1})):
-            if route in ("direct", "fused_global_atomics") and groups != 1: continue
+        for route, opts in (("fused", {"dcn.bwd_blas": 0}), ("fused_window_lds_atomics", {"dcn.bwd_owner": 0}), ("fused_global_atomics", {"dcn.bwd_owner": 0, "dcn.bwd_window": 0}),
+                            ("direct", {"dcn.bwd_blas": 0, "dcn.bwd_mfma": 0}), ("blas_r03", {"dcn.bwd_blas": 1})):
+            if route in ("direct", "fused_global_atomics", "fused_window_lds_atomics") and groups != 1: continue
             if route == "direct" and dt != torch.float32: continue
             for k, v in opts.items(): torch.ops.tvmi.set_option(k, v)
             key = f"c4 backward g={groups} {str(dt).split('.')[-1]} {route}"
@@ -102,5 +106,5 @@ for groups in (1, 256):
             except Exception as e:  # noqa
                 out[key] = {"error": repr(e)[:300]}
             print(key, out[key], flush=True)
-            torch.ops.tvmi.set_option("dcn.bwd_blas", 0); torch.ops.tvmi.set_option("dcn.bwd_mfma", 1); torch.ops.tvmi.set_option("dcn.bwd_window", 1)
+            torch.ops.tvmi.set_option("dcn.bwd_blas", 0); torch.ops.tvmi.set_option("dcn.bwd_mfma", 1); torch.ops.tvmi.set_option("dcn.bwd_window", 1); torch.ops.tvmi.set_option("dcn.bwd_owner", 1)
 if len(sys.argv) > 1: json.dump(out, open(sys.argv[1], "w"), indent=1)

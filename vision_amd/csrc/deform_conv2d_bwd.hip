@@ -37,6 +37,7 @@ namespace {
 
 std::atomic<int> g_bwd_mfma{1};   // option "dcn.bwd_mfma": 0 sends every problem to the direct kernels
 std::atomic<int> g_bwd_window{1}; // option "dcn.bwd_window": 0 = the data-gradient kernel scatters with global atomics only
+std::atomic<int> g_bwd_owner{1};  // option "dcn.bwd_owner": 0 = never the owner form of the data-gradient kernel (dcn_bwd_data_own)
 std::atomic<int> g_bwd_blas{0};   // option "dcn.bwd_blas" (measurement only): the dispatcher glue takes the round-3 route (library GEMMs)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -615,6 +616,427 @@ inline size_t win_lds_bytes(const WinGeom& w) {
   return ((size_t)2 * kBwBK * (kWinCH + kWinTH * kWinTW) + (size_t)kWinCH * w.wsz) * sizeof(float);
 }
 
+// ------------------------------------------------------------------ data gradients, owner form (lane = channel)
+// What the probe tools/probe/lds_atomic_rate.hip measured on gfx950: a wave-level ds_add_f32 costs ~193 cycles per CU whatever its
+// addresses (3 cycles per lane: the LDS float atomic is serialised), a ds_read_b32 + v_add + ds_write_b32 on the same 64
+// addresses ~15.  dcn_bwd_data_mfma_win above is bound by exactly that (1.4 of its 2.2 ms at config 4 are the 250 M LDS
+// atomic lane-operations), and by its slab loop: one 16-deep slab of global loads in flight and 8 MFMAs per wave to cover it.
+// This kernel removes both:
+//   * accumulator blocks are D[pixel][channel]: lane & 31 = CHANNEL, the 16 registers x 2 lane halves = 32 pixels (two rows of
+//     the 8 x 16 pixel tile; the halves hold pixels 8 columns apart).  The LDS window of the grad_input tile is [position][64
+//     channels]: one scatter instruction adds to 32 consecutive channels of 2 positions that can never coincide (|offset| <=
+//     kOwnR, 8 columns apart), so a plain read + add + write is exact.  Waves that hold the same channels (the 4 pixel blocks)
+//     take turns, a barrier between them; program order inside a wave does the rest (the LDS is in-order per wave).
+//   * channel chunk (64) outer, the 9 taps in groups of 5 + 4 whose accumulators are resident together (80 registers), K = out
+//     channels in 16-deep slabs: a grad_out slab serves five taps, an iteration is 40 MFMAs per wave (2560 matrix-pipe cycles
+//     against one global-load round trip), and the epilogues of a group run back to back.  (All nine taps resident — 144
+//     registers — was measured first: the allocator spills the slab prefetch registers, i.e. a vmcnt(0) behind every load:
+//     1.85 ms for the whole backward at config 4 instead of 1.64.)
+//   * input and the grad_input sums are channels-last ([B, H*W, C]; a transposing pre-pass and a transposing finish): corner
+//     reads, far-offset atomics and the window flush are 128 contiguous bytes per half wave.
+//   * grad_offset / grad_mask: per pixel 3 products per lane, reduced over the 32 channel lanes by a reduce-scatter butterfly
+//     (30 exchanges per epilogue instead of 3 x 16 x 5), one atomic per (tap, chunk half, pixel, component).
+constexpr int kOwnTH = 8, kOwnTW = 16, kOwnR = 3, kOwnCH = 64, kOwnKB = 16, kOwnTG = 5;
+constexpr int kOwnAP = kOwnTH * kOwnTW + 32;   // A slab row pitch in floats: row k + 1 starts 32 banks further
+constexpr int kOwnTabDw = 12;                  // dwords per (pixel, tap) table entry
+
+inline WinGeom own_geom(const DcnParams& p) {
+  WinGeom w{};
+  w.wh = (kOwnTH - 1) * p.sh + (p.kh - 1) * p.dh + 2 * kOwnR + 2;
+  w.ww = (kOwnTW - 1) * p.sw + (p.kw - 1) * p.dw + 2 * kOwnR + 2;
+  w.wsz = w.wh * w.ww;
+  w.ntx = (int)ceil_div(p.ow, kOwnTW);
+  w.nty = (int)ceil_div(p.oh, kOwnTH);
+  return w;
+}
+inline size_t own_lds_bytes(const WinGeom& w) {
+  return ((size_t)kOwnKB * kOwnAP + (size_t)kOwnKB * (kOwnTG * kOwnCH + 32) + (size_t)8 * 32 * kOwnTabDw + (size_t)(w.wsz + 1) * kOwnCH) *
+         sizeof(float);
+}
+
+// in [N][R][S] -> out [N][S][R] (64 x 64 tiles through LDS)
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(256) void dcn_transpose_planes(const Tin* __restrict__ in, Tout* __restrict__ out, int R, int S) {
+  __shared__ float tile[64][65];
+  const int64_t n = blockIdx.z;
+  const int r0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const Tin* src = in + n * (int64_t)R * S;
+  Tout* dst = out + n * (int64_t)R * S;
+  for (int j = ty; j < 64; j += 4) {
+    const int r = r0 + j, s = s0 + tx;
+    tile[j][tx] = (r < R && s < S) ? (float)ld(src + (int64_t)r * S + s) : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    const int s = s0 + j, r = r0 + tx;
+    if (s < S && r < R) st(dst + (int64_t)s * R + r, tile[tx][j]);
+  }
+}
+
+template <typename T, int KK>
+__global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt, const float* __restrict__ wtb,
+                                                        const T* __restrict__ offset, const T* __restrict__ mask,
+                                                        const T* __restrict__ gout, float* git, float* __restrict__ goff,
+                                                        float* __restrict__ gmask, DcnParams p, int OCg_pad, int ICg_pad,
+                                                        WinGeom wg) {
+  constexpr int NT = 512;
+  constexpr int NPX = kOwnTH * kOwnTW;          // 128 pixels = 4 blocks of 32
+  constexpr int TG = kOwnTG;                    // taps per group (accumulators resident at a time)
+  constexpr int BP = TG * kOwnCH + 32;          // B slab row pitch
+  constexpr int BQ = kOwnKB * TG * (kOwnCH / 4);   // float4 pieces of a B slab
+  constexpr int BE = (BQ + NT - 1) / NT;
+  constexpr int AE = kOwnKB * NPX / NT;         // 4 grad_out values per thread and slab
+  static_assert(AE * NT == kOwnKB * NPX, "A slab shape");
+  extern __shared__ __attribute__((aligned(16))) float dcn_own_lds[];
+  float* As = dcn_own_lds;                                    // [KB][AP]
+  float* Bs = As + kOwnKB * kOwnAP;                           // [KB][BP]
+  float* tab = Bs + kOwnKB * BP;                              // [8 waves][32 pixels][12]
+  float* win = tab + 8 * 32 * kOwnTabDw;                      // [wsz + 1][64]; the last row is the lanes' dummy target
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave >> 1, wc = wave & 1;
+  const int kq = lane >> 5, l31 = lane & 31;
+  const int g = blockIdx.z, b = blockIdx.y;
+  const int64_t oplane = (int64_t)p.oh * p.ow;
+  const int HW = p.H * p.W;
+  const int ty0 = (blockIdx.x / wg.ntx) * kOwnTH, tx0 = (blockIdx.x % wg.ntx) * kOwnTW;
+  const int wy0 = ty0 * p.sh - p.ph - kOwnR, wx0 = tx0 * p.sw - p.pw - kOwnR;   // image coordinates of window element (0, 0)
+
+  // block row i (0..31) -> pixel of the wave's two tile rows: bit 2 of i (the lane half of an accumulator) moves x by 8
+  auto row_x = [](int i) { return (i & 3) | (((i >> 3) & 1) << 2) | (((i >> 2) & 1) << 3); };
+
+  // A producer: column m of the slab = (pixel block m >> 5, block row m & 31); rows k = tid / 128 + 4 e.  Addresses are a
+  // uniform 64-bit base plus a 32-bit lane offset (per-lane 64-bit pointers here were what the allocator spilled first).
+  const int am = tid & (NPX - 1);
+  const int ak = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int a_oy = ty0 + 2 * (am >> 5) + ((am & 31) >> 4), a_ox = tx0 + row_x(am & 31);
+  const bool a_ok = a_oy < p.oh && a_ox < p.ow;
+  const int a_off = a_ok ? a_oy * p.ow + a_ox : 0;
+  const T* gout_g = gout + ((int64_t)b * p.OC + (int64_t)g * p.OCg) * oplane;
+  // B producer: float4 piece j = tid + 512 e of the slab = (row k, tap, channel quad)
+  int b_src[BE], b_dst[BE], b_u[BE];
+#pragma unroll
+  for (int e = 0; e < BE; ++e) {
+    const int j = tid + e * NT;
+    const int k = j / (TG * 16), rem = j - k * (TG * 16), u = rem >> 4, c4 = rem & 15;
+    b_u[e] = j < BQ ? u : TG;   // tap of the group; TG = no piece
+    b_src[e] = (u * OCg_pad + k) * ICg_pad + 4 * c4;
+    b_dst[e] = k * BP + u * kOwnCH + 4 * c4;
+  }
+  const float* wtb_g = wtb + (int64_t)g * KK * OCg_pad * ICg_pad;
+
+  // the pixel whose table entry this lane builds (block row l31; both lane halves compute it, half 0 writes)
+  const int t_oy = ty0 + 2 * wp + (l31 >> 4), t_ox = tx0 + row_x(l31);
+  const bool t_ok = t_oy < p.oh && t_ox < p.ow;
+
+  const int nks = OCg_pad / kOwnKB;
+  const int ncc = p.ICg / kOwnCH;
+  const T* xt_b = xt + (int64_t)b * HW * p.C;
+  float* git_b = git + (int64_t)b * HW * p.C;
+
+  for (int e = tid; e < (wg.wsz + 1) * kOwnCH; e += NT) win[e] = 0.f;   // (ordered by the barriers of the first slab)
+
+  f32x16 acc[TG];
+  T av[AE];
+  float4 bv[BE];
+  auto issue = [&](int c0, int oc0, int tg, int nt) {
+#pragma unroll
+    for (int e = 0; e < AE; ++e) {
+      const int oc = oc0 + ak + 4 * e;   // (scalar)
+      if (a_ok && oc < p.OCg) av[e] = (gout_g + (int64_t)oc * oplane)[a_off];
+      else st(&av[e], 0.f);
+    }
+    const float* wsrc = wtb_g + (((int64_t)tg * OCg_pad + oc0) * ICg_pad + c0);
+#pragma unroll
+    for (int e = 0; e < BE; ++e) {
+      bv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_u[e] < nt) bv[e] = *reinterpret_cast<const float4*>(wsrc + b_src[e]);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < AE; ++e) As[(ak + 4 * e) * kOwnAP + am] = (float)ld(&av[e]);
+#pragma unroll
+    for (int e = 0; e < BE; ++e)
+      if (b_u[e] < TG) *reinterpret_cast<float4*>(&Bs[b_dst[e]]) = bv[e];
+  };
+
+  float* mytab = tab + wave * 32 * kOwnTabDw;
+  TapRaw<T> raw = tap_raw_identity<T>();
+  bool far_any = false;   // (wave-uniform) some pixel of the wave's block has a weighted corner beyond the reach, current tap
+  auto fetch_raw = [&](int tap, int og) {
+    if (t_ok) load_tap_raw<T>(raw, p, offset, mask, b, og, tap, t_oy, t_ox);
+  };
+  // table entry of (pixel l31, tap): {window offsets x4 (float index of channel 0), image positions x4, dy, dx, m, flags}
+  // flags: bits 0-3 corner validity of get_coordinate_weight, 4-7 corner added in the window, 8-11 corner added with global
+  // atomics (weighted but beyond the reach), 12 location inside (-1, H) x (-1, W)
+  auto build_table = [&](int tap) {
+    const int i = tap / p.kw, j = tap - i * p.kw;
+    const float oh_ = (float)ld(&raw.off_h), ow_ = (float)ld(&raw.off_w);
+    const float y = (float)(t_oy * p.sh - p.ph) + (float)(i * p.dh) + oh_;
+    const float x = (float)(t_ox * p.sw - p.pw) + (float)(j * p.dw) + ow_;
+    BwdTap<float> tp;
+    make_bwd_tap<float>(tp, p.H, p.W, y, x, (float)ld(&raw.m));
+    const bool reach = fabsf(oh_) <= (float)kOwnR && fabsf(ow_) <= (float)kOwnR;   // (false for NaN)
+    const bool inside = !(y <= -1.f || (float)p.H <= y || x <= -1.f || (float)p.W <= x);
+    int flags = inside ? (1 << 12) : 0;
+    int wo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cy = tp.o[k] / p.W, cx = tp.o[k] - cy * p.W;
+      const int wy = cy - wy0, wx = cx - wx0;
+      const bool in_window = reach && wy >= 0 && wy < wg.wh && wx >= 0 && wx < wg.ww;
+      const bool weighted = t_ok && tp.bw[k] != 0.f;
+      if (tp.cv[k]) flags |= 1 << k;
+      if (weighted && in_window) flags |= 16 << k;
+      if (weighted && !in_window) flags |= 256 << k;
+      wo[k] = ((weighted && in_window) ? wy * wg.ww + wx : wg.wsz) * kOwnCH;
+    }
+    far_any = __any(t_ok && (flags & 0xF00));
+    if (kq == 0) {
+      int4* e = reinterpret_cast<int4*>(mytab + l31 * kOwnTabDw);
+      e[0] = make_int4(wo[0], wo[1], wo[2], wo[3]);
+      e[1] = make_int4(tp.o[0], tp.o[1], tp.o[2], tp.o[3]);
+      e[2] = make_int4(__float_as_int(tp.dy), __float_as_int(tp.dx), __float_as_int(t_ok ? tp.m : 0.f), t_ok ? flags : 0);
+    }
+  };
+  // (a wave writes its table and reads it with other lanes: the LDS is in-order per wave, the fences keep the compiler's order)
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // The epilogue's lane-derived values (table addresses, channel offsets, pixel coordinates) are rebuilt from an OPAQUE copy of
+  // the lane id inside the tap loop: left visible, they are hoisted out of the chunk loop, stay live across the slab loop next to
+  // the 144 accumulators, and the register allocator answers by spilling the PREFETCH registers of the slab loop — a
+  // vmcnt(0) and a scratch store right behind every global load (measured: 2.16 ms instead of 1.85 with a few more of them).
+  struct LaneView {
+    int kq, l31;
+    const float* tabq;   // table entry of block row 4 kq
+    float* wl;           // window element (position 0, this lane's channel)
+    int cl;              // this lane's channel inside the chunk
+  };
+  auto lane_view = [&]() {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    LaneView v;
+    v.kq = lo >> 5;
+    v.l31 = lo & 31;
+    v.tabq = mytab + 4 * v.kq * kOwnTabDw;
+    v.cl = wc * 32 + v.l31;
+    v.wl = win + v.cl;
+    return v;
+  };
+  // table entry of accumulator register r (block row 8 (r >> 2) + 4 kq + (r & 3))
+  auto entry_of = [&](const LaneView& lv, int r) {
+    return reinterpret_cast<const int4*>(lv.tabq + (8 * (r >> 2) + (r & 3)) * kOwnTabDw);
+  };
+
+  // grad_offset / grad_mask of one tap: products per pixel, reduce-scatter over the 32 channel lanes.  The 16 registers are
+  // taken in 4 batches of 4 (block rows 8 bi + 4 kq + q), one copy of the code: `bi` is wave-uniform but not a constant, the
+  // state of the binary-counter merge (L2, L3) lives across the calls.
+  struct CoordState {
+    float L2[3], L3[3];
+  };
+  auto coord_batch = [&](const LaneView& lv, CoordState& cs, int bi, const f32x16& a, int c0) {
+    const T* xc = xt_b + (g * p.ICg + c0 + lv.cl);
+    auto merge = [&](const float* lo, const float* hi, float* out, int level) {
+      const bool s = (lv.l31 >> (level + 1)) & 1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float keep = s ? hi[q] : lo[q], send = s ? lo[q] : hi[q];
+        out[q] = keep + __shfl_xor(send, 2 << level);
+      }
+    };
+    float xv[4][4];
+    int4 e2[4];
+    const float* eb = lv.tabq + 8 * bi * kOwnTabDw;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4* e = reinterpret_cast<const int4*>(eb + q * kOwnTabDw);
+      const int4 gp = e[1];
+      e2[q] = e[2];
+      xv[q][0] = (float)ld(xc + (int64_t)gp.x * p.C);
+      xv[q][1] = (float)ld(xc + (int64_t)gp.y * p.C);
+      xv[q][2] = (float)ld(xc + (int64_t)gp.z * p.C);
+      xv[q][3] = (float)ld(xc + (int64_t)gp.w * p.C);
+    }
+    float P[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float dy = __int_as_float(e2[q].x), dx = __int_as_float(e2[q].y), m = __int_as_float(e2[q].z);
+      const int fl = e2[q].w;
+      const float v = bi == 0 ? a[q] : (bi == 1 ? a[4 + q] : (bi == 2 ? a[8 + q] : a[12 + q]));
+      const float x0 = xv[q][0], x1 = xv[q][1], x2 = xv[q][2], x3 = xv[q][3];
+      const float v0 = (fl & 1) ? x0 : 0.f, v1 = (fl & 2) ? x1 : 0.f, v2 = (fl & 4) ? x2 : 0.f, v3 = (fl & 8) ? x3 : 0.f;
+      const float wy = dx * (v3 - v1) + (1.f - dx) * (v2 - v0);   // get_coordinate_weight, y direction
+      const float wx = dy * (v3 - v2) + (1.f - dy) * (v1 - v0);   // x direction
+      const bool inside = (fl >> 12) & 1;
+      const float hh = 1.f - dy, hw = 1.f - dx;
+      const float b0 = (inside && (fl & 1)) ? hh * hw : 0.f, b1 = (inside && (fl & 2)) ? hh * dx : 0.f;
+      const float b2 = (inside && (fl & 4)) ? dy * hw : 0.f, b3 = (inside && (fl & 8)) ? dy * dx : 0.f;
+      P[q][0] = m * wy * v;
+      P[q][1] = m * wx * v;
+      P[q][2] = v * (b0 * x0 + b1 * x1 + b2 * x2 + b3 * x3);
+    }
+    // register bit 0 <-> lane bit 1, bit 1 <-> lane bit 2, bit 2 <-> lane bit 3, bit 3 <-> lane bit 4
+    float Ma[3], Mb[3], M1[3];
+    merge(P[0], P[1], Ma, 0);
+    merge(P[2], P[3], Mb, 0);
+    merge(Ma, Mb, M1, 1);
+    if ((bi & 1) == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) cs.L2[c] = M1[c];
+    } else {
+      float M2[3];
+      merge(cs.L2, M1, M2, 2);
+      if ((bi & 2) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cs.L3[c] = M2[c];
+      } else {
+        merge(cs.L3, M2, cs.L3, 3);
+      }
+    }
+  };
+  auto coord_finish = [&](const LaneView& lv, CoordState& cs, int tap, int c0) {
+    const int og = (g * p.ICg + c0 + wc * 32) / p.cpog;
+    // L3: the sums (over this lane pair's channels so far) of register r = lane bits 1..4
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cs.L3[c] += __shfl_xor(cs.L3[c], 1);
+    if ((lv.l31 & 1) == 0) {
+      const int r = lv.l31 >> 1;
+      const int i = 8 * (r >> 2) + 4 * lv.kq + (r & 3);
+      const int oy = ty0 + 2 * wp + (i >> 4), ox = tx0 + row_x(i);
+      if (oy < p.oh && ox < p.ow) {
+        const int64_t pix = (int64_t)oy * p.ow + ox;
+        float* o = goff + ((int64_t)(b * p.ogroups + og) * 2 * KK + 2 * tap) * oplane + pix;
+        unsafeAtomicAdd(o, cs.L3[0]);
+        unsafeAtomicAdd(o + oplane, cs.L3[1]);
+        if (p.use_mask) unsafeAtomicAdd(gmask + ((int64_t)(b * p.ogroups + og) * KK + tap) * oplane + pix, cs.L3[2]);
+      }
+    }
+  };
+
+  // the grad_input contributions of one tap of this wave's block: read + add + write per pixel, in register order.  The
+  // table entry of the NEXT register is read before the window writes of the current one (the compiler cannot know that
+  // table and window never alias; written in this order it need not).
+  auto scatter = [&](const LaneView& lv, const f32x16& a) {
+    int4 wo = entry_of(lv, 0)[0], e2 = entry_of(lv, 0)[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int4 wo_c = wo, e2_c = e2;
+      if (r + 1 < 16) {
+        wo = entry_of(lv, r + 1)[0];
+        e2 = entry_of(lv, r + 1)[2];
+      }
+      const float dy = __int_as_float(e2_c.x), dx = __int_as_float(e2_c.y), m = __int_as_float(e2_c.z);
+      const int fl = e2_c.w;
+      const bool inside = (fl >> 12) & 1;
+      const float hh = 1.f - dy, hw = 1.f - dx;
+      const float g0 = m * ((inside && (fl & 1)) ? hh * hw : 0.f), g1 = m * ((inside && (fl & 2)) ? hh * dx : 0.f);
+      const float g2 = m * ((inside && (fl & 4)) ? dy * hw : 0.f), g3 = m * ((inside && (fl & 8)) ? dy * dx : 0.f);
+      const float v = a[r];
+      const float t0 = lv.wl[wo_c.x], t1 = lv.wl[wo_c.y], t2 = lv.wl[wo_c.z], t3 = lv.wl[wo_c.w];
+      lv.wl[wo_c.x] = t0 + ((fl & 16) ? g0 * v : 0.f);
+      lv.wl[wo_c.y] = t1 + ((fl & 32) ? g1 * v : 0.f);
+      lv.wl[wo_c.z] = t2 + ((fl & 64) ? g2 * v : 0.f);
+      lv.wl[wo_c.w] = t3 + ((fl & 128) ? g3 * v : 0.f);
+    }
+  };
+  // a weighted corner beyond the reach of the window: rare; channels-last global atomics, one pixel (register) at a time
+  auto scatter_far = [&](const LaneView& lv, const f32x16& a, int c0) {
+    float* gc = git_b + (g * p.ICg + c0 + lv.cl);
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+      const int4* e = entry_of(lv, r);
+      const int4 e2 = e[2];
+      const int fl = e2.w;
+      if (!(fl & 0xF00)) continue;
+      float v = 0.f;   // (a[r] with a run-time r: selects, not a scratch array)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) v = rr == r ? a[rr] : v;
+      const int4 gp = e[1];
+      const float dy = __int_as_float(e2.x), dx = __int_as_float(e2.y), m = __int_as_float(e2.z);
+      const float hh = 1.f - dy, hw = 1.f - dx;   // (a weighted corner is valid and the location inside)
+      if (fl & 0x100) unsafeAtomicAdd(gc + (int64_t)gp.x * p.C, m * (hh * hw) * v);
+      if (fl & 0x200) unsafeAtomicAdd(gc + (int64_t)gp.y * p.C, m * (hh * dx) * v);
+      if (fl & 0x400) unsafeAtomicAdd(gc + (int64_t)gp.z * p.C, m * (dy * hw) * v);
+      if (fl & 0x800) unsafeAtomicAdd(gc + (int64_t)gp.w * p.C, m * (dy * dx) * v);
+    }
+  };
+
+#pragma unroll 1
+  for (int cc = 0; cc < ncc; ++cc) {
+    const int c0 = cc * kOwnCH;
+    const int og = (g * p.ICg + c0 + wc * 32) / p.cpog;   // one offset group per 32-channel block (the launcher checks)
+#pragma unroll 1
+    for (int tg = 0; tg < KK; tg += TG) {
+      const int nt = min(TG, KK - tg);
+      issue(c0, 0, tg, nt);   // (not held across the epilogue before: its registers there cost more than the exposed latency here)
+#pragma unroll
+      for (int u = 0; u < TG; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+      fetch_raw(tg, og);
+#pragma unroll 1
+      for (int ks = 0; ks < nks; ++ks) {
+        __syncthreads();   // every wave has read the previous slab
+        commit();
+        __syncthreads();
+        if (ks + 1 < nks) issue(c0, (ks + 1) * kOwnKB, tg, nt);
+#pragma unroll
+        for (int kk = 0; kk < kOwnKB; kk += 2) {
+          const float a = As[(kk + kq) * kOwnAP + wp * 32 + l31];
+#pragma unroll
+          for (int u = 0; u < TG; ++u) {
+            if (u < nt) {   // (uniform)
+              const float bb = Bs[(kk + kq) * BP + u * kOwnCH + wc * 32 + l31];
+              acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[u], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // one copy of the epilogue code for the taps of the group: the tap's block is moved into `cur`
+#pragma unroll 1
+      for (int u = 0; u < nt; ++u) {
+        const int t = tg + u;
+        f32x16 cur = acc[0];
+#pragma unroll
+        for (int w = 1; w < TG; ++w)
+          if (u == w) cur = acc[w];   // (wave-uniform)
+        build_table(t);
+        if (u + 1 < nt) fetch_raw(t + 1, og);
+        wave_sync();
+        const LaneView lv = lane_view();
+        // coordinate gradients first (all waves at once; batches inside the scatter phases of the other waves were measured:
+        // a phase then lasts one global-load round trip instead of one wave's 16 read-add-write steps, 1.64 -> 1.71 ms), then
+        // the four waves that hold the same channels scatter one after the other
+        CoordState cs;
+#pragma unroll 1
+        for (int bi = 0; bi < 4; ++bi) coord_batch(lv, cs, bi, cur, c0);
+        coord_finish(lv, cs, t, c0);
+#pragma unroll 1
+        for (int ph = 0; ph < 4; ++ph) {
+          if (wp == ph) scatter(lv, cur);
+          __syncthreads();
+        }
+        if (far_any) scatter_far(lv, cur, c0);
+      }
+    }
+    // flush the window: one position (64 channels, 256 contiguous bytes of the channels-last sums) per wave and step
+#pragma unroll 1
+    for (int pos = wave; pos < wg.wsz; pos += NT / 64) {
+      const float v = win[pos * kOwnCH + lane];
+      win[pos * kOwnCH + lane] = 0.f;
+      const int wy = pos / wg.ww, wx = pos - wy * wg.ww;
+      const int iy = wy0 + wy, ix = wx0 + wx;
+      if (v != 0.f && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        unsafeAtomicAdd(git_b + ((int64_t)(iy * p.W + ix) * p.C + g * p.ICg + c0 + lane), v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ weight gradient on the matrix cores
 // 8 waves: 4 along M (out channels, 64 each) x 2 along N (in channels, 64 each); K = output pixels in slabs of 16.
 // LDS rows are [row][k] with a pitch of 17 floats: both operands arrive pixel-fastest (grad_out rows from memory, the sampled
@@ -876,10 +1298,19 @@ inline bool bwd_mfma_shape(const DcnParams& p, tvmi_dtype dt) {
   return p.ogroups == 1 || (p.cpog % 32 == 0 && p.ICg % 32 == 0);
 }
 
+// the owner form of the data-gradient kernel: 3 x 3 taps, whole 64-channel chunks, the window in LDS
+inline bool bwd_own_shape(const DcnParams& p, tvmi_dtype dt) {
+  if (!bwd_mfma_shape(p, dt)) return false;
+  if (p.kh * p.kw != 9 || p.ICg % kOwnCH) return false;
+  if ((int64_t)p.H * p.W * p.C >= (1ll << 31)) return false;
+  const WinGeom w = own_geom(p);
+  return own_lds_bytes(w) <= (size_t)160 * 1024 && (int64_t)w.ntx * w.nty < (1ll << 31) && p.B <= 65535 && p.groups <= 65535;
+}
+
 struct BwdPlan {
-  bool mfma, wide;          // wide: 16-bit tensors (sums live in fp32 buffers of the workspace)
+  bool mfma, wide, own;     // wide: 16-bit tensors (sums live in fp32 buffers of the workspace); own: channels-last copies
   int OCg_pad, ICg_pad;
-  size_t at_wtb, at_gw, at_gi, at_goff, at_gmask, bytes;
+  size_t at_wtb, at_gw, at_gi, at_goff, at_gmask, at_xt, at_git, bytes;
 };
 inline BwdPlan bwd_plan(const DcnParams& p, tvmi_dtype dt) {
   BwdPlan q{};
@@ -903,6 +1334,15 @@ inline BwdPlan bwd_plan(const DcnParams& p, tvmi_dtype dt) {
     at += dcn_align256((size_t)p.B * 2 * KK * p.ogroups * p.oh * p.ow * sizeof(float));
     q.at_gmask = at;
     at += dcn_align256((size_t)p.B * KK * p.ogroups * p.oh * p.ow * sizeof(float));
+  }
+  const bool own_shape = shape && bwd_own_shape(p, dt);
+  q.own = own_shape && q.mfma && g_bwd_owner.load(std::memory_order_relaxed);
+  if (own_shape) {
+    const size_t n = (size_t)p.B * p.C * p.H * p.W;
+    q.at_xt = at;
+    at += dcn_align256(n * (dt == TVMI_F32 ? 4 : 2));
+    q.at_git = at;
+    at += dcn_align256(n * sizeof(float));
   }
   q.bytes = at;
   return q;
@@ -934,6 +1374,29 @@ int launch_bwd_data_mfma(const T* input, const float* wtb, const T* offset, cons
   const int64_t npix = (int64_t)p.B * p.oh * p.ow;
   dcn_bwd_data_mfma<T><<<dim3((unsigned)ceil_div(npix, 64), 1, (unsigned)p.groups), dim3(512), 0, s>>>(
       input, wtb, offset, mask, gout, gi, goff, gmask, p, OCg_pad, ICg_pad);
+  return 0;
+}
+
+// owner form: transposing pre-pass of the input, the kernel, transposing finish of the grad_input sums (git is zeroed by the caller)
+template <typename T>
+int launch_bwd_data_own(const T* input, T* xt, const float* wtb, const T* offset, const T* mask, const T* gout, float* git,
+                        T* grad_input, float* goff, float* gmask, const DcnParams& p, int OCg_pad, int ICg_pad, hipStream_t s) {
+  const WinGeom w = own_geom(p);
+  const size_t lds = own_lds_bytes(w);
+  auto kern = dcn_bwd_data_own<T, 9>;
+  static size_t attr_set[64] = {};  // the largest size set so far, per instantiation and device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || attr_set[dev] < lds) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return set_error((int)hipErrorInvalidValue, "deform_conv2d backward: cannot reserve the LDS window");
+    if (dev >= 0 && dev < 64) attr_set[dev] = lds;
+  }
+  const int HW = p.H * p.W;
+  dcn_transpose_planes<T, T><<<dim3((unsigned)ceil_div(HW, 64), (unsigned)ceil_div(p.C, 64), (unsigned)p.B), dim3(256), 0, s>>>(input, xt, p.C, HW);
+  kern<<<dim3((unsigned)(w.ntx * w.nty), (unsigned)p.B, (unsigned)p.groups), dim3(512), lds, s>>>(xt, wtb, offset, mask, gout, git, goff,
+                                                                                                gmask, p, OCg_pad, ICg_pad, w);
+  dcn_transpose_planes<float, T><<<dim3((unsigned)ceil_div(p.C, 64), (unsigned)ceil_div(HW, 64), (unsigned)p.B), dim3(256), 0, s>>>(git, grad_input, HW, p.C);
   return 0;
 }
 
@@ -981,6 +1444,10 @@ int set_dcn_bwd_option(const char* name, int64_t value) {
     g_bwd_window.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "dcn.bwd_owner") == 0) {
+    g_bwd_owner.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
   return -1;
 }
 int get_dcn_bwd_option(const char* name, int64_t* value) {
@@ -994,6 +1461,10 @@ int get_dcn_bwd_option(const char* name, int64_t* value) {
   }
   if (std::strcmp(name, "dcn.bwd_window") == 0) {
     *value = g_bwd_window.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.bwd_owner") == 0) {
+    *value = g_bwd_owner.load(std::memory_order_relaxed) ? 1 : 0;
     return 0;
   }
   return -1;
@@ -1060,7 +1531,8 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
   void* goff_acc = q.wide ? (void*)(ws + q.at_goff) : grad_offset;
   void* gmask_acc = q.wide ? (void*)(ws + q.at_gmask) : grad_mask;
   const size_t asz = q.wide ? 4 : esz;
-  TVMI_HIP_OK(hipMemsetAsync(gi_acc, 0, (size_t)n_gi * asz, s));   // the scatter accumulates
+  if (q.own) TVMI_HIP_OK(hipMemsetAsync(ws + q.at_git, 0, (size_t)n_gi * sizeof(float), s));   // channels-last sums, transposed at the end
+  else TVMI_HIP_OK(hipMemsetAsync(gi_acc, 0, (size_t)n_gi * asz, s));   // the scatter accumulates
   if (q.mfma) {                                                   // ... and so do the per-wave partial sums of the matrix-core route
     TVMI_HIP_OK(hipMemsetAsync(goff_acc, 0, (size_t)n_goff * asz, s));
     if (use_mask) TVMI_HIP_OK(hipMemsetAsync(gmask_acc, 0, (size_t)n_gmask * asz, s));
@@ -1076,9 +1548,15 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
 #define TVMI_BWD_MFMA(scalar_t)                                                                                        \
   do {                                                                                                                 \
     dcn_weight_relayout_bwd<scalar_t><<<dcn_grid1d(wtotal), dim3(256), 0, s>>>((const scalar_t*)weight, wtb, p, q.OCg_pad, q.ICg_pad); \
-    st_ = launch_bwd_data_mfma<scalar_t>((const scalar_t*)input, wtb, (const scalar_t*)offset, (const scalar_t*)mask,   \
-                                         (const scalar_t*)grad_out, (float*)gi_acc, (float*)goff_acc, (float*)gmask_acc, \
-                                         p, q.OCg_pad, q.ICg_pad, s);                                                  \
+    if (q.own)                                                                                                         \
+      st_ = launch_bwd_data_own<scalar_t>((const scalar_t*)input, (scalar_t*)(ws + q.at_xt), wtb, (const scalar_t*)offset, \
+                                          (const scalar_t*)mask, (const scalar_t*)grad_out, (float*)(ws + q.at_git),      \
+                                          (scalar_t*)grad_input, (float*)goff_acc, (float*)gmask_acc, p, q.OCg_pad,       \
+                                          q.ICg_pad, s);                                                                \
+    else                                                                                                               \
+      st_ = launch_bwd_data_mfma<scalar_t>((const scalar_t*)input, wtb, (const scalar_t*)offset, (const scalar_t*)mask, \
+                                           (const scalar_t*)grad_out, (float*)gi_acc, (float*)goff_acc, (float*)gmask_acc, \
+                                           p, q.OCg_pad, q.ICg_pad, s);                                                \
     if (st_ == 0) st_ = launch_bwd_weight_mfma<scalar_t>((const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,      \
                                            (const scalar_t*)grad_out, gw_ws, p, s);                                    \
     if (st_ == 0)                                                                                                      \
@@ -1111,7 +1589,8 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
   if (q.wide) {
 #define TVMI_BWD_ROUND(scalar_t)                                                                                        \
   do {                                                                                                                 \
-    dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_gi), dim3(256), 0, s>>>((const float*)gi_acc, (scalar_t*)grad_input, n_gi); \
+    if (!q.own)                                                                                                        \
+      dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_gi), dim3(256), 0, s>>>((const float*)gi_acc, (scalar_t*)grad_input, n_gi); \
     dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_goff), dim3(256), 0, s>>>((const float*)goff_acc, (scalar_t*)grad_offset, n_goff); \
     if (use_mask)                                                                                                      \
       dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_gmask), dim3(256), 0, s>>>((const float*)gmask_acc, (scalar_t*)grad_mask, n_gmask); \
