@@ -421,7 +421,8 @@ def other_configs(device):
                           time of torchvision::nms incl. the score sort and the output-size sync; bound =
                           max(pairs * 20 flop / 157.3 TF, mask bytes / 8 TB/s)
       deform_conv2d     : 2x256x100x136, k3, 256 -> 256: groups=1 fp32 / bf16 against the dense MFMA peak of the dtype,
-                          groups=256 (depthwise) against HBM on its compulsory bytes"""
+                          groups=256 (depthwise) against HBM on its compulsory bytes; the backward (five gradients) of the
+                          groups=1 problem against the fp32 MFMA peak on its two contractions"""
     import vision_amd
 
     tv = torch.ops.torchvision
@@ -488,6 +489,17 @@ def other_configs(device):
     dw_bytes = (2 * B * C * H * W + B * 18 * H * W + 256 * 9 + 256) * 4      # in + out + offsets + weights + bias
     out["deform_conv2d_g256_fp32"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "compulsory_MB": round(dw_bytes / 1e6, 1),
                                       "GBs": round(dw_bytes / ms / 1e6, 1), "frac_of_hbm_peak": round(dw_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    # backward of the same problem (all five gradients of torchvision::_deform_conv2d_backward, mask in use): two contractions of the
+    # forward's size (grad_input / grad_offset / grad_mask from W^T x grad_out, grad_weight from grad_out x columns)
+    for tag, sets in (("fp32", cfg4), ("bf16", h)):
+        gsets = [dict(d, go=torch.randn(B, 256, H, W, device=device).to(d["x"].dtype), m=torch.rand(B, 9, H, W, device=device).to(d["x"].dtype))
+                 for d in sets]
+        ms, mn = med(lambda i: tv._deform_conv2d_backward(gsets[i % nsets]["go"], gsets[i % nsets]["x"], gsets[i % nsets]["w1"],
+                                                          gsets[i % nsets]["off"], gsets[i % nsets]["m"], gsets[i % nsets]["bias"],
+                                                          1, 1, 1, 1, 1, 1, 1, 1, True), n=12)
+        out[f"deform_conv2d_backward_g1_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "TFLOPs": round(2 * flops / ms / 1e9, 1),
+                                                   "frac_of_mfma_peak": round(2 * flops / ms / 1e9 / FP32_PEAK_TF, 4), "peak_TFLOPs": FP32_PEAK_TF,
+                                                   "note": "contracted in fp32 on the matrix cores for every tensor type; 12 calls"}
     return out
 
 
