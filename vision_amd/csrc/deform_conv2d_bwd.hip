@@ -114,6 +114,27 @@ __device__ __forceinline__ void accumulate_coord(CoordSums<A>& s, const BwdTap<A
   if (use_mask) s.gm += v * (t.bw[0] * x0 + t.bw[1] * x1 + t.bw[2] * x2 + t.bw[3] * x3);
 }
 
+// load_tap_raw of dcn_common.h with every load unconditional: `if (use_mask) r.m = mask[...]` (and an `if (pixel exists)` around
+// the call) makes the loaded value one input of a phi, the copy that resolves it is a use, and the s_waitcnt vmcnt(0) it needs
+// lands wherever the copy does — in dcn_bwd_weight_mfma in front of the MFMAs of the slab, with the whole next slab of gathers
+// in flight.  Here the mask is read from a legal address in any case (the offset tensor when there is no mask) and the caller
+// selects 1 at the point of use; the pixel must be a legal one.
+template <typename T>
+__device__ __forceinline__ void load_tap_raw_u(TapRaw<T>& r, const DcnParams& p, const T* __restrict__ offset,
+                                               const T* __restrict__ mask, int b, int og, int tap, int oy, int ox) {
+  const int64_t plane = (int64_t)p.oh * p.ow;
+  const int64_t pix = (int64_t)oy * p.ow + ox;
+  const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * p.kh * p.kw + 2 * tap) * plane + pix;
+  const T* mptr = p.use_mask ? mask + ((int64_t)(b * p.ogroups + og) * p.kh * p.kw + tap) * plane + pix : optr;
+  r.off_h = optr[0];
+  r.off_w = optr[plane];
+  r.m = mptr[0];
+}
+template <typename T>
+__device__ __forceinline__ float raw_mask(const DcnParams& p, const TapRaw<T>& r) {
+  return p.use_mask ? (float)ld(&r.m) : 1.f;
+}
+
 // ------------------------------------------------------------------ small kernels around the two contractions
 // weight [OC, ICg, kh, kw] (T) -> wtb [groups][tap][OCg_pad][ICg_pad] fp32 (ic fastest, zero padded): the A operand of
 // the data-gradient contraction, rows = out channels (K), columns = in channels (M)
@@ -766,7 +787,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
   TapRaw<T> raw = tap_raw_identity<T>();
   bool far_any = false;   // (wave-uniform) some pixel of the wave's block has a weighted corner beyond the reach, current tap
   auto fetch_raw = [&](int tap, int og) {
-    if (t_ok) load_tap_raw<T>(raw, p, offset, mask, b, og, tap, t_oy, t_ox);
+    load_tap_raw_u<T>(raw, p, offset, mask, b, og, tap, min(t_oy, p.oh - 1), min(t_ox, p.ow - 1));
   };
   // table entry of (pixel l31, tap): {window offsets x4 (float index of channel 0), image positions x4, dy, dx, m, flags}
   // flags: bits 0-3 corner validity of get_coordinate_weight, 4-7 corner added in the window, 8-11 corner added with global
@@ -777,7 +798,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
     const float y = (float)(t_oy * p.sh - p.ph) + (float)(i * p.dh) + oh_;
     const float x = (float)(t_ox * p.sw - p.pw) + (float)(j * p.dw) + ow_;
     BwdTap<float> tp;
-    make_bwd_tap<float>(tp, p.H, p.W, y, x, (float)ld(&raw.m));
+    make_bwd_tap<float>(tp, p.H, p.W, y, x, raw_mask<T>(p, raw));
     const bool reach = fabsf(oh_) <= (float)kOwnR && fabsf(ow_) <= (float)kOwnR;   // (false for NaN)
     const bool inside = !(y <= -1.f || (float)p.H <= y || x <= -1.f || (float)p.W <= x);
     int flags = inside ? (1 << 12) : 0;
@@ -1043,7 +1064,13 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
 // values per producer pixel) and are read as fragments with the row across the lanes — 17 l mod 64 is a permutation of the banks.
 constexpr int kBwPitch = kBwBK + 1;
 
-template <typename T>
+// CL: `input` is the channels-last copy [B, H*W, C] the owner form of the data kernel makes.  The im2col production is bound by
+// the rate at which the texture path retires scattered loads: planar, a producer thread fetches 4 channels x 4
+// corners with 16 dword loads; channels-last it is (pixel, channel quad) and fetches the same values with 4 16-byte loads — the
+// four quads of a pixel that meet in a wave read one 64-byte line.  LDS row of channel c0 + 4 q + j = 32 j + q (the same
+// expression as the planar rsub + 32 e, conflict-free for the same reason), so accumulator column n of block (wn, ni) is channel
+// c0 + 4 (n & 31) + (wn NI + ni).
+template <typename T, bool CL>
 __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__ input, const T* __restrict__ offset,
                                                            const T* __restrict__ mask, const T* __restrict__ gout,
                                                            float* __restrict__ gw_ws, DcnParams p, int pix_per_wg, int ncc,
@@ -1107,26 +1134,63 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
 
   // the offset group of this thread's first row: its raw (offset_h, offset_w, mask) are fetched one slab AHEAD (a dependent
   // load in front of the gathers of every slab otherwise); rows in other offset groups load theirs on the spot
-  const int og_first = (g * p.ICg + min(c0 + rsub, p.ICg - 1)) / p.cpog;
+  const int og_first = (g * p.ICg + min(c0 + (CL ? 4 * rsub : rsub), p.ICg - 1)) / p.cpog;
   TapRaw<T> raw = tap_raw_identity<T>();
-  auto fetch_raw = [&]() {
-    if (pn < n_end) load_tap_raw<T>(raw, p, offset, mask, pb, og_first, tap, poy, pox);
-  };
+  auto fetch_raw = [&]() { load_tap_raw_u<T>(raw, p, offset, mask, pb, og_first, tap, poy, pox); };   // ((pb, poy, pox) is always a legal pixel)
 
-  float ga[AV];       // grad_out values of the next slab
-  float xb[BV][4];    // corner values of the next slab
+  // Every load of a slab is UNCONDITIONAL (rows clamped to a legal one, values kept in the tensor's type) and what must be
+  // zero is zeroed at commit: a `cond ? load : 0` or a 16-bit conversion is a USE of the loaded value, and the wait it needs
+  // lands in front of the MFMAs of the current slab — load latency and matrix work in series (measured: 0.69 ms).
+  T ga[AV];           // grad_out values of the next slab
+  bool ga_live = false;
+  T xb[BV][4];        // corner values of the next slab
   float wgt[BV][4];   // their bilinear weights, zero for rows / pixels that do not exist
   float wmask[BV];    // the modulation mask of the row's offset group (multiplies the sum, as in the forward: sample_tap)
   auto issue = [&]() {
     const bool ok = pn < n_end;
     const int64_t pin = (int64_t)poy * p.ow + pox;
+    ga_live = ok;
 #pragma unroll
     for (int e = 0; e < AV; ++e) {
-      const int o = o0 + rsub + e * RSUB;
-      ga[e] = (ok && o < p.OCg) ? (float)ld(gout + ((int64_t)pb * p.OC + (int64_t)g * p.OCg + o) * oplane + pin) : 0.f;
+      const int o = min(o0 + rsub + e * RSUB, p.OCg - 1);
+      ga[e] = gout[((int64_t)pb * p.OC + (int64_t)g * p.OCg + o) * oplane + pin];
     }
     Tap<float> t;
-    tap_from_raw<T, float>(t, p, raw, tap, poy, pox);
+    {
+      const int i = tap / p.kw, j = tap - i * p.kw;
+      const float y = (float)(poy * p.sh - p.ph) + (float)(i * p.dh) + (float)ld(&raw.off_h);
+      const float x = (float)(pox * p.sw - p.pw) + (float)(j * p.dw) + (float)ld(&raw.off_w);
+      make_tap<float>(t, p.H, p.W, y, x, raw_mask<T>(p, raw));
+    }
+    if constexpr (CL) {
+      static_assert(BV == 4, "a producer thread owns one channel quad");
+      struct alignas(sizeof(T) * 4) Quad {
+        T v[4];
+      };
+      const int c = c0 + 4 * rsub;
+      const bool cok = ok && c < p.ICg;   // (ICg is a multiple of 4 here: whole quads)
+      const int cl = min(c, p.ICg - 4);
+      const T* px = input + (int64_t)pb * iplane * p.C + ((int64_t)g * p.ICg + cl);
+      const Quad q1 = *reinterpret_cast<const Quad*>(px + (int64_t)t.o1 * p.C);
+      const Quad q2 = *reinterpret_cast<const Quad*>(px + (int64_t)t.o2 * p.C);
+      const Quad q3 = *reinterpret_cast<const Quad*>(px + (int64_t)t.o3 * p.C);
+      const Quad q4 = *reinterpret_cast<const Quad*>(px + (int64_t)t.o4 * p.C);
+#pragma unroll
+      for (int e = 0; e < BV; ++e) {
+        xb[e][0] = q1.v[e];
+        xb[e][1] = q2.v[e];
+        xb[e][2] = q3.v[e];
+        xb[e][3] = q4.v[e];
+      }
+      wgt[0][0] = cok ? t.w1 : 0.f;   // (one pixel and one offset group per thread: one set of weights)
+      wgt[0][1] = cok ? t.w2 : 0.f;
+      wgt[0][2] = cok ? t.w3 : 0.f;
+      wgt[0][3] = cok ? t.w4 : 0.f;
+      wmask[0] = cok ? t.m : 0.f;
+      advance();
+      fetch_raw();
+      return;
+    }
     int og_cur = og_first;
 #pragma unroll
     for (int e = 0; e < BV; ++e) {
@@ -1139,10 +1203,10 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
         og_cur = og;
       }
       const T* pl = input + ((int64_t)pb * p.C + (int64_t)g * p.ICg + cl) * iplane;
-      xb[e][0] = (float)ld(pl + t.o1);
-      xb[e][1] = (float)ld(pl + t.o2);
-      xb[e][2] = (float)ld(pl + t.o3);
-      xb[e][3] = (float)ld(pl + t.o4);
+      xb[e][0] = pl[t.o1];
+      xb[e][1] = pl[t.o2];
+      xb[e][2] = pl[t.o3];
+      xb[e][3] = pl[t.o4];
       wgt[e][0] = cok ? t.w1 : 0.f;
       wgt[e][1] = cok ? t.w2 : 0.f;
       wgt[e][2] = cok ? t.w3 : 0.f;
@@ -1154,12 +1218,15 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < AV; ++e) As[buf][rsub + e * RSUB][pk] = ga[e];
+    for (int e = 0; e < AV; ++e)
+      As[buf][rsub + e * RSUB][pk] = (ga_live && o0 + rsub + e * RSUB < p.OCg) ? (float)ld(&ga[e]) : 0.f;
 #pragma unroll
     for (int e = 0; e < BV; ++e) {
       // a row / pixel that does not exist contributes exactly zero (its corner values may be anything, even inf)
-      const bool live = wmask[e] != 0.f || wgt[e][0] != 0.f || wgt[e][1] != 0.f || wgt[e][2] != 0.f || wgt[e][3] != 0.f;
-      const float v = wmask[e] * (wgt[e][0] * xb[e][0] + wgt[e][1] * xb[e][1] + wgt[e][2] * xb[e][2] + wgt[e][3] * xb[e][3]);
+      const int w = CL ? 0 : e;
+      const bool live = wmask[w] != 0.f || wgt[w][0] != 0.f || wgt[w][1] != 0.f || wgt[w][2] != 0.f || wgt[w][3] != 0.f;
+      const float v = wmask[w] * (wgt[w][0] * (float)ld(&xb[e][0]) + wgt[w][1] * (float)ld(&xb[e][1]) +
+                                  wgt[w][2] * (float)ld(&xb[e][2]) + wgt[w][3] * (float)ld(&xb[e][3]));
       Bs[buf][rsub + e * RSUB][pk] = live ? v : 0.f;
     }
   };
@@ -1190,7 +1257,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
   float* dst = gw_ws + ((int64_t)g * KK + tap) * p.OCg * p.ICg;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int c = c0 + (wn * NI + ni) * 32 + l31;
+    const int c = CL ? c0 + 4 * l31 + (wn * NI + ni) : c0 + (wn * NI + ni) * 32 + l31;
     if (c >= p.ICg) continue;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1400,12 +1467,12 @@ int launch_bwd_data_own(const T* input, T* xt, const float* wtb, const T* offset
   return 0;
 }
 
-template <typename T>
+template <typename T, bool CL>
 int launch_bwd_weight_mfma(const T* input, const T* offset, const T* mask, const T* gout, float* gw_ws, const DcnParams& p,
                            hipStream_t s) {
   constexpr int BM = 256, BN = 128;
   constexpr size_t lds = (size_t)2 * (BM + BN) * kBwPitch * sizeof(float);
-  auto kern = dcn_bwd_weight_mfma<T>;
+  auto kern = dcn_bwd_weight_mfma<T, CL>;
   static bool attr_set[64] = {};  // per instantiation and device; racing threads set the same value
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1418,8 +1485,18 @@ int launch_bwd_weight_mfma(const T* input, const T* offset, const T* mask, const
   const int64_t npix = (int64_t)p.B * p.oh * p.ow;
   const int ncc = (int)ceil_div(p.ICg, BN), nmc = (int)ceil_div(p.OCg, BM);
   const int64_t per_pixel_range = (int64_t)KK * ncc * nmc * p.groups;
-  // ~3 workgroups per CU in total, pixel ranges of whole slabs, at least 8 slabs each
-  int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(768, per_pixel_range), ceil_div(npix, 8 * kBwBK)));
+  // ONE workgroup per CU in total (144 - 175 VGPRs: one 8-wave workgroup is resident per CU, so the grid runs in rounds and
+  // a grid a few workgroups above a multiple of the CU count pays a whole extra round: 774 workgroups = 4 rounds measured
+  // 0.70 ms at config 4), pixel ranges of whole slabs, at least 8 slabs each
+  static int cus[64] = {};
+  if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  const int64_t ncu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+  // (the channels-last form squeezed to 128 VGPRs for two resident workgroups spills addresses inside the slab loop: 1.46 -> 1.59 ms)
+  int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(ncu / per_pixel_range, ceil_div(npix, 8 * kBwBK)));
   const int64_t pix_per_wg = ceil_div(ceil_div(npix, nchunks), kBwBK) * kBwBK;
   nchunks = ceil_div(npix, pix_per_wg);
   if ((int64_t)KK * ncc * nmc > 65535 || p.groups > 65535)
@@ -1557,8 +1634,12 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
       st_ = launch_bwd_data_mfma<scalar_t>((const scalar_t*)input, wtb, (const scalar_t*)offset, (const scalar_t*)mask, \
                                            (const scalar_t*)grad_out, (float*)gi_acc, (float*)goff_acc, (float*)gmask_acc, \
                                            p, q.OCg_pad, q.ICg_pad, s);                                                \
-    if (st_ == 0) st_ = launch_bwd_weight_mfma<scalar_t>((const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,      \
-                                           (const scalar_t*)grad_out, gw_ws, p, s);                                    \
+    if (st_ == 0 && q.own)   /* the channels-last copy of the input exists */                                           \
+      st_ = launch_bwd_weight_mfma<scalar_t, true>((const scalar_t*)(ws + q.at_xt), (const scalar_t*)offset, (const scalar_t*)mask, \
+                                                   (const scalar_t*)grad_out, gw_ws, p, s);                            \
+    else if (st_ == 0)                                                                                                 \
+      st_ = launch_bwd_weight_mfma<scalar_t, false>((const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask, \
+                                                    (const scalar_t*)grad_out, gw_ws, p, s);                           \
     if (st_ == 0)                                                                                                      \
       dcn_bwd_weight_finish<scalar_t><<<dcn_grid1d((int64_t)p.OC * p.ICg * KK), dim3(256), 0, s>>>(gw_ws, (scalar_t*)grad_weight, p); \
   } while (0)
