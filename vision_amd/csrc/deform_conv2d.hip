@@ -1203,16 +1203,29 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3(const T* _
   int toff[KK];
   float lw[KK], hhm[KK], lhm[KK];
   unsigned far = 0;
+  // the 27 raw values first, every load unconditional (pixel clamped, the mask read from the offset tensor when there is none
+  // and replaced by 1 below): written per tap under `if (live)` / `if (use_mask)` the nine taps were nine dependent round
+  // trips in front of the first chunk (s_waitcnt vmcnt(0) per tap in the ISA)
+  T raw_h[KK], raw_w[KK], raw_m[KK];
+  {
+    const int64_t pixc = (int64_t)min(oy, p.oh - 1) * p.ow + min(ox, p.ow - 1);
+    const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * oplane + pixc;
+    const T* mptr = p.use_mask ? mask + ((int64_t)(b * p.ogroups + og) * KK) * oplane + pixc : optr;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      raw_h[t] = optr[(int64_t)(2 * t) * oplane];
+      raw_w[t] = optr[(int64_t)(2 * t + 1) * oplane];
+      raw_m[t] = mptr[(int64_t)t * oplane];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < KK; ++t) {
     toff[t] = 0;
     lw[t] = hhm[t] = lhm[t] = 0.f;
     if (live) {
       const int i = t / 3, j = t - 3 * i;
-      const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * oplane + (int64_t)oy * p.ow + ox;
-      const float off_h = ld(optr + (int64_t)(2 * t) * oplane), off_w = ld(optr + (int64_t)(2 * t + 1) * oplane);
-      float m = 1.f;
-      if (p.use_mask) m = ld(mask + ((int64_t)(b * p.ogroups + og) * KK + t) * oplane + (int64_t)oy * p.ow + ox);
+      const float off_h = ld(&raw_h[t]), off_w = ld(&raw_w[t]);
+      const float m = p.use_mask ? (float)ld(&raw_m[t]) : 1.f;
       const float y = (float)(oy * p.sh - p.ph) + (float)(i * p.dh) + off_h;
       const float x = (float)(ox * p.sw - p.pw) + (float)(j * p.dw) + off_w;
       if (!(y <= -1.f || (float)p.H <= y || x <= -1.f || (float)p.W <= x)) {   // else: the sample is zero (reference :99-101)
