@@ -659,6 +659,8 @@ DCN_BWD_CFGS = [
     dict(B=1, C=64, OC=32, H=40, W=40, k=(3, 3), groups=1, og=1, stride=(2, 2), pad=(1, 1), dil=(1, 1), mask=True, off_scale=0.5),  # stride 2: window too large for LDS -> global atomics
     dict(B=1, C=64, OC=32, H=8, W=8, k=(3, 3), groups=1, og=1, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True, zero_off=True),   # owner form, y = -1 / x = -1 exactly
     dict(B=2, C=128, OC=64, H=17, W=21, k=(3, 3), groups=2, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False, off_scale=4),  # owner form: two weight groups, most offsets beyond the window's reach
+    dict(B=2, C=128, OC=128, H=12, W=14, k=(3, 3), groups=128, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True),            # depthwise, channels-last route, one 64-channel pass per offset group
+    dict(B=1, C=128, OC=128, H=13, W=9, k=(3, 2), groups=128, og=1, stride=(2, 1), pad=(1, 0), dil=(1, 2), mask=False),            # depthwise, two passes, strides / dilation, no mask
 ]
 
 

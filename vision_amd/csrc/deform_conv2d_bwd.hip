@@ -1357,6 +1357,97 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_direct(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------ depthwise (groups = C = OC), channels-last
+// The direct kernels above take 5.9 ms at config 4 with groups = 256: one thread per (pixel, tap) walks 256 channels and every
+// one of its 250 M grad_input atomics lands in a different plane — a 64-byte granule each at the atomic unit.  Here lanes are
+// CHANNELS: a wave owns (image, offset group, tap, run of pixels), reads the channels-last copies of the input and of grad_out
+// (256 contiguous bytes per access), adds to channels-last grad_input sums (a wave atomic = 4 granules instead of 64), keeps the
+// weight-gradient partials of its 64 x NPASS channels in registers over the run (one atomic per channel at the end), and owns
+// its grad_offset / grad_mask elements: the channel sum is a wave reduction, stored plainly.
+template <typename T, int NPASS>
+__global__ __launch_bounds__(256) void dcn_bwd_dw_cl(const T* __restrict__ xt, const T* __restrict__ got, const T* __restrict__ weight,
+                                                     const T* __restrict__ offset, const T* __restrict__ mask, float* git,
+                                                     float* __restrict__ goff, float* __restrict__ gmask, float* gw, DcnParams p,
+                                                     int pix_per_wave, int nchunk, int64_t nitems) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (item >= nitems) return;
+  const int KK = p.kh * p.kw;
+  const int chunk = (int)(item % nchunk);
+  const int tap = (int)((item / nchunk) % KK);
+  const int og = (int)((item / ((int64_t)nchunk * KK)) % p.ogroups);
+  const int b = (int)(item / ((int64_t)nchunk * KK * p.ogroups));
+  const int oplane = p.oh * p.ow, HW = p.H * p.W;
+  const int n0 = chunk * pix_per_wave, n1 = min(n0 + pix_per_wave, oplane);
+  const int cf = og * p.cpog + lane;   // this lane's channel of pass 0
+  const int ti = tap / p.kw, tj = tap - ti * p.kw;
+
+  float wv[NPASS], gwacc[NPASS];
+#pragma unroll
+  for (int q = 0; q < NPASS; ++q) {
+    wv[q] = ld(weight + (int64_t)(cf + 64 * q) * KK + tap);
+    gwacc[q] = 0.f;
+  }
+  const T* xb = xt + (int64_t)b * HW * p.C;
+  float* gb = git + (int64_t)b * HW * p.C;
+  TapRaw<T> raw = tap_raw_identity<T>();
+  {
+    const int oy = n0 / p.ow;
+    load_tap_raw_u<T>(raw, p, offset, mask, b, og, tap, oy, n0 - oy * p.ow);
+  }
+  for (int n = n0; n < n1; ++n) {
+    const int oy = n / p.ow, ox = n - oy * p.ow;
+    BwdTap<float> tp;
+    {
+      const float y = (float)(oy * p.sh - p.ph) + (float)(ti * p.dh) + (float)ld(&raw.off_h);
+      const float x = (float)(ox * p.sw - p.pw) + (float)(tj * p.dw) + (float)ld(&raw.off_w);
+      make_bwd_tap<float>(tp, p.H, p.W, y, x, raw_mask<T>(p, raw));
+    }
+    {   // the next pixel's raw values travel under this pixel's work (the last pixel re-reads itself)
+      const int nn = min(n + 1, n1 - 1), noy = nn / p.ow;
+      load_tap_raw_u<T>(raw, p, offset, mask, b, og, tap, noy, nn - noy * p.ow);
+    }
+    const T* gop = got + ((int64_t)b * oplane + n) * p.C;
+    CoordSums<float> s{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int c = cf + 64 * q;
+      const float go = ld(gop + c);
+      const float v = wv[q] * go;
+      const float x0 = ld(xb + (int64_t)tp.o[0] * p.C + c), x1 = ld(xb + (int64_t)tp.o[1] * p.C + c);
+      const float x2 = ld(xb + (int64_t)tp.o[2] * p.C + c), x3 = ld(xb + (int64_t)tp.o[3] * p.C + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (tp.bw[k] != 0.f) unsafeAtomicAdd(gb + (int64_t)tp.o[k] * p.C + c, tp.m * tp.bw[k] * v);   // (wave-uniform condition)
+      accumulate_coord<float>(s, tp, v, x0, x1, x2, x3, p.use_mask != 0);
+      gwacc[q] += go * (tp.m * (tp.bw[0] * x0 + tp.bw[1] * x1 + tp.bw[2] * x2 + tp.bw[3] * x3));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      s.gy += __shfl_xor(s.gy, d);
+      s.gx += __shfl_xor(s.gx, d);
+      s.gm += __shfl_xor(s.gm, d);
+    }
+    if (lane == 0) {
+      float* o = goff + ((int64_t)(b * p.ogroups + og) * 2 * KK + 2 * tap) * oplane + n;
+      o[0] = s.gy;
+      o[oplane] = s.gx;
+      if (p.use_mask) gmask[((int64_t)(b * p.ogroups + og) * KK + tap) * oplane + n] = s.gm;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NPASS; ++q) unsafeAtomicAdd(gw + (int64_t)(cf + 64 * q) * KK + tap, gwacc[q]);
+}
+
+inline int bwd_dw_passes(const DcnParams& p, tvmi_dtype dt) {
+  if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16)) return 0;
+  if (p.ICg != 1 || p.OCg != 1 || p.C != p.OC || p.cpog % 64) return 0;
+  const int n = p.cpog / 64;
+  if (!(n == 1 || n == 2 || n == 4)) return 0;
+  if ((int64_t)p.H * p.W * p.C >= (1ll << 31) || (int64_t)p.oh * p.ow * p.C >= (1ll << 31)) return 0;
+  return n;
+}
+
 // the matrix-core kernels: fp32 / fp16 / bf16 tensors with a real contraction on both sides, one offset group per 32-channel
 // accumulator block
 inline bool bwd_mfma_shape(const DcnParams& p, tvmi_dtype dt) {
@@ -1376,8 +1467,9 @@ inline bool bwd_own_shape(const DcnParams& p, tvmi_dtype dt) {
 
 struct BwdPlan {
   bool mfma, wide, own;     // wide: 16-bit tensors (sums live in fp32 buffers of the workspace); own: channels-last copies
+  int dw;                   // depthwise channels-last route: 64-channel passes per offset group (0 = not taken)
   int OCg_pad, ICg_pad;
-  size_t at_wtb, at_gw, at_gi, at_goff, at_gmask, at_xt, at_git, bytes;
+  size_t at_wtb, at_gw, at_gi, at_goff, at_gmask, at_xt, at_git, at_got, bytes;
 };
 inline BwdPlan bwd_plan(const DcnParams& p, tvmi_dtype dt) {
   BwdPlan q{};
@@ -1410,6 +1502,19 @@ inline BwdPlan bwd_plan(const DcnParams& p, tvmi_dtype dt) {
     at += dcn_align256(n * (dt == TVMI_F32 ? 4 : 2));
     q.at_git = at;
     at += dcn_align256(n * sizeof(float));
+  }
+  const int dw_passes = bwd_dw_passes(p, dt);
+  q.dw = g_bwd_owner.load(std::memory_order_relaxed) ? dw_passes : 0;
+  if (dw_passes) {   // (never together with the matrix-core shapes: ICg = 1)
+    const size_t n = (size_t)p.B * p.C * p.H * p.W, no = (size_t)p.B * p.OC * p.oh * p.ow, esz = dt == TVMI_F32 ? 4 : 2;
+    q.at_xt = at;
+    at += dcn_align256(n * esz);
+    q.at_got = at;
+    at += dcn_align256(no * esz);
+    q.at_git = at;
+    at += dcn_align256(n * sizeof(float));
+    q.at_gw = at;
+    at += dcn_align256((size_t)p.OC * KK * sizeof(float));
   }
   q.bytes = at;
   return q;
@@ -1608,8 +1713,9 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
   void* goff_acc = q.wide ? (void*)(ws + q.at_goff) : grad_offset;
   void* gmask_acc = q.wide ? (void*)(ws + q.at_gmask) : grad_mask;
   const size_t asz = q.wide ? 4 : esz;
-  if (q.own) TVMI_HIP_OK(hipMemsetAsync(ws + q.at_git, 0, (size_t)n_gi * sizeof(float), s));   // channels-last sums, transposed at the end
+  if (q.own || q.dw) TVMI_HIP_OK(hipMemsetAsync(ws + q.at_git, 0, (size_t)n_gi * sizeof(float), s));   // channels-last sums, transposed at the end
   else TVMI_HIP_OK(hipMemsetAsync(gi_acc, 0, (size_t)n_gi * asz, s));   // the scatter accumulates
+  if (q.dw) TVMI_HIP_OK(hipMemsetAsync(q.wide ? (void*)(ws + q.at_gw) : grad_weight, 0, (size_t)p.OC * KK * sizeof(float), s));
   if (q.mfma) {                                                   // ... and so do the per-wave partial sums of the matrix-core route
     TVMI_HIP_OK(hipMemsetAsync(goff_acc, 0, (size_t)n_goff * asz, s));
     if (use_mask) TVMI_HIP_OK(hipMemsetAsync(gmask_acc, 0, (size_t)n_gmask * asz, s));
@@ -1617,7 +1723,37 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
   }
 #undef TVMI_HIP_OK
 
-  if (q.mfma) {
+  if (q.dw) {
+    const int HW = p.H * p.W, OHW = p.oh * p.ow;
+    const int ppw = 32;   // pixels per wave: B * offset groups * taps * ceil(oh ow / 32) waves
+    const int nchunk = (int)ceil_div(OHW, ppw);
+    const int64_t nitems = (int64_t)p.B * p.ogroups * KK * nchunk;
+    TVMI_CHECK_ARG(ceil_div(nitems, 4) < (1ll << 31), "deform_conv2d backward: too many work items");
+    float* gw_acc = q.wide ? reinterpret_cast<float*>(ws + q.at_gw) : static_cast<float*>(grad_weight);
+#define TVMI_BWD_DW(scalar_t, NP)                                                                                       \
+  dcn_bwd_dw_cl<scalar_t, NP><<<dim3((unsigned)ceil_div(nitems, 4)), dim3(256), 0, s>>>(                                 \
+      (const scalar_t*)(ws + q.at_xt), (const scalar_t*)(ws + q.at_got), (const scalar_t*)weight, (const scalar_t*)offset, \
+      (const scalar_t*)mask, (float*)(ws + q.at_git), (float*)goff_acc, (float*)gmask_acc, gw_acc, p, ppw, nchunk, nitems)
+#define TVMI_BWD_DW_T(scalar_t)                                                                                         \
+  do {                                                                                                                 \
+    dcn_transpose_planes<scalar_t, scalar_t><<<dim3((unsigned)ceil_div(HW, 64), (unsigned)ceil_div(p.C, 64), (unsigned)p.B), dim3(256), 0, s>>>( \
+        (const scalar_t*)input, (scalar_t*)(ws + q.at_xt), p.C, HW);                                                    \
+    dcn_transpose_planes<scalar_t, scalar_t><<<dim3((unsigned)ceil_div(OHW, 64), (unsigned)ceil_div(p.OC, 64), (unsigned)p.B), dim3(256), 0, s>>>( \
+        (const scalar_t*)grad_out, (scalar_t*)(ws + q.at_got), p.OC, OHW);                                              \
+    if (q.dw == 1) TVMI_BWD_DW(scalar_t, 1);                                                                            \
+    else if (q.dw == 2) TVMI_BWD_DW(scalar_t, 2);                                                                       \
+    else TVMI_BWD_DW(scalar_t, 4);                                                                                      \
+    dcn_transpose_planes<float, scalar_t><<<dim3((unsigned)ceil_div(p.C, 64), (unsigned)ceil_div(HW, 64), (unsigned)p.B), dim3(256), 0, s>>>( \
+        (const float*)(ws + q.at_git), (scalar_t*)grad_input, HW, p.C);                                                 \
+    if (q.wide)                                                                                                        \
+      dcn_round_from_f32<scalar_t><<<dcn_grid1d((int64_t)p.OC * KK), dim3(256), 0, s>>>(gw_acc, (scalar_t*)grad_weight, (int64_t)p.OC * KK); \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_BWD_DW_T(float);
+    else if (dt == TVMI_F16) TVMI_BWD_DW_T(__half);
+    else TVMI_BWD_DW_T(__hip_bfloat16);
+#undef TVMI_BWD_DW_T
+#undef TVMI_BWD_DW
+  } else if (q.mfma) {
     float* wtb = reinterpret_cast<float*>(ws + q.at_wtb);
     float* gw_ws = reinterpret_cast<float*>(ws + q.at_gw);
     const int64_t wtotal = (int64_t)p.groups * KK * q.OCg_pad * q.ICg_pad;
@@ -1670,7 +1806,7 @@ extern "C" int tvmi_deform_conv2d_backward(const void* grad_out, const void* inp
   if (q.wide) {
 #define TVMI_BWD_ROUND(scalar_t)                                                                                        \
   do {                                                                                                                 \
-    if (!q.own)                                                                                                        \
+    if (!q.own && !q.dw)                                                                                               \
       dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_gi), dim3(256), 0, s>>>((const float*)gi_acc, (scalar_t*)grad_input, n_gi); \
     dcn_round_from_f32<scalar_t><<<dcn_grid1d(n_goff), dim3(256), 0, s>>>((const float*)goff_acc, (scalar_t*)grad_offset, n_goff); \
     if (use_mask)                                                                                                      \
