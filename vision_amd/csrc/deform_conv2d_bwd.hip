@@ -659,7 +659,7 @@ inline size_t win_lds_bytes(const WinGeom& w) {
 //     (30 exchanges per epilogue instead of 3 x 16 x 5), one atomic per (tap, chunk half, pixel, component).
 constexpr int kOwnTH = 8, kOwnTW = 16, kOwnR = 3, kOwnCH = 64, kOwnKB = 16, kOwnTG = 5;
 constexpr int kOwnAP = kOwnTH * kOwnTW + 32;   // A slab row pitch in floats: row k + 1 starts 32 banks further
-constexpr int kOwnTabDw = 12;                  // dwords per (pixel, tap) table entry
+constexpr int kOwnTabDw = 16;                  // dwords per (pixel, tap) table entry
 
 inline WinGeom own_geom(const DcnParams& p) {
   WinGeom w{};
@@ -789,7 +789,8 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
   auto fetch_raw = [&](int tap, int og) {
     load_tap_raw_u<T>(raw, p, offset, mask, b, og, tap, min(t_oy, p.oh - 1), min(t_ox, p.ow - 1));
   };
-  // table entry of (pixel l31, tap): {window offsets x4 (float index of channel 0), image positions x4, dy, dx, m, flags}
+  // table entry of (pixel l31, tap): {window offsets x4 (float index of channel 0), image positions x4, dy, dx, m, flags,
+  // scatter weights x4}
   // flags: bits 0-3 corner validity of get_coordinate_weight, 4-7 corner added in the window, 8-11 corner added with global
   // atomics (weighted but beyond the reach), 12 location inside (-1, H) x (-1, W)
   auto build_table = [&](int tap) {
@@ -803,6 +804,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
     const bool inside = !(y <= -1.f || (float)p.H <= y || x <= -1.f || (float)p.W <= x);
     int flags = inside ? (1 << 12) : 0;
     int wo[4];
+    float gw_[4];   // what the scatter multiplies the accumulator with: mask x bilinear weight, 0 for a corner it does not add
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int cy = tp.o[k] / p.W, cx = tp.o[k] - cy * p.W;
@@ -813,6 +815,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
       if (weighted && in_window) flags |= 16 << k;
       if (weighted && !in_window) flags |= 256 << k;
       wo[k] = ((weighted && in_window) ? wy * wg.ww + wx : wg.wsz) * kOwnCH;
+      gw_[k] = (weighted && in_window) ? tp.m * tp.bw[k] : 0.f;
     }
     far_any = __any(t_ok && (flags & 0xF00));
     if (kq == 0) {
@@ -820,6 +823,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
       e[0] = make_int4(wo[0], wo[1], wo[2], wo[3]);
       e[1] = make_int4(tp.o[0], tp.o[1], tp.o[2], tp.o[3]);
       e[2] = make_int4(__float_as_int(tp.dy), __float_as_int(tp.dx), __float_as_int(t_ok ? tp.m : 0.f), t_ok ? flags : 0);
+      e[3] = make_int4(__float_as_int(gw_[0]), __float_as_int(gw_[1]), __float_as_int(gw_[2]), __float_as_int(gw_[3]));
     }
   };
   // (a wave writes its table and reads it with other lanes: the LDS is in-order per wave, the fences keep the compiler's order)
@@ -943,26 +947,22 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
   // table entry of the NEXT register is read before the window writes of the current one (the compiler cannot know that
   // table and window never alias; written in this order it need not).
   auto scatter = [&](const LaneView& lv, const f32x16& a) {
-    int4 wo = entry_of(lv, 0)[0], e2 = entry_of(lv, 0)[2];
+    // (the phase is bound by instruction issue — two waves of eight are at work — so the weights come ready from the table:
+    // ~16 vector instructions per register instead of ~40 when they were rebuilt from dy, dx and the flags)
+    int4 wo = entry_of(lv, 0)[0], gq = entry_of(lv, 0)[3];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int4 wo_c = wo, e2_c = e2;
+      const int4 wo_c = wo, g_c = gq;
       if (r + 1 < 16) {
         wo = entry_of(lv, r + 1)[0];
-        e2 = entry_of(lv, r + 1)[2];
+        gq = entry_of(lv, r + 1)[3];
       }
-      const float dy = __int_as_float(e2_c.x), dx = __int_as_float(e2_c.y), m = __int_as_float(e2_c.z);
-      const int fl = e2_c.w;
-      const bool inside = (fl >> 12) & 1;
-      const float hh = 1.f - dy, hw = 1.f - dx;
-      const float g0 = m * ((inside && (fl & 1)) ? hh * hw : 0.f), g1 = m * ((inside && (fl & 2)) ? hh * dx : 0.f);
-      const float g2 = m * ((inside && (fl & 4)) ? dy * hw : 0.f), g3 = m * ((inside && (fl & 8)) ? dy * dx : 0.f);
       const float v = a[r];
       const float t0 = lv.wl[wo_c.x], t1 = lv.wl[wo_c.y], t2 = lv.wl[wo_c.z], t3 = lv.wl[wo_c.w];
-      lv.wl[wo_c.x] = t0 + ((fl & 16) ? g0 * v : 0.f);
-      lv.wl[wo_c.y] = t1 + ((fl & 32) ? g1 * v : 0.f);
-      lv.wl[wo_c.z] = t2 + ((fl & 64) ? g2 * v : 0.f);
-      lv.wl[wo_c.w] = t3 + ((fl & 128) ? g3 * v : 0.f);
+      lv.wl[wo_c.x] = t0 + __int_as_float(g_c.x) * v;
+      lv.wl[wo_c.y] = t1 + __int_as_float(g_c.y) * v;
+      lv.wl[wo_c.z] = t2 + __int_as_float(g_c.z) * v;
+      lv.wl[wo_c.w] = t3 + __int_as_float(g_c.w) * v;
     }
   };
   // a weighted corner beyond the reach of the window: rare; channels-last global atomics, one pixel (register) at a time
