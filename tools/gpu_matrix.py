@@ -143,6 +143,26 @@ if "c4" in sections:
         for dt in (torch.bfloat16, torch.float16):
             t = tm(lambda: vision_amd.deform_conv2d(x.to(dt), off.to(dt), w.to(dt), bias.to(dt), padding=1), n=10)
             put(f"c4_deform_conv2d_g{groups}_{str(dt)[6:]}", t, TFLOPs=round(fl / t / 1e9, 2))
+        # backward: all five gradients of torchvision::_deform_conv2d_backward (mask in use), the shipped route and the
+        # measurement-only ones of DESIGN 4.3
+        go = torch.randn(B, 256, H, W, generator=g).to(dev)
+        for dt in (torch.float32, torch.bfloat16):
+            ts = [v.to(dt) for v in (go, x, w, off, m, bias)]
+            routes = [("", {})]
+            if groups == 1:
+                routes += [("_window_lds_atomics", {"dcn.bwd_owner": 0}), ("_global_atomics", {"dcn.bwd_owner": 0, "dcn.bwd_window": 0})]
+            else:
+                routes += [("_direct", {"dcn.bwd_owner": 0})]
+            routes += [("_library_gemm_r03", {"dcn.bwd_blas": 1})]
+            for tag, opts in routes:
+                for k, v in opts.items():
+                    torch.ops.tvmi.set_option(k, v)
+                try:
+                    t = tm(lambda: tv._deform_conv2d_backward(*ts, 1, 1, 1, 1, 1, 1, groups, 1, True), n=5, batches=2)
+                    put(f"c4_deform_conv2d_backward_g{groups}_{str(dt)[6:]}{tag}", t, TFLOPs=round(2 * fl / t / 1e9, 2))
+                finally:
+                    for k in opts:
+                        torch.ops.tvmi.set_option(k, 1 if k != "dcn.bwd_blas" else 0)
 
 if "resize" in sections:
     g = torch.Generator().manual_seed(0)

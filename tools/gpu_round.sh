@@ -24,6 +24,8 @@ done
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_bwd7 -o k -- python $ROOTDIR/tools/run_kernel.py bwd7 20 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_bwd14 -o k -- python $ROOTDIR/tools/run_kernel.py bwd14 20 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_nms100k -o k -- python $ROOTDIR/tools/run_kernel.py nms100k 10 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_dcn_bwd -o k -- python $ROOTDIR/tools/run_kernel.py dcn_bwd 10 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_dcn_bwd_dw -o k -- python $ROOTDIR/tools/run_kernel.py dcn_bwd_dw 10 > /dev/null 2>&1
 cd $ROOTDIR
 # probe binaries are not tracked: build the calibration probe here if it did not travel with the snapshot
 [ -x $ROOTDIR/tools/probe/fetch_calib ] || hipcc --offload-arch=gfx950 -O3 -o $ROOTDIR/tools/probe/fetch_calib $ROOTDIR/tools/probe/fetch_calib.hip > /dev/null 2>&1

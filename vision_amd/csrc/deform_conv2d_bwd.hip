@@ -1141,12 +1141,23 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
   // Every load of a slab is UNCONDITIONAL (rows clamped to a legal one, values kept in the tensor's type) and what must be
   // zero is zeroed at commit: a `cond ? load : 0` or a 16-bit conversion is a USE of the loaded value, and the wait it needs
   // lands in front of the MFMAs of the current slab — load latency and matrix work in series (measured: 0.69 ms).
-  T ga[AV];           // grad_out values of the next slab
-  bool ga_live = false;
-  T xb[BV][4];        // corner values of the next slab
-  float wgt[BV][4];   // their bilinear weights, zero for rows / pixels that do not exist
-  float wmask[BV];    // the modulation mask of the row's offset group (multiplies the sum, as in the forward: sample_tap)
-  auto issue = [&]() {
+  // TWO slabs of loads are in flight (register stages st0 / st1, the loop unrolled by two so that every stage index is static):
+  // one 8-wave workgroup is resident per CU whatever the register count below 256, a slab is 32 MFMAs per wave (~1.7 us of
+  // matrix pipe per SIMD) and a gather round trip under load is longer than that.
+  struct Stage {
+    T ga[AV];           // grad_out values of a coming slab
+    bool ga_live;
+    T xb[BV][4];        // its corner values
+    float wgt[BV][4];   // their bilinear weights, zero for rows / pixels that do not exist
+    float wmask[BV];    // the modulation mask of the row's offset group (multiplies the sum, as in the forward: sample_tap)
+  };
+  Stage st0, st1;
+  auto issue = [&](Stage& st) {
+    T(&ga)[AV] = st.ga;
+    bool& ga_live = st.ga_live;
+    T(&xb)[BV][4] = st.xb;
+    float(&wgt)[BV][4] = st.wgt;
+    float(&wmask)[BV] = st.wmask;
     const bool ok = pn < n_end;
     const int64_t pin = (int64_t)poy * p.ow + pox;
     ga_live = ok;
@@ -1216,7 +1227,12 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
     advance();
     fetch_raw();
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, const Stage& st) {
+    const T(&ga)[AV] = st.ga;
+    const bool ga_live = st.ga_live;
+    const T(&xb)[BV][4] = st.xb;
+    const float(&wgt)[BV][4] = st.wgt;
+    const float(&wmask)[BV] = st.wmask;
 #pragma unroll
     for (int e = 0; e < AV; ++e)
       As[buf][rsub + e * RSUB][pk] = (ga_live && o0 + rsub + e * RSUB < p.OCg) ? (float)ld(&ga[e]) : 0.f;
@@ -1231,13 +1247,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
     }
   };
 
-  fetch_raw();
-  issue();
-  int buf = 0;
-  for (int s = 0; s < nslab; ++s) {
-    commit(buf);
-    __syncthreads();
-    if (s + 1 < nslab) issue();
+  auto contract = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < kBwBK; kk += 2) {
       float a[MI], b[NI];
@@ -1250,7 +1260,22 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
-    buf ^= 1;
+  };
+  fetch_raw();
+  issue(st0);
+  if (nslab > 1) issue(st1);
+#pragma unroll 1
+  for (int s = 0; s < nslab; s += 2) {
+    commit(0, st0);
+    __syncthreads();
+    if (s + 2 < nslab) issue(st0);
+    contract(0);
+    if (s + 1 < nslab) {
+      commit(1, st1);
+      __syncthreads();
+      if (s + 3 < nslab) issue(st1);
+      contract(1);
+    }
   }
 
   // D[row][col]: col = lane & 31 = in channel (adjacent lanes, adjacent addresses), row = out channel
