@@ -9,7 +9,10 @@ for r in csv.DictReader(open(path)):
     if r["Kind"] != "KERNEL_DISPATCH": continue
     wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
     grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-    key = (r["Kernel_Name"][:110], grid // max(wg, 1), wg, int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]), int(r["LDS_Block_Size"]))
+    # rocprofv3 reports the register count of gfx950 kernels HALVED (dcn_bwd_data_own: 251 VGPRs in the ISA, 128 in the trace) and
+    # LDS_Block_Size without the dynamic part (0 for kernels that take all of theirs at launch): resident counts of such kernels
+    # are upper bounds
+    key = (r["Kernel_Name"][:110], grid // max(wg, 1), wg, 2 * (int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"])), int(r["LDS_Block_Size"]))
     d = rows.setdefault(key, [0, 0.0])
     d[0] += 1; d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 print(f"{'kernel':<72} {'WGs':>7} {'thr':>4} {'vgpr':>4} {'lds':>6} {'res/CU':>6} {'rounds':>7} {'us':>8} {'calls':>5}")
