@@ -332,10 +332,12 @@ int tvmi_deformable_col2im_coord(const void* columns, const void* input, const v
  * (ignored unless use_mask) / grad_bias (may be NULL) have the shapes of input / weight / offset / mask / [OC] and are FULLY
  * overwritten.  fp32 / fp16 / bf16 problems with at least 16 channels per weight group on both sides (and whole 32-channel
  * blocks per offset group) contract on the fp32 matrix cores inside two fused kernels — sums in fp32, 16-bit results rounded
- * once; everything else (fp64, depthwise, tiny channel counts) runs direct kernels with the same fusion.  grad_input is
- * accumulated with float atomics like the reference's (not bit-reproducible run to run).  `workspace`:
+ * once; depthwise problems (groups = C = OC, 64 / 128 / 256 channels per offset group) take a channels-last kernel, everything
+ * else (fp64, tiny channel counts) direct kernels with the same fusion.  grad_input is accumulated with float adds whose order
+ * is not fixed, like the reference's (not bit-reproducible run to run).  `workspace`:
  * tvmi_deform_conv2d_backward_workspace_bytes (re-laid-out weights, the [tap][oc][ic] weight-gradient sums, fp32 sums of
- * 16-bit problems; 0 for fp64). */
+ * 16-bit problems, channels-last copies of input / grad_out and channels-last grad_input sums where a kernel wants them; 0 for
+ * fp64). */
 size_t tvmi_deform_conv2d_backward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC,
                                                    int64_t kh, int64_t kw, int64_t oh, int64_t ow, int64_t groups,
                                                    int64_t offset_groups);
