@@ -403,25 +403,37 @@ __device__ __forceinline__ void owner_item(OwnShared<PH, PW>& sh, int item, cons
   for (int base = rs; base < re; base += kScanChunk) {
     // ---- scan: wave w looks at descriptors [base + 256 w, base + 256 (w + 1)), 64 at a time, and appends
     // the hits to its own list segment (ascending index)
+    // Both tables are read UNCONDITIONALLY (positions past the range clamped to its last descriptor, the window of a RoI that
+    // does not hit read anyway — 16 KB per image, L2-resident) and all four 64-descriptor groups are in flight together: written
+    // as `if (pos < re) load scan; if (hit) load win` per group, the ISA was eight dependent round trips — load, s_waitcnt
+    // vmcnt(0), conditional load, s_waitcnt vmcnt(0), four times — in front of every workgroup's first FMA.
+    constexpr int NG = kScanChunk / 256;
     int cnt = 0;
+    int kk[NG];
+    int2 dsc[NG];
+    int4 wnd[NG];
 #pragma unroll
-    for (int j = 0; j < kScanChunk / 256; ++j) {
+    for (int j = 0; j < NG; ++j) {
+      const int pos = min(base + wave * (kScanChunk / 4) + j * 64 + lane, re - 1);
+      kk[j] = klist ? klist[pos] : pos;
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) dsc[j] = ws.scan[kk[j]];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) wnd[j] = ws.win[kk[j]];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
       const int pos = base + wave * (kScanChunk / 4) + j * 64 + lane;
-      const int k = (klist && pos < re) ? klist[pos] : pos;
-      bool hit = false;
-      if (pos < re) {
-        const int2 d = ws.scan[k];
-        const int r = d.y;
-        hit = d.x == key && ty >= (r & 255) && ty <= ((r >> 8) & 255) && tx >= ((r >> 16) & 255) && tx <= ((r >> 24) & 255);
-      }
+      const int r = dsc[j].y;
+      const bool hit = pos < re && dsc[j].x == key && ty >= (r & 255) && ty <= ((r >> 8) & 255) && tx >= ((r >> 16) & 255) &&
+                       tx <= ((r >> 24) & 255);
       const unsigned long long b = __ballot(hit);
       if (hit) {
-        const int4 wi = ws.win[k];
         OwnEntry e;
-        e.k = k;
-        e.y0 = wi.x;
-        e.x0 = wi.y;
-        e.wh = wi.z;
+        e.k = kk[j];
+        e.y0 = wnd[j].x;
+        e.x0 = wnd[j].y;
+        e.wh = wnd[j].z;
         sh.list[wave][cnt + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = e;
       }
       cnt += __builtin_popcountll(b);
@@ -459,39 +471,50 @@ __device__ __forceinline__ void owner_item(OwnShared<PH, PW>& sh, int item, cons
           wh = TVMI_UNIFORM(en.wh);
         };
         U4u gin[NLD];   // raw 16-byte pieces (4 floats, or 8 16-bit elements; C is even on the 16-bit path: dword-aligned runs)
+        const GT* run_held = grad;   // the run `gin` was loaded from (stage_run patches the straddling piece from it)
+        // EVERY lane loads a whole 16-byte piece, unconditionally: its own when that lies inside the run, piece 0 of the run
+        // otherwise (zeroed / patched in stage_run, where the values are used anyway).  Written as `if (inside) v = load; else
+        // if (straddles) {...}` the loaded value was one input of a phi, and the copy that resolves it put an s_waitcnt
+        // vmcnt(0) right behind the load (ISA) — the prefetch of entry e + 1 never ran under the FMAs of entry e.
         auto issue_run = [&](int k) {
-          const GT* run = grad + (int64_t)k * ns + (int64_t)ch0w * cs;
+          const GT* run = grad + (int64_t)k * ns + (int64_t)(nvalid > 0 ? ch0w : 0) * cs;
+          run_held = run;
 #pragma unroll
           for (int u = 0; u < NLD; ++u) {
             const int f0 = EPP * (u * 64 + lane);  // first element of this lane's piece
-            U4u v{0u, 0u, 0u, 0u};
-            if (f0 + EPP <= nvalid) {
-              v = *reinterpret_cast<const U4u*>(run + f0);
-            } else if (f0 < nvalid) {  // the piece that straddles the end of the run (never read past the tensor)
-              if constexpr (std::is_same<GT, float>::value) {
-                v.x = __float_as_uint(run[f0]);
-                if (f0 + 1 < nvalid) v.y = __float_as_uint(run[f0 + 1]);
-                if (f0 + 2 < nvalid) v.z = __float_as_uint(run[f0 + 2]);
-              } else {
-                const unsigned short* r16 = reinterpret_cast<const unsigned short*>(run);
-                unsigned short e[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) e[q] = f0 + q < nvalid ? r16[f0 + q] : (unsigned short)0;
-                v.x = e[0] | ((unsigned)e[1] << 16);
-                v.y = e[2] | ((unsigned)e[3] << 16);
-                v.z = e[4] | ((unsigned)e[5] << 16);
-                v.w = e[6] | ((unsigned)e[7] << 16);
-              }
-            }
-            gin[u] = v;
+            gin[u] = *reinterpret_cast<const U4u*>(run + (f0 + EPP <= nvalid ? f0 : 0));
           }
+        };
+        auto straddling_piece = [&](int f0) {   // the piece that straddles the end of the run (never read past the tensor); rare
+          const GT* run = run_held;
+          U4u v{0u, 0u, 0u, 0u};
+          if constexpr (std::is_same<GT, float>::value) {
+            v.x = __float_as_uint(run[f0]);
+            if (f0 + 1 < nvalid) v.y = __float_as_uint(run[f0 + 1]);
+            if (f0 + 2 < nvalid) v.z = __float_as_uint(run[f0 + 2]);
+          } else {
+            const unsigned short* r16 = reinterpret_cast<const unsigned short*>(run);
+            unsigned short e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = f0 + q < nvalid ? r16[f0 + q] : (unsigned short)0;
+            v.x = e[0] | ((unsigned)e[1] << 16);
+            v.y = e[2] | ((unsigned)e[3] << 16);
+            v.z = e[4] | ((unsigned)e[5] << 16);
+            v.w = e[6] | ((unsigned)e[7] << 16);
+          }
+          return v;
         };
         auto stage_run = [&](float* gb) {   // registers -> this wave's LDS run, as fp32
 #pragma unroll
           for (int u = 0; u < NLD; ++u) {
             const int piece = u * 64 + lane;
             if (piece < NPIECE) {
-              const U4u v = gin[u];
+              const int f0 = EPP * piece;
+              U4u v = gin[u];
+              if (f0 + EPP > nvalid) {   // not a whole piece of the run: nothing, or the straddling one
+                v = U4u{0u, 0u, 0u, 0u};
+                if ((nvalid % EPP) != 0 && f0 < nvalid) v = straddling_piece(f0);   // (first test wave-uniform, false for whole 8-channel runs)
+              }
               if constexpr (std::is_same<GT, float>::value) {
                 *reinterpret_cast<float4*>(gb + 4 * piece) =
                     make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -517,11 +540,6 @@ __device__ __forceinline__ void owner_item(OwnShared<PH, PW>& sh, int item, cons
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          int kn = 0, y0n = 0, x0n = 0, whn = 0;
-          if (e + 1 < total) {
-            entry_at(e + 1, kn, y0n, x0n, whn);
-            issue_run(kn);
-          }
           // -- coefficient rows (scalar loads), AxD columns (vector loads), grads of this lane's channel (LDS)
           const float* arow = ws.ayt + ((int64_t)k * kAyRows + (ybase - y0 + kTile)) * PH;
           float cfa[RB * PH], cfb[RB * PH];
@@ -532,6 +550,13 @@ __device__ __forceinline__ void owner_item(OwnShared<PH, PW>& sh, int item, cons
           const float* xt = ws.axt + (int64_t)k * PW * kAyRows + (xl - x0 + kTile);
 #pragma unroll
           for (int pw = 0; pw < PW; ++pw) axd[pw] = ld2u(xt + pw * kAyRows);
+          // the next entry's grads AFTER this entry's AxD loads: vector loads return in order, so the wait for AxD (needed at
+          // once) would otherwise also be a wait for the prefetch issued in front of it
+          // ... and UNCONDITIONALLY (the last entry re-loads itself): behind an `if (e + 1 < total)` the compiler's counted waits
+          // must assume the loads were not issued, and the last of them becomes a vmcnt(0) that includes the prefetch
+          int kn = 0, y0n = 0, x0n = 0, whn = 0;
+          entry_at(min(e + 1, total - 1), kn, y0n, x0n, whn);
+          issue_run(kn);
           // grads row by row out of LDS, one row ahead of the FMAs that consume it (14 VGPRs instead of 49)
           const float* gch = gb + cslot * (PH * PW);
           v2f t[PH];
