@@ -1259,24 +1259,47 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3(const T* _
     }
   }
   const int nchunks = (c_end - c_begin + g.CB - 1) / g.CB;
-  float stage[kDwMaxStage];
+  // Round 4, from the ISA: (1) the staging loads were conditional (`stage = 0; if (inside) stage = load`), (2) the 16-bit weight
+  // vector of a channel was loaded inside the channel loop — its wait is a wait for the whole prefetch issued in front of it —
+  // and (3) the output stores of a chunk sat between the prefetch and the s_waitcnt vmcnt(0) of `park` (stores count in vmcnt
+  // on this ISA: every chunk waited for its own write acknowledgements).  Now every load is unconditional (clamped address,
+  // zeroed at park), the weight vectors of the NEXT chunk travel with its window, and a chunk's results stay in registers
+  // until its successor is parked.
+  constexpr int kCBMax = 8;   // (depthwise_geom caps CB at 8)
+  T stage[kDwMaxStage];
+  float wv_cur[kCBMax], wv_nxt[kCBMax];
+#pragma unroll
+  for (int cb = 0; cb < kCBMax; ++cb) wv_cur[cb] = wv_nxt[cb] = 0.f;
   auto fetch = [&](int chunk) {
     const int c0 = c_begin + chunk * g.CB;
     const T* src = input + ((int64_t)b * p.C + c0) * plane;
     const int lim = (c_end - c0) * (int)plane;   // channels past the range are not touched
 #pragma unroll
     for (int i = 0; i < kDwMaxStage; ++i) {
-      stage[i] = 0.f;
-      if (i < g.nstage && gsrc[i] >= 0 && gsrc[i] < lim) stage[i] = ld(src + gsrc[i]);
+      const int o = (gsrc[i] >= 0 && gsrc[i] < lim) ? gsrc[i] : 0;   // (element 0 of the chunk's first plane: always legal)
+      stage[i] = src[o];
+    }
+    if constexpr (!std::is_same<T, float>::value) {
+      // 16-bit types have no scalar load: ONE vector load per channel (lane t = weight t, lane 9 = bias), readlane broadcasts
+      const int wl_ = min(tid & 63, KK);
+#pragma unroll
+      for (int cb = 0; cb < kCBMax; ++cb) {
+        const int c = min(c0 + cb, c_end - 1);
+        T raw = wl_ < KK ? weight[(int64_t)c * KK + wl_] : bias[c];
+        wv_nxt[cb] = (float)ld(&raw);
+      }
     }
   };
-  auto park = [&](int buf) {
-    float* dst = dw_lds + buf * g.CB * g.tile_sz;
+  auto park = [&](int chunk) {
+    float* dst = dw_lds + (chunk & 1) * g.CB * g.tile_sz;
+    const int lim = (c_end - (c_begin + chunk * g.CB)) * (int)plane;
 #pragma unroll
     for (int i = 0; i < kDwMaxStage; ++i) {
       const int e = tid + i * kDwThreads;
-      if (i < g.nstage && e < g.CB * g.tile_sz) dst[e] = stage[i];
+      if (i < g.nstage && e < g.CB * g.tile_sz) dst[e] = (gsrc[i] >= 0 && gsrc[i] < lim) ? (float)ld(&stage[i]) : 0.f;
     }
+#pragma unroll
+    for (int cb = 0; cb < kCBMax; ++cb) wv_cur[cb] = wv_nxt[cb];
   };
   fetch(0);
   park(0);
@@ -1285,43 +1308,47 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3(const T* _
     if (chunk + 1 < nchunks) fetch(chunk + 1);   // the next chunk's window is in flight while this one is used
     const float* tile = dw_lds + (chunk & 1) * g.CB * g.tile_sz;
     const int c0 = c_begin + chunk * g.CB, nc = min(g.CB, c_end - c0);
-    for (int cb = 0; cb < nc; ++cb) {
-      const int c = c0 + cb;   // depthwise: output channel = input channel = weight row
-      const float* tc = tile + cb * g.tile_sz;
-      const T* wrow = weight + (int64_t)c * KK;
-      // the 9 weights and the bias of this channel are wave-uniform: fp32 -> scalar loads; 16-bit types have no scalar
-      // load, so ONE vector load (lane t = weight t, lane 9 = bias) and readlane broadcasts instead of 10 VMEM instructions
-      float wv = 0.f;
-      if constexpr (!std::is_same<T, float>::value) {
-        const int wl_ = tid & 63;
-        if (wl_ < KK) wv = ld(wrow + wl_);
-        else if (wl_ == KK) wv = ld(bias + c);
-      }
-      auto wt = [&](int t) -> float {
-        if constexpr (std::is_same<T, float>::value) return t < KK ? wrow[t] : bias[c];
-        else return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), t));
-      };
-      float acc = 0.f;
+    float res[kCBMax];
 #pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const float* q = tc + toff[t];
-        const float top = __builtin_fmaf(lw[t], q[1], (1.f - lw[t]) * q[0]);
-        const float bot = __builtin_fmaf(lw[t], q[tile_w + 1], (1.f - lw[t]) * q[tile_w]);
-        const float val = __builtin_fmaf(lhm[t], bot, hhm[t] * top);
-        acc = __builtin_fmaf(wt(t), val, acc);
+    for (int cb = 0; cb < kCBMax; ++cb) {
+      res[cb] = 0.f;
+      if (cb < nc) {   // (uniform)
+        const int c = c0 + cb;   // depthwise: output channel = input channel = weight row
+        const float* tc = tile + cb * g.tile_sz;
+        const T* wrow = weight + (int64_t)c * KK;
+        // the 9 weights and the bias of this channel are wave-uniform: fp32 -> scalar loads; 16-bit: the prefetched vector
+        const float wv = wv_cur[cb];
+        auto wt = [&](int t) -> float {
+          if constexpr (std::is_same<T, float>::value) return t < KK ? wrow[t] : bias[c];
+          else return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), t));
+        };
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+          const float* q = tc + toff[t];
+          const float top = __builtin_fmaf(lw[t], q[1], (1.f - lw[t]) * q[0]);
+          const float bot = __builtin_fmaf(lw[t], q[tile_w + 1], (1.f - lw[t]) * q[tile_w]);
+          const float val = __builtin_fmaf(lhm[t], bot, hhm[t] * top);
+          acc = __builtin_fmaf(wt(t), val, acc);
+        }
+        if (any_far) {   // taps outside the staged window: the reference arithmetic on global memory
+          const T* pl = input + ((int64_t)b * p.C + c) * plane;
+          for (int t = 0; t < KK; ++t)
+            if ((far >> t) & 1u) {
+              Tap<float> tp;
+              load_tap<T, float>(tp, p, offset, mask, b, og, t, oy, ox);
+              acc = __builtin_fmaf(wt(t), sample_tap<T, float>(tp, pl), acc);
+            }
+        }
+        res[cb] = acc + wt(KK);
       }
-      if (any_far) {   // taps outside the staged window: the reference arithmetic on global memory
-        const T* pl = input + ((int64_t)b * p.C + c) * plane;
-        for (int t = 0; t < KK; ++t)
-          if ((far >> t) & 1u) {
-            Tap<float> tp;
-            load_tap<T, float>(tp, p, offset, mask, b, og, t, oy, ox);
-            acc = __builtin_fmaf(wt(t), sample_tap<T, float>(tp, pl), acc);
-          }
-      }
-      if (live) st(out + ((int64_t)b * p.OC + c) * oplane + (int64_t)oy * p.ow + ox, acc + wt(KK));
     }
-    if (chunk + 1 < nchunks) park((chunk + 1) & 1);
+    if (chunk + 1 < nchunks) park(chunk + 1);
+    if (live) {
+#pragma unroll
+      for (int cb = 0; cb < kCBMax; ++cb)
+        if (cb < nc) st(out + ((int64_t)b * p.OC + c0 + cb) * oplane + (int64_t)oy * p.ow + ox, res[cb]);
+    }
     __syncthreads();
   }
 }
