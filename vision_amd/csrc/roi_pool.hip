@@ -366,13 +366,22 @@ __global__ __launch_bounds__(64) void roi_pool_bwd_plane(const T* __restrict__ g
   for (int i = lane; i < HW; i += 64) plane[i] = 0.f;
   for (int k0 = 0; k0 < K; k0 += kPlaneList) {
     // RoIs of image b among [k0, k0 + kPlaneList), in index order
+    // (eight 64-RoI groups of batch indices in flight, every load unconditional with a clamped index: one dependent load per
+    // group — `kk < K && load == b` — made the scan of 4000 RoIs 63 round trips per plane)
     int cnt = 0;
-    for (int j = 0; j < kPlaneList && k0 + j < K; j += 64) {
-      const int kk = k0 + j + lane;
-      const bool mine = kk < K && (int)ld(rois + (int64_t)kk * 5) == b;
-      const unsigned long long m = __ballot(mine);
-      if (mine) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = kk;
-      cnt += __popcll(m);
+    for (int j0 = 0; j0 < kPlaneList && k0 + j0 < K; j0 += 512) {
+      float bi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bi[u] = ld(rois + (int64_t)min(k0 + j0 + u * 64 + lane, K - 1) * 5);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * 64;
+        const int kk = k0 + j + lane;
+        const bool mine = j < kPlaneList && kk < K && (int)bi[u] == b;
+        const unsigned long long m = __ballot(mine);
+        if (mine) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = kk;
+        cnt += __popcll(m);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -381,23 +390,22 @@ __global__ __launch_bounds__(64) void roi_pool_bwd_plane(const T* __restrict__ g
     constexpr int U = 16;
     for (int e0 = 0; e0 < total; e0 += 64 * U) {
       int am[U];
-      float g[U];
+      T graw[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * 64 + lane;
-        am[u] = -1;
-        g[u] = 0.f;
-        if (e < total) {
-          const int r = e / bins, bin = e - r * bins;
-          const int64_t k = list[r];
-          am[u] = argmax[(k * C + c) * bins + bin];   // raw: arithmetic on it here would put a wait between the loads
-          g[u] = ld(grad + k * ns + c * cs + (bin / PW) * hs + (bin % PW) * ws);
-        }
+        // unconditional (the stream position clamped to its last element, the surplus dropped below): behind `if (e < total)` each
+        // of the 2 x 16 loads was followed by its own s_waitcnt vmcnt(0) — the phi copy of `am = -1; if (..) am = load`
+        const int ec = min(e, total - 1);
+        const int r = ec / bins, bin = ec - r * bins;
+        const int64_t k = list[r];
+        am[u] = argmax[(k * C + c) * bins + bin];   // raw: arithmetic on it here would put a wait between the loads
+        graw[u] = grad[k * ns + c * cs + (bin / PW) * hs + (bin % PW) * ws];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int a = am[u] - p0;   // argmax -1 (empty bin) and pixels of other strips stay out
-        if (am[u] >= 0 && a >= 0 && a < HW) atomicAdd(&plane[a], g[u]);  // ds_add_f32, program order
+        if (e0 + u * 64 + lane < total && am[u] >= 0 && a >= 0 && a < HW) atomicAdd(&plane[a], (float)ld(&graw[u]));  // ds_add_f32, program order
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -598,13 +606,22 @@ __global__ __launch_bounds__(64) void ps_bwd_plane(const T* __restrict__ grad, c
   const float scale = (float)spatial_scale;
   for (int i = lane; i < HW; i += 64) plane[i] = 0.f;
   for (int k0 = 0; k0 < K; k0 += kPlaneList) {
+    // (eight 64-RoI groups of batch indices in flight, every load unconditional with a clamped index: one dependent load per
+    // group — `kk < K && load == b` — made the scan of 4000 RoIs 63 round trips per plane)
     int cnt = 0;
-    for (int j = 0; j < kPlaneList && k0 + j < K; j += 64) {
-      const int kk = k0 + j + lane;
-      const bool mine = kk < K && (int)ld(rois + (int64_t)kk * 5) == b;
-      const unsigned long long m = __ballot(mine);
-      if (mine) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = kk;
-      cnt += __popcll(m);
+    for (int j0 = 0; j0 < kPlaneList && k0 + j0 < K; j0 += 512) {
+      float bi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bi[u] = ld(rois + (int64_t)min(k0 + j0 + u * 64 + lane, K - 1) * 5);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * 64;
+        const int kk = k0 + j + lane;
+        const bool mine = j < kPlaneList && kk < K && (int)bi[u] == b;
+        const unsigned long long m = __ballot(mine);
+        if (mine) list[cnt + __popcll(m & ((1ull << lane) - 1ull))] = kk;
+        cnt += __popcll(m);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
