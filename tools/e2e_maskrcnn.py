@@ -116,21 +116,32 @@ def main():
             entry = {"detections": [len(a["scores"]), len(b["scores"])], "labels_equal": lab, "max_score_diff": ds,
                      "max_box_diff_px": db, "max_mask_diff": dm}
             good = same_n and lab and ds < 2e-4 and db < 0.25 and dm < 5e-3
-            if not good and same_n and ds < 2e-4 and n and not has_masks:
-                cut = float(torch.minimum(a["scores"][:n].min(), b["scores"][:n].min())) + 1e-6
-
-                # one-to-one matching of the detections above the cut: same label, every coordinate within 0.25 px (rounding the
-                # coordinates and comparing sorted lists, as this did before, flips on boxes that sit on a rounding boundary:
-                # the same run came out True on one GPU-box visit and False on the next)
-                ka, kb = a["scores"] > cut, b["scores"] > cut
-                la, lb, xa, xb = a["labels"][ka], b["labels"][kb], a["boxes"][ka], b["boxes"][kb]
-                good = bool(la.numel() == lb.numel())
-                if good and la.numel():
-                    d = (xa[:, None, :] - xb[None, :, :]).abs().amax(-1)
-                    d = torch.where(la[:, None] == lb[None, :], d, torch.full_like(d, 1e9))
-                    near, idx = d.min(1)
-                    good = bool((near < 0.25).all()) and int(torch.unique(idx).numel()) == int(idx.numel())
-                entry["order_differs_only_among_tied_scores"] = good
+            if not good and same_n and n:
+                # Same detections in another ORDER: two scores closer than the fp32 noise the two pipelines carry (5e-5: a
+                # random-init network produces many such pairs, a RetinaNet's sigmoid even exact ties) swap ranks, and every
+                # rank-wise difference above explodes.  One-to-one matching instead: same label, score within 2e-4, every
+                # coordinate within 0.25 px (and the mask within 5e-3); a detection may stay unmatched only if its score is
+                # within 2e-4 of the lowest one (a tie that straddles the detections_per_img cut).
+                # (An earlier form rounded the coordinates to 0.1 px and compared sorted lists: it flipped on boxes that sit on a
+                # rounding boundary — the same run came out True on one GPU-box visit and False on the next.)
+                d = (a["boxes"][:, None, :] - b["boxes"][None, :, :]).abs().amax(-1)
+                ok_pair = (a["labels"][:, None] == b["labels"][None, :]) & ((a["scores"][:, None] - b["scores"][None, :]).abs() < 2e-4)
+                d = torch.where(ok_pair, d, torch.full_like(d, 1e9))
+                near, idx = d.min(1)
+                matched = near < 0.25
+                cut = float(torch.minimum(a["scores"].min(), b["scores"].min())) + 2e-4
+                good = bool((matched | (a["scores"] <= cut)).all())
+                mi = idx[matched]
+                good = good and int(torch.unique(mi).numel()) == int(mi.numel())
+                unmatched_b = torch.ones(len(b["scores"]), dtype=torch.bool, device=mi.device)
+                unmatched_b[mi] = False
+                good = good and bool((b["scores"][unmatched_b] <= cut).all())
+                if good and has_masks and int(matched.sum()):
+                    dm2 = float((a["masks"][matched] - b["masks"][mi]).abs().max())
+                    entry["max_mask_diff_matched"] = dm2
+                    good = dm2 < 5e-3
+                entry["same_detections_in_another_order"] = good
+                entry["matched"] = int(matched.sum())
             rep.append(entry)
             # the two pipelines differ by the rounding of their first op (fused normalise + resize vs F.interpolate) carried through
             # a random-init 50-layer network: 5e-5 .. 6e-5 in the scores and 0.003 .. 0.06 px in the boxes across GPU-box visits
