@@ -137,3 +137,59 @@ def test_roi_align_dma_loop_keeps_its_prefetch_in_flight(tmp_path):
             assert len(re.findall(r"ds_read2_b32", body)) == 7 * 8, name
         if "IfLi14ELi14E" in name:
             assert len(re.findall(r"ds_read2_b32", body)) == 5 * 8 * 4, name
+
+
+def _synchronous_loads(body, window=6):
+    """Global loads that are followed by `s_waitcnt vmcnt(0)` within `window` instructions: a load made synchronous (tools/isa_waits.py)."""
+    n, left = 0, 0
+    for ln in body.splitlines():
+        t = ln.split(";")[0].strip()
+        if not t or t.endswith(":") or t.startswith("."):
+            continue
+        op = t.split()[0]
+        if op.startswith("global_load") or op.startswith("flat_load"):
+            left = window
+        elif op == "s_waitcnt" and "vmcnt(0)" in t and left > 0:
+            n, left = n + 1, 0
+        elif left > 0:
+            left -= 1
+    return n
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_roi_align_backward_owner_keeps_its_prefetch_in_flight(tmp_path):
+    """Round 4: the tile-owner backward lost 20-30 % to loads the compiler had made synchronous — the grads prefetch of entry
+    e + 1 was `v = 0; if (inside) v = load; else if (straddles) {...}` (a phi: its copy and an s_waitcnt vmcnt(0) sat right
+    behind the load), it was issued in front of the AxD loads and behind an `if (e + 1 < total)`.  Guard: in the fp32 owner
+    kernels no 16-byte load is followed by vmcnt(0) within a few instructions, and the FMAs of an entry start behind a COUNTED
+    wait that leaves the prefetch in flight (7 AxD pairs + 2 prefetch pieces -> vmcnt(8) at 7x7; 14 + 7 -> vmcnt(20) at 14x14)."""
+    text, res = _kernel_resources(os.path.join(CSRC, "roi_align_bwd.hip"), tmp_path)
+    bodies = {k: v for k, v in _kernel_bodies(text, "roi_align_bwd_ownerI").items() if "_bigI" not in k}
+    assert len(bodies) == 6, sorted(bodies)      # {fp32, fp16, bf16} x {7x7, 14x14}
+    for name, body in bodies.items():
+        assert "scratch_" not in body, name
+        assert not re.search(r"global_load_dwordx4[^\n]*\n(?:[^\n]*\n){0,3}?\s*s_waitcnt vmcnt\(0\)", body), name
+    b7 = next(v for k, v in bodies.items() if "IfLi7ELi7E" in k)
+    b14 = next(v for k, v in bodies.items() if "IfLi14ELi14E" in k)
+    assert re.search(r"s_waitcnt vmcnt\(8\)", b7) and re.search(r"s_waitcnt vmcnt\(20\)", b14)
+    own7 = next(v for k, v in res.items() if "roi_align_bwd_ownerIfLi7ELi7E" in k)
+    assert own7["vgpr"] <= 96 and own7["spill"] == 0, own7       # five 256-thread workgroups per CU (DESIGN 4.1)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_deform_conv2d_backward_slab_loops_are_asynchronous(tmp_path):
+    """The fused backward: the owner data kernel must not spill (with all nine taps resident the allocator spilled
+    the slab PREFETCH registers — a vmcnt(0) and a scratch store behind every load), and neither it nor the channels-last
+    weight-gradient kernel may wait for a load right behind it (the phi copy of a conditional load / of `if (use_mask) m =
+    mask[...]` did exactly that in front of the MFMAs)."""
+    text, res = _kernel_resources(os.path.join(CSRC, "deform_conv2d_bwd.hip"), tmp_path)
+    own = {k: v for k, v in res.items() if "dcn_bwd_data_ownI" in k}
+    assert len(own) == 3, sorted(res)
+    for k, r in own.items():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 256, (k, r)
+    bodies = _kernel_bodies(text, "dcn_bwd_")
+    for name, body in bodies.items():
+        if "dcn_bwd_data_ownI" in name or ("dcn_bwd_weight_mfmaI" in name and "Lb1E" in name):
+            assert "scratch_" not in body, name
+            assert _synchronous_loads(body) == 0, (name, _synchronous_loads(body))
+            assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) >= 32, name
