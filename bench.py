@@ -415,7 +415,8 @@ BF16_PEAK_TF = 2500.0    # dense bf16 / fp16 MFMA peak
 
 
 def other_configs(device):
-    """BASELINE configs 3 and 4 inside the contract line: ms = MEDIAN of per-call HIP-event times over
+    """BASELINE configs 3 and 4 (and the legs of config 2 that the step does not contain) inside the contract line (VERDICT r03
+    item 2): ms = MEDIAN of per-call HIP-event times over
     >= 20 calls, inputs rotated over independent sets; every entry carries the fraction of the SURVEY.md section-8d bound.
       nms / batched_nms : 100,000 boxes (80 classes), IoU 0.5, sparse (1000 px canvas) and dense (200 px) variants; wall
                           time of torchvision::nms incl. the score sort and the output-size sync; bound =
@@ -443,6 +444,32 @@ def other_configs(device):
         return ts[len(ts) // 2], ts[0]
 
     out = {"timing": "median (and min) of 24 per-call HIP-event times, 3 rotated input sets"}
+    # config 2, the legs the headline step does not contain: the 14x14 forward and the fused multi-scale BACKWARD (7x7 / 14x14,
+    # fp32 / bf16) against HBM on their algorithmic bytes (grads read once + every gradient map written once)
+    from vision_amd.poolers import _convert_to_roi_format
+    c2 = []
+    for i in range(3):
+        f, b, _ = make_inputs(device, 300 + i)
+        c2.append(([f[str(l)] for l in range(4)], _convert_to_roi_format(b).float()))
+    hs, ws = [t.shape[2] for t in c2[0][0]], [t.shape[3] for t in c2[0][0]]
+    scales, ms_args = [1.0 / st for st in STRIDES], (2, 5, 224.0, 4.0, 1e-6)
+    map_bytes = sum(t.numel() for t in c2[0][0])
+    for P in (7, 14):
+        for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+            esz = 4 if dt == torch.float32 else 2
+            sets = [([t.to(dt) for t in fl], r, torch.randn(BATCH * PROPOSALS, CHANNELS, P, P, device=device).to(dt)) for fl, r in c2]
+            bytes_ = (BATCH * PROPOSALS * CHANNELS * P * P + map_bytes) * esz
+            if P == 14:
+                ms, mn = med(lambda i: torch.ops.tvmi.multiscale_roi_align(sets[i % 3][0], sets[i % 3][1], scales, P, P, 2, False, *ms_args))
+                out[f"roi_align_fwd_{P}x{P}_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "GBs": round(bytes_ / ms / 1e6, 1),
+                                                       "frac_of_hbm_peak": round(bytes_ / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            ms, mn = med(lambda i: torch.ops.tvmi.multiscale_roi_align_backward(sets[i % 3][2], sets[i % 3][1], hs, ws, scales, BATCH, P, P, 2,
+                                                                                False, *ms_args))
+            out[f"roi_align_bwd_{P}x{P}_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "GBs": round(bytes_ / ms / 1e6, 1),
+                                                   "frac_of_hbm_peak": round(bytes_ / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                   "note": "fused multi-scale tile-owner backward, deterministic, no atomics, no zero-fill"}
+            del sets
+    del c2
     n, nsets = 100_000, 3
     pairs = n * (n - 1) / 2
     for canvas, tag in ((1000, "sparse"), (200, "dense")):
