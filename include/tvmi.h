@@ -164,10 +164,9 @@ int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_
  * cpu/roi_align_common.h:32-124.
  *   input  [N,C,H,W]  output [K,C,PH,PW] (fully overwritten, no pre-zero needed)
  *   workspace (optional, may be NULL): tvmi_roi_align_forward_workspace_bytes(K, PH, PW, sampling_ratio) bytes of
- *   device scratch: per-RoI "declined by the LDS-DMA kernel" flags (the first K*4 bytes; a workspace of only that
- *   size selects the per-RoI kernels alone) and, for 7x7 / 14x14 bins with sampling_ratio 2, the tables of the
- *   shared-staging kernel (roi_align_plane.hip: per-RoI level / band key + axis-sample table, per-level window
- *   pixel sums).  Results do not depend on it, only which kernels run.
+ *   device scratch: the work list of the RoIs the LDS-DMA kernel declines (windows that do not fit its LDS blocks; a small
+ *   fixed-grid mop-up launch serves them) and the launch order of the counting-sort pre-pass (RoIs of one image / level /
+ *   band next to each other).  Results do not depend on it, only which kernels run.
  * backward: grad [K,C,PH,PW] read with the given element strides.  Two regimes:
  *   - TILE-OWNER path (deterministic; what torchvision/ops/roi_align.py:276-281 reroutes to python for):
  *     float32, 7x7 or 14x14 bins (any sampling_ratio), the [C,PH,PW] block of a RoI contiguous (w_stride 1,
