@@ -245,11 +245,30 @@ def test_fuse_detection_model_gives_the_reference_detections(tmp_path):
             assert len(ref) == len(fus) == 2
             for a, b in zip(ref, fus):
                 assert a["boxes"].shape == b["boxes"].shape and a["boxes"].shape[0] > 0, (name, a["boxes"].shape, b["boxes"].shape)
-                assert torch.equal(a["labels"], b["labels"]), name
-                assert float((a["scores"] - b["scores"]).abs().max()) < 2e-4, name
-                assert float((a["boxes"] - b["boxes"]).abs().max()) < 0.25, name
-                if "masks" in a:
-                    assert a["masks"].shape == b["masks"].shape and float((a["masks"] - b["masks"]).abs().max()) < 5e-3, name
+                rankwise = (torch.equal(a["labels"], b["labels"]) and float((a["scores"] - b["scores"]).abs().max()) < 2e-4
+                            and float((a["boxes"] - b["boxes"]).abs().max()) < 0.25)
+                if rankwise:
+                    if "masks" in a:
+                        assert a["masks"].shape == b["masks"].shape and float((a["masks"] - b["masks"]).abs().max()) < 5e-3, name
+                    continue
+                # Two detections whose scores are closer than the 5e-5 the two pipelines differ by may swap ranks (seen once in
+                # five runs of the 100-detection config-5 harness): then the SAME detections must be there — one-to-one, same
+                # label, score within 2e-4, every coordinate within 0.25 px, masks of matched pairs within 5e-3; a detection may
+                # be unmatched only if its score is within 2e-4 of the lowest one (a near-tie across the detections_per_img cut).
+                d = (a["boxes"][:, None, :] - b["boxes"][None, :, :]).abs().amax(-1)
+                okp = (a["labels"][:, None] == b["labels"][None, :]) & ((a["scores"][:, None] - b["scores"][None, :]).abs() < 2e-4)
+                d = torch.where(okp, d, torch.full_like(d, 1e9))
+                near, idx = d.min(1)
+                matched = near < 0.25
+                cut = float(torch.minimum(a["scores"].min(), b["scores"].min())) + 2e-4
+                assert bool((matched | (a["scores"] <= cut)).all()), (name, "reference detections without a fused counterpart")
+                mi = idx[matched]
+                assert int(torch.unique(mi).numel()) == int(mi.numel()), (name, "two reference detections matched one fused detection")
+                left = torch.ones(b["scores"].shape[0], dtype=torch.bool, device=mi.device)
+                left[mi] = False
+                assert bool((b["scores"][left] <= cut).all()), (name, "fused detections without a reference counterpart")
+                if "masks" in a and int(matched.sum()):
+                    assert float((a["masks"][matched] - b["masks"][mi]).abs().max()) < 5e-3, name
         print("OVERLAY_OK", torchvision.__file__)
         """
     )
