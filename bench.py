@@ -10,9 +10,9 @@ workload : BASELINE config 2 — a batch of 4 padded 800x1344 images per GPU, 4 
            NMS (batched_nms over the image index, IoU 0.5), packing of the padded top-100 detections of every
            image (fixed shape) and — when N > 1 — their one RCCL all-gather.  The per-rank part has no host
            synchronisation, so the launches queue back to back (--graph replays them from captured hipGraphs, one
-           per input set).  The NMS + packing chain does not depend on the RoIAlign output: `--overlap` runs it on a
-           second HIP stream under the RoIAlign launch; the line is measured on one stream and carries the two-stream
-           time beside it (config.two_stream_ms_per_step: -4 % in one visit, +25 % in another — not the default).
+           per input set).  The NMS + packing chain does not depend on the RoIAlign output: it runs on a second HIP
+           stream under the RoIAlign launch (forked from and joined back into the step's stream); `--one-stream`
+           keeps it on the launch stream, and the line carries that time beside it (config.one_stream_ms_per_step).
 inputs   : synthetic (seeded), resident in HBM before the timed region.
 scaling  : weak — every rank owns its own batch of images (the path shards over images; no data-path
            collective besides the detection all-gather).  value = boxes processed by ALL ranks / time.
@@ -43,6 +43,7 @@ rank count that differs from --gpus, or fewer visible GPUs than ranks, is an err
 used by tests/test_dist.py; it measures nothing.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -93,8 +94,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="run the NMS + packing chain of a step on a second HIP stream under the "
-                    "RoIAlign launch (measured: -4 %% at best, +25 %% on a noisy box; the default is one stream)")
+    ap.add_argument("--one-stream", dest="overlap", action="store_false", help="keep the NMS + packing chain of a step on the "
+                    "RoIAlign launch's stream; the default runs it on a second HIP stream under that launch (-3..-6 %% per step in "
+                    "eight of eight round-4/5 visits once the collector stall was out of the way)")
+    ap.set_defaults(overlap=True)
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -148,10 +151,9 @@ def main():
     def device_step(which=None):
         # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable).  The two halves of the
         # step do not depend on each other (RoIAlign reads the maps and the boxes, NMS the boxes and the scores), and the
-        # NMS chain is ~8 short latency-bound launches: with `--overlap` it runs on a second HIP stream UNDER the RoIAlign
-        # launch, forked from and joined back into the step's stream.  Measured on the box: 0.335 vs 0.350 ms per step in
-        # one visit, 0.438 vs 0.338 ms in another — the chain's 1024-thread workgroups wait for wave slots the RoIAlign
-        # kernel occupies — so the contract line is measured on ONE stream and the overlapped time is reported beside it.
+        # NMS chain is ~8 short latency-bound launches: it runs on a second HIP stream UNDER the RoIAlign launch, forked
+        # from and joined back into the step's stream (0.295-0.300 vs 0.306-0.313 ms per step, gpurun_out r05b; a +25 %
+        # outlier seen once in round 3 has not reproduced in eight visits since).  `--one-stream` keeps one stream.
         d = sets[counter["i"] % N_SETS if which is None else which]
         counter["i"] += 1
         cur = torch.cuda.current_stream()
@@ -211,20 +213,73 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # the contract region: EXACTLY K steps between two (barrier + synchronize); an event after every step (no sync, ~1 us of
-    # host time each) gives the per-step spread of the same run
+    # ---- the contract region.  Round 4's driver line lost 89 % of its timed region to ONE step of 38-47 ms: a CPython
+    # generation-2 garbage collection (36-39 ms in a process with torch imported) that the object counts of 5 warm-up + 5 timed
+    # steps happened to trigger inside step 4 (profiles/r05_stall_root_cause_r04_loop.log: 3 of 3 runs, host time of that step
+    # = the collection).  So, like `timeit`: collect, freeze and disable the collector around the region; and the warm-up is the
+    # timed loop byte for byte (holds `out` across the next step, records an event per step), followed by an internal pre-roll
+    # until two consecutive steps agree within 10 %, so that no first-use cost (second 200 MB output block, event creation)
+    # is left for the timed steps.  Nothing is trimmed out of `value`: it is K steps between two (barrier + synchronize).
+    gc_seen = []
+
+    def gc_probe(phase, info):
+        if phase == "stop":
+            gc_seen.append(info["generation"])
+
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        out = step()
-        marks[i + 1].record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    wm = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for m in marks + wm:
+        m.record()                        # creates the HIP event now, not inside a timed region
+    held = {"out": None}
+
+    def contract_region():
+        """warm-up (= the timed loop) + pre-roll + EXACTLY K steps between two (barrier + synchronize); returns
+        (seconds of the K steps, pre-roll steps run, per-step event times in step order)"""
+        for _ in range(args.warmup):
+            held["out"] = step()
+            marks[1].record()
+        preroll = 0
+        while preroll < 64:
+            wm[0].record()
+            held["out"] = step()
+            wm[1].record()
+            held["out"] = step()
+            wm[2].record()
+            sync()
+            preroll += 2
+            a, b = wm[0].elapsed_time(wm[1]), wm[1].elapsed_time(wm[2])
+            stable = torch.tensor([1 if abs(a - b) <= 0.1 * min(a, b) else 0], device=device, dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(stable, op=dist.ReduceOp.MIN)     # every rank leaves the pre-roll after the same step
+            if int(stable.item()):
+                break
+        sync()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            held["out"] = step()
+            marks[i + 1].record()
+        sync()
+        dt = time.perf_counter() - t0
+        return dt, preroll, [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    gc.callbacks.append(gc_probe)
+    elapsed, preroll, per_step_seq = contract_region()
+    # the same K steps in the OTHER stream mode (reported next to `value`, never `value` itself)
+    other_stream_ms = None
+    if graph is None:
+        overlap["on"] = not args.overlap
+        other_stream_ms = contract_region()[0] / max(args.steps, 1) * 1e3
+        overlap["on"] = args.overlap
+    gc.callbacks.remove(gc_probe)
+    gc.enable()
+    gc.unfreeze()
+    out = held["out"]
+    argmax_step = max(range(args.steps), key=lambda i: per_step_seq[i]) if args.steps else None
+    per_step = sorted(per_step_seq)
     if world > 1:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -232,19 +287,6 @@ def main():
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     boxes_per_step = BATCH * PROPOSALS * world
     value = boxes_per_step / (ms_per_step / 1e3)
-    # the same K steps with the NMS chain on a second stream (reported next to `value`, never `value` itself)
-    two_stream_ms = None
-    if graph is None:
-        overlap["on"] = True
-        for _ in range(min(args.warmup, 5)):
-            step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        two_stream_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
-        overlap["on"] = args.overlap
 
     # ---- roofline of the dominant kernel, measured live with events on the launch stream (input sets rotated)
     from vision_amd.poolers import LevelMapper, _convert_to_roi_format
@@ -332,7 +374,12 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "ms_per_step_stats": ({"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4),
                                "p90": round(per_step[int(len(per_step) * 0.9)], 4), "max": round(per_step[-1], 4),
-                               "how": "HIP events between consecutive steps of the timed region (rank 0)"} if per_step else None),
+                               "argmax_step": argmax_step, "max_over_median": round(per_step[-1] / per_step[len(per_step) // 2], 3),
+                               "steps_ms": [round(x, 4) for x in per_step_seq[:64]],
+                               "preroll_steps": preroll, "gc_collections_in_timed_region": len(gc_seen),
+                               "how": "HIP events between consecutive steps of the timed region (rank 0), in step order; the "
+                                      "collector is frozen + disabled around warm-up and region, the warm-up loop is the timed loop, "
+                                      "then pairs of pre-roll steps until two consecutive steps agree within 10 %"} if per_step else None),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -352,7 +399,7 @@ def main():
             "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
             "rotated_input_sets": N_SETS,
             "streams": "NMS + packing chain on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream",
-            "two_stream_ms_per_step": None if two_stream_ms is None else round(two_stream_ms, 4),
+            ("one_stream_ms_per_step" if args.overlap else "two_stream_ms_per_step"): None if other_stream_ms is None else round(other_stream_ms, 4),
             "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
         },
