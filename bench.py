@@ -647,6 +647,8 @@ def config5_block(rank, local_rank, world):
             r = json.loads(line[-1])
             out["retinanet_reference_python_img_s"] = r.get("reference_python_img_s", r.get("value"))
             out["retinanet_fused_img_s"] = r.get("fused_img_s")          # vision_amd.fuse_detection_model: fused post-processing + transform
+            out["retinanet_reference_python_autofuse_img_s"] = r.get("reference_python_autofuse_img_s")   # TVMI_AUTOFUSE=1 class-level swaps
+            out["retinanet_same_detections_autofuse"] = r.get("same_detections_autofuse")
             out["retinanet_same_detections_both_ways"] = r.get("same_detections_both_ways")
             out["retinanet_detections_per_image"] = r.get("detections_per_image")
         elif rank == 0:

@@ -44,7 +44,7 @@ typedef enum {
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
  * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
-#define TVMI_ABI_VERSION 303
+#define TVMI_ABI_VERSION 304
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
@@ -156,6 +156,24 @@ size_t tvmi_nms_small_segments_workspace_bytes(int64_t n, int64_t num_segments);
 int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
                             int64_t num_segments, double iou_threshold, tvmi_dtype dt, void* workspace,
                             size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream);
+
+/* Device-count forms of the two batched paths (round 5: sync-free detector post-processing, SURVEY.md §8f-1 — replaces
+ * the `torch.where` / boolean-index compaction before every batched_nms of models/detection/roi_heads.py:716-729,
+ * rpn.py:268-283, retinanet.py:537-565, each of which reads a count on the host).  The lists are laid out for `capacity`
+ * candidates; the ones that take part are the first *n_dev entries of `order` (and, segment-major form, of `seg_keys` /
+ * `perm`): tvmi_nms_mask_inputs gives masked-out candidates the score -inf and the key INT64_MAX, so the caller's two
+ * stable sorts put them behind every live candidate, and counts the live ones on the device (n_live [1] int64, zeroed
+ * by the call).  keep_out / num_keep_out as in the host-count forms; launch grids are sized for the capacity and
+ * surplus workgroups retire at once.  No entry synchronises. */
+int tvmi_nms_mask_inputs(const float* scores, const int64_t* seg, const uint8_t* valid, int64_t n, float* scores_out,
+                         int64_t* seg_out, int64_t* n_live, void* stream);
+int tvmi_nms_segmented_devcount(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
+                                int64_t capacity, const int64_t* n_dev, double iou_threshold, tvmi_dtype dt, void* workspace,
+                                size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream);
+int tvmi_nms_small_segments_devcount(const void* dets, const int64_t* order, const int64_t* seg, int64_t capacity,
+                                     const int64_t* n_dev, int64_t num_segments, double iou_threshold, tvmi_dtype dt,
+                                     void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
+                                     void* stream);
 
 /* ------------------------------------------------------------- RoIAlign ----------
  * Replaces: torchvision/csrc/ops/cuda/roi_align_kernel.cu:68-143,334-394 (forward),

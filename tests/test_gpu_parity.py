@@ -1119,6 +1119,74 @@ def test_filter_proposals_golden_and_fused_decode():
             np.testing.assert_allclose(b[i].cpu().numpy(), G[f"rpn_boxes{i}"], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,nseg,live_frac", [(3000, 12, 0.4), (3000, 12, 0.0), (4096, 1024, 0.9), (20000, 364, 0.03), (20000, 364, 1.0),
+                                              (150000, 364, 0.5), (70000, 5000, 0.2)])
+def test_masked_segmented_nms_equals_compaction(n, nseg, live_frac):
+    """tvmi::nms_segmented_masked (round 5: filtered-out candidates leave the problem on the device — score -inf / largest key,
+    live count read from memory) == boolean compaction + tvmi::nms_segmented, index for index, on both device-count paths
+    (small segments up to 4096 candidates, banded segment-major above), incl. nothing / everything live."""
+    g = gen(500 + n + nseg)
+    boxes = random_boxes(n, 600, 500, 4, 120, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    seg = torch.randint(0, nseg, (n,), generator=g).to(DEV)
+    valid = (torch.rand(n, generator=g) < live_frac).to(DEV)
+    keep, num = torch.ops.tvmi.nms_segmented_masked(boxes, scores, seg, valid.to(torch.uint8), 0.5, nseg)
+    sel = valid.nonzero()[:, 0]
+    want = sel[torch.ops.tvmi.nms_segmented(boxes[sel], scores[sel], seg[sel], 0.5, nseg)] if sel.numel() else sel
+    assert int(num) == want.numel(), (int(num), want.numel())
+    assert torch.equal(keep[: int(num)], want)
+
+
+def test_detector_postprocessing_is_sync_free_in_padded_form():
+    """the three fused post-processing functions (RoIHeads.postprocess_detections roi_heads.py:680-737,
+    RegionProposalNetwork.filter_proposals rpn.py:242-297, RetinaNet.postprocess_detections retinanet.py:509-571) run in
+    their padded form under torch.cuda.set_sync_debug_mode("error") — no nonzero, no .item(), no blocking copy — and give
+    what the list-returning form (one read of the counts at the end) gives."""
+    g = gen(93)
+    shapes = [(800, 1333), (800, 1200), (750, 1333)]
+    B = len(shapes)
+    props = [random_boxes(600, w, h, 8, 500, g).to(DEV) for h, w in shapes]
+    logits = (torch.randn(B * 600, 91, generator=g) * 3).to(DEV)
+    reg = (torch.randn(B * 600, 364, generator=g) * 0.5).to(DEV)
+    A_lvls = [3000, 800, 200]
+    A = sum(A_lvls)
+    anchors = random_boxes(B * A, 1200, 750, 16, 300, g).reshape(B, A, 4).to(DEV)
+    obj = torch.randn(B, A, generator=g).to(DEV)
+    deltas = (torch.randn(B, A, 4, generator=g) * 0.3).to(DEV)
+    K = 20
+    cls = [(torch.randn(B, a, K, generator=g) * 2 - 2).to(DEV) for a in A_lvls]
+    breg = [(torch.randn(B, a, 4, generator=g) * 0.3).to(DEV) for a in A_lvls]
+    off = [0, 3000, 3800, 4000]
+    anc_lists = [[anchors[i, off[l]:off[l + 1]] for l in range(3)] for i in range(B)]
+    calls = {
+        "roi_heads": lambda padded: vision_amd.postprocess_detections(logits, reg, props, shapes, score_thresh=0.05, padded=padded),
+        "rpn": lambda padded: vision_amd.filter_proposals(anchors, obj, shapes, A_lvls, pre_nms_top_n=1000, post_nms_top_n=300,
+                                                          score_thresh=0.2, pred_bbox_deltas=deltas, padded=padded),
+        "retinanet": lambda padded: vision_amd.retinanet_postprocess_detections(cls, breg, anc_lists, shapes, score_thresh=0.05,
+                                                                                topk_candidates=500, detections_per_img=100, padded=padded),
+    }
+    for name, fn in calls.items():
+        want = fn(False)
+        fn(True)                                   # first use: workspace allocations etc. happen outside the checked region
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            dets, counts = fn(True)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        counts = counts.tolist()
+        assert all(c >= 0 for c in counts), (name, counts)
+        if name == "retinanet":
+            want = ([w["boxes"] for w in want], [w["scores"] for w in want], [w["labels"] for w in want])
+        assert sum(counts) > 0, name
+        for i in range(B):
+            d = dets[i, : counts[i]]
+            assert counts[i] == want[0][i].shape[0], (name, i)
+            assert torch.equal(d[:, :4], want[0][i]) and torch.equal(d[:, 4], want[1][i]), (name, i)
+            if len(want) == 3:
+                assert torch.equal(d[:, 5].to(torch.int64), want[2][i]), (name, i)
+
+
 def test_sync_free_nms_pack_chain_and_graph_replay():
     """batched_nms_padded + pack_kept_detections(num_keep=...) == the synchronising pair, eagerly and when the
     chain is captured in a hipGraph and replayed on fresh input values."""
@@ -1329,6 +1397,10 @@ def test_nms_and_fused_ops_opcheck():
     s = torch.rand(50, generator=g).to(DEV)
     torch.library.opcheck(torch.ops.torchvision.nms, args=(b, s, 0.5))
     torch.library.opcheck(torch.ops.tvmi.nms_segmented, args=(b, s, torch.randint(0, 3, (50,), generator=g).to(DEV), 0.5))
+    seg3 = torch.randint(0, 3, (50,), generator=g).to(DEV)
+    torch.library.opcheck(torch.ops.tvmi.nms_segmented_masked, args=(b, s, seg3, (torch.rand(50, generator=g) < 0.5).to(DEV), 0.5, 3))
+    kp, nk = torch.ops.tvmi.nms_segmented_padded(b, s, seg3, 0.5, 3)
+    torch.library.opcheck(torch.ops.tvmi.pack_detections_payload, args=(b, s, None, seg3, kp, nk, 3, 10))
     feats = [torch.rand(1, 8, 64 // k, 64 // k, generator=g).to(DEV).requires_grad_(True) for k in (1, 2)]
     rois = torch.cat([torch.zeros(50, 1), random_boxes(50, 64, 64, 2, 40, g)], 1).to(DEV)
     torch.library.opcheck(torch.ops.tvmi.multiscale_roi_align,

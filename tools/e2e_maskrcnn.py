@@ -13,8 +13,10 @@ variant reference : nothing swapped — every torchvision.ops call of the refere
                     F.interpolate in resize.hip)
 variant fused     : vision_amd.{MultiScaleRoIAlign, postprocess_detections, filter_proposals, paste_masks_in_image,
                     transform_images} swapped in
-variant both      : ONE process, one model: the reference variant is timed, then the fused pieces are swapped in and timed,
-                    and the detections of both on the same images are compared (what bench.py puts into its `config5` block)
+variant both      : ONE process, one model: the reference variant is timed, then the same unchanged model with the opt-in
+                    class-level swaps of TVMI_AUTOFUSE=1 (vision_amd/autofuse.py), then the fused pieces bound to the model
+                    (vision_amd.fuse_detection_model); the detections of all three on the same images are compared (what
+                    bench.py puts into its `config5` block)
 Prints one JSON object.  Launched by `bench.py --e2e` in a fresh process (the overlay needs TVMI_NO_PY_REGISTRATIONS=1
 before vision_amd is imported: the reference package brings its own fake / autograd registrations)."""
 import argparse
@@ -209,6 +211,15 @@ def main():
         ref_run = timed_run("reference")
         with torch.no_grad():
             ref_out = model(batches[0])
+        # the same UNCHANGED model object with the opt-in class-level swaps of TVMI_AUTOFUSE=1 (vision_amd/autofuse.py) ...
+        from vision_amd import autofuse
+        autofuse.install()
+        auto_run = timed_run("autofuse")
+        with torch.no_grad():
+            auto_out = model(batches[0])
+        auto_images, auto_ok = compare(ref_out, auto_out)
+        autofuse.uninstall()
+        # ... and with the fused pieces bound to this one model (vision_amd.fuse_detection_model)
         apply_fused()
         fus_run = timed_run("fused")
         with torch.no_grad():
@@ -218,6 +229,8 @@ def main():
                "box_score_thresh": args.score_thresh, "steps": args.steps, "warmup": args.warmup,
                "reference_python_img_s": ref_run["value"], "reference_python_ms_per_step": ref_run["ms_per_step"],
                "fused_img_s": fus_run["value"], "fused_ms_per_step": fus_run["ms_per_step"],
+               "reference_python_autofuse_img_s": auto_run["value"], "reference_python_autofuse_ms_per_step": auto_run["ms_per_step"],
+               "same_detections_autofuse": auto_ok,
                "detections_per_image": fus_run["detections_per_image"],
                "aten_upsample_calls_per_step": [ref_run["aten_upsample_calls_per_step"], fus_run["aten_upsample_calls_per_step"]],
                "same_detections_both_ways": ok, "check": images, "data": "synthetic", "weights": "random init (seed 0)",

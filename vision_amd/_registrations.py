@@ -172,6 +172,14 @@ def _fake_nms_padded(dets, scores, idxs, iou_threshold, num_segments=-1):
     return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
 
 
+def _fake_nms_masked(dets, scores, idxs, valid, iou_threshold, num_segments=-1):
+    return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
+
+
+def _fake_pack_payload(boxes, scores, labels, image_idx, keep, num_keep, num_images, max_dets):
+    return boxes.new_empty((num_images, max_dets * 6 + 1), dtype=torch.float32)
+
+
 def _fake_pack_devcount(boxes, scores, labels, image_idx, keep, num_keep, num_images, max_dets):
     return boxes.new_empty((num_images, max_dets, 6), dtype=torch.float32), boxes.new_empty((num_images,), dtype=torch.int32)
 
@@ -215,6 +223,8 @@ _FAKES = {
     "tvmi::normalize_resize_batch": _fake_normalize_resize_batch,
     "tvmi::box_iou_pairwise": _fake_box_iou_pairwise,
     "tvmi::nms_segmented_padded": _fake_nms_padded,
+    "tvmi::nms_segmented_masked": _fake_nms_masked,
+    "tvmi::pack_detections_payload": _fake_pack_payload,
     "tvmi::pack_detections_devcount": _fake_pack_devcount,
     "tvmi::paste_masks": _fake_paste_masks,
     "tvmi::detection_candidates": _fake_detection_candidates,

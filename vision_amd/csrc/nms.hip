@@ -1119,8 +1119,20 @@ __device__ __forceinline__ int upper_bound_key(const int64_t* __restrict__ keys,
   return lo;
 }
 
+// `n_dev` (all kernels of the segment-major and the small-segment path): the boxes that take part, read on the device.
+// The caller's lists are laid out for the CAPACITY n, and the boxes that take part are the first *n_dev of BOTH the
+// score order and the segment-major order (masked-out candidates carry score -inf and the largest key, so both sorts
+// put them last): every kernel clamps its n and the launch grids, sized for the capacity, retire their surplus blocks.
+__device__ __forceinline__ int live_boxes(int n, const int64_t* __restrict__ n_dev) {
+  if (n_dev == nullptr) return n;
+  const int64_t v = *n_dev;
+  return (int)min(max(v, (int64_t)0), (int64_t)n);
+}
+
 __global__ __launch_bounds__(256) void nms_seg_layout(const int64_t* __restrict__ order, const int64_t* __restrict__ perm,
-                                                      int n, int64_t* __restrict__ oidx, int* __restrict__ invperm) {
+                                                      int n, const int64_t* __restrict__ n_dev, int64_t* __restrict__ oidx,
+                                                      int* __restrict__ invperm) {
+  n = live_boxes(n, n_dev);
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const int64_t g = perm[p];
@@ -1132,7 +1144,8 @@ __global__ __launch_bounds__(256) void nms_seg_layout(const int64_t* __restrict_
 template <typename T>
 __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T* __restrict__ dets,
                                                                          const int64_t* __restrict__ oidx,
-                                                                         const int64_t* __restrict__ keys, int n, int CB,
+                                                                         const int64_t* __restrict__ keys, int n,
+                                                                         const int64_t* __restrict__ n_dev, int CB,
                                                                          double thr, ThrBand band, u64* __restrict__ mask) {
   __shared__ __attribute__((aligned(16))) T s_row[5][64];
   __shared__ long long s_key[64];
@@ -1141,6 +1154,8 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int rb = blockIdx.x;
   const int row0 = rb * 64;
+  n = live_boxes(n, n_dev);
+  if (row0 >= n) return;
   if (threadIdx.x < 64) {
     const int r = row0 + lane;
     T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
@@ -1186,20 +1201,23 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
     const T jarea = (jx2 - jx1) * (jy2 - jy1);
     const u64 mine = suppression_tile<T, 64>(&s_row[0][0], s_key, min(64, n - row0), jx1, jy1, jx2, jy2, jarea, jkey, jvalid,
                                              cb == rb, thr, band);
-    mask[((size_t)rb * CB + cb) * 64 + lane] = mine;
+    mask[((size_t)rb * CB + (cb - rb)) * 64 + lane] = mine;
   }
 }
 
 // one workgroup per 64-box block in which at least one segment starts: it sweeps the blocks
 // from its own to the end of the last segment that starts in it
 __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_seg(const u64* __restrict__ mask,
-                                                                const int64_t* __restrict__ keys, int n, int CB,
+                                                                const int64_t* __restrict__ keys, int n,
+                                                                const int64_t* __restrict__ n_dev, int CB,
                                                                 u64* __restrict__ keepbits, int* __restrict__ err) {
   __shared__ u64 s_keepbits[kSegMaxBlocks];
   __shared__ int s_info[3];  // first start position, end position, number of blocks
   const int lane = threadIdx.x & 63;
   const int c_loc = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int B0 = blockIdx.x;
+  n = live_boxes(n, n_dev);
+  if (B0 * 64 >= n) return;
   if (threadIdx.x < 64) {
     const int p = B0 * 64 + lane;
     const bool start = p < n && (p == 0 || keys[p] != keys[p - 1]);
@@ -1229,16 +1247,16 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_seg(const u64* __res
     const int cb = B0 + lb;
     const bool have = lb < b1;
     u64 diag = 0ull, above[kSuper - 1];
-    if (have) diag = mask[((size_t)cb * CB + cb) * 64 + lane];
+    if (have) diag = mask[((size_t)cb * CB) * 64 + lane];
 #pragma unroll
     for (int q = 0; q < kSuper - 1; ++q) {
       above[q] = 0ull;
-      if (have && q < c_loc) above[q] = mask[((size_t)(B0 + b0 + q) * CB + cb) * 64 + lane];
+      if (have && q < c_loc) above[q] = mask[((size_t)(B0 + b0 + q) * CB + (cb - (B0 + b0 + q))) * 64 + lane];
     }
     u64 acc = 0ull;
     if (have) {
       for (int rl = 0; rl < b0; ++rl) {
-        const u64 w = mask[((size_t)(B0 + rl) * CB + cb) * 64 + lane];
+        const u64 w = mask[((size_t)(B0 + rl) * CB + (cb - (B0 + rl))) * 64 + lane];
         if ((s_keepbits[rl] >> lane) & 1ull) acc |= w;
       }
     }
@@ -1284,8 +1302,9 @@ __device__ __forceinline__ bool seg_kept(const u64* __restrict__ keepbits, const
 }
 
 __global__ __launch_bounds__(1024) void nms_seg_count(const u64* __restrict__ keepbits, const int* __restrict__ invperm, int n,
-                                                      int* __restrict__ counts) {
+                                                      const int64_t* __restrict__ n_dev, int* __restrict__ counts) {
   __shared__ int s_w[16];
+  n = live_boxes(n, n_dev);
   const int g = blockIdx.x * 1024 + threadIdx.x;
   const u64 bal = __ballot(seg_kept(keepbits, invperm, g, n));
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = __popcll(bal);
@@ -1299,10 +1318,11 @@ __global__ __launch_bounds__(1024) void nms_seg_count(const u64* __restrict__ ke
 
 __global__ __launch_bounds__(1024) void nms_seg_emit(const u64* __restrict__ keepbits, const int* __restrict__ invperm,
                                                      const int64_t* __restrict__ order, const int* __restrict__ counts, int n,
-                                                     const int* __restrict__ err, int64_t* __restrict__ keep_out,
-                                                     int64_t* __restrict__ num_keep) {
+                                                     const int64_t* __restrict__ n_dev, const int* __restrict__ err,
+                                                     int64_t* __restrict__ keep_out, int64_t* __restrict__ num_keep) {
   __shared__ int s_w[16];
   __shared__ int s_part[16];
+  n = live_boxes(n, n_dev);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // exclusive prefix of the chunk counts before this chunk
   int part = 0;
@@ -1375,10 +1395,12 @@ inline size_t small_seg_workspace_layout(int64_t n, int64_t S, char* base, Small
 
 template <typename T>
 __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict__ dets, const int64_t* __restrict__ order,
-                                                            const int64_t* __restrict__ seg, int n, int S, double thr, ThrBand band,
+                                                            const int64_t* __restrict__ seg, int n,
+                                                            const int64_t* __restrict__ n_dev, int S, double thr, ThrBand band,
                                                             SmallSegWorkspace ws) {
   __shared__ __attribute__((aligned(16))) T s_box[5][kSmallSegBoxes];  // component-major
   __shared__ int s_wcnt[16];
+  n = live_boxes(n, n_dev);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const int me = blockIdx.x;
@@ -1447,9 +1469,11 @@ __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict_
 }
 
 __global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int64_t* __restrict__ order, int n,
+                                                                      const int64_t* __restrict__ n_dev,
                                                                       SmallSegWorkspace ws, int64_t* __restrict__ keep_out,
                                                                       int64_t* __restrict__ num_keep) {
   static_assert(kSmallSegBlocks == kSuper, "one super-block per segment");
+  n = live_boxes(n, n_dev);
   __shared__ u64 s_keepbits[kSmallSegBlocks];
   __shared__ int s_wcnt[16];
   __shared__ int s_flag;
@@ -1638,7 +1662,7 @@ inline size_t seg_workspace_layout(int64_t n, char* base, SegWorkspace* w) {
     off += (bytes + 255) & ~(size_t)255;
     return ptr;
   };
-  char* m = take(CB * CB * 64 * sizeof(u64));
+  char* m = take(CB * std::min<size_t>(CB, (size_t)kSegMaxBlocks) * 64 * sizeof(u64));  // banded: tile (rb, cb) at row rb, slot cb - rb
   char* kb = take((CB + 1) * sizeof(u64));  // keep bits + (err, pad) right behind them: one memset
   char* oi = take((size_t)n * sizeof(int64_t));
   char* ip = take((size_t)n * sizeof(int));
@@ -1655,20 +1679,23 @@ inline size_t seg_workspace_layout(int64_t n, char* base, SegWorkspace* w) {
 }
 
 template <typename T>
-int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, const int64_t* perm, int64_t n, double thr,
-               void* workspace, int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
+int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, const int64_t* perm, int64_t n,
+               const int64_t* n_dev, double thr, void* workspace, int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
   const int CB = (int)ceil_div(n, 64), NC = (int)ceil_div(n, 1024);
+  // the mask is banded: a row block only meets column blocks of its own segments, at most kSegMaxBlocks ahead, so a row
+  // of tiles is min(CB, kSegMaxBlocks) slots wide (n x 1 KB instead of n^2 / 8 bytes: 0.37 GB instead of 16 GB at 360k boxes)
+  const int W = std::min(CB, kSegMaxBlocks);
   SegWorkspace w;
   seg_workspace_layout(n, static_cast<char*>(workspace), &w);
   hipError_t e = hipMemsetAsync(w.keepbits, 0, sizeof(u64) * ((size_t)CB + 1), stream);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms_segmented: memset");
-  nms_seg_layout<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream>>>(order, perm, (int)n, w.oidx, w.invperm);
+  nms_seg_layout<<<dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream>>>(order, perm, (int)n, n_dev, w.oidx, w.invperm);
   nms_mask_tiles_seg<T><<<dim3((unsigned)CB), dim3(kMaskWaves * kWave), 0, stream>>>(static_cast<const T*>(dets), w.oidx, keys,
-                                                                                  (int)n, CB, thr, thr_band(thr), w.mask);
-  nms_sweep_seg<<<dim3((unsigned)CB), dim3(kSuper * kWave), 0, stream>>>(w.mask, keys, (int)n, CB, w.keepbits, w.err);
-  nms_seg_count<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, (int)n, w.counts);
-  nms_seg_emit<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, order, w.counts, (int)n, w.err, keep_out,
-                                                            num_keep);
+                                                                                  (int)n, n_dev, W, thr, thr_band(thr), w.mask);
+  nms_sweep_seg<<<dim3((unsigned)CB), dim3(kSuper * kWave), 0, stream>>>(w.mask, keys, (int)n, n_dev, W, w.keepbits, w.err);
+  nms_seg_count<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, (int)n, n_dev, w.counts);
+  nms_seg_emit<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, order, w.counts, (int)n, n_dev, w.err,
+                                                            keep_out, num_keep);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_segmented");
 }
 
@@ -1762,23 +1789,110 @@ extern "C" size_t tvmi_nms_segmented_workspace_bytes(int64_t n) {
   return tvmi::seg_workspace_layout(n, nullptr, nullptr);
 }
 
-extern "C" int tvmi_nms_segmented(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
-                                  int64_t n, double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
-                                  int64_t* keep_out, int64_t* num_keep_out, void* stream) {
+namespace tvmi {
+namespace {
+int nms_segmented_entry(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm, int64_t n,
+                        const int64_t* n_dev, double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
+                        int64_t* keep_out, int64_t* num_keep_out, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   TVMI_CHECK_ARG(n >= 0, "nms_segmented: negative box count");
   TVMI_CHECK_ARG(num_keep_out != nullptr, "nms_segmented: num_keep_out is null");
   if (n == 0) {
     hipError_t e = hipMemsetAsync(num_keep_out, 0, sizeof(int64_t), s);
-    return e == hipSuccess ? 0 : tvmi::set_error((int)e, "tvmi_nms_segmented: memset");
+    return e == hipSuccess ? 0 : set_error((int)e, "tvmi_nms_segmented: memset");
   }
   TVMI_CHECK_ARG(dets && order && seg_keys && perm && keep_out && workspace, "nms_segmented: null pointer");
   TVMI_CHECK_ARG(n <= 1200000, "nms_segmented: more than 1.2M boxes is not supported by the bitmask path");
   TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_segmented_workspace_bytes(n), "nms_segmented: workspace too small");
   TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms_segmented: dets must be float32 or float64");
   if (dt == TVMI_F32)
-    return tvmi::launch_seg<float>(dets, order, seg_keys, perm, n, iou_threshold, workspace, keep_out, num_keep_out, s);
-  return tvmi::launch_seg<double>(dets, order, seg_keys, perm, n, iou_threshold, workspace, keep_out, num_keep_out, s);
+    return launch_seg<float>(dets, order, seg_keys, perm, n, n_dev, iou_threshold, workspace, keep_out, num_keep_out, s);
+  return launch_seg<double>(dets, order, seg_keys, perm, n, n_dev, iou_threshold, workspace, keep_out, num_keep_out, s);
+}
+
+int nms_small_segments_entry(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, const int64_t* n_dev,
+                             int64_t num_segments, double iou_threshold, tvmi_dtype dt, void* workspace,
+                             size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_CHECK_ARG(n >= 0 && num_keep_out != nullptr, "nms_small_segments: bad arguments");
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(num_keep_out, 0, sizeof(int64_t), s);
+    return e == hipSuccess ? 0 : set_error((int)e, "tvmi_nms_small_segments: memset");
+  }
+  TVMI_CHECK_ARG(dets && order && seg && keep_out && workspace, "nms_small_segments: null pointer");
+  TVMI_CHECK_ARG(n <= 4096 && num_segments >= 1 && num_segments <= 1024,
+                 "nms_small_segments: needs n <= 4096 and 1 <= num_segments <= 1024");
+  TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_small_segments_workspace_bytes(n, num_segments),
+                 "nms_small_segments: workspace too small");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms_small_segments: dets must be float32 or float64");
+  SmallSegWorkspace w;
+  small_seg_workspace_layout(n, num_segments, static_cast<char*>(workspace), &w);
+  hipError_t e = hipMemsetAsync(w.sync_words, 0, 2 * sizeof(int), s);
+  if (e != hipSuccess) return set_error((int)e, "tvmi_nms_small_segments: memset");
+  // a segment of m boxes has ceil(m/64)*(ceil(m/64)+1)/2 tiles; m <= min(n, 1024)
+  const int nbmax = (int)std::min<int64_t>(kSmallSegBlocks, ceil_div(n, 64));
+  const dim3 grid((unsigned)num_segments, (unsigned)ceil_div(nbmax * (nbmax + 1) / 2, 16));
+  if (dt == TVMI_F32)
+    nms_small_seg_tiles<float><<<grid, dim3(1024), 0, s>>>(static_cast<const float*>(dets), order, seg, (int)n, n_dev,
+                                                           (int)num_segments, iou_threshold, thr_band(iou_threshold), w);
+  else
+    nms_small_seg_tiles<double><<<grid, dim3(1024), 0, s>>>(static_cast<const double*>(dets), order, seg, (int)n, n_dev,
+                                                            (int)num_segments, iou_threshold, thr_band(iou_threshold), w);
+  nms_small_seg_sweep<<<dim3((unsigned)num_segments), dim3(kSuper * kWave), 0, s>>>(order, (int)n, n_dev, w, keep_out, num_keep_out);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_small_segments");
+}
+
+// masked candidates -> inputs of the device-count forms: score -inf and the largest key for a masked-out candidate (both sorts
+// put it behind every live one), and the number of live candidates.  n_live must be zero before the launch.
+__global__ __launch_bounds__(256) void nms_mask_inputs_kernel(const float* __restrict__ scores, const int64_t* __restrict__ seg,
+                                                              const uint8_t* __restrict__ valid, int64_t n,
+                                                              float* __restrict__ scores_out, int64_t* __restrict__ seg_out,
+                                                              int64_t* __restrict__ n_live) {
+  __shared__ int s_cnt[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n && valid[i] != 0;
+  if (i < n) {
+    scores_out[i] = live ? scores[i] : -INFINITY;
+    seg_out[i] = live ? seg[i] : INT64_MAX;
+  }
+  const u64 bal = __ballot(live);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (t) atomicAdd(reinterpret_cast<unsigned long long*>(n_live), (unsigned long long)t);
+  }
+}
+}  // namespace
+}  // namespace tvmi
+
+extern "C" int tvmi_nms_segmented(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
+                                  int64_t n, double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
+                                  int64_t* keep_out, int64_t* num_keep_out, void* stream) {
+  return tvmi::nms_segmented_entry(dets, order, seg_keys, perm, n, nullptr, iou_threshold, dt, workspace, workspace_bytes, keep_out,
+                                   num_keep_out, stream);
+}
+
+extern "C" int tvmi_nms_segmented_devcount(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
+                                           int64_t capacity, const int64_t* n_dev, double iou_threshold, tvmi_dtype dt,
+                                           void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
+                                           void* stream) {
+  TVMI_CHECK_ARG(n_dev != nullptr, "nms_segmented_devcount: n_dev is null");
+  return tvmi::nms_segmented_entry(dets, order, seg_keys, perm, capacity, n_dev, iou_threshold, dt, workspace, workspace_bytes,
+                                   keep_out, num_keep_out, stream);
+}
+
+extern "C" int tvmi_nms_mask_inputs(const float* scores, const int64_t* seg, const uint8_t* valid, int64_t n, float* scores_out,
+                                    int64_t* seg_out, int64_t* n_live, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TVMI_CHECK_ARG(n >= 0 && n_live != nullptr, "nms_mask_inputs: bad arguments");
+  hipError_t e = hipMemsetAsync(n_live, 0, sizeof(int64_t), s);
+  if (e != hipSuccess) return tvmi::set_error((int)e, "tvmi_nms_mask_inputs: memset");
+  if (n == 0) return 0;
+  TVMI_CHECK_ARG(scores && seg && valid && scores_out && seg_out, "nms_mask_inputs: null pointer");
+  tvmi::nms_mask_inputs_kernel<<<dim3((unsigned)tvmi::ceil_div(n, 256)), dim3(256), 0, s>>>(scores, seg, valid, n, scores_out, seg_out,
+                                                                                         n_live);
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_mask_inputs");
 }
 
 extern "C" size_t tvmi_nms_small_segments_workspace_bytes(int64_t n, int64_t num_segments) {
@@ -1789,34 +1903,17 @@ extern "C" size_t tvmi_nms_small_segments_workspace_bytes(int64_t n, int64_t num
 extern "C" int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_t* seg, int64_t n,
                                        int64_t num_segments, double iou_threshold, tvmi_dtype dt, void* workspace,
                                        size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TVMI_CHECK_ARG(n >= 0 && num_keep_out != nullptr, "nms_small_segments: bad arguments");
-  if (n == 0) {
-    hipError_t e = hipMemsetAsync(num_keep_out, 0, sizeof(int64_t), s);
-    return e == hipSuccess ? 0 : tvmi::set_error((int)e, "tvmi_nms_small_segments: memset");
-  }
-  TVMI_CHECK_ARG(dets && order && seg && keep_out && workspace, "nms_small_segments: null pointer");
-  TVMI_CHECK_ARG(n <= 4096 && num_segments >= 1 && num_segments <= 1024,
-                 "nms_small_segments: needs n <= 4096 and 1 <= num_segments <= 1024");
-  TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_small_segments_workspace_bytes(n, num_segments),
-                 "nms_small_segments: workspace too small");
-  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms_small_segments: dets must be float32 or float64");
-  tvmi::SmallSegWorkspace w;
-  tvmi::small_seg_workspace_layout(n, num_segments, static_cast<char*>(workspace), &w);
-  hipError_t e = hipMemsetAsync(w.sync_words, 0, 2 * sizeof(int), s);
-  if (e != hipSuccess) return tvmi::set_error((int)e, "tvmi_nms_small_segments: memset");
-  // a segment of m boxes has ceil(m/64)*(ceil(m/64)+1)/2 tiles; m <= min(n, 1024)
-  const int nbmax = (int)std::min<int64_t>(tvmi::kSmallSegBlocks, tvmi::ceil_div(n, 64));
-  const dim3 grid((unsigned)num_segments, (unsigned)tvmi::ceil_div(nbmax * (nbmax + 1) / 2, 16));
-  if (dt == TVMI_F32)
-    tvmi::nms_small_seg_tiles<float><<<grid, dim3(1024), 0, s>>>(static_cast<const float*>(dets), order, seg, (int)n,
-                                                                 (int)num_segments, iou_threshold, tvmi::thr_band(iou_threshold), w);
-  else
-    tvmi::nms_small_seg_tiles<double><<<grid, dim3(1024), 0, s>>>(static_cast<const double*>(dets), order, seg, (int)n,
-                                                                  (int)num_segments, iou_threshold, tvmi::thr_band(iou_threshold), w);
-  tvmi::nms_small_seg_sweep<<<dim3((unsigned)num_segments), dim3(tvmi::kSuper * tvmi::kWave), 0, s>>>(order, (int)n, w, keep_out,
-                                                                                                    num_keep_out);
-  TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_small_segments");
+  return tvmi::nms_small_segments_entry(dets, order, seg, n, nullptr, num_segments, iou_threshold, dt, workspace, workspace_bytes,
+                                        keep_out, num_keep_out, stream);
+}
+
+extern "C" int tvmi_nms_small_segments_devcount(const void* dets, const int64_t* order, const int64_t* seg, int64_t capacity,
+                                                const int64_t* n_dev, int64_t num_segments, double iou_threshold, tvmi_dtype dt,
+                                                void* workspace, size_t workspace_bytes, int64_t* keep_out,
+                                                int64_t* num_keep_out, void* stream) {
+  TVMI_CHECK_ARG(n_dev != nullptr, "nms_small_segments_devcount: n_dev is null");
+  return tvmi::nms_small_segments_entry(dets, order, seg, capacity, n_dev, num_segments, iou_threshold, dt, workspace,
+                                        workspace_bytes, keep_out, num_keep_out, stream);
 }
 
 extern "C" int tvmi_sort_scores_desc(const float* scores, int64_t n, int64_t* order, void* stream) {

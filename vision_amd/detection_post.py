@@ -6,11 +6,14 @@ Host-side mirrors of
 with the same argument meaning and the same per-image list results, but run as
   [torch.topk per level]  ->  ONE candidate kernel for the whole batch (tvmi::rpn_candidates /
   tvmi::detection_candidates: gather / softmax-sigmoid / BoxCoder.decode / clip / filters)
-  ->  one `nonzero` (the only host sync; the reference takes ~6 per image)
-  ->  ONE segmented NMS over all images (tvmi::nms_segmented, segment = image x level|class)
-  ->  ONE top-k packing launch (tvmi::pack_detections).
+  ->  ONE masked segmented NMS over all images (tvmi::nms_segmented_masked, segment = image x level|class:
+      filtered-out candidates leave the problem ON THE DEVICE — score -inf / largest key put them behind every live
+      candidate in both sorts and the kernels read the live count from memory; no `nonzero`, no gathers)
+  ->  ONE top-k packing launch (tvmi::pack_detections_devcount, keep length read on the device).
 `padded=True` returns the fixed-shape payload ([B, max, 6] + counts) without the final split, which
-is what `vision_amd.sharding.all_gather_detections` ships between GPUs.
+is what `vision_amd.sharding.all_gather_detections` ships between GPUs — and that form has NO host
+synchronisation at all (it runs under `torch.cuda.set_sync_debug_mode("error")`, tests/test_gpu_parity.py); the
+list-returning form reads the per-image counts once, at the very end (the reference takes ~6 reads per image).
 Device tensors only — there is no CPU fallback in the product path.
 """
 import math
@@ -24,8 +27,14 @@ from ._loader import load as _load
 BBOX_XFORM_CLIP = math.log(1000.0 / 16)  # models/detection/_utils.py:141
 
 
+def _host_to_device(values, dtype, device) -> Tensor:
+    """Small host-built table -> device without a blocking copy (pinned staging + non_blocking: a pageable
+    `torch.tensor(..., device=)` is a synchronising memcpy, which the sync-free forms must not contain)."""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
+
+
 def _image_hw(image_shapes: Sequence[Tuple[int, int]], device) -> Tensor:
-    return torch.tensor([[float(h), float(w)] for h, w in image_shapes], dtype=torch.float32, device=device)
+    return _host_to_device([[float(h), float(w)] for h, w in image_shapes], torch.float32, device)
 
 
 def _need_cuda(t: Tensor, what: str):
@@ -63,15 +72,14 @@ def filter_proposals(proposals: Tensor, objectness: Tensor, image_shapes: Sequen
         off += n
     top_idx = torch.cat(idx, dim=1)
     T, L = top_idx.shape[1], len(num_anchors_per_level)
-    offsets = torch.tensor([0] + list(num_anchors_per_level[:-1]), dtype=torch.int64).cumsum(0).to(proposals.device)
+    offsets = _host_to_device([sum(num_anchors_per_level[:i]) for i in range(L)], torch.int64, proposals.device)
     boxes, scores, levels, valid = torch.ops.tvmi.rpn_candidates(
         objectness, proposals.reshape(B, A, 4), None if pred_bbox_deltas is None else pred_bbox_deltas.detach().reshape(B, A, 4),
         top_idx, offsets, _image_hw(image_shapes, proposals.device), BBOX_XFORM_CLIP, float(score_thresh), float(min_size))
-    sel = valid.reshape(-1).nonzero()[:, 0]
-    img = sel // T
-    b, s = boxes.reshape(-1, 4)[sel], scores.reshape(-1)[sel]
-    keep = torch.ops.tvmi.nms_segmented(b, s, img * L + levels.reshape(-1)[sel], float(nms_thresh), B * L)
-    dets, counts = torch.ops.tvmi.pack_detections(b, s, None, img, keep, B, int(post_nms_top_n))
+    img = torch.arange(B, device=proposals.device, dtype=torch.int64).repeat_interleave(T)          # image of candidate i (static shape)
+    b, s = boxes.reshape(-1, 4), scores.reshape(-1)
+    keep, num = torch.ops.tvmi.nms_segmented_masked(b, s, img * L + levels.reshape(-1), valid.reshape(-1), float(nms_thresh), B * L)
+    dets, counts = torch.ops.tvmi.pack_detections_devcount(b, s, None, img, keep, num, B, int(post_nms_top_n))
     return (dets, counts) if padded else _split(dets, counts, False)
 
 
@@ -85,18 +93,18 @@ def postprocess_detections(class_logits: Tensor, box_regression: Tensor, proposa
     _need_cuda(class_logits, "postprocess_detections")
     B, C = len(proposals), class_logits.shape[-1]
     dev = class_logits.device
-    row_image = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32),
-                                        torch.tensor([p.shape[0] for p in proposals], device=dev))
+    row_image = torch.arange(B, dtype=torch.int32).repeat_interleave(torch.tensor([p.shape[0] for p in proposals]))   # host
+    row_image = row_image.pin_memory().to(dev, non_blocking=True)
     cb, cs, cv = torch.ops.tvmi.detection_candidates(
         class_logits, box_regression, torch.cat(list(proposals), 0), row_image, _image_hw(image_shapes, dev),
         [float(w) for w in bbox_reg_weights], BBOX_XFORM_CLIP, float(score_thresh), 1e-2)
-    sel = cv.reshape(-1).nonzero()[:, 0]
-    r = sel // (C - 1)
-    labels = sel - r * (C - 1) + 1
-    img = row_image[r].to(torch.int64)
-    b, s = cb.reshape(-1, 4)[sel], cs.reshape(-1)[sel]
-    keep = torch.ops.tvmi.nms_segmented(b, s, img * C + labels, float(nms_thresh), B * C)
-    dets, counts = torch.ops.tvmi.pack_detections(b, s, labels, img, keep, B, int(detections_per_img))
+    R = class_logits.shape[0]
+    # candidate (r, c) of the [R, C-1] grid: label c + 1, image of row r — static-shape index arithmetic, no compaction
+    labels = torch.arange(1, C, device=dev, dtype=torch.int64).repeat(R)
+    img = row_image.to(torch.int64).repeat_interleave(C - 1)
+    b, s = cb.reshape(-1, 4), cs.reshape(-1)
+    keep, num = torch.ops.tvmi.nms_segmented_masked(b, s, img * C + labels, cv.reshape(-1), float(nms_thresh), B * C)
+    dets, counts = torch.ops.tvmi.pack_detections_devcount(b, s, labels, img, keep, num, B, int(detections_per_img))
     return (dets, counts) if padded else _split(dets, counts, True)
 
 
@@ -109,8 +117,8 @@ def retinanet_postprocess_detections(cls_logits: Sequence[Tensor], bbox_regressi
     head outputs into, :624-636), `anchors[i][l]` [A_l, 4] per image and level.  The reference loops images x levels (sigmoid,
     threshold, top-k, decode, clip: ~12 launches each) and calls batched_nms per image; here: per level ONE sigmoid + top-k over
     the batch (library plumbing), ONE gather / decode / clip kernel for all survivors (`tvmi::rpn_candidates`: BoxCoder weights
-    (1, 1, 1, 1) and the clip of `det_utils.BoxCoder`, the same as the RPN's), one `nonzero`, ONE class-segmented NMS over all
-    images and one packing launch.  Returns the reference's list of {boxes, scores, labels} dicts (or the padded payload)."""
+    (1, 1, 1, 1) and the clip of `det_utils.BoxCoder`, the same as the RPN's), ONE masked class-segmented NMS over all
+    images (below-threshold candidates leave on the device) and one packing launch.  Returns the reference's list of {boxes, scores, labels} dicts (or the padded payload)."""
     _load()
     _need_cuda(cls_logits[0], "retinanet_postprocess_detections")
     B, K = cls_logits[0].shape[0], cls_logits[0].shape[-1]
@@ -135,14 +143,13 @@ def retinanet_postprocess_detections(cls_logits: Sequence[Tensor], bbox_regressi
     labels, ok = torch.cat(cand_label, 1), torch.cat(cand_ok, 1)
     T = logit.shape[1]
     top_idx = torch.arange(T, device=dev, dtype=torch.int64).expand(B, T).contiguous()
-    offsets = torch.tensor([0] + per_level[:-1], dtype=torch.int64).cumsum(0).to(dev)
+    offsets = _host_to_device([sum(per_level[:i]) for i in range(len(per_level))], torch.int64, dev)
     boxes, scores, _, _ = torch.ops.tvmi.rpn_candidates(logit.contiguous(), anc, dlt, top_idx, offsets, _image_hw(image_shapes, dev),
                                                         BBOX_XFORM_CLIP, 0.0, -1.0)
-    sel = ok.reshape(-1).nonzero()[:, 0]
-    img = sel // T
-    b, sc, lab = boxes.reshape(-1, 4)[sel], scores.reshape(-1)[sel], labels.reshape(-1)[sel]
-    keep = torch.ops.tvmi.nms_segmented(b, sc, img * K + lab, float(nms_thresh), B * K)
-    dets, counts = torch.ops.tvmi.pack_detections(b, sc, lab, img, keep, B, int(detections_per_img))
+    img = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(T)
+    b, sc, lab = boxes.reshape(-1, 4), scores.reshape(-1), labels.reshape(-1)
+    keep, num = torch.ops.tvmi.nms_segmented_masked(b, sc, img * K + lab, ok.reshape(-1), float(nms_thresh), B * K)
+    dets, counts = torch.ops.tvmi.pack_detections_devcount(b, sc, lab, img, keep, num, B, int(detections_per_img))
     if padded:
         return dets, counts
     bl, sl, ll = _split(dets, counts, True)

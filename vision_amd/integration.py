@@ -37,6 +37,139 @@ def make_overlay(dst: str, reference_pkg: str) -> str:
     return dst
 
 
+def _is_retinanet(model) -> bool:
+    """True for the reference's RetinaNet (retinanet.py:324) and its subclasses: class name in the MRO, the anchor-box coder
+    with unit weights (retinanet.py:433) and a head without a centerness branch."""
+    if not (hasattr(model, "topk_candidates") and hasattr(model, "postprocess_detections")):
+        return False
+    if not any(c.__name__ == "RetinaNet" for c in type(model).__mro__):
+        return False
+    weights = getattr(getattr(model, "box_coder", None), "weights", None)
+    if weights is None or tuple(float(w) for w in weights) != (1.0, 1.0, 1.0, 1.0):
+        return False
+    head = getattr(model, "head", None)
+    return head is not None and hasattr(head, "classification_head") and not hasattr(getattr(head, "regression_head", None), "bbox_ctrness")
+
+
+class _ImageList:
+    """models/detection/image_list.py:6-24 — `tensors` + `image_sizes` is all the detectors read."""
+
+    def __init__(self, tensors, image_sizes):
+        self.tensors, self.image_sizes = tensors, image_sizes
+
+    def to(self, device):
+        return _ImageList(self.tensors.to(device), self.image_sizes)
+
+
+def _tracing() -> bool:
+    import torch
+
+    return torch.jit.is_scripting() or torch.jit.is_tracing()
+
+
+# ---- the fused pieces as METHODS of the reference's classes.  Each factory takes the reference's own method and returns a
+# replacement with the same signature that runs the fused path when it applies (device tensors, eager mode, the configuration
+# the fused launch implements) and calls the reference's method otherwise.  `fuse_detection_model` binds them to ONE model;
+# `vision_amd.autofuse` installs them at class level when TVMI_AUTOFUSE=1 (the unchanged reference python, fast by default).
+def make_pool_forward(orig):
+    """MultiScaleRoIAlign.forward (ops/poolers.py:289-321) -> ONE multi-scale launch instead of the per-level
+    where / roi_align / index_put loop (ops/poolers.py:199-222).  Scales and the level mapper are the reference's own
+    (`self.scales`, `self.map_levels`, set up by ITS `_setup_scales` through `orig`'s module)."""
+    import torch
+
+    from . import poolers
+
+    def forward(self, x, boxes, image_shapes):
+        feats = [v for k, v in x.items() if k in self.featmap_names]
+        if (_tracing() or len(feats) < 2 or not all(f.is_cuda for f in feats) or not len(boxes) or not boxes[0].is_cuda
+                or feats[0].dtype not in (torch.float32, torch.float16, torch.bfloat16)):
+            return orig(self, x, boxes, image_shapes)
+        if self.scales is None or self.map_levels is None:
+            self.scales, self.map_levels = poolers._setup_scales(feats, image_shapes, self.canonical_scale, self.canonical_level)
+        return poolers._multiscale_roi_align(feats, boxes, tuple(self.output_size), int(self.sampling_ratio), self.scales, self.map_levels)
+    return forward
+
+
+def make_postprocess_detections(orig):
+    """RoIHeads.postprocess_detections (roi_heads.py:680-737), batched over the images."""
+    import vision_amd
+
+    def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
+        if _tracing() or not class_logits.is_cuda:
+            return orig(self, class_logits, box_regression, proposals, image_shapes)
+        return vision_amd.postprocess_detections(class_logits, box_regression, proposals, image_shapes,
+                                                 bbox_reg_weights=self.box_coder.weights, score_thresh=self.score_thresh,
+                                                 nms_thresh=self.nms_thresh, detections_per_img=self.detections_per_img)
+    return postprocess_detections
+
+
+def make_filter_proposals(orig):
+    """RegionProposalNetwork.filter_proposals (rpn.py:242-297), batched over images and levels."""
+    import vision_amd
+
+    def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
+        if _tracing() or not proposals.is_cuda:
+            return orig(self, proposals, objectness, image_shapes, num_anchors_per_level)
+        return vision_amd.filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level,
+                                           pre_nms_top_n=self.pre_nms_top_n(), post_nms_top_n=self.post_nms_top_n(),
+                                           nms_thresh=self.nms_thresh, score_thresh=self.score_thresh, min_size=self.min_size)
+    return filter_proposals
+
+
+def make_retinanet_postprocess(orig):
+    """RetinaNet.postprocess_detections (retinanet.py:509-571); anything that is not the reference's RetinaNet arithmetic
+    (a subclass with another box coder or head) keeps the reference's method."""
+    import vision_amd
+
+    def postprocess_detections(self, head_outputs, anchors, image_shapes):
+        cls = head_outputs["cls_logits"]
+        if _tracing() or not _is_retinanet(self) or not isinstance(cls, (list, tuple)) or not cls[0].is_cuda:
+            return orig(self, head_outputs, anchors, image_shapes)
+        return vision_amd.retinanet_postprocess_detections(
+            cls, head_outputs["bbox_regression"], anchors, image_shapes, score_thresh=self.score_thresh,
+            topk_candidates=self.topk_candidates, nms_thresh=self.nms_thresh, detections_per_img=self.detections_per_img)
+    return postprocess_detections
+
+
+def make_transform_forward(orig, image_list_cls=None):
+    """GeneralizedRCNNTransform.forward in eval mode (transform.py:119-255): normalise + resize + pad of the batch in one launch.
+    Training, targets, fixed_size / _skip_resize transforms (SSD builds its transform with fixed_size=size, ssd.py:331-334;
+    transform.py:174-191) and CPU images run the reference's own forward."""
+    import vision_amd
+
+    if image_list_cls is None:
+        image_list_cls = _ImageList
+
+    def forward(self, images, targets=None):
+        if (_tracing() or self.training or targets is not None or getattr(self, "fixed_size", None) is not None
+                or getattr(self, "_skip_resize", False) or not len(images) or not all(im.is_cuda and im.dim() == 3 for im in images)):
+            return orig(self, images, targets)
+        tensors, sizes = vision_amd.transform_images(images, self.min_size, self.max_size, self.image_mean, self.image_std,
+                                                     self.size_divisible)
+        return image_list_cls(tensors, [tuple(s) for s in sizes]), targets
+    return forward
+
+
+def make_transform_postprocess(orig):
+    """GeneralizedRCNNTransform.postprocess (transform.py:257-276) with the batched paste (roi_heads.py:378-500)."""
+    import vision_amd
+
+    def postprocess(self, result, image_shapes, original_image_sizes):
+        if self.training:
+            return result
+        if _tracing() or not len(result) or not result[0]["boxes"].is_cuda:
+            return orig(self, result, image_shapes, original_image_sizes)
+        for i, (pred, im_s, o_im_s) in enumerate(zip(result, image_shapes, original_image_sizes)):
+            boxes = vision_amd.resize_boxes(pred["boxes"], im_s, o_im_s)
+            result[i]["boxes"] = boxes
+            if "masks" in pred:
+                result[i]["masks"] = vision_amd.paste_masks_in_image(pred["masks"], boxes, o_im_s)
+            if "keypoints" in pred:
+                result[i]["keypoints"] = vision_amd.resize_keypoints(pred["keypoints"], im_s, o_im_s)
+        return result
+    return postprocess
+
+
 def fuse_detection_model(model, paste_masks: bool = True, transform: bool = True):
     """Swap the fused `vision_amd` pieces into a detection model of the reference (`torchvision.models.detection`:
     Faster R-CNN / Mask R-CNN / Keypoint R-CNN = GeneralizedRCNN with RoIHeads + RPN, or RetinaNet), in place, and return it.
@@ -50,9 +183,12 @@ def fuse_detection_model(model, paste_masks: bool = True, transform: bool = True
       transform.forward (eval)           -> `vision_amd.transform_images`         (transform.py:119-255: one launch per batch)
       transform.postprocess              -> the reference's method with `vision_amd.paste_masks_in_image` (roi_heads.py:378-500)
 
-    Only attributes of THIS model are replaced (no module-level monkey patching).  Training mode keeps the reference transform
-    (targets are resized there) and the reference post-processing is not used in training anyway.  Duck-typed: nothing of the
-    reference package is imported here."""
+    Only attributes of THIS model are replaced (no module-level monkey patching; `vision_amd.autofuse` is the class-level,
+    opt-in form of the same swaps).  Every replaced method calls the reference's own when the fused path does not apply:
+    training mode / targets (targets are resized by the reference transform), CPU tensors, fixed_size / _skip_resize transforms.
+    RetinaNet only: FCOS (fcos.py:426,489) and SSD / SSDlite (ssd.py:240,414) carry the same `topk_candidates` /
+    `postprocess_detections` attributes but score with sqrt(cls * centerness) + BoxLinearCoder resp. softmax over one logits
+    tensor — they keep the reference's post-processing.  Duck-typed: nothing of the reference package is imported."""
     import vision_amd
 
     def swap_pool(owner, name):
@@ -64,52 +200,22 @@ def fuse_detection_model(model, paste_masks: bool = True, transform: bool = True
                                             canonical_level=int(getattr(old, "canonical_level", 4)))
         setattr(owner, name, new)
 
+    def bind(owner, name, factory):
+        setattr(owner, name, types.MethodType(factory(getattr(type(owner), name)), owner))
+
     rh, rpn = getattr(model, "roi_heads", None), getattr(model, "rpn", None)
     if rh is not None:
         for name in ("box_roi_pool", "mask_roi_pool", "keypoint_roi_pool"):
             swap_pool(rh, name)
-
-        def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
-            return vision_amd.postprocess_detections(class_logits, box_regression, proposals, image_shapes,
-                                                     bbox_reg_weights=self.box_coder.weights, score_thresh=self.score_thresh,
-                                                     nms_thresh=self.nms_thresh, detections_per_img=self.detections_per_img)
-        rh.postprocess_detections = types.MethodType(postprocess_detections, rh)
+        if hasattr(rh, "box_coder") and hasattr(rh, "detections_per_img"):
+            bind(rh, "postprocess_detections", make_postprocess_detections)
     if rpn is not None and hasattr(rpn, "pre_nms_top_n"):
-        def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
-            return vision_amd.filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level,
-                                               pre_nms_top_n=self.pre_nms_top_n(), post_nms_top_n=self.post_nms_top_n(),
-                                               nms_thresh=self.nms_thresh, score_thresh=self.score_thresh, min_size=self.min_size)
-        rpn.filter_proposals = types.MethodType(filter_proposals, rpn)
-    if rh is None and hasattr(model, "topk_candidates") and hasattr(model, "postprocess_detections"):   # RetinaNet
-        def retina_post(self, head_outputs, anchors, image_shapes):
-            return vision_amd.retinanet_postprocess_detections(
-                head_outputs["cls_logits"], head_outputs["bbox_regression"], anchors, image_shapes, score_thresh=self.score_thresh,
-                topk_candidates=self.topk_candidates, nms_thresh=self.nms_thresh, detections_per_img=self.detections_per_img)
-        model.postprocess_detections = types.MethodType(retina_post, model)
+        bind(rpn, "filter_proposals", make_filter_proposals)
+    if rh is None and _is_retinanet(model):
+        bind(model, "postprocess_detections", make_retinanet_postprocess)
     tr = getattr(model, "transform", None)
     if tr is not None and transform and hasattr(tr, "image_mean"):
-        ref_forward = tr.forward
-
-        def fused_forward(images, targets=None):
-            if tr.training or targets is not None:
-                return ref_forward(images, targets)
-            tensors, sizes = vision_amd.transform_images(images, tr.min_size, tr.max_size, tr.image_mean, tr.image_std,
-                                                         tr.size_divisible)
-            image_list = type("ImageList", (), {})()      # models/detection/image_list.py: `tensors` + `image_sizes`, nothing else is read
-            image_list.tensors, image_list.image_sizes = tensors, [tuple(s) for s in sizes]
-            return image_list, targets
-        tr.forward = fused_forward
+        bind(tr, "forward", make_transform_forward)
     if tr is not None and paste_masks and hasattr(tr, "postprocess"):
-        def postprocess(self, result, image_shapes, original_image_sizes):
-            if self.training:
-                return result
-            for i, (pred, im_s, o_im_s) in enumerate(zip(result, image_shapes, original_image_sizes)):
-                boxes = vision_amd.resize_boxes(pred["boxes"], im_s, o_im_s)
-                result[i]["boxes"] = boxes
-                if "masks" in pred:
-                    result[i]["masks"] = vision_amd.paste_masks_in_image(pred["masks"], boxes, o_im_s)
-                if "keypoints" in pred:
-                    result[i]["keypoints"] = vision_amd.resize_keypoints(pred["keypoints"], im_s, o_im_s)
-            return result
-        tr.postprocess = types.MethodType(postprocess, tr)
+        bind(tr, "postprocess", make_transform_postprocess)
     return model
