@@ -310,9 +310,6 @@ int tvmi_ps_roi_pool_backward(const void* grad, const void* rois, const int32_t*
  * weight [OC,C/groups,kh,kw], offset [B,2*og*kh*kw,oh,ow], mask [B,og*kh*kw,oh,ow]
  * (ignored unless use_mask), bias [OC], output [B,OC,oh,ow] (fully overwritten).
  * `workspace` holds the re-laid-out weights (tvmi_deform_conv2d_workspace_bytes).
- * The three deformable_* launchers are the building blocks of the backward pass
- * (cuda/deform_conv2d_kernel.cu:319-750): columns is [C*kh*kw, B*oh*ow]; col2im accumulates
- * into a caller-zeroed grad_input; col2im_coord overwrites grad_offset (and grad_mask).
  */
 size_t tvmi_deform_conv2d_workspace_bytes(tvmi_dtype dt, int64_t C, int64_t OC, int64_t kh, int64_t kw,
                                           int64_t groups);
@@ -329,19 +326,6 @@ int tvmi_deform_conv2d_forward(const void* input, const void* weight, const void
                                int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w,
                                int64_t groups, int64_t offset_groups, int use_mask, void* workspace,
                                size_t workspace_bytes, void* stream);
-int tvmi_deformable_im2col(const void* input, const void* offset, const void* mask, void* columns,
-                           tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw,
-                           int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h,
-                           int64_t dil_w, int64_t offset_groups, int use_mask, void* stream);
-int tvmi_deformable_col2im(const void* columns, const void* offset, const void* mask, void* grad_input,
-                           tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw,
-                           int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h,
-                           int64_t dil_w, int64_t offset_groups, int use_mask, void* stream);
-int tvmi_deformable_col2im_coord(const void* columns, const void* input, const void* offset, const void* mask,
-                                 void* grad_offset, void* grad_mask, tvmi_dtype dt, int64_t B, int64_t C,
-                                 int64_t H, int64_t W, int64_t kh, int64_t kw, int64_t stride_h,
-                                 int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h, int64_t dil_w,
-                                 int64_t offset_groups, int use_mask, void* stream);
 /* The whole backward pass in one call, no materialised `columns` and no library GEMM.  Replaces the reference's
  * backward_gradient_inputs + backward_gradient_parameters (cpu/deform_conv2d_kernel.cpp:554-919, 1153-1226;
  * cuda/deform_conv2d_kernel.cu:752-1033, 1257-1330: a GEMM per weight group into [C*kh*kw, B*oh*ow], col2im_coord, col2im,
@@ -354,9 +338,12 @@ int tvmi_deformable_col2im_coord(const void* columns, const void* input, const v
  * is not fixed, like the reference's (not bit-reproducible run to run).  `workspace`:
  * tvmi_deform_conv2d_backward_workspace_bytes (re-laid-out weights, the [tap][oc][ic] weight-gradient sums, fp32 sums of
  * 16-bit problems, channels-last copies of input / grad_out and channels-last grad_input sums where a kernel wants them; 0 for
- * fp64). */
+ * fp64).  The query takes the geometry of the call (ABI 304: stride / padding / dilation instead of the output size), because
+ * the route — and with it the buffers — depends on it: a strided or dilated 3 x 3 problem whose window no longer fits the
+ * owner kernel's LDS asks for no channels-last buffers. */
 size_t tvmi_deform_conv2d_backward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC,
-                                                   int64_t kh, int64_t kw, int64_t oh, int64_t ow, int64_t groups,
+                                                   int64_t kh, int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                                                   int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t groups,
                                                    int64_t offset_groups);
 int tvmi_deform_conv2d_backward(const void* grad_out, const void* input, const void* weight, const void* offset,
                                 const void* mask, void* grad_input, void* grad_weight, void* grad_offset, void* grad_mask,

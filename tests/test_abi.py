@@ -143,21 +143,25 @@ def test_deform_conv2d_backward_workspace_plan_is_host_side_and_covers_its_buffe
     lib = vision_amd._loader.kernels()
     f = lib.tvmi_deform_conv2d_backward_workspace_bytes
     f.restype = ctypes.c_size_t
-    f.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 11
+    f.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 15
     header = open(HEADER).read()
     dt = {k: int(re.search(rf"\b{k}\s*=\s*(\d+)", header).group(1)) for k in ("TVMI_F32", "TVMI_F64", "TVMI_F16", "TVMI_BF16")}
     B, C, H, W, OC, k = 2, 256, 100, 136, 256, 3
     n_in, n_out, KK = B * C * H * W, B * OC * H * W, k * k
     # groups = 1, fp32: re-laid-out weights + [tap][oc][ic] sums + channels-last input copy + channels-last grad_input sums
-    g1 = f(dt["TVMI_F32"], B, C, H, W, OC, k, k, H, W, 1, 1)
+    g1 = f(dt["TVMI_F32"], B, C, H, W, OC, k, k, 1, 1, 1, 1, 1, 1, 1, 1)
     assert g1 >= 4 * (KK * OC * C) * 2 + 4 * n_in * 2
     # 16-bit: additionally fp32 sums of grad_offset / grad_mask (and grad_input for the routes that want it planar)
-    g1h = f(dt["TVMI_BF16"], B, C, H, W, OC, k, k, H, W, 1, 1)
+    g1h = f(dt["TVMI_BF16"], B, C, H, W, OC, k, k, 1, 1, 1, 1, 1, 1, 1, 1)
     assert g1h >= 4 * (KK * OC * C) * 2 + 2 * n_in + 4 * n_in + 4 * B * 3 * KK * H * W
     # depthwise: channels-last copies of input and grad_out, channels-last sums, fp32 weight-gradient sums
-    dw = f(dt["TVMI_F32"], B, C, H, W, OC, k, k, H, W, C, 1)
+    dw = f(dt["TVMI_F32"], B, C, H, W, OC, k, k, 1, 1, 1, 1, 1, 1, C, 1)
     assert dw >= 4 * n_in + 4 * n_out + 4 * n_in + 4 * OC * KK
     # fp64 runs the direct kernels in place; nonsense shapes ask for nothing
-    assert f(dt["TVMI_F64"], B, C, H, W, OC, k, k, H, W, 1, 1) == 0
-    assert f(dt["TVMI_F32"], 0, C, H, W, OC, k, k, H, W, 1, 1) == 0
-    assert f(dt["TVMI_F32"], B, C, H, W, OC, k, k, H, W, 3, 1) == 0      # C % groups != 0
+    assert f(dt["TVMI_F64"], B, C, H, W, OC, k, k, 1, 1, 1, 1, 1, 1, 1, 1) == 0
+    assert f(dt["TVMI_F32"], 0, C, H, W, OC, k, k, 1, 1, 1, 1, 1, 1, 1, 1) == 0
+    assert f(dt["TVMI_F32"], B, C, H, W, OC, k, k, 1, 1, 1, 1, 1, 1, 3, 1) == 0      # C % groups != 0
+    # the owner form's channels-last buffers (2 x 4 bytes per input element) are asked for only where that form can
+    # run — a dilation-7 window does not fit its LDS, a 1 x 9 kernel is not its shape
+    assert f(dt["TVMI_F32"], B, C, H, W, OC, k, k, 1, 1, 7, 7, 7, 7, 1, 1) <= g1 - 8 * n_in
+    assert f(dt["TVMI_F32"], B, C, H, W, OC, 1, 9, 1, 1, 0, 4, 1, 1, 1, 1) <= g1 - 8 * n_in

@@ -661,6 +661,8 @@ DCN_BWD_CFGS = [
     dict(B=2, C=128, OC=64, H=17, W=21, k=(3, 3), groups=2, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=False, off_scale=4),  # owner form: two weight groups, most offsets beyond the window's reach
     dict(B=2, C=128, OC=128, H=12, W=14, k=(3, 3), groups=128, og=2, stride=(1, 1), pad=(1, 1), dil=(1, 1), mask=True),            # depthwise, channels-last route, one 64-channel pass per offset group
     dict(B=1, C=128, OC=128, H=13, W=9, k=(3, 2), groups=128, og=1, stride=(2, 1), pad=(1, 0), dil=(1, 2), mask=False),            # depthwise, two passes, strides / dilation, no mask
+    dict(B=1, C=64, OC=32, H=12, W=20, k=(1, 9), groups=1, og=1, stride=(1, 1), pad=(0, 4), dil=(1, 1), mask=True, off_scale=0.5),   # 9 taps that are NOT 3 x 3: not the owner form
+    dict(B=1, C=64, OC=32, H=20, W=12, k=(9, 1), groups=1, og=1, stride=(1, 1), pad=(4, 0), dil=(1, 1), mask=False, off_scale=0.5),  # ... and the transposed one
 ]
 
 
@@ -745,8 +747,9 @@ def test_deform_conv2d_backward_through_the_c_abi():
     oh, ow = gr.shape[2:]
     i64 = ctypes.c_int64
     lib.tvmi_deform_conv2d_backward_workspace_bytes.restype = ctypes.c_size_t
-    lib.tvmi_deform_conv2d_backward_workspace_bytes.argtypes = [ctypes.c_int] + [i64] * 11
-    nbytes = lib.tvmi_deform_conv2d_backward_workspace_bytes(0, B, C, H, W, OC, kh, kw, oh, ow, cfg["groups"], cfg["og"])
+    lib.tvmi_deform_conv2d_backward_workspace_bytes.argtypes = [ctypes.c_int] + [i64] * 15
+    nbytes = lib.tvmi_deform_conv2d_backward_workspace_bytes(0, B, C, H, W, OC, kh, kw, *cfg["stride"], *cfg["pad"], *cfg["dil"],
+                                                              cfg["groups"], cfg["og"])
     assert nbytes > 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     lib.tvmi_deform_conv2d_backward.restype = ctypes.c_int

@@ -1,6 +1,6 @@
 """deform_conv2d backward: every route of tvmi_deform_conv2d_backward (matrix-core kernels, direct kernels, 16-bit, fp64)
 against the reference CPU kernels (oracle/_ref) on small problems — error statistics per gradient, nothing asserted — and
-the config-4 timings of the fused backward next to the round-3 route (library GEMMs, option dcn.bwd_blas).
+the config-4 timings of the fused backward (the round-3 library-GEMM route was removed in round 5).
 python tools/dcn_bwd_check.py out.json"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -95,8 +95,8 @@ for groups in (1, 256):
     w = torch.randn(OC, C // groups, 3, 3, generator=g) * (0.01 if groups == 1 else 0.2)
     for dt in (torch.float32, torch.bfloat16):
         ts = [t.to(dev, dt) for t in (gr, x, w, off, m, b)]
-        for route, opts in (("fused", {"dcn.bwd_blas": 0}), ("fused_window_lds_atomics", {"dcn.bwd_owner": 0}), ("fused_global_atomics", {"dcn.bwd_owner": 0, "dcn.bwd_window": 0}),
-                            ("direct", {"dcn.bwd_blas": 0, "dcn.bwd_mfma": 0}), ("blas_r03", {"dcn.bwd_blas": 1})):
+        for route, opts in (("fused", {}), ("fused_window_lds_atomics", {"dcn.bwd_owner": 0}), ("fused_global_atomics", {"dcn.bwd_owner": 0, "dcn.bwd_window": 0}),
+                            ("direct", {"dcn.bwd_mfma": 0})):
             if route in ("direct", "fused_global_atomics", "fused_window_lds_atomics") and groups != 1: continue
             if route == "direct" and dt != torch.float32: continue
             for k, v in opts.items(): torch.ops.tvmi.set_option(k, v)
@@ -106,5 +106,5 @@ for groups in (1, 256):
             except Exception as e:  # noqa
                 out[key] = {"error": repr(e)[:300]}
             print(key, out[key], flush=True)
-            torch.ops.tvmi.set_option("dcn.bwd_blas", 0); torch.ops.tvmi.set_option("dcn.bwd_mfma", 1); torch.ops.tvmi.set_option("dcn.bwd_window", 1); torch.ops.tvmi.set_option("dcn.bwd_owner", 1)
+            torch.ops.tvmi.set_option("dcn.bwd_mfma", 1); torch.ops.tvmi.set_option("dcn.bwd_window", 1); torch.ops.tvmi.set_option("dcn.bwd_owner", 1)
 if len(sys.argv) > 1: json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -170,19 +170,31 @@ def main():
         return out
 
     def timed_run(variant):
-        for i in range(args.warmup):
-            out = step(i)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        calls0 = int(torch.ops.tvmi.aten_upsample_calls())
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(i)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # like bench.py's contract region (and `timeit`): the collector is frozen + disabled around warm-up and timed steps — a
+        # generation-2 collection of a process with torch imported is a 40-50 ms stop (one landed in 1 of 6 steps of the
+        # round-5 first visit: 18.3 ms steps, one of 70 ms), which is not what a steps-per-second figure over 6 steps is about
+        import gc
+
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        try:
+            for i in range(args.warmup):
+                out = step(i)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            calls0 = int(torch.ops.tvmi.aten_upsample_calls())
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                out = step(i)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+            gc.unfreeze()
         if world > 1:
             tmax = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -153,7 +153,6 @@ if "c4" in sections:
                 routes += [("_window_lds_atomics", {"dcn.bwd_owner": 0}), ("_global_atomics", {"dcn.bwd_owner": 0, "dcn.bwd_window": 0})]
             else:
                 routes += [("_direct", {"dcn.bwd_owner": 0})]
-            routes += [("_library_gemm_r03", {"dcn.bwd_blas": 1})]
             for tag, opts in routes:
                 for k, v in opts.items():
                     torch.ops.tvmi.set_option(k, v)
@@ -162,7 +161,7 @@ if "c4" in sections:
                     put(f"c4_deform_conv2d_backward_g{groups}_{str(dt)[6:]}{tag}", t, TFLOPs=round(2 * fl / t / 1e9, 2))
                 finally:
                     for k in opts:
-                        torch.ops.tvmi.set_option(k, 1 if k != "dcn.bwd_blas" else 0)
+                        torch.ops.tvmi.set_option(k, 1)
 
 if "resize" in sections:
     g = torch.Generator().manual_seed(0)

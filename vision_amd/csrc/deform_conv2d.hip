@@ -19,7 +19,8 @@
 // MFMAs of slab s (register staging, double-buffered LDS, one barrier per slab); bias is
 // added in the epilogue and the result is stored coalesced along the pixel dimension.
 // Other dtypes / tiny channel counts use a direct (non-MFMA) kernel with the same maths.
-// Backward pieces (im2col, col2im, col2im_coord) are separate kernels combined with plain
+// (round 5: the im2col / col2im / col2im_coord building blocks of the round-3 library-GEMM backward are gone — the
+// backward is deform_conv2d_bwd.hip)  Backward pieces were separate kernels combined with plain
 // library GEMMs by the dispatcher glue.
 #include <algorithm>
 #include <atomic>
@@ -1379,136 +1380,6 @@ inline DwGeom depthwise_geom(const DcnParams& p, tvmi_dtype dt) {
   return g;
 }
 
-// ------------------------------------------------------------------ backward building blocks
-// columns layout: [C*kh*kw][B*oh*ow]  (k = (c*kh + i)*kw + j ; n = (b*oh + y)*ow + x)
-template <typename T>
-__global__ __launch_bounds__(256) void dcn_im2col(const T* __restrict__ input, const T* __restrict__ offset,
-                                                  const T* __restrict__ mask, T* __restrict__ columns,
-                                                  DcnParams p, int64_t total) {
-  using A = typename Acc<T>::type;
-  const int KK = p.kh * p.kw;
-  const int64_t ncols = (int64_t)p.B * p.oh * p.ow;
-  // one thread per (c, b, y, x); writes KK column entries
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(idx % p.ow);
-    const int oy = (int)((idx / p.ow) % p.oh);
-    const int b = (int)((idx / ((int64_t)p.ow * p.oh)) % p.B);
-    const int c = (int)(idx / ((int64_t)p.ow * p.oh * p.B));
-    const int og = c / p.cpog;
-    const T* pl = input + ((int64_t)b * p.C + c) * p.H * p.W;
-    const int64_t n = ((int64_t)b * p.oh + oy) * p.ow + ox;
-    for (int tap = 0; tap < KK; ++tap) {
-      Tap<A> t;
-      load_tap<T, A>(t, p, offset, mask, b, og, tap, oy, ox);
-      st(columns + ((int64_t)c * KK + tap) * ncols + n, sample_tap<T, A>(t, pl));
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void dcn_col2im(const T* __restrict__ col, const T* __restrict__ offset,
-                                                  const T* __restrict__ mask, T* __restrict__ grad_im,
-                                                  DcnParams p, int64_t total) {
-  using A = typename Acc<T>::type;
-  const int KK = p.kh * p.kw;
-  const int64_t plane = (int64_t)p.oh * p.ow;
-  const int64_t ncols = (int64_t)p.B * plane;
-  // idx enumerates the columns buffer: (c, i, j, b, y, x)
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t n = idx % ncols;
-    const int k = (int)(idx / ncols);
-    const int ox = (int)(n % p.ow);
-    const int oy = (int)((n / p.ow) % p.oh);
-    const int b = (int)(n / plane);
-    const int tap = k % KK, c = k / KK;
-    const int i = tap / p.kw, j = tap - i * p.kw;
-    const int og = c / p.cpog;
-    const int64_t pix = (int64_t)oy * p.ow + ox;
-    const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * plane;
-    const A off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
-    const A off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
-    A mval = (A)1;
-    if (p.use_mask) mval = ld(mask + ((int64_t)(b * p.ogroups + og) * KK + tap) * plane + pix);
-    const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + off_h;
-    const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + off_w;
-    const A cv = ld(col + idx);
-    T* gi = grad_im + ((int64_t)b * p.C + c) * p.H * p.W;
-    for (int dy = -1; dy <= 1; ++dy) {
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int yp = (int)y + dy, xp = (int)x + dx;
-        const A ay = fabs(y - (A)yp), ax = fabs(x - (A)xp);
-        if (0 <= yp && yp < p.H && 0 <= xp && xp < p.W && ay < (A)1 && ax < (A)1) {
-          const A wgt = ((A)1 - ay) * ((A)1 - ax);
-          atomic_accum(gi + (int64_t)yp * p.W + xp, mval * wgt * cv);
-        }
-      }
-    }
-  }
-}
-
-template <typename T, typename A>
-__device__ __forceinline__ A coord_weight(const T* __restrict__ im, int H, int W, A y, A x, bool ydir) {
-  const int yl = (int)floor(y), xl = (int)floor(x);
-  const int yh = yl + 1, xh = xl + 1;
-  const bool vyl = 0 <= yl && yl < H, vyh = 0 <= yh && yh < H;
-  const bool vxl = 0 <= xl && xl < W, vxh = 0 <= xh && xh < W;
-  const A v_yx = (vyl && vxl) ? ld(im + yl * W + xl) : (A)0;
-  const A v_yX = (vyl && vxh) ? ld(im + yl * W + xh) : (A)0;
-  const A v_Yx = (vyh && vxl) ? ld(im + yh * W + xl) : (A)0;
-  const A v_YX = (vyh && vxh) ? ld(im + yh * W + xh) : (A)0;
-  if (ydir) {
-    const A dx = x - (A)xl;
-    return dx * (v_YX - v_yX) + ((A)1 - dx) * (v_Yx - v_yx);
-  }
-  const A dy = y - (A)yl;
-  return dy * (v_YX - v_Yx) + ((A)1 - dy) * (v_yX - v_yx);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void dcn_col2im_coord(const T* __restrict__ col, const T* __restrict__ im,
-                                                        const T* __restrict__ offset,
-                                                        const T* __restrict__ mask, T* __restrict__ grad_offset,
-                                                        T* __restrict__ grad_mask, DcnParams p, int64_t total) {
-  using A = typename Acc<T>::type;
-  const int KK = p.kh * p.kw;
-  const int64_t plane = (int64_t)p.oh * p.ow;
-  const int64_t ncols = (int64_t)p.B * plane;
-  const int off_ch = 2 * KK * p.ogroups;
-  // one thread per grad_offset element (b, c_off, y, x)
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(idx % p.ow);
-    const int oy = (int)((idx / p.ow) % p.oh);
-    const int c = (int)((idx / plane) % off_ch);
-    const int b = (int)(idx / (plane * off_ch));
-    const int og = c / (2 * KK);
-    const int oc_in = c - og * 2 * KK;
-    const bool ydir = (oc_in % 2) == 0;
-    const int tap = oc_in / 2;
-    const int i = tap / p.kw, j = tap - i * p.kw;
-    const int64_t pix = (int64_t)oy * p.ow + ox;
-    const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * plane;
-    const A off_h = ld(optr + (int64_t)(2 * tap) * plane + pix);
-    const A off_w = ld(optr + (int64_t)(2 * tap + 1) * plane + pix);
-    A mval = (A)1;
-    if (p.use_mask) mval = ld(mask + ((int64_t)(b * p.ogroups + og) * KK + tap) * plane + pix);
-    const A y = (A)(oy * p.sh - p.ph) + (A)(i * p.dh) + off_h;
-    const A x = (A)(ox * p.sw - p.pw) + (A)(j * p.dw) + off_w;
-    Tap<A> t;
-    make_tap<A>(t, p.H, p.W, y, x, (A)1);
-    const int64_t n = (int64_t)b * plane + pix;
-    A g_off = (A)0, g_mask = (A)0;
-    for (int cc = 0; cc < p.cpog; ++cc) {
-      const int ch = og * p.cpog + cc;
-      const T* im_c = im + ((int64_t)b * p.C + ch) * p.H * p.W;
-      const A cv = ld(col + ((int64_t)ch * KK + tap) * ncols + n);
-      g_off += mval * coord_weight<T, A>(im_c, p.H, p.W, y, x, ydir) * cv;
-      if (p.use_mask && ydir) g_mask += cv * sample_tap<T, A>(t, im_c);
-    }
-    st(grad_offset + idx, g_off);
-    if (p.use_mask && ydir) st(grad_mask + ((int64_t)(b * p.ogroups + og) * KK + tap) * plane + pix, g_mask);
-  }
-}
-
 int fill_params(DcnParams& p, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC, int64_t kh, int64_t kw,
                 int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, int64_t groups,
                 int64_t ogroups, int use_mask) {
@@ -1750,60 +1621,3 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
   TVMI_RETURN_LAUNCH_STATUS("tvmi_deform_conv2d_forward");
 }
 
-extern "C" int tvmi_deformable_im2col(const void* input, const void* offset, const void* mask, void* columns,
-                                      tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
-                                      int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h,
-                                      int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t offset_groups,
-                                      int use_mask, void* stream) {
-  DcnParams p;
-  if (int e = fill_params(p, B, C, H, W, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1,
-                          offset_groups, use_mask))
-    return e;
-  const int64_t total = (int64_t)C * B * p.oh * p.ow;
-  if (total == 0) return 0;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TVMI_DISPATCH_FLOAT(dt, "deformable_im2col",
-                      dcn_im2col<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
-                          (const scalar_t*)input, (const scalar_t*)offset, (const scalar_t*)mask,
-                          (scalar_t*)columns, p, total));
-  TVMI_RETURN_LAUNCH_STATUS("tvmi_deformable_im2col");
-}
-
-extern "C" int tvmi_deformable_col2im(const void* columns, const void* offset, const void* mask, void* grad_input,
-                                      tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
-                                      int64_t kw, int64_t stride_h, int64_t stride_w, int64_t pad_h,
-                                      int64_t pad_w, int64_t dil_h, int64_t dil_w, int64_t offset_groups,
-                                      int use_mask, void* stream) {
-  DcnParams p;
-  if (int e = fill_params(p, B, C, H, W, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1,
-                          offset_groups, use_mask))
-    return e;
-  const int64_t total = (int64_t)C * kh * kw * B * p.oh * p.ow;
-  if (total == 0) return 0;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TVMI_DISPATCH_FLOAT(dt, "deformable_col2im",
-                      dcn_col2im<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
-                          (const scalar_t*)columns, (const scalar_t*)offset, (const scalar_t*)mask,
-                          (scalar_t*)grad_input, p, total));
-  TVMI_RETURN_LAUNCH_STATUS("tvmi_deformable_col2im");
-}
-
-extern "C" int tvmi_deformable_col2im_coord(const void* columns, const void* input, const void* offset,
-                                            const void* mask, void* grad_offset, void* grad_mask, tvmi_dtype dt,
-                                            int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh, int64_t kw,
-                                            int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
-                                            int64_t dil_h, int64_t dil_w, int64_t offset_groups, int use_mask,
-                                            void* stream) {
-  DcnParams p;
-  if (int e = fill_params(p, B, C, H, W, 1, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, 1,
-                          offset_groups, use_mask))
-    return e;
-  const int64_t total = (int64_t)B * 2 * kh * kw * offset_groups * p.oh * p.ow;
-  if (total == 0) return 0;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  TVMI_DISPATCH_FLOAT(dt, "deformable_col2im_coord",
-                      dcn_col2im_coord<scalar_t><<<grid1d(total), dim3(256), 0, s>>>(
-                          (const scalar_t*)columns, (const scalar_t*)input, (const scalar_t*)offset,
-                          (const scalar_t*)mask, (scalar_t*)grad_offset, (scalar_t*)grad_mask, p, total));
-  TVMI_RETURN_LAUNCH_STATUS("tvmi_deformable_col2im_coord");
-}

@@ -38,7 +38,6 @@ namespace {
 std::atomic<int> g_bwd_mfma{1};   // option "dcn.bwd_mfma": 0 sends every problem to the direct kernels
 std::atomic<int> g_bwd_window{1}; // option "dcn.bwd_window": 0 = the data-gradient kernel scatters with global atomics only
 std::atomic<int> g_bwd_owner{1};  // option "dcn.bwd_owner": 0 = never the owner form of the data-gradient kernel (dcn_bwd_data_own)
-std::atomic<int> g_bwd_blas{0};   // option "dcn.bwd_blas" (measurement only): the dispatcher glue takes the round-3 route (library GEMMs)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1484,7 +1483,7 @@ inline bool bwd_mfma_shape(const DcnParams& p, tvmi_dtype dt) {
 // the owner form of the data-gradient kernel: 3 x 3 taps, whole 64-channel chunks, the window in LDS
 inline bool bwd_own_shape(const DcnParams& p, tvmi_dtype dt) {
   if (!bwd_mfma_shape(p, dt)) return false;
-  if (p.kh * p.kw != 9 || p.ICg % kOwnCH) return false;
+  if (p.kh != 3 || p.kw != 3 || p.ICg % kOwnCH) return false;   // 3 x 3 taps only (1 x 9 / 9 x 1 windows are another shape)
   if ((int64_t)p.H * p.W * p.C >= (1ll << 31)) return false;
   const WinGeom w = own_geom(p);
   return own_lds_bytes(w) <= (size_t)160 * 1024 && (int64_t)w.ntx * w.nty < (1ll << 31) && p.B <= 65535 && p.groups <= 65535;
@@ -1643,10 +1642,6 @@ int set_dcn_bwd_option(const char* name, int64_t value) {
     g_bwd_mfma.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
-  if (std::strcmp(name, "dcn.bwd_blas") == 0) {
-    g_bwd_blas.store(value != 0, std::memory_order_relaxed);
-    return 0;
-  }
   if (std::strcmp(name, "dcn.bwd_window") == 0) {
     g_bwd_window.store(value != 0, std::memory_order_relaxed);
     return 0;
@@ -1660,10 +1655,6 @@ int set_dcn_bwd_option(const char* name, int64_t value) {
 int get_dcn_bwd_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "dcn.bwd_mfma") == 0) {
     *value = g_bwd_mfma.load(std::memory_order_relaxed) ? 1 : 0;
-    return 0;
-  }
-  if (std::strcmp(name, "dcn.bwd_blas") == 0) {
-    *value = g_bwd_blas.load(std::memory_order_relaxed) ? 1 : 0;
     return 0;
   }
   if (std::strcmp(name, "dcn.bwd_window") == 0) {
@@ -1681,25 +1672,16 @@ int get_dcn_bwd_option(const char* name, int64_t* value) {
 using namespace tvmi;
 
 extern "C" size_t tvmi_deform_conv2d_backward_workspace_bytes(tvmi_dtype dt, int64_t B, int64_t C, int64_t H, int64_t W,
-                                                              int64_t OC, int64_t kh, int64_t kw, int64_t oh, int64_t ow,
-                                                              int64_t groups, int64_t offset_groups) {
-  if (B <= 0 || C <= 0 || OC <= 0 || groups <= 0 || offset_groups <= 0 || kh <= 0 || kw <= 0 || oh <= 0 || ow <= 0) return 0;
+                                                              int64_t OC, int64_t kh, int64_t kw, int64_t stride_h,
+                                                              int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t dil_h,
+                                                              int64_t dil_w, int64_t groups, int64_t offset_groups) {
+  if (B <= 0 || C <= 0 || OC <= 0 || groups <= 0 || offset_groups <= 0 || kh <= 0 || kw <= 0) return 0;
   if (C % groups || OC % groups || C % offset_groups) return 0;
-  DcnParams p{};
-  p.B = (int)B;
-  p.C = (int)C;
-  p.H = (int)H;
-  p.W = (int)W;
-  p.OC = (int)OC;
-  p.kh = (int)kh;
-  p.kw = (int)kw;
-  p.oh = (int)oh;
-  p.ow = (int)ow;
-  p.groups = (int)groups;
-  p.ogroups = (int)offset_groups;
-  p.ICg = (int)(C / groups);
-  p.OCg = (int)(OC / groups);
-  p.cpog = (int)(C / offset_groups);
+  // the SAME parameter block the call builds (stride / dilation decide whether the owner form of the data-gradient kernel
+  // fits its window in LDS, i.e. whether its channels-last buffers are needed at all — ADVICE r04)
+  DcnParams p;
+  if (fill_params_common(p, B, C, H, W, OC, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups, offset_groups, 0)) return 0;
+  if (p.oh <= 0 || p.ow <= 0) return 0;
   BwdPlan q = bwd_plan(p, dt);
   return q.bytes;
 }

@@ -551,67 +551,6 @@ at::Tensor deform_conv2d_forward(const at::Tensor& input, const at::Tensor& weig
   return out;
 }
 
-// MEASUREMENT ONLY (option "dcn.bwd_blas", off by default): the round-3 backward — the gather/scatter kernels are
-// ours; the two plain GEMMs per weight group go to the BLAS library through ATen.  Images
-// are processed in chunks so that the materialised columns stay below ~1 GiB.
-std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_conv2d_backward_blas(
-    const at::Tensor& grad, const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
-    const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
-    int64_t dilation_h, int64_t dilation_w, int64_t n_weight_grps, int64_t n_offset_grps, bool use_mask) {
-  at::Tensor grad_c = grad.contiguous(), input_c = input.contiguous(), offset_c = offset.contiguous();
-  at::Tensor weight_c = weight.contiguous(), mask_c = mask.contiguous(), bias_c = bias.contiguous();
-  const DcnShape s = dcn_check(input_c, weight_c, offset_c, mask_c, bias_c, stride_h, stride_w, pad_h, pad_w,
-                               dilation_h, dilation_w, n_weight_grps, n_offset_grps, use_mask);
-  c10::DeviceGuard guard(input.device());
-  at::globalContext().alertNotDeterministic("deform_conv2d_backward_kernel");
-  at::Tensor grad_input = at::zeros_like(input_c);
-  at::Tensor grad_offset = at::zeros_like(offset_c);
-  at::Tensor grad_mask = at::zeros_like(mask_c);
-  at::Tensor grad_weight = at::zeros_like(weight_c);
-  at::Tensor grad_bias = at::ones_like(bias_c);
-  if (s.B == 0) return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
-  grad_bias = grad_c.sum({0, 2, 3});
-  const tvmi_dtype dt = dtype_of(input_c, "_deform_conv2d_backward");
-  void* stream = current_stream(input);
-  const int64_t G = n_weight_grps, ICg = s.C / G, OCg = s.OC / G, KK = s.kh * s.kw, plane = s.oh * s.ow;
-  const int64_t col_rows = s.C * KK;
-  const int64_t bytes_per_img = col_rows * plane * (int64_t)input_c.element_size();
-  int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(s.B, (int64_t(1) << 30) / std::max<int64_t>(bytes_per_img, 1)));
-  at::Tensor wg = weight_c.view({G, OCg, ICg * KK});
-  at::Tensor gw = grad_weight.view({G, OCg, ICg * KK});
-  for (int64_t b0 = 0; b0 < s.B; b0 += chunk) {
-    const int64_t nb = std::min(chunk, s.B - b0);
-    at::Tensor in_b = input_c.narrow(0, b0, nb), off_b = offset_c.narrow(0, b0, nb);
-    at::Tensor mask_b = use_mask ? mask_c.narrow(0, b0, nb) : mask_c;
-    at::Tensor go_b = grad_c.narrow(0, b0, nb);                       // [nb, OC, oh, ow]
-    // [G, OCg, nb*plane] with column index n = b*plane + pix
-    at::Tensor go_g = go_b.view({nb, G, OCg, plane}).permute({1, 2, 0, 3}).reshape({G, OCg, nb * plane});
-    // (1) columns = W^T * grad_out  -> grad_input, grad_offset, grad_mask
-    at::Tensor columns = at::bmm(wg.transpose(1, 2), go_g).view({col_rows, nb * plane});
-    at::Tensor gi_b = grad_input.narrow(0, b0, nb), goff_b = grad_offset.narrow(0, b0, nb);
-    at::Tensor gmask_b = use_mask ? grad_mask.narrow(0, b0, nb) : grad_mask;
-    check_status(tvmi_deformable_col2im_coord(columns.const_data_ptr(), in_b.const_data_ptr(), off_b.const_data_ptr(),
-                                              mask_b.const_data_ptr(), goff_b.mutable_data_ptr(),
-                                              gmask_b.mutable_data_ptr(), dt, nb, s.C, s.H, s.W, s.kh, s.kw, stride_h,
-                                              stride_w, pad_h, pad_w, dilation_h, dilation_w, n_offset_grps,
-                                              use_mask ? 1 : 0, stream),
-                 "_deform_conv2d_backward(col2im_coord)");
-    check_status(tvmi_deformable_col2im(columns.const_data_ptr(), off_b.const_data_ptr(), mask_b.const_data_ptr(),
-                                        gi_b.mutable_data_ptr(), dt, nb, s.C, s.H, s.W, s.kh, s.kw, stride_h, stride_w,
-                                        pad_h, pad_w, dilation_h, dilation_w, n_offset_grps, use_mask ? 1 : 0, stream),
-                 "_deform_conv2d_backward(col2im)");
-    // (2) grad_weight += grad_out * im2col(input)^T
-    check_status(tvmi_deformable_im2col(in_b.const_data_ptr(), off_b.const_data_ptr(), mask_b.const_data_ptr(),
-                                        columns.mutable_data_ptr(), dt, nb, s.C, s.H, s.W, s.kh, s.kw, stride_h,
-                                        stride_w, pad_h, pad_w, dilation_h, dilation_w, n_offset_grps,
-                                        use_mask ? 1 : 0, stream),
-                 "_deform_conv2d_backward(im2col)");
-    at::Tensor col_g = columns.view({G, ICg * KK, nb * plane});
-    gw.baddbmm_(go_g, col_g.transpose(1, 2));
-  }
-  return std::make_tuple(grad_input, grad_weight, grad_offset, grad_mask, grad_bias);
-}
-
 // Backward (cpu/deform_conv2d_kernel.cpp:1153-1226, cuda/deform_conv2d_kernel.cu:752-1033,1257-1330): ONE call into the kernels
 // library — two fused matrix-core kernels (or the direct ones), no materialised `columns`, no library GEMM
 // (deform_conv2d_bwd.hip).
@@ -619,14 +558,16 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_co
     const at::Tensor& grad, const at::Tensor& input, const at::Tensor& weight, const at::Tensor& offset,
     const at::Tensor& mask, const at::Tensor& bias, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
     int64_t dilation_h, int64_t dilation_w, int64_t n_weight_grps, int64_t n_offset_grps, bool use_mask) {
-  int64_t blas = 0;
-  if (tvmi_get_option("dcn.bwd_blas", &blas) == 0 && blas)
-    return deform_conv2d_backward_blas(grad, input, weight, offset, mask, bias, stride_h, stride_w, pad_h, pad_w, dilation_h,
-                                       dilation_w, n_weight_grps, n_offset_grps, use_mask);
   at::Tensor grad_c = grad.contiguous(), input_c = input.contiguous(), offset_c = offset.contiguous();
   at::Tensor weight_c = weight.contiguous(), mask_c = mask.contiguous(), bias_c = bias.contiguous();
   const DcnShape s = dcn_check(input_c, weight_c, offset_c, mask_c, bias_c, stride_h, stride_w, pad_h, pad_w,
                                dilation_h, dilation_w, n_weight_grps, n_offset_grps, use_mask);
+  // the kernels read grad through its raw pointer as [B, OC, oh, ow] of the input's type
+  TORCH_CHECK(grad.is_cuda() && grad.device() == input.device(), "_deform_conv2d_backward: grad must be on the input's device");
+  TORCH_CHECK(grad.scalar_type() == input.scalar_type(), "_deform_conv2d_backward: grad must have the input's dtype, got ",
+              grad.scalar_type(), " and ", input.scalar_type());
+  TORCH_CHECK(grad.dim() == 4 && grad.size(0) == s.B && grad.size(1) == s.OC && grad.size(2) == s.oh && grad.size(3) == s.ow,
+              "_deform_conv2d_backward: grad must be [", s.B, ", ", s.OC, ", ", s.oh, ", ", s.ow, "], got ", grad.sizes());
   c10::DeviceGuard guard(input.device());
   at::globalContext().alertNotDeterministic("deform_conv2d_backward_kernel");
   // every output is fully overwritten by the call (it zero-fills what it accumulates into)
@@ -635,10 +576,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> deform_co
   at::Tensor grad_weight = at::empty_like(weight_c);
   at::Tensor grad_bias = at::ones_like(bias_c);
   if (s.B == 0 || input_c.numel() == 0 || weight_c.numel() == 0)
-    return std::make_tuple(at::zeros_like(input_c), at::zeros_like(weight_c), at::zeros_like(offset_c), at::zeros_like(mask_c), grad_bias);
+    // grad_bias = ones * grad.sum((0, 2, 3)) in the reference (cpu/deform_conv2d_kernel.cpp:1211-1213): zero for an empty problem
+    return std::make_tuple(at::zeros_like(input_c), at::zeros_like(weight_c), at::zeros_like(offset_c), at::zeros_like(mask_c),
+                           at::zeros_like(bias_c));
   const tvmi_dtype dt = dtype_of(input_c, "_deform_conv2d_backward");
-  const size_t ws_bytes = tvmi_deform_conv2d_backward_workspace_bytes(dt, s.B, s.C, s.H, s.W, s.OC, s.kh, s.kw, s.oh, s.ow,
-                                                                      n_weight_grps, n_offset_grps);
+  const size_t ws_bytes = tvmi_deform_conv2d_backward_workspace_bytes(dt, s.B, s.C, s.H, s.W, s.OC, s.kh, s.kw, stride_h, stride_w,
+                                                                      pad_h, pad_w, dilation_h, dilation_w, n_weight_grps,
+                                                                      n_offset_grps);
   at::Tensor ws = at::empty({(int64_t)ws_bytes}, input_c.options().dtype(at::kByte));
   check_status(tvmi_deform_conv2d_backward(grad_c.const_data_ptr(), input_c.const_data_ptr(), weight_c.const_data_ptr(),
                                            offset_c.const_data_ptr(), mask_c.const_data_ptr(), grad_input.mutable_data_ptr(),
