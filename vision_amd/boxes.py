@@ -49,6 +49,10 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
             min_coordinate, max_coordinate = torch.aminmax(boxes)
             offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
             shifted = boxes + offsets[:, None]
+            if torch.compiler.is_compiling() or torch.jit.is_tracing():
+                # a traced / compiled graph must stay branch-free like the reference's: its own formulation,
+                # one global-order nms() of the shifted boxes — the same result, cross-category side effect included
+                return torch.ops.torchvision.nms(shifted, scores, iou_threshold)
             keep = torch.ops.tvmi.nms_segmented(shifted, scores, idxs, iou_threshold, int(num_segments))
             if bool(min_coordinate < -1):      # shifted categories overlap: the reference's nms() sees cross-category pairs
                 keep = torch.ops.torchvision.nms(shifted, scores, iou_threshold)

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ inpu
 }
 
 std::atomic<int> g_xcd_tiles{1};   // option "dcn.xcd_tiles": contiguous pixel-tile ranges per XCD (tile_of_block)
+std::atomic<int> g_dw_variant{1};  // option "dcn.dw_variant": 0 = the round-2..4 depthwise forward kernel, 1 = the packed one (round 5)
 std::atomic<int> g_cl_variant{1};  // option "dcn.cl_variant": 0 = the round-3 channels-last kernel, 1 = the pipelined one, 2 = its 4-wave tile
 std::atomic<int> g_cl_gather{1};  // option "dcn.channels_last_gather": the 16-bit MFMA kernel samples a [B, H*W, C] copy
 
@@ -1380,6 +1381,239 @@ inline DwGeom depthwise_geom(const DcnParams& p, tvmi_dtype dt) {
   return g;
 }
 
+// ------------------------------------------------------------------ depthwise forward, packed form (round 5)
+// The kernel above is bound by issue slots, not by data (rocprofv3 r03/r04: waves waiting 65 %, LDS 30 %, VALU 23 %): per
+// (channel, tap) it issues two LDS pair reads and eight scalar-width VALU ops, and its 780 workgroups are 12 more than
+// the 768 it can have resident — a second, nearly empty round.  This form keeps the workgroup shape (lane = pixel, 8 x 64
+// output tile, window of the tile in LDS, double-buffered through registers) and changes what a wave issues:
+//   * the window holds FOUR channels interleaved ([y][x][4]): one ds_read_b128 fetches a corner of four channels, i.e. one
+//     LDS instruction per (channel, tap) instead of two, and the same 16 bytes;
+//   * the four bilinear corner weights of a tap (mask folded in) are per-lane constants kept as two register PAIRS
+//     (c00, c01), (c10, c11); the blend of four channels is 8 packed ops (v_pk_mul_f32 / v_pk_fma_f32, two channels per
+//     instruction, the corner weight broadcast from one half of its pair by op_sel) + 4 weight FMAs with a scalar
+//     operand: 3 VALU instructions per (channel, tap) instead of 8;
+//   * the channel ranges are sized so that every workgroup is resident at once (2 per CU at <= 128 VGPRs).
+// Values: the blend is c00*q00 + c01*q01 + c10*q10 + c11*q11 with c = (1-lh | lh) * (1-lw | lw) * mask — the reference's
+// own formula (cpu/deform_conv2d_kernel.cpp:117-131: w1..w4 * v1..v4), other rounding order than the kernel above.
+// Needs whole chunks: channels per offset group % 4 == 0.
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kDwPkCB = 4, kDwPkMaxStage = 4;
+
+// d = broadcast(c.lo | c.hi) * q (+ d): the packed-fp32 ops take either half of a 64-bit source for both results (op_sel)
+__device__ __forceinline__ dw_f32x2 pk_mul_bl(dw_f32x2 c, dw_f32x2 q) {
+  dw_f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(c), "v"(q));
+  return d;
+}
+__device__ __forceinline__ dw_f32x2 pk_fma_bh(dw_f32x2 c, dw_f32x2 q, dw_f32x2 d) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(c), "v"(q));
+  return d;
+}
+__device__ __forceinline__ dw_f32x2 pk_fma_bl(dw_f32x2 c, dw_f32x2 q, dw_f32x2 d) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "v"(c), "v"(q));
+  return d;
+}
+
+// NS: staged window pixels per thread (3 for the stride-1 / dilation-1 window of 19 x 75)
+template <typename T, int TWC, int NS>
+__global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T* __restrict__ input, const T* __restrict__ weight,
+                                                                        const T* __restrict__ offset, const T* __restrict__ mask,
+                                                                        const T* __restrict__ bias, T* __restrict__ out,
+                                                                        DcnParams p, DwGeom g) {
+  constexpr int KK = 9, CB = kDwPkCB;
+  extern __shared__ __attribute__((aligned(16))) float dw_lds[];   // [2][tile_h][tile_w][4]
+  dw_f32x4* const lds4 = reinterpret_cast<dw_f32x4*>(dw_lds);
+  const int tile_w = TWC > 0 ? TWC : g.tile_w;
+  const int tid = threadIdx.x;
+  const int px = tid & (kDwTW - 1), py = tid >> 6;
+  const int tx0 = (blockIdx.x % g.ntx) * kDwTW, ty0 = (blockIdx.x / g.ntx) * kDwTH;
+  const int og = blockIdx.y / g.csplit, cs = blockIdx.y - og * g.csplit;
+  const int b = blockIdx.z;
+  const int c_begin = og * p.cpog + cs * g.cper, c_end = min((og + 1) * p.cpog, c_begin + g.cper);   // whole chunks of 4
+  if (c_begin >= c_end) return;
+  const int ox = tx0 + px, oy = ty0 + py;
+  const bool live = ox < p.ow && oy < p.oh;
+  const int in_y0 = ty0 * p.sh - p.ph - kDwHalo, in_x0 = tx0 * p.sw - p.pw - kDwHalo;
+  const int64_t plane = (int64_t)p.H * p.W, oplane = (int64_t)p.oh * p.ow;
+
+  // ---- tap geometry of this lane's pixel, once for all channels: window pixel of the top-left corner + 4 corner weights
+  int toff[KK];
+  dw_f32x2 ctop[KK], cbot[KK];   // (c00, c01), (c10, c11)
+  unsigned far = 0;
+  T raw_h[KK], raw_w[KK], raw_m[KK];
+  {
+    const int64_t pixc = (int64_t)min(oy, p.oh - 1) * p.ow + min(ox, p.ow - 1);
+    const T* optr = offset + ((int64_t)(b * p.ogroups + og) * 2 * KK) * oplane + pixc;
+    const T* mptr = p.use_mask ? mask + ((int64_t)(b * p.ogroups + og) * KK) * oplane + pixc : optr;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      raw_h[t] = optr[(int64_t)(2 * t) * oplane];
+      raw_w[t] = optr[(int64_t)(2 * t + 1) * oplane];
+      raw_m[t] = mptr[(int64_t)t * oplane];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    toff[t] = 0;
+    ctop[t] = cbot[t] = dw_f32x2{0.f, 0.f};
+    if (live) {
+      const int i = t / 3, j = t - 3 * i;
+      const float off_h = ld(&raw_h[t]), off_w = ld(&raw_w[t]);
+      const float m = p.use_mask ? (float)ld(&raw_m[t]) : 1.f;
+      const float y = (float)(oy * p.sh - p.ph) + (float)(i * p.dh) + off_h;
+      const float x = (float)(ox * p.sw - p.pw) + (float)(j * p.dw) + off_w;
+      if (!(y <= -1.f || (float)p.H <= y || x <= -1.f || (float)p.W <= x)) {   // else: the sample is zero (reference :99-101)
+        const float fy = floorf(y), fx = floorf(x);
+        const int ty = (int)fy - in_y0, tx = (int)fx - in_x0;
+        if (ty >= 0 && ty + 1 < g.tile_h && tx >= 0 && tx + 1 < tile_w) {
+          const float lh = y - fy, lw = x - fx;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          toff[t] = ty * tile_w + tx;
+          ctop[t] = dw_f32x2{hh * hw * m, hh * lw * m};
+          cbot[t] = dw_f32x2{lh * hw * m, lh * lw * m};
+        } else {
+          far |= 1u << t;   // inside the image but outside the staged window
+        }
+      }
+    }
+  }
+  const bool any_far = __ballot(far != 0) != 0ull;
+
+  // ---- staging plan: window pixel e = tid + i * threads, its four channels by one thread (4 plane loads -> one 16-byte LDS store)
+  int gsrc[NS];   // y * W + x inside a plane, -1 = outside the image (zero) / no such pixel
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    gsrc[i] = -1;
+    const int e = tid + i * kDwThreads;
+    if (e < g.tile_sz) {
+      const int r = e / tile_w, c = e - r * tile_w;
+      const int iy = in_y0 + r, ix = in_x0 + c;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) gsrc[i] = iy * p.W + ix;
+    }
+  }
+  const int nchunks = (c_end - c_begin) / CB;
+  T stage[NS][CB];
+  float wv_cur[CB], wv_nxt[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) wv_cur[cb] = wv_nxt[cb] = 0.f;
+  auto fetch = [&](int chunk) {
+    const int c0 = c_begin + chunk * CB;
+    const T* src = input + ((int64_t)b * p.C + c0) * plane;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int o = gsrc[i] >= 0 ? gsrc[i] : 0;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) stage[i][cb] = src[(int64_t)cb * plane + o];   // every load unconditional
+    }
+    if constexpr (!std::is_same<T, float>::value) {
+      const int wl_ = min(tid & 63, KK);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        T raw = wl_ < KK ? weight[(int64_t)(c0 + cb) * KK + wl_] : bias[c0 + cb];
+        wv_nxt[cb] = (float)ld(&raw);
+      }
+    }
+  };
+  auto park = [&](int chunk) {
+    dw_f32x4* dst = lds4 + (chunk & 1) * g.tile_sz;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int e = tid + i * kDwThreads;
+      if (e < g.tile_sz) {
+        const bool in = gsrc[i] >= 0;
+        dw_f32x4 v;
+        v.x = in ? (float)ld(&stage[i][0]) : 0.f;
+        v.y = in ? (float)ld(&stage[i][1]) : 0.f;
+        v.z = in ? (float)ld(&stage[i][2]) : 0.f;
+        v.w = in ? (float)ld(&stage[i][3]) : 0.f;
+        dst[e] = v;
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) wv_cur[cb] = wv_nxt[cb];
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) fetch(chunk + 1);   // the next chunk's window is in flight while this one is used
+    const dw_f32x4* tile = lds4 + (chunk & 1) * g.tile_sz;
+    const int c0 = c_begin + chunk * CB;
+    // the weights and the bias of the chunk's channels are wave-uniform: fp32 -> scalar loads (36 contiguous floats);
+    // 16-bit: the prefetched vectors
+    const T* wrow = weight + (int64_t)c0 * KK;
+    auto wt = [&](int cb, int t) -> float {
+      if constexpr (std::is_same<T, float>::value) return t < KK ? wrow[cb * KK + t] : bias[c0 + cb];
+      else return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv_cur[cb]), t));
+    };
+    float acc[CB] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const dw_f32x4* q = tile + toff[t];
+      const dw_f32x4 q00 = q[0], q01 = q[1], q10 = q[tile_w], q11 = q[tile_w + 1];
+      dw_f32x2 lo = pk_mul_bl(ctop[t], q00.xy), hi = pk_mul_bl(ctop[t], q00.zw);
+      lo = pk_fma_bh(ctop[t], q01.xy, lo);
+      hi = pk_fma_bh(ctop[t], q01.zw, hi);
+      lo = pk_fma_bl(cbot[t], q10.xy, lo);
+      hi = pk_fma_bl(cbot[t], q10.zw, hi);
+      lo = pk_fma_bh(cbot[t], q11.xy, lo);
+      hi = pk_fma_bh(cbot[t], q11.zw, hi);
+      acc[0] = __builtin_fmaf(wt(0, t), lo.x, acc[0]);
+      acc[1] = __builtin_fmaf(wt(1, t), lo.y, acc[1]);
+      acc[2] = __builtin_fmaf(wt(2, t), hi.x, acc[2]);
+      acc[3] = __builtin_fmaf(wt(3, t), hi.y, acc[3]);
+    }
+    if (any_far) {   // taps outside the staged window: the reference arithmetic on global memory
+      for (int t = 0; t < KK; ++t)
+        if ((far >> t) & 1u) {
+          Tap<float> tp;
+          load_tap<T, float>(tp, p, offset, mask, b, og, t, oy, ox);
+          const float w0 = wt(0, t), w1 = wt(1, t), w2 = wt(2, t), w3 = wt(3, t);   // (static indices: a run-time one puts acc[] into scratch)
+          const T* pl = input + ((int64_t)b * p.C + c0) * plane;
+          acc[0] = __builtin_fmaf(w0, sample_tap<T, float>(tp, pl), acc[0]);
+          acc[1] = __builtin_fmaf(w1, sample_tap<T, float>(tp, pl + plane), acc[1]);
+          acc[2] = __builtin_fmaf(w2, sample_tap<T, float>(tp, pl + 2 * plane), acc[2]);
+          acc[3] = __builtin_fmaf(w3, sample_tap<T, float>(tp, pl + 3 * plane), acc[3]);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] += wt(cb, KK);
+    if (chunk + 1 < nchunks) park(chunk + 1);
+    if (live) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) st(out + ((int64_t)b * p.OC + c0 + cb) * oplane + (int64_t)oy * p.ow + ox, acc[cb]);
+    }
+    __syncthreads();
+  }
+}
+
+// geometry of the packed depthwise kernel (.CB = 0: does not apply): four interleaved channels per chunk, two window buffers,
+// two workgroups per CU, every workgroup resident at once where the problem allows it
+inline DwGeom depthwise_pk_geom(const DcnParams& p, tvmi_dtype dt) {
+  DwGeom g{};
+  g.CB = 0;
+  if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16)) return g;
+  if (!(p.ICg == 1 && p.OCg == 1 && p.kh == 3 && p.kw == 3) || p.cpog % kDwPkCB) return g;
+  g.tile_h = (kDwTH - 1) * p.sh + 2 * p.dh + 2 * kDwHalo + 2;
+  g.tile_w = (kDwTW - 1) * p.sw + 2 * p.dw + 2 * kDwHalo + 2;
+  g.tile_sz = g.tile_h * g.tile_w;
+  if ((size_t)2 * g.tile_sz * kDwPkCB * sizeof(float) > (size_t)64 * 1024) return g;   // two workgroups per CU
+  if ((int64_t)p.H * p.W >= (1ll << 31) / 8) return g;
+  g.nstage = (int)ceil_div(g.tile_sz, kDwThreads);
+  if (g.nstage > kDwPkMaxStage) return g;
+  g.ntx = (int)ceil_div(p.ow, kDwTW);
+  g.nty = (int)ceil_div(p.oh, kDwTH);
+  const int64_t tiles = (int64_t)g.ntx * g.nty * p.B * p.ogroups;
+  const int64_t slots = 2 * 256;
+  int64_t csplit = std::max<int64_t>(1, std::min<int64_t>(slots / std::max<int64_t>(tiles, 1), std::max<int64_t>(1, p.cpog / 16)));
+  g.cper = (int)ceil_div(ceil_div(p.cpog, csplit), kDwPkCB) * kDwPkCB;   // whole chunks per range
+  g.csplit = (int)ceil_div(p.cpog, g.cper);
+  if ((int64_t)g.csplit * p.ogroups > 65535 || p.B > 65535) return g;
+  g.CB = kDwPkCB;
+  return g;
+}
+
 int fill_params(DcnParams& p, int64_t B, int64_t C, int64_t H, int64_t W, int64_t OC, int64_t kh, int64_t kw,
                 int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, int64_t groups,
                 int64_t ogroups, int use_mask) {
@@ -1455,6 +1689,10 @@ int set_dcn_option(const char* name, int64_t value) {
     g_cl_variant.store((int)value, std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "dcn.dw_variant") == 0) {
+    g_dw_variant.store((int)value, std::memory_order_relaxed);
+    return 0;
+  }
   if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
     g_xcd_tiles.store(value != 0, std::memory_order_relaxed);
     return 0;
@@ -1469,6 +1707,10 @@ int get_dcn_option(const char* name, int64_t* value) {
   }
   if (std::strcmp(name, "dcn.cl_variant") == 0) {
     *value = g_cl_variant.load(std::memory_order_relaxed);
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.dw_variant") == 0) {
+    *value = g_dw_variant.load(std::memory_order_relaxed);
     return 0;
   }
   if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
@@ -1594,6 +1836,24 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     else TVMI_DCN16(__hip_bfloat16);
 #undef TVMI_DCN16
 #undef TVMI_DCN16_T
+  } else if (const DwGeom pg = depthwise_pk_geom(p, dt); pg.CB > 0 && g_dw_variant.load(std::memory_order_relaxed) == 1) {
+    const dim3 grid((unsigned)(pg.ntx * pg.nty), (unsigned)(pg.csplit * p.ogroups), (unsigned)p.B);
+    const size_t lds = (size_t)2 * pg.tile_sz * kDwPkCB * sizeof(float);
+#define TVMI_DWPK(scalar_t)                                                                                       \
+  do {                                                                                                            \
+    if (pg.tile_w == 75 && pg.nstage == 3)                                                                        \
+      dcn_fwd_depthwise3x3_pk<scalar_t, 75, 3><<<grid, dim3(kDwThreads), lds, s>>>(                               \
+          (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,        \
+          (const scalar_t*)bias, (scalar_t*)output, p, pg);                                                       \
+    else                                                                                                          \
+      dcn_fwd_depthwise3x3_pk<scalar_t, 0, kDwPkMaxStage><<<grid, dim3(kDwThreads), lds, s>>>(                    \
+          (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,        \
+          (const scalar_t*)bias, (scalar_t*)output, p, pg);                                                       \
+  } while (0)
+    if (dt == TVMI_F32) TVMI_DWPK(float);
+    else if (dt == TVMI_F16) TVMI_DWPK(__half);
+    else TVMI_DWPK(__hip_bfloat16);
+#undef TVMI_DWPK
   } else if (const DwGeom dg = depthwise_geom(p, dt); dg.CB > 0) {
     const dim3 grid((unsigned)(dg.ntx * dg.nty), (unsigned)(dg.csplit * p.ogroups), (unsigned)p.B);
     const size_t lds = (size_t)2 * dg.CB * dg.tile_sz * sizeof(float);
