@@ -1415,8 +1415,9 @@ __device__ __forceinline__ dw_f32x2 pk_fma_bl(dw_f32x2 c, dw_f32x2 q, dw_f32x2 d
   return d;
 }
 
-// NS: staged window pixels per thread (3 for the stride-1 / dilation-1 window of 19 x 75)
-template <typename T, int TWC, int NS>
+// NS: staged window pixels per thread (3 for the stride-1 / dilation-1 window of 19 x 80); TG: taps whose corner reads are issued
+// together (3: 12 reads in flight, the register budget of the NS = 3 shape; 1 for the general shape)
+template <typename T, int TWC, int NS, int TG>
 __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T* __restrict__ input, const T* __restrict__ weight,
                                                                         const T* __restrict__ offset, const T* __restrict__ mask,
                                                                         const T* __restrict__ bias, T* __restrict__ out,
@@ -1438,7 +1439,7 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
   const int64_t plane = (int64_t)p.H * p.W, oplane = (int64_t)p.oh * p.ow;
 
   // ---- tap geometry of this lane's pixel, once for all channels: window pixel of the top-left corner + 4 corner weights
-  int toff[KK];
+  unsigned tpack[(KK + 1) / 2];   // BYTE offset of a tap's top-left corner in a window buffer (< 32 KB), taps 2k | 2k+1 in the halves
   dw_f32x2 ctop[KK], cbot[KK];   // (c00, c01), (c10, c11)
   unsigned far = 0;
   T raw_h[KK], raw_w[KK], raw_m[KK];
@@ -1454,8 +1455,9 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
     }
   }
 #pragma unroll
+  for (int k = 0; k < (KK + 1) / 2; ++k) tpack[k] = 0u;
+#pragma unroll
   for (int t = 0; t < KK; ++t) {
-    toff[t] = 0;
     ctop[t] = cbot[t] = dw_f32x2{0.f, 0.f};
     if (live) {
       const int i = t / 3, j = t - 3 * i;
@@ -1469,7 +1471,7 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
         if (ty >= 0 && ty + 1 < g.tile_h && tx >= 0 && tx + 1 < tile_w) {
           const float lh = y - fy, lw = x - fx;
           const float hh = 1.f - lh, hw = 1.f - lw;
-          toff[t] = ty * tile_w + tx;
+          tpack[t >> 1] |= (unsigned)((ty * tile_w + tx) * 16) << ((t & 1) * 16);
           ctop[t] = dw_f32x2{hh * hw * m, hh * lw * m};
           cbot[t] = dw_f32x2{lh * hw * m, lh * lw * m};
         } else {
@@ -1494,9 +1496,7 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
   }
   const int nchunks = (c_end - c_begin) / CB;
   T stage[NS][CB];
-  float wv_cur[CB], wv_nxt[CB];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) wv_cur[cb] = wv_nxt[cb] = 0.f;
+  float wv_cur = 0.f, wv_nxt = 0.f;   // lane cb * 16 + t: weight t (t < 9) / bias (t = 9) of channel c0 + cb
   auto fetch = [&](int chunk) {
     const int c0 = c_begin + chunk * CB;
     const T* src = input + ((int64_t)b * p.C + c0) * plane;
@@ -1506,13 +1506,13 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) stage[i][cb] = src[(int64_t)cb * plane + o];   // every load unconditional
     }
-    if constexpr (!std::is_same<T, float>::value) {
-      const int wl_ = min(tid & 63, KK);
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        T raw = wl_ < KK ? weight[(int64_t)(c0 + cb) * KK + wl_] : bias[c0 + cb];
-        wv_nxt[cb] = (float)ld(&raw);
-      }
+    // the 9 weights + the bias of the chunk's four channels: ONE vector load (lane cb * 16 + t) that travels with the window;
+    // v_readlane broadcasts them in the tap loop.  (Scalar loads inside the loop share lgkmcnt with the LDS reads and return
+    // out of order: every wait would have to drain the LDS queue.)
+    {
+      const int l = tid & 63, cb = l >> 4, t = min(l & 15, KK);
+      T raw = t < KK ? weight[(int64_t)(c0 + cb) * KK + t] : bias[c0 + cb];
+      wv_nxt = (float)ld(&raw);
     }
   };
   auto park = [&](int chunk) {
@@ -1530,8 +1530,7 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
         dst[e] = v;
       }
     }
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) wv_cur[cb] = wv_nxt[cb];
+    wv_cur = wv_nxt;
   };
   fetch(0);
   park(0);
@@ -1540,29 +1539,41 @@ __global__ __launch_bounds__(kDwThreads, 4) void dcn_fwd_depthwise3x3_pk(const T
     if (chunk + 1 < nchunks) fetch(chunk + 1);   // the next chunk's window is in flight while this one is used
     const dw_f32x4* tile = lds4 + (chunk & 1) * g.tile_sz;
     const int c0 = c_begin + chunk * CB;
-    // the weights and the bias of the chunk's channels are wave-uniform: fp32 -> scalar loads (36 contiguous floats);
-    // 16-bit: the prefetched vectors
-    const T* wrow = weight + (int64_t)c0 * KK;
     auto wt = [&](int cb, int t) -> float {
-      if constexpr (std::is_same<T, float>::value) return t < KK ? wrow[cb * KK + t] : bias[c0 + cb];
-      else return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv_cur[cb]), t));
+      return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv_cur), cb * 16 + t));
     };
     float acc[CB] = {0.f, 0.f, 0.f, 0.f};
+    // three taps at a time: their 12 corner reads are issued back to back (the LDS reaches its rate only with many reads in
+    // flight per wait — with two per wait, as the compiler scheduled the plain loop, the kernel sat at 0.045 ms), then blended
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-      const dw_f32x4* q = tile + toff[t];
-      const dw_f32x4 q00 = q[0], q01 = q[1], q10 = q[tile_w], q11 = q[tile_w + 1];
-      dw_f32x2 lo = pk_mul_bl(ctop[t], q00.xy), hi = pk_mul_bl(ctop[t], q00.zw);
-      lo = pk_fma_bh(ctop[t], q01.xy, lo);
-      hi = pk_fma_bh(ctop[t], q01.zw, hi);
-      lo = pk_fma_bl(cbot[t], q10.xy, lo);
-      hi = pk_fma_bl(cbot[t], q10.zw, hi);
-      lo = pk_fma_bh(cbot[t], q11.xy, lo);
-      hi = pk_fma_bh(cbot[t], q11.zw, hi);
-      acc[0] = __builtin_fmaf(wt(0, t), lo.x, acc[0]);
-      acc[1] = __builtin_fmaf(wt(1, t), lo.y, acc[1]);
-      acc[2] = __builtin_fmaf(wt(2, t), hi.x, acc[2]);
-      acc[3] = __builtin_fmaf(wt(3, t), hi.y, acc[3]);
+    for (int t0 = 0; t0 < KK; t0 += TG) {
+      dw_f32x4 q[TG][4];
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        const int t = t0 + u;
+        const dw_f32x4* qp = reinterpret_cast<const dw_f32x4*>(reinterpret_cast<const char*>(tile) + ((tpack[t >> 1] >> ((t & 1) * 16)) & 0xffffu));
+        q[u][0] = qp[0];
+        q[u][1] = qp[1];
+        q[u][2] = qp[tile_w];
+        q[u][3] = qp[tile_w + 1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        const int t = t0 + u;
+        dw_f32x2 lo = pk_mul_bl(ctop[t], q[u][0].xy), hi = pk_mul_bl(ctop[t], q[u][0].zw);
+        lo = pk_fma_bh(ctop[t], q[u][1].xy, lo);
+        hi = pk_fma_bh(ctop[t], q[u][1].zw, hi);
+        lo = pk_fma_bl(cbot[t], q[u][2].xy, lo);
+        hi = pk_fma_bl(cbot[t], q[u][2].zw, hi);
+        lo = pk_fma_bh(cbot[t], q[u][3].xy, lo);
+        hi = pk_fma_bh(cbot[t], q[u][3].zw, hi);
+        acc[0] = __builtin_fmaf(wt(0, t), lo.x, acc[0]);
+        acc[1] = __builtin_fmaf(wt(1, t), lo.y, acc[1]);
+        acc[2] = __builtin_fmaf(wt(2, t), hi.x, acc[2]);
+        acc[3] = __builtin_fmaf(wt(3, t), hi.y, acc[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (any_far) {   // taps outside the staged window: the reference arithmetic on global memory
       for (int t = 0; t < KK; ++t)
@@ -1596,7 +1607,10 @@ inline DwGeom depthwise_pk_geom(const DcnParams& p, tvmi_dtype dt) {
   if (!(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16)) return g;
   if (!(p.ICg == 1 && p.OCg == 1 && p.kh == 3 && p.kw == 3) || p.cpog % kDwPkCB) return g;
   g.tile_h = (kDwTH - 1) * p.sh + 2 * p.dh + 2 * kDwHalo + 2;
-  g.tile_w = (kDwTW - 1) * p.sw + 2 * p.dw + 2 * kDwHalo + 2;
+  // row pitch = a multiple of 16 pixels (16 x 16 bytes = all 64 banks): a ds_read_b128 is served in groups of 16 lanes, whose
+  // pixels then keep distinct bank slots whatever row their offsets send them to; what is left are the collisions of the
+  // horizontal jitter (simulated with N(0,1) offsets: 2.37 instead of 2.66 LDS cycles per group at pitch 75)
+  g.tile_w = ((kDwTW - 1) * p.sw + 2 * p.dw + 2 * kDwHalo + 2 + 15) / 16 * 16;
   g.tile_sz = g.tile_h * g.tile_w;
   if ((size_t)2 * g.tile_sz * kDwPkCB * sizeof(float) > (size_t)64 * 1024) return g;   // two workgroups per CU
   if ((int64_t)p.H * p.W >= (1ll << 31) / 8) return g;
@@ -1841,12 +1855,12 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     const size_t lds = (size_t)2 * pg.tile_sz * kDwPkCB * sizeof(float);
 #define TVMI_DWPK(scalar_t)                                                                                       \
   do {                                                                                                            \
-    if (pg.tile_w == 75 && pg.nstage == 3)                                                                        \
-      dcn_fwd_depthwise3x3_pk<scalar_t, 75, 3><<<grid, dim3(kDwThreads), lds, s>>>(                               \
+    if (pg.tile_w == 80 && pg.nstage == 3)                                                                        \
+      dcn_fwd_depthwise3x3_pk<scalar_t, 80, 3, 3><<<grid, dim3(kDwThreads), lds, s>>>(                               \
           (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,        \
           (const scalar_t*)bias, (scalar_t*)output, p, pg);                                                       \
     else                                                                                                          \
-      dcn_fwd_depthwise3x3_pk<scalar_t, 0, kDwPkMaxStage><<<grid, dim3(kDwThreads), lds, s>>>(                    \
+      dcn_fwd_depthwise3x3_pk<scalar_t, 0, kDwPkMaxStage, 1><<<grid, dim3(kDwThreads), lds, s>>>(                    \
           (const scalar_t*)input, (const scalar_t*)weight, (const scalar_t*)offset, (const scalar_t*)mask,        \
           (const scalar_t*)bias, (scalar_t*)output, p, pg);                                                       \
   } while (0)
