@@ -627,7 +627,7 @@ def config5_block(rank, local_rank, world):
     env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_maskrcnn.py"), "--variant", "both", "--score-thresh", "0.0",
-           "--steps", "6", "--warmup", "2"]
+           "--steps", "12", "--warmup", "4"]
     t0 = time.perf_counter()
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
@@ -639,7 +639,7 @@ def config5_block(rank, local_rank, world):
     # batched_nms, models/detection/retinanet.py:509-571, landing in our NMS kernels), then vision_amd.fuse_detection_model
     try:
         cmd_r = [sys.executable, os.path.join(ROOT, "tools", "e2e_maskrcnn.py"), "--model", "retinanet", "--variant", "both",
-                 "--score-thresh", "0.0", "--steps", "4", "--warmup", "2"]
+                 "--score-thresh", "0.0", "--steps", "8", "--warmup", "3"]
         env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
         p = subprocess.run(cmd_r, capture_output=True, text=True, timeout=300, env=env)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

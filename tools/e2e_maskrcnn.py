@@ -192,6 +192,13 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            # the spread of single steps (each one synchronised; not part of `value`)
+            per = []
+            for i in range(min(args.steps, 6)):
+                t1 = time.perf_counter()
+                out = step(i)
+                torch.cuda.synchronize()
+                per.append(round((time.perf_counter() - t1) * 1e3, 2))
         finally:
             gc.enable()
             gc.unfreeze()
@@ -207,6 +214,7 @@ def main():
             "n_gpus": world,
             "images_per_gpu_per_step": args.batch,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "synced_single_steps_ms": per,
             "steps": args.steps,
             "warmup": args.warmup,
             "box_score_thresh": args.score_thresh,
@@ -242,6 +250,8 @@ def main():
                "reference_python_img_s": ref_run["value"], "reference_python_ms_per_step": ref_run["ms_per_step"],
                "fused_img_s": fus_run["value"], "fused_ms_per_step": fus_run["ms_per_step"],
                "reference_python_autofuse_img_s": auto_run["value"], "reference_python_autofuse_ms_per_step": auto_run["ms_per_step"],
+               "synced_single_steps_ms": {"reference": ref_run["synced_single_steps_ms"], "autofuse": auto_run["synced_single_steps_ms"],
+                                          "fused": fus_run["synced_single_steps_ms"]},
                "same_detections_autofuse": auto_ok,
                "detections_per_image": fus_run["detections_per_image"],
                "aten_upsample_calls_per_step": [ref_run["aten_upsample_calls_per_step"], fus_run["aten_upsample_calls_per_step"]],

@@ -93,8 +93,13 @@ def postprocess_detections(class_logits: Tensor, box_regression: Tensor, proposa
     _need_cuda(class_logits, "postprocess_detections")
     B, C = len(proposals), class_logits.shape[-1]
     dev = class_logits.device
-    row_image = torch.arange(B, dtype=torch.int32).repeat_interleave(torch.tensor([p.shape[0] for p in proposals]))   # host
-    row_image = row_image.pin_memory().to(dev, non_blocking=True)
+    # image of every RoI row, built ON THE DEVICE with a host-known output size (no synchronisation).  Not on the host:
+    # aten's CPU repeat_interleave is an OpenMP parallel_for with grain size 1 — its worker threads spin after the region,
+    # and inside a CPU-quota'd container that burns the process's CFS budget: measured on the GPU box as a 45-60 ms stop of
+    # the whole process in every third Mask R-CNN step (profiles/r05_e2e_stall.md)
+    sizes = [int(p.shape[0]) for p in proposals]
+    row_image = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), _host_to_device(sizes, torch.int64, dev),
+                                        output_size=sum(sizes))
     cb, cs, cv = torch.ops.tvmi.detection_candidates(
         class_logits, box_regression, torch.cat(list(proposals), 0), row_image, _image_hw(image_shapes, dev),
         [float(w) for w in bbox_reg_weights], BBOX_XFORM_CLIP, float(score_thresh), 1e-2)
