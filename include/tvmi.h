@@ -168,8 +168,20 @@ int tvmi_nms_small_segments(const void* dets, const int64_t* order, const int64_
 int tvmi_nms_mask_inputs(const float* scores, const int64_t* seg, const uint8_t* valid, int64_t n, float* scores_out,
                          int64_t* seg_out, int64_t* n_live, void* stream);
 int tvmi_nms_segmented_devcount(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
-                                int64_t capacity, const int64_t* n_dev, double iou_threshold, tvmi_dtype dt, void* workspace,
-                                size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream);
+                                int64_t capacity, const int64_t* n_dev, const int* partition_flag, double iou_threshold,
+                                tvmi_dtype dt, void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
+                                void* stream);
+/* The stable partition of the score order by segment id that the segment-major forms take (`seg_keys`, `perm`): a stable LSD
+ * radix sort over the id bits of the sequence that is already in score order — the permutation of the reference's
+ * formulation (ops/boxes.py:113-126: per-class index lists in score order).  Ids must lie in [0, num_segments) when
+ * num_segments > 0 (the sort then covers ceil(log2) + 1 bits), in [0, 2^31) otherwise; an id outside raises *flag_out (device
+ * int, zeroed by the call), which tvmi_nms_segmented_devcount turns into num_keep_out = -1.  With n_dev, ranks >= *n_dev are
+ * dead (masked-out candidates) and are placed behind every live one.  n_dev and partition_flag of
+ * tvmi_nms_segmented_devcount may be NULL (all boxes live / ids known to be in range). */
+size_t tvmi_partition_by_segment_workspace_bytes(int64_t n);
+int tvmi_partition_by_segment(const int64_t* order, const int64_t* seg, int64_t n, const int64_t* n_dev, int64_t num_segments,
+                              int64_t* keys_out, int64_t* perm_out, int* flag_out, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int tvmi_nms_small_segments_devcount(const void* dets, const int64_t* order, const int64_t* seg, int64_t capacity,
                                      const int64_t* n_dev, int64_t num_segments, double iou_threshold, tvmi_dtype dt,
                                      void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,

@@ -1110,6 +1110,27 @@ constexpr int kSegMaxBlocks = 128;  // blocks one sweep workgroup handles (8,192
                                    // earlier super-blocks is O(blocks^2) tile reads by ONE workgroup, so larger
                                    // segments are sent back to the global-order pipeline (colreduce + resolve)
 
+// The same bound found by a whole wave (all 64 lanes call it with the same arguments): 64 probes per round trip instead of
+// one — 3 dependent loads for 100k keys instead of 17.  (Round 4's lane-0 binary searches, two per row block, were most of
+// nms_mask_tiles_seg's 70 us at 100k boxes x 80 classes: every workgroup began with 34 serial global round trips.)
+__device__ __forceinline__ int upper_bound_key_wave(const int64_t* __restrict__ keys, int n, int64_t v) {
+  const int lane = threadIdx.x & 63;
+  int lo = 0, hi = n;   // invariant: every p < lo has keys[p] <= v, every p >= hi has keys[p] > v
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) >> 6;
+    const int p = lo + lane * step;
+    const bool le = p < hi && keys[p] <= v;
+    const int cnt = __builtin_popcountll(__ballot(le));   // keys ascending: the lanes with le form a prefix
+    const int nlo = cnt > 0 ? lo + (cnt - 1) * step + 1 : lo;   // probe cnt - 1 holds <= v
+    const int nhi = min(hi, lo + cnt * step);                   // probe cnt (if any) holds > v
+    lo = __builtin_amdgcn_readfirstlane(nlo);
+    hi = __builtin_amdgcn_readfirstlane(nhi);
+  }
+  const int p = lo + lane;
+  const bool le = p < hi && keys[p] <= v;
+  return lo + __builtin_popcountll(__ballot(le));
+}
+
 __device__ __forceinline__ int upper_bound_key(const int64_t* __restrict__ keys, int n, int64_t v) {
   int lo = 0, hi = n;  // first p with keys[p] > v
   while (lo < hi) {
@@ -1174,13 +1195,13 @@ __global__ __launch_bounds__(kMaskWaves * kWave) void nms_mask_tiles_seg(const T
     s_row[3][lane] = y2;
     s_row[4][lane] = (x2 - x1) * (y2 - y1);
     s_key[lane] = k;
-    if (lane == 0) {
+    {
       // column blocks that share a segment with this row block end with the segment of its last row; a
       // segment beyond the sweep limit is going to be redone by the global-order pipeline: skip its tiles
       const int64_t klast = keys[min(n - 1, row0 + 63)];
-      const int cbm = (upper_bound_key(keys, n, klast) - 1) >> 6;
-      const int first_blk = upper_bound_key(keys, n, klast - 1) >> 6;  // ids are integers: first p with key >= klast
-      s_cbmax = (cbm - first_blk + 1 > kSegMaxBlocks) ? rb - 1 : cbm;
+      const int cbm = (upper_bound_key_wave(keys, n, klast) - 1) >> 6;
+      const int first_blk = upper_bound_key_wave(keys, n, klast - 1) >> 6;  // ids are integers: first p with key >= klast
+      if (lane == 0) s_cbmax = (cbm - first_blk + 1 > kSegMaxBlocks) ? rb - 1 : cbm;
     }
   }
   __syncthreads();
@@ -1222,11 +1243,11 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_sweep_seg(const u64* __res
     const int p = B0 * 64 + lane;
     const bool start = p < n && (p == 0 || keys[p] != keys[p - 1]);
     const u64 starts = __ballot(start);
-    if (lane == 0) {
-      if (starts == 0ull) {
-        s_info[2] = 0;
-      } else {
-        const int end = upper_bound_key(keys, n, keys[min(n - 1, B0 * 64 + 63)]);
+    if (starts == 0ull) {   // (wave-uniform)
+      if (lane == 0) s_info[2] = 0;
+    } else {
+      const int end = upper_bound_key_wave(keys, n, keys[min(n - 1, B0 * 64 + 63)]);
+      if (lane == 0) {
         s_info[0] = B0 * 64 + __builtin_ctzll(starts);
         s_info[1] = end;
         s_info[2] = ((end - 1) >> 6) + 1 - B0;
@@ -1319,7 +1340,8 @@ __global__ __launch_bounds__(1024) void nms_seg_count(const u64* __restrict__ ke
 __global__ __launch_bounds__(1024) void nms_seg_emit(const u64* __restrict__ keepbits, const int* __restrict__ invperm,
                                                      const int64_t* __restrict__ order, const int* __restrict__ counts, int n,
                                                      const int64_t* __restrict__ n_dev, const int* __restrict__ err,
-                                                     int64_t* __restrict__ keep_out, int64_t* __restrict__ num_keep) {
+                                                     const int* __restrict__ ext_err, int64_t* __restrict__ keep_out,
+                                                     int64_t* __restrict__ num_keep) {
   __shared__ int s_w[16];
   __shared__ int s_part[16];
   n = live_boxes(n, n_dev);
@@ -1343,7 +1365,7 @@ __global__ __launch_bounds__(1024) void nms_seg_emit(const u64* __restrict__ kee
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     int tot = base;
     for (int w = 0; w < 16; ++w) tot += s_w[w];
-    *num_keep = *err ? -1 : tot;
+    *num_keep = (*err || (ext_err && *ext_err)) ? -1 : tot;   // ext_err: the partition saw an id outside its promised range
   }
 }
 
@@ -1680,7 +1702,8 @@ inline size_t seg_workspace_layout(int64_t n, char* base, SegWorkspace* w) {
 
 template <typename T>
 int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, const int64_t* perm, int64_t n,
-               const int64_t* n_dev, double thr, void* workspace, int64_t* keep_out, int64_t* num_keep, hipStream_t stream) {
+               const int64_t* n_dev, const int* ext_err, double thr, void* workspace, int64_t* keep_out, int64_t* num_keep,
+               hipStream_t stream) {
   const int CB = (int)ceil_div(n, 64), NC = (int)ceil_div(n, 1024);
   // the mask is banded: a row block only meets column blocks of its own segments, at most kSegMaxBlocks ahead, so a row
   // of tiles is min(CB, kSegMaxBlocks) slots wide (n x 1 KB instead of n^2 / 8 bytes: 0.37 GB instead of 16 GB at 360k boxes)
@@ -1695,7 +1718,7 @@ int launch_seg(const void* dets, const int64_t* order, const int64_t* keys, cons
   nms_sweep_seg<<<dim3((unsigned)CB), dim3(kSuper * kWave), 0, stream>>>(w.mask, keys, (int)n, n_dev, W, w.keepbits, w.err);
   nms_seg_count<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, (int)n, n_dev, w.counts);
   nms_seg_emit<<<dim3((unsigned)NC), dim3(1024), 0, stream>>>(w.keepbits, w.invperm, order, w.counts, (int)n, n_dev, w.err,
-                                                            keep_out, num_keep);
+                                                            ext_err, keep_out, num_keep);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_segmented");
 }
 
@@ -1792,8 +1815,8 @@ extern "C" size_t tvmi_nms_segmented_workspace_bytes(int64_t n) {
 namespace tvmi {
 namespace {
 int nms_segmented_entry(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm, int64_t n,
-                        const int64_t* n_dev, double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
-                        int64_t* keep_out, int64_t* num_keep_out, void* stream) {
+                        const int64_t* n_dev, const int* ext_err, double iou_threshold, tvmi_dtype dt, void* workspace,
+                        size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   TVMI_CHECK_ARG(n >= 0, "nms_segmented: negative box count");
   TVMI_CHECK_ARG(num_keep_out != nullptr, "nms_segmented: num_keep_out is null");
@@ -1806,8 +1829,8 @@ int nms_segmented_entry(const void* dets, const int64_t* order, const int64_t* s
   TVMI_CHECK_ARG(workspace_bytes >= tvmi_nms_segmented_workspace_bytes(n), "nms_segmented: workspace too small");
   TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F64, "nms_segmented: dets must be float32 or float64");
   if (dt == TVMI_F32)
-    return launch_seg<float>(dets, order, seg_keys, perm, n, n_dev, iou_threshold, workspace, keep_out, num_keep_out, s);
-  return launch_seg<double>(dets, order, seg_keys, perm, n, n_dev, iou_threshold, workspace, keep_out, num_keep_out, s);
+    return launch_seg<float>(dets, order, seg_keys, perm, n, n_dev, ext_err, iou_threshold, workspace, keep_out, num_keep_out, s);
+  return launch_seg<double>(dets, order, seg_keys, perm, n, n_dev, ext_err, iou_threshold, workspace, keep_out, num_keep_out, s);
 }
 
 int nms_small_segments_entry(const void* dets, const int64_t* order, const int64_t* seg, int64_t n, const int64_t* n_dev,
@@ -1869,17 +1892,16 @@ __global__ __launch_bounds__(256) void nms_mask_inputs_kernel(const float* __res
 extern "C" int tvmi_nms_segmented(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
                                   int64_t n, double iou_threshold, tvmi_dtype dt, void* workspace, size_t workspace_bytes,
                                   int64_t* keep_out, int64_t* num_keep_out, void* stream) {
-  return tvmi::nms_segmented_entry(dets, order, seg_keys, perm, n, nullptr, iou_threshold, dt, workspace, workspace_bytes, keep_out,
-                                   num_keep_out, stream);
+  return tvmi::nms_segmented_entry(dets, order, seg_keys, perm, n, nullptr, nullptr, iou_threshold, dt, workspace, workspace_bytes,
+                                   keep_out, num_keep_out, stream);
 }
 
 extern "C" int tvmi_nms_segmented_devcount(const void* dets, const int64_t* order, const int64_t* seg_keys, const int64_t* perm,
-                                           int64_t capacity, const int64_t* n_dev, double iou_threshold, tvmi_dtype dt,
-                                           void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
-                                           void* stream) {
-  TVMI_CHECK_ARG(n_dev != nullptr, "nms_segmented_devcount: n_dev is null");
-  return tvmi::nms_segmented_entry(dets, order, seg_keys, perm, capacity, n_dev, iou_threshold, dt, workspace, workspace_bytes,
-                                   keep_out, num_keep_out, stream);
+                                           int64_t capacity, const int64_t* n_dev, const int* partition_flag, double iou_threshold,
+                                           tvmi_dtype dt, void* workspace, size_t workspace_bytes, int64_t* keep_out,
+                                           int64_t* num_keep_out, void* stream) {
+  return tvmi::nms_segmented_entry(dets, order, seg_keys, perm, capacity, n_dev, partition_flag, iou_threshold, dt, workspace,
+                                   workspace_bytes, keep_out, num_keep_out, stream);
 }
 
 extern "C" int tvmi_nms_mask_inputs(const float* scores, const int64_t* seg, const uint8_t* valid, int64_t n, float* scores_out,

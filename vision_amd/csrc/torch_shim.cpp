@@ -66,6 +66,24 @@ void check_status(int status, const char* op) {
   TORCH_CHECK(status == 0, op, " failed: ", tvmi_last_error());
 }
 
+// partition of the score order by segment id + the segment-major NMS on it (n_live: device count of the masked form, or null)
+int segment_major_nms(const at::Tensor& boxes, const at::Tensor& order, const at::Tensor& seg, const int64_t* n_live,
+                      int64_t num_segments, double iou_threshold, at::Tensor& nms_ws, at::Tensor& keep, at::Tensor& num) {
+  const int64_t n = boxes.size(0);
+  const auto lopt = boxes.options().dtype(at::kLong);
+  at::Tensor keys = at::empty({n}, lopt), perm = at::empty({n}, lopt), flag = at::empty({1}, boxes.options().dtype(at::kInt));
+  const size_t pb = tvmi_partition_by_segment_workspace_bytes(n);
+  at::Tensor pws = at::empty({(int64_t)pb}, boxes.options().dtype(at::kByte));
+  int st = tvmi_partition_by_segment(order.const_data_ptr<int64_t>(), seg.const_data_ptr<int64_t>(), n, n_live, num_segments,
+                                     keys.mutable_data_ptr<int64_t>(), perm.mutable_data_ptr<int64_t>(), flag.mutable_data_ptr<int>(),
+                                     pws.mutable_data_ptr(), pb, current_stream(boxes));
+  if (st != 0) return st;
+  return tvmi_nms_segmented_devcount(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), keys.const_data_ptr<int64_t>(),
+                                     perm.const_data_ptr<int64_t>(), n, n_live, flag.const_data_ptr<int>(), iou_threshold,
+                                     dtype_of(boxes, "nms"), nms_ws.mutable_data_ptr(), (size_t)nms_ws.numel(),
+                                     keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(), current_stream(boxes));
+}
+
 // ---- nms: cuda/nms_kernel.cu:166-258 (checks and messages), cpu/nms_kernel.cpp (semantics)
 // Returns (keep [n] with a valid prefix, num [1] int64 on the device).  `allow_sync`: the segment-major path needs
 // one look at `num` to detect an over-long segment; without it (graph-capturable form) n > 4096 still takes that path
@@ -134,17 +152,11 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
     // a segment above 1024 boxes or an id outside [0, num_segments): general path below
   }
   if (seg_ptr && n > 4096) {  // up to 4096 boxes the single-launch global sweep is as fast
-    // segment-major path: stable partition of the score order by segment (a second sort), block-diagonal
-    // masks, one sweep workgroup per segment
-    auto parted = at::sort(seg_c.index_select(0, order), /*stable=*/true, /*dim=*/0, /*descending=*/false);
-    at::Tensor keys = std::get<0>(parted), perm = std::get<1>(parted);
+    // segment-major path: stable partition of the score order by segment (a radix sort over the id bits of the sequence that
+    // is already in score order), block-diagonal masks, one sweep workgroup per segment
     const size_t sb = tvmi_nms_segmented_workspace_bytes(n);
     at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
-    check_status(tvmi_nms_segmented(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), keys.const_data_ptr<int64_t>(),
-                                    perm.const_data_ptr<int64_t>(), n, iou_threshold, dtype_of(boxes, "nms"),
-                                    sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(),
-                                    num.mutable_data_ptr<int64_t>(), current_stream(dets)),
-                 "nms_segmented");
+    check_status(segment_major_nms(boxes, order, seg_c, nullptr, num_segments, iou_threshold, sws, keep, num), "nms_segmented");
     if (!allow_sync || num.item<int64_t>() >= 0) return std::make_tuple(keep, num);
     // a segment above 8,192 boxes: fall through to the global-order pipeline
   }
@@ -234,14 +246,10 @@ std::tuple<at::Tensor, at::Tensor> nms_segmented_masked(const at::Tensor& dets, 
                  "nms_small_segments");
     return std::make_tuple(keep, num);
   }
-  auto parted = at::sort(sg_m.index_select(0, order), /*stable=*/true, /*dim=*/0, /*descending=*/false);
-  at::Tensor keys = std::get<0>(parted), perm = std::get<1>(parted);
   const size_t sb = tvmi_nms_segmented_workspace_bytes(n);
   at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
-  check_status(tvmi_nms_segmented_devcount(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), keys.const_data_ptr<int64_t>(),
-                                           perm.const_data_ptr<int64_t>(), n, n_live.const_data_ptr<int64_t>(), iou_threshold,
-                                           TVMI_F32, sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(),
-                                           num.mutable_data_ptr<int64_t>(), current_stream(dets)),
+  // (the unmasked ids go in: dead ranks are recognised by their position behind *n_live, not by their key)
+  check_status(segment_major_nms(boxes, order, sg, n_live.const_data_ptr<int64_t>(), num_segments, iou_threshold, sws, keep, num),
                "nms_segmented");
   return std::make_tuple(keep, num);
 }
