@@ -571,9 +571,10 @@ def other_configs(device):
         ms, mn = med(lambda i: tv._deform_conv2d_backward(gsets[i % nsets]["go"], gsets[i % nsets]["x"], gsets[i % nsets]["w1"],
                                                           gsets[i % nsets]["off"], gsets[i % nsets]["m"], gsets[i % nsets]["bias"],
                                                           1, 1, 1, 1, 1, 1, 1, 1, True), n=12)
+        peak = FP32_PEAK_TF if tag == "fp32" else BF16_PEAK_TF     # the matrix-core peak of the type the contraction runs in
         out[f"deform_conv2d_backward_g1_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "TFLOPs": round(2 * flops / ms / 1e9, 1),
-                                                   "frac_of_mfma_peak": round(2 * flops / ms / 1e9 / FP32_PEAK_TF, 4), "peak_TFLOPs": FP32_PEAK_TF,
-                                                   "note": "contracted in fp32 on the matrix cores for every tensor type; 12 calls"}
+                                                   "frac_of_mfma_peak": round(2 * flops / ms / 1e9 / peak, 4), "peak_TFLOPs": peak,
+                                                   "note": "fp32 tensors on v_mfma_f32_32x32x2_f32, 16-bit tensors on v_mfma_f32_32x32x16_{bf16,f16} (round 5), fp32 accumulation; 12 calls"}
     return out
 
 

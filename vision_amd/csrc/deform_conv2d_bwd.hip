@@ -22,9 +22,10 @@
 //     with the offset-gather + bilinear "im2col" values of a 16-pixel slab produced straight into LDS (as the forward kernel
 //     does), and adds its partial block to a [tap][o][c] fp32 buffer (coalesced atomics), which a last small kernel
 //     transposes into the weight layout.
-//   * 16-bit tensors are read natively and contracted in fp32 (sums in fp32 buffers, rounded once at the end — the reference
-//     accumulates grad_input in 16-bit atomics); fp64, depthwise and tiny channel counts take the direct kernels below
-//     (same fusion, no matrix cores).
+//   * 16-bit tensors are read natively and contracted on v_mfma_f32_32x32x16_{f16,bf16} in the owner form of the data kernel
+//     and in the weight kernel (round 5: operands in the tensor type as in the reference's 16-bit GEMMs, fp32 accumulation;
+//     1.43 -> 1.17 ms at config 4), sums in fp32 buffers, rounded once at the end — the reference accumulates grad_input in
+//     16-bit atomics; fp64, depthwise and tiny channel counts take the direct kernels below (same fusion, no matrix cores).
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -40,6 +41,28 @@ std::atomic<int> g_bwd_window{1}; // option "dcn.bwd_window": 0 = the data-gradi
 std::atomic<int> g_bwd_owner{1};  // option "dcn.bwd_owner": 0 = never the owner form of the data-gradient kernel (dcn_bwd_data_own)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-bit tensors contract on v_mfma_f32_32x32x16_{f16,bf16} (round 5; the reference runs the backward GEMMs in the 16-bit type
+// too, cuda/deform_conv2d_kernel.cu:855,1021): a lane supplies 8 consecutive k of one row as one 16-byte LDS read from
+// [row][k] rows of 48 bytes (16 k + 8 pad: 16 lanes x 48 B tile the 64 banks without conflict).  fp32 accumulation.
+typedef _Float16 bw_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kBwPitch16 = 24;
+template <typename T>
+__device__ __forceinline__ f32x16 bw_mfma16(uint4 a, uint4 b, f32x16 c) {
+  if constexpr (std::is_same<T, __half>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bw_f16x8, a), __builtin_bit_cast(bw_f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, a), __builtin_bit_cast(bw_bf16x8, b), c, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ unsigned short bw_bits16(float v) {
+  if constexpr (std::is_same<T, __half>::value) return __half_as_ushort(__float2half(v));
+  else {
+    const __hip_bfloat16 b = __float2bfloat16(v);
+    return *reinterpret_cast<const unsigned short*>(&b);
+  }
+}
 
 // One sampling location as the backward needs it: the 4 corner offsets (clamped to a legal address), the bilinear weights of
 // the forward (zero for corners outside the image and for locations outside (-1, H) x (-1, W): deform_conv2d_kernel.cpp:95-132
@@ -774,7 +797,28 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
       if (b_u[e] < nt) bv[e] = *reinterpret_cast<const float4*>(wsrc + b_src[e]);
     }
   };
+  // 16-bit tensors: the slabs as 16-bit [row][k] rows of 48 bytes in the same two regions (A: 128 pixels, B: TG x 64 channels;
+  // the 16 out channels of a slab = ONE 32x32x16 step per tap), the weights back in the tensor type (an exact conversion:
+  // wtb is their fp32 re-layout)
+  constexpr bool k16 = sizeof(T) == 2;
+  unsigned short* const As16 = reinterpret_cast<unsigned short*>(As);
+  unsigned short* const Bs16 = reinterpret_cast<unsigned short*>(Bs);
   auto commit = [&]() {
+    if constexpr (k16) {
+#pragma unroll
+      for (int e = 0; e < AE; ++e) As16[am * kBwPitch16 + ak + 4 * e] = *reinterpret_cast<const unsigned short*>(&av[e]);
+#pragma unroll
+      for (int e = 0; e < BE; ++e)
+        if (b_u[e] < TG) {
+          const int k = b_dst[e] / BP, row = b_dst[e] - k * BP;   // (row = tap * 64 + channel)
+          unsigned short* d = Bs16 + row * kBwPitch16 + k;
+          d[0] = bw_bits16<T>(bv[e].x);
+          d[kBwPitch16] = bw_bits16<T>(bv[e].y);
+          d[2 * kBwPitch16] = bw_bits16<T>(bv[e].z);
+          d[3 * kBwPitch16] = bw_bits16<T>(bv[e].w);
+        }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < AE; ++e) As[(ak + 4 * e) * kOwnAP + am] = (float)ld(&av[e]);
 #pragma unroll
@@ -1005,6 +1049,18 @@ __global__ __launch_bounds__(512) void dcn_bwd_data_own(const T* __restrict__ xt
         commit();
         __syncthreads();
         if (ks + 1 < nks) issue(c0, (ks + 1) * kOwnKB, tg, nt);
+        if constexpr (k16) {
+          static_assert(kOwnKB == 16, "one 32x32x16 step per slab");
+          const uint4 a = *reinterpret_cast<const uint4*>(As16 + (wp * 32 + l31) * kBwPitch16 + 8 * kq);
+#pragma unroll
+          for (int u = 0; u < TG; ++u) {
+            if (u < nt) {   // (uniform)
+              const uint4 bb = *reinterpret_cast<const uint4*>(Bs16 + (u * kOwnCH + wc * 32 + l31) * kBwPitch16 + 8 * kq);
+              acc[u] = bw_mfma16<T>(a, bb, acc[u]);
+            }
+          }
+          continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < kOwnKB; kk += 2) {
           const float a = As[(kk + kq) * kOwnAP + wp * 32 + l31];
@@ -1084,6 +1140,11 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
   extern __shared__ __attribute__((aligned(16))) float dcn_bww_lds[];
   float(*As)[BM][kBwPitch] = reinterpret_cast<float(*)[BM][kBwPitch]>(dcn_bww_lds);
   float(*Bs)[BN][kBwPitch] = reinterpret_cast<float(*)[BN][kBwPitch]>(dcn_bww_lds + 2 * BM * kBwPitch);
+  // 16-bit tensors: the same slabs as 16-bit [row][k] rows (the 16 pixels of a slab = ONE 32x32x16 step per accumulator block)
+  constexpr bool k16 = sizeof(T) == 2;
+  unsigned short(*As16)[BM][kBwPitch16] = reinterpret_cast<unsigned short(*)[BM][kBwPitch16]>(dcn_bww_lds);
+  unsigned short(*Bs16)[BN][kBwPitch16] =
+      reinterpret_cast<unsigned short(*)[BN][kBwPitch16]>(reinterpret_cast<unsigned short*>(dcn_bww_lds) + 2 * BM * kBwPitch16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -1233,8 +1294,11 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
     const float(&wgt)[BV][4] = st.wgt;
     const float(&wmask)[BV] = st.wmask;
 #pragma unroll
-    for (int e = 0; e < AV; ++e)
-      As[buf][rsub + e * RSUB][pk] = (ga_live && o0 + rsub + e * RSUB < p.OCg) ? (float)ld(&ga[e]) : 0.f;
+    for (int e = 0; e < AV; ++e) {
+      const bool a_ok = ga_live && o0 + rsub + e * RSUB < p.OCg;
+      if constexpr (k16) As16[buf][rsub + e * RSUB][pk] = a_ok ? *reinterpret_cast<const unsigned short*>(&ga[e]) : (unsigned short)0;
+      else As[buf][rsub + e * RSUB][pk] = a_ok ? (float)ld(&ga[e]) : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < BV; ++e) {
       // a row / pixel that does not exist contributes exactly zero (its corner values may be anything, even inf)
@@ -1242,11 +1306,26 @@ __global__ __launch_bounds__(512) void dcn_bwd_weight_mfma(const T* __restrict__
       const bool live = wmask[w] != 0.f || wgt[w][0] != 0.f || wgt[w][1] != 0.f || wgt[w][2] != 0.f || wgt[w][3] != 0.f;
       const float v = wmask[w] * (wgt[w][0] * (float)ld(&xb[e][0]) + wgt[w][1] * (float)ld(&xb[e][1]) +
                                   wgt[w][2] * (float)ld(&xb[e][2]) + wgt[w][3] * (float)ld(&xb[e][3]));
-      Bs[buf][rsub + e * RSUB][pk] = live ? v : 0.f;
+      // (16-bit: the sampled value rounded to the tensor type, as the reference's 16-bit `columns` holds it)
+      if constexpr (k16) Bs16[buf][rsub + e * RSUB][pk] = live ? bw_bits16<T>(v) : (unsigned short)0;
+      else Bs[buf][rsub + e * RSUB][pk] = live ? v : 0.f;
     }
   };
 
   auto contract = [&](int buf) {
+    if constexpr (k16) {
+      static_assert(kBwBK == 16, "one 32x32x16 step per slab");
+      uint4 a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const uint4*>(&As16[buf][(wm * MI + mi) * 32 + l31][8 * kq]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const uint4*>(&Bs16[buf][(wn * NI + ni) * 32 + l31][8 * kq]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = bw_mfma16<T>(a[mi], b[ni], acc[mi][ni]);
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < kBwBK; kk += 2) {
       float a[MI], b[NI];
