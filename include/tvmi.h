@@ -265,14 +265,17 @@ int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void*
  * Output is still the reference's NCHW-contiguous [K,C,PH,PW]; rois are float32.  float32 maps (or float16 / bfloat16 with
  * an even channel count: two channels per lane), 7x7 bins, sampling_ratio 2, every level H,W >= 2; a single level with k_min == k_max is plain
  * roi_align.  The reference instead copies every map to NCHW first
- * (cuda/roi_align_kernel.cu:365 `input.contiguous()`).
+ * (cuda/roi_align_kernel.cu:365 `input.contiguous()`).  `workspace` (optional, ABI 304): K ints of scratch for the launch
+ * order of the RoIs — with it the units start sorted by (image, level, window-top band) and every XCD serves a contiguous
+ * eighth of that order; NULL / too small: input order.  Results do not depend on it.
  */
 int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs, const int64_t* heights, const int64_t* widths,
                                            const double* spatial_scales, int64_t n_levels, const void* rois,
                                            void* output, tvmi_dtype dt, int64_t N, int64_t C, int64_t K,
                                            int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio, int aligned,
                                            int64_t k_min, int64_t k_max, double canonical_scale,
-                                           double canonical_level, double eps, void* stream);
+                                           double canonical_level, double eps, void* workspace, size_t workspace_bytes,
+                                           void* stream);
 
 /* ----------------------------------------------- RoIPool / PSRoIAlign / PSRoIPool ------
  * Replaces: cuda/roi_pool_kernel.cu:15-125,127-260, cuda/ps_roi_align_kernel.cu,

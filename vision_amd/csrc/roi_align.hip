@@ -928,12 +928,22 @@ __device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const UnitMap&
   return true;
 }
 
-inline bool unit_map_can_pin(int nchunks) { return nchunks >= 8 && nchunks % 8 == 0; }
+__host__ __device__ inline bool unit_map_can_pin(int nchunks) { return nchunks >= 8 && nchunks % 8 == 0; }
 
+// Units of the channels_last kernel: (RoI, group of 64 lanes' channels).  XCD x serves the x-th EIGHTH OF THE RoIs IN LAUNCH ORDER
+// (sorted by image, level, window-top band: the eighths are contiguous runs of that order, i.e. different images / levels /
+// bands) with all their channel groups, group-major: an XCD's L2 sees one region of the maps, neighbouring windows one after
+// the other.  Round 4 split the RoIs in INPUT order (every XCD touched every map: 1.77 x the algorithmic bytes fetched, now
+// 1.05 x).  Measured and rejected on the way: one channel group per XCD pair (the NCHW kernel's pinning) — a group is a 256-byte
+// slice of every 1 KB pixel, so an XCD then reads through a quarter of its L2 channels: same traffic, 0.21 instead of 0.18 ms.
+__device__ __forceinline__ bool wave_unit_nhwc(int64_t K, int ngroups, const int* __restrict__ perm, int& k, int& gi) {
+  return wave_unit(K, ngroups, UnitMap{perm, 0}, k, gi);
+}
 inline unsigned wave_unit_grid(int64_t K, int nchunks, bool pinned = false, int wpb = kThreads / 64) {
   const int64_t per_xcd = pinned ? ceil_div(K * (nchunks / 8), wpb) : ceil_div(ceil_div(K, 8) * nchunks, wpb);
   return (unsigned)(8 * per_xcd);
 }
+inline unsigned wave_unit_grid_nhwc(int64_t K, int ngroups, bool) { return wave_unit_grid(K, ngroups); }
 
 // Launch order of the RoIs (forward, pinned placement): a one-workgroup counting sort by (image, level, window-top band).
 // Only the ORDER in which units start depends on it — never a result — so the key uses the hardware's approximate
@@ -1269,7 +1279,7 @@ struct NhwcShared {
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, const float* __restrict__ rois,
                                                                T* __restrict__ output, int C, int aligned,
-                                                               int ngroups, int64_t nunits) {
+                                                               int ngroups, int64_t nunits, const int* __restrict__ perm) {
   constexpr int PHW = PHT * PWT;
   constexpr int NS = SRT * SRT;
   constexpr int CPL = 4 / (int)sizeof(T);  // channels per lane: every tap is one 32-bit load per lane
@@ -1278,7 +1288,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   int k, gi;
-  if (!wave_unit(nunits / ngroups, ngroups, UnitMap{nullptr, 0}, k, gi)) return;
+  if (!wave_unit_nhwc(nunits / ngroups, ngroups, perm, k, gi)) return;
   const int c0 = gi * GC;
   // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
   const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
@@ -1388,17 +1398,26 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
 }
 
 template <typename T>
-int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64_t C, int64_t K, int64_t PH, int64_t PW,
-                       int64_t sr, int aligned, hipStream_t stream) {
+int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH, int64_t PW,
+                       int64_t sr, int aligned, int* perm, hipStream_t stream) {
   constexpr int GC = 64 * (4 / (int)sizeof(T));
   const int ngroups = (int)ceil_div(C, GC);
   const int64_t nunits = K * ngroups;
-  const dim3 grid(wave_unit_grid(K, ngroups)), block(kThreads);
   if (!(PH == 7 && PW == 7 && sr == 2))
     return set_error((int)hipErrorInvalidValue,
                      "roi_align (channels_last): only 7x7 bins with sampling_ratio 2 have a native NHWC kernel");
+  // launch order (the NCHW kernel's one-workgroup counting sort by image, level, window-top band) when the caller gave scratch
+  const int* order = nullptr;
+  const int64_t L = lv.n_levels;
+  if (perm && g_fwd_opt.order && N >= 1 && N * L <= kOrderBuckets && K <= kOrderMaxRois) {
+    const int bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * L)));
+    roi_fwd_order<float><<<dim3(1), dim3(kOrderThreads), 0, stream>>>(lv, static_cast<const float*>(rois), (int)K, (int)N, 1, bands, perm,
+                                                                        nullptr);
+    order = perm;
+  }
+  const dim3 grid(wave_unit_grid_nhwc(K, ngroups, order != nullptr)), block(kThreads);
   roi_align_fwd_nhwc<T, 7, 7, 2><<<grid, block, 0, stream>>>(lv, static_cast<const float*>(rois), static_cast<T*>(output), (int)C,
-                                                             aligned, ngroups, nunits);
+                                                             aligned, ngroups, nunits, order);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward_nhwc");
 }
 
@@ -1550,7 +1569,7 @@ extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs,
                                                       int64_t N, int64_t C, int64_t K, int64_t pooled_h, int64_t pooled_w,
                                                       int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
                                                       double canonical_scale, double canonical_level, double eps,
-                                                      void* stream) {
+                                                      void* workspace, size_t workspace_bytes, void* stream) {
   TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "roi_align (channels_last): 1..8 levels supported");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(inputs && heights && widths && spatial_scales && rois && output, "roi_align (channels_last): null pointer");
@@ -1565,7 +1584,11 @@ extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs,
   tvmi::MsLevels lv;
   tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dt == TVMI_F32) return tvmi::launch_ms_fwd_nhwc<float>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
-  if (dt == TVMI_F16) return tvmi::launch_ms_fwd_nhwc<__half>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
-  return tvmi::launch_ms_fwd_nhwc<__hip_bfloat16>(lv, rois, output, C, K, pooled_h, pooled_w, sampling_ratio, aligned, s);
+  // optional scratch: K ints for the launch order (tvmi_roi_align_forward_workspace_bytes covers it); without it the RoIs run in
+  // input order
+  int* perm = (workspace && workspace_bytes >= (size_t)K * sizeof(int) && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0)
+                  ? static_cast<int*>(workspace) : nullptr;
+  if (dt == TVMI_F32) return tvmi::launch_ms_fwd_nhwc<float>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, perm, s);
+  if (dt == TVMI_F16) return tvmi::launch_ms_fwd_nhwc<__half>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, perm, s);
+  return tvmi::launch_ms_fwd_nhwc<__hip_bfloat16>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, perm, s);
 }

@@ -280,9 +280,10 @@ at::Tensor roi_align_forward(const at::Tensor& input, const at::Tensor& rois, do
     const void* ptr = input.const_data_ptr();
     const double scale = spatial_scale;
     at::Tensor r = rois.to(at::kFloat).contiguous();  // the multi-scale entries take float32 RoIs (exact upcast)
+    at::Tensor order_ws = at::empty({K}, input.options().dtype(at::kInt));   // launch order of the RoIs
     check_status(tvmi_multiscale_roi_align_forward_nhwc(&ptr, &H, &W, &scale, 1, r.const_data_ptr(), output.mutable_data_ptr(),
                                                         dtype_of(input, "roi_align"), input.size(0), C, K, 7, 7, 2, aligned ? 1 : 0, 0, 0, 224.0,
-                                                        4.0, 1e-6, current_stream(input)),
+                                                        4.0, 1e-6, order_ws.mutable_data_ptr(), (size_t)K * sizeof(int), current_stream(input)),
                  "roi_align");
     return output;
   }
@@ -777,11 +778,13 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
     at::Tensor r = rois.to(at::kFloat).contiguous();
     at::Tensor out = at::empty({rois.size(0), f0.size(1), pooled_height, pooled_width}, f0.options().memory_format(at::MemoryFormat::Contiguous));
     if (out.numel() == 0) return out;
+    at::Tensor order_ws = at::empty({rois.size(0)}, f0.options().dtype(at::kInt));   // launch order of the RoIs
     check_status(tvmi_multiscale_roi_align_forward_nhwc(ptrs.data(), hs.data(), ws.data(), scales.data(),
                                                         (int64_t)features.size(), r.const_data_ptr(), out.mutable_data_ptr(),
                                                         dtype_of(f0, "multiscale_roi_align"), f0.size(0), f0.size(1), rois.size(0), pooled_height,
                                                         pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max,
-                                                        canonical_scale, canonical_level, eps, current_stream(f0)),
+                                                        canonical_scale, canonical_level, eps, order_ws.mutable_data_ptr(),
+                                                        (size_t)rois.size(0) * sizeof(int), current_stream(f0)),
                  "multiscale_roi_align");
     return out;
   }
