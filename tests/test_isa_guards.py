@@ -192,4 +192,32 @@ def test_deform_conv2d_backward_slab_loops_are_asynchronous(tmp_path):
         if "dcn_bwd_data_ownI" in name or ("dcn_bwd_weight_mfmaI" in name and "Lb1E" in name):
             assert "scratch_" not in body, name
             assert _synchronous_loads(body) == 0, (name, _synchronous_loads(body))
-            assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) >= 32, name
+            # fp32 tensors: 32x32x2 fp32 steps; 16-bit tensors (round 5): ONE 32x32x16 step per accumulator block and K slab
+            if "I6__half" in name:
+                assert len(re.findall(r"v_mfma_f32_32x32x16_f16", body)) >= 4 and "v_mfma_f32_32x32x2_f32" not in body, name
+            elif "I14__hip_bfloat16" in name:
+                assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) >= 4 and "v_mfma_f32_32x32x2_f32" not in body, name
+            else:
+                assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) >= 32, name
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_depthwise_deform_conv2d_packed_kernel_shape(tmp_path):
+    """The packed depthwise forward (round 5): two 512-thread workgroups per CU need <= 128 VGPRs without a spill (a
+    spill in the tap loop is a scratch load + s_waitcnt vmcnt(0) in front of the LDS reads — that also waits for the window
+    prefetch); per chunk of four channels it must issue 36 16-byte corner reads, 72 packed ops (v_pk_mul / v_pk_fma with the
+    op_sel broadcast of the corner weight) and take its weights from v_readlane, never from a scalar load inside the loop
+    (scalar loads share lgkmcnt with the LDS reads and return out of order)."""
+    text, res = _kernel_resources(os.path.join(CSRC, "deform_conv2d.hip"), tmp_path)
+    fast = {k: v for k, v in res.items() if "dcn_fwd_depthwise3x3_pkI" in k and "Li80ELi3ELi3E" in k}
+    assert len(fast) == 3, sorted(res)           # fp32, fp16, bf16
+    for k, r in {k: v for k, v in res.items() if "dcn_fwd_depthwise3x3_pkI" in k}.items():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128, (k, r)
+    body = next(v for k, v in _kernel_bodies(text, "dcn_fwd_depthwise3x3_pkIfLi80ELi3ELi3E").items())
+    assert len(re.findall(r"ds_read_b128", body)) == 36, len(re.findall(r"ds_read_b128", body))
+    assert len(re.findall(r"v_pk_fma_f32", body)) == 54 and len(re.findall(r"v_pk_mul_f32", body)) == 18
+    assert len(re.findall(r"v_readlane_b32", body)) >= 40
+    # 12 corner reads in flight before the first blend of a tap group: a counted wait that leaves 11 of them outstanding
+    assert re.search(r"s_waitcnt lgkmcnt\(11\)", body), "the tap groups' reads are no longer issued together"
+    loop = body[body.index("ds_read_b128"):body.rindex("ds_read_b128")]
+    assert "s_load_" not in loop and "scratch_" not in loop
