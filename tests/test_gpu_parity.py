@@ -1140,6 +1140,47 @@ def test_masked_segmented_nms_equals_compaction(n, nseg, live_frac):
     assert torch.equal(keep[: int(num)], want)
 
 
+def test_batched_nms_partition_edge_cases():
+    """The radix partition of the segment-major path (round 5) against the reference arithmetic of the oracle: exact score
+    ties inside and across segments (stable order), ids that are large, sparse, negative or beyond 2^31 (the partition raises
+    its flag and the glue takes the general path — the reference accepts any int64 ids), one box per segment, one segment;
+    and the device-count form with a segment above the per-segment limit reporting -1 instead of a wrong list."""
+    g = gen(77)
+    n = 6000
+    boxes = random_boxes(n, 500, 400, 4, 90, g)
+    scores = (torch.rand(n, generator=g) * 64).round() / 64          # 65 distinct values: thousands of exact ties
+    for name, ids in {
+        "dense80": torch.randint(0, 80, (n,), generator=g),
+        "sparse_large": torch.randint(0, 50, (n,), generator=g) * 40_000_003 + 7,          # up to ~2e9 < 2^31
+        "negative": torch.randint(-20, 20, (n,), generator=g),
+        "beyond_int32": torch.randint(0, 30, (n,), generator=g) * (1 << 33),
+        "one_per_segment": torch.randperm(n, generator=g),
+        "one_segment": torch.zeros(n, dtype=torch.int64),
+    }.items():
+        want = O.nms(boxes.numpy(), scores.numpy(), 0.5, ids.numpy())
+        got = torch.ops.tvmi.nms_segmented(boxes.to(DEV), scores.to(DEV), ids.to(DEV), 0.5, -1).cpu().numpy()
+        assert np.array_equal(got, want), name
+    # device-count form: 9000 live boxes in ONE segment (limit 8192) -> num = -1, never a silently wrong keep list
+    nb = 9500
+    b2 = random_boxes(nb, 3000, 3000, 4, 30, g).to(DEV)
+    s2 = torch.rand(nb, generator=g).to(DEV)
+    valid = torch.ones(nb, dtype=torch.uint8, device=DEV)
+    valid[9000:] = 0
+    keep, num = torch.ops.tvmi.nms_segmented_masked(b2, s2, torch.zeros(nb, dtype=torch.int64, device=DEV), valid, 0.5, 1)
+    assert int(num) == -1
+    # ... and an id outside the promised range in the masked form
+    ids = torch.randint(0, 5, (nb,), generator=g).to(DEV)
+    ids[17] = 9
+    keep, num = torch.ops.tvmi.nms_segmented_masked(b2, s2, ids, valid, 0.5, 5)
+    assert int(num) == -1
+    ids[17] = 3
+    ids[9100] = 9                      # the same id on a masked-out candidate does not matter
+    keep, num = torch.ops.tvmi.nms_segmented_masked(b2, s2, ids, valid, 0.5, 5)
+    sel = valid.bool().nonzero()[:, 0]
+    want = sel[torch.ops.tvmi.nms_segmented(b2[sel], s2[sel], ids[sel], 0.5, 5)]
+    assert int(num) == want.numel() and torch.equal(keep[: int(num)], want)
+
+
 def test_detector_postprocessing_is_sync_free_in_padded_form():
     """the three fused post-processing functions (RoIHeads.postprocess_detections roi_heads.py:680-737,
     RegionProposalNetwork.filter_proposals rpn.py:242-297, RetinaNet.postprocess_detections retinanet.py:509-571) run in
