@@ -157,6 +157,26 @@ def _synchronous_loads(body, window=6):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_roi_align_wave_kernels_stage_their_window_asynchronously(tmp_path):
+    """The register-staged wave kernels (generic pooled shapes / adaptive sampling, the mop-up launch, calls without a workspace)
+    load a window with 12-16 loads in flight per lane.  Rounds 1-4 guarded every load with the wave-uniform `if (rg < nrg)`: each
+    became a branch + load + `s_waitcnt vmcnt(0)` (7 of 16 synchronous, profiles/r04_isa_waits.txt).  Guard: at most two loads in
+    a kernel are waited for at once (the RoI row), the loads use the SGPR-base + 32-bit-offset form (not a 64-bit VGPR pair per
+    row group), and the 7x7 / generic kernels stay within 168 VGPRs (three waves per SIMD; they need 121-129, their 10 KB of LDS per
+    wave allows four)."""
+    text, res = _kernel_resources(os.path.join(CSRC, "roi_align.hip"), tmp_path)
+    bodies = {k: v for k, v in _kernel_bodies(text, "roi_align_fwd_").items() if "_waveI" in k}
+    assert len(bodies) == 18, sorted(bodies)     # {single level, multi-scale} x {fp32, fp16, bf16} x {7x7, 14x14, generic}
+    for name, body in bodies.items():
+        assert "scratch_" not in body, name
+        assert _synchronous_loads(body) <= 2, (name, _synchronous_loads(body))
+        staged = re.findall(r"global_load_(?:ushort|dword) v\d+, v\d+, s\[\d+:\d+\]", body)
+        assert len(staged) >= 100, (name, len(staged))
+        if "Li14ELi14E" not in name:
+            assert res[name]["vgpr"] <= 168 and res[name]["spill"] == 0, (name, res[name])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_roi_align_backward_owner_keeps_its_prefetch_in_flight(tmp_path):
     """Round 4: the tile-owner backward lost 20-30 % to loads the compiler had made synchronous — the grads prefetch of entry
     e + 1 was `v = 0; if (inside) v = load; else if (straddles) {...}` (a phi: its copy and an s_waitcnt vmcnt(0) sat right

@@ -87,47 +87,71 @@ struct WaveShared {
 };
 
 
-// Stages CH channel windows (rows y0.., cols x0.., clamped into the tensor) with RG row-groups
-// each: RG*CH independent loads are in flight per lane before the first LDS write.  Lanes
-// beyond the window edge re-read the edge element (same address, same value), so there is no
-// predication and no integer division anywhere on this path; the channel base pointer is
-// wave-uniform (SGPR) and the per-lane offsets are 32-bit.
+// Stages gc channel windows (rows y0.., cols x0.., clamped into the tensor), RG row groups of CH channels at a time:
+// RG*CH (12..16) independent loads are in flight per lane before the first LDS write.  Every load and every LDS write is
+// UNCONDITIONAL: a row group past the window (RG is the row-group count rounded up to the next instantiation) and a channel
+// past the group re-read the last row / channel — same address, same value, same LDS slot.  (Rounds 1-4 guarded them with the
+// wave-uniform `if (rg < nrg)`: the compiler turned every guarded load into a branch, a load and an `s_waitcnt vmcnt(0)` for
+// the phi — 7 of 16 loads synchronous; profiles/r04_isa_waits.txt, tests/test_isa_guards.py.)  Lanes beyond the window edge
+// re-read the edge element, so there is no predication and no integer division anywhere on this path; the channel base
+// pointer is wave-uniform (SGPR) and the per-lane offsets are 32-bit.
 template <typename T, int RG, int CH>
 __device__ __forceinline__ void stage_window(float* __restrict__ win, const T* __restrict__ in_cg, int64_t plane_sz,
-                                             int gc, int nrg, int wsz, const int (&goff)[RG], const int (&loff)[RG]) {
+                                             int gc, int wsz, int rpi, int rsub, int colc, int gxc, int y0, int wh,
+                                             int wstride, int H, int W) {
+  unsigned gbyte[RG];   // zero-extended byte offsets off the uniform channel pointer: one VGPR per row group, SGPR-base loads
+  int loff[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    const int r = min(rg * rpi + rsub, wh - 1);
+    gbyte[rg] = (unsigned)(min(y0 + r, H - 1) * W + gxc) * (unsigned)sizeof(T);
+    loff[rg] = r * wstride + colc;
+  }
   for (int ch0 = 0; ch0 < gc; ch0 += CH) {
     float v[CH][RG];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int ch = min(ch0 + c, gc - 1);  // tail: duplicate the last channel (idempotent)
-      const T* chp = in_cg + (int64_t)ch * plane_sz;
+      const char* chp = reinterpret_cast<const char*>(in_cg + (int64_t)min(ch0 + c, gc - 1) * plane_sz);
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg)
-        if (rg < nrg) v[c][rg] = ld(chp + goff[rg]);
+      for (int rg = 0; rg < RG; ++rg) {
+        // the empty asm keeps the zero-extension of the offset in THIS block: hoisted out of the channel loop it becomes a 64-bit
+        // VGPR pair per row group and the load loses its SGPR-base + 32-bit-offset addressing form (instruction selection works
+        // per block) — 32 more VGPRs at RG = 16: the 7x7 wave kernels went from 126 to 243 VGPRs and the scheduler serialised the loads
+        unsigned o = gbyte[rg];
+        asm("" : "+v"(o));
+        v[c][rg] = ld(reinterpret_cast<const T*>(chp + o));
+      }
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int ch = min(ch0 + c, gc - 1);
-      float* wch = win + ch * wsz;
+      float* wch = win + min(ch0 + c, gc - 1) * wsz;
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg)
-        if (rg < nrg) wch[loff[rg]] = v[c][rg];
+      for (int rg = 0; rg < RG; ++rg) wch[loff[rg]] = v[c][rg];
     }
   }
 }
 
-template <typename T, int RG, int CH>
+// nrg (1..16 row groups, wave-uniform) -> the instantiation with the fewest re-read rows (none up to 8, at most one beyond)
+template <typename T>
 __device__ __forceinline__ void stage_window_setup(float* __restrict__ win, const T* __restrict__ in_cg,
                                                    int64_t plane_sz, int gc, int nrg, int wsz, int rpi, int rsub,
                                                    int colc, int gxc, int y0, int wh, int wstride, int H, int W) {
-  int goff[RG], loff[RG];
-#pragma unroll
-  for (int rg = 0; rg < RG; ++rg) {
-    const int r = min(rg * rpi + rsub, wh - 1);
-    goff[rg] = min(y0 + r, H - 1) * W + gxc;
-    loff[rg] = r * wstride + colc;
+#define TVMI_STAGE(RG, CH) stage_window<T, RG, CH>(win, in_cg, plane_sz, gc, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W)
+  switch (nrg) {
+    case 1: TVMI_STAGE(1, 16); break;
+    case 2: TVMI_STAGE(2, 8); break;
+    case 3: TVMI_STAGE(3, 5); break;
+    case 4: TVMI_STAGE(4, 4); break;
+    case 5: TVMI_STAGE(5, 3); break;
+    case 6: TVMI_STAGE(6, 2); break;
+    case 7: TVMI_STAGE(7, 2); break;
+    case 8: TVMI_STAGE(8, 2); break;
+    case 9: case 10: TVMI_STAGE(10, 1); break;
+    case 11: case 12: TVMI_STAGE(12, 1); break;
+    case 13: case 14: TVMI_STAGE(14, 1); break;
+    default: TVMI_STAGE(16, 1); break;
   }
-  stage_window<T, RG, CH>(win, in_cg, plane_sz, gc, nrg, wsz, goff, loff);
+#undef TVMI_STAGE
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
@@ -253,12 +277,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_unit(WaveShared& s, const T* 
   for (int cg = 0; cg < cc; cg += G) {
     const int gc = min(G, cc - cg);
     const T* in_cg = in0 + (int64_t)cg * plane_sz;
-    if (nrg <= 4)
-      stage_window_setup<T, 4, 4>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
-    else if (nrg <= 8)
-      stage_window_setup<T, 8, 2>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
-    else
-      stage_window_setup<T, 16, 1>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    stage_window_setup<T>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -426,14 +445,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_fast(WaveShared& s, const T* 
   for (int cg = 0; cg < cc; cg += G) {
     const int gc = min(G, cc - cg);
     const T* in_cg = in0 + (int64_t)cg * plane_sz;
-    if (nrg <= 2)
-      stage_window_setup<T, 2, 8>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
-    else if (nrg <= 4)
-      stage_window_setup<T, 4, 4>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
-    else if (nrg <= 8)
-      stage_window_setup<T, 8, 2>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
-    else
-      stage_window_setup<T, 16, 1>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
+    stage_window_setup<T>(s.win, in_cg, plane_sz, gc, nrg, wsz, rpi, rsub, colc, gxc, y0, wh, wstride, H, W);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1074,6 +1086,9 @@ __device__ __forceinline__ bool mop_unit(const int* __restrict__ mop, int nchunk
   return true;
 }
 
+// (Measured on the ISA, round 5: asking for four waves per SIMD with __launch_bounds__(kThreads, 4) — the 7 x 7 / generic forms
+// need 121-129 VGPRs — makes the scheduler serialise the staging loads of some instantiations again to stay under 128.  Left to
+// the register allocator: three or four waves, every staging load asynchronous; tests/test_isa_guards.py.)
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_wave(const T* __restrict__ input, const T* __restrict__ rois,
                                                                T* __restrict__ output, int C, int H, int W, int PH_,
@@ -1520,7 +1535,8 @@ extern "C" int tvmi_roi_align_forward(const void* input, const void* rois, void*
   TVMI_CHECK_ARG(N >= 0 && C >= 0 && H >= 0 && W >= 0 && K >= 0, "roi_align: negative size");
   if (K * C * pooled_h * pooled_w == 0) return 0;
   TVMI_CHECK_ARG(input && rois && output, "roi_align: null pointer");
-  TVMI_CHECK_ARG(H * W < (1ll << 31) && K * tvmi::ceil_div(C, 32) < (1ll << 31),
+  // in-plane BYTE offsets of the wave kernels are unsigned 32-bit (stage_window)
+  TVMI_CHECK_ARG(H * W < (1ll << 31) && (dt != TVMI_F32 || H * W < (1ll << 30)) && K * tvmi::ceil_div(C, 32) < (1ll << 31),
                  "roi_align: size exceeds 32-bit launch limits");
   hipStream_t s = static_cast<hipStream_t>(stream);
   TVMI_DISPATCH_FLOAT(dt, "roi_align_forward",
@@ -1546,7 +1562,7 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
                  "multiscale_roi_align: float32 / float16 / bfloat16 only");
   TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align: size exceeds 32-bit launch limits");
   for (int64_t i = 0; i < n_levels; ++i)
-    TVMI_CHECK_ARG(inputs[i] != nullptr && heights[i] * widths[i] < (1ll << 31), "multiscale_roi_align: bad level");
+    TVMI_CHECK_ARG(inputs[i] != nullptr && heights[i] * widths[i] < (1ll << 30), "multiscale_roi_align: bad level");
   tvmi::MsLevels lv;
   tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
   hipStream_t s = static_cast<hipStream_t>(stream);
