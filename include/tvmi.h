@@ -44,7 +44,7 @@ typedef enum {
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
  * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
-#define TVMI_ABI_VERSION 304
+#define TVMI_ABI_VERSION 305
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
@@ -471,6 +471,38 @@ size_t tvmi_upsample_aa2d_workspace_bytes(int mode, int64_t IH, int64_t IW, int6
 int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt, int mode, int64_t NC, int64_t IH,
                        int64_t IW, int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Nearest / nearest-exact for ANY element type (elem_bytes 1, 2, 4 or 8: the op is a copy) — the reference resizes uint8
+ * images and masks with InterpolationMode.NEAREST without a cast (transforms/v2/functional/_geometry.py:316-323), i.e.
+ * through aten::upsample_nearest2d on integer tensors. */
+int tvmi_upsample_nearest2d_any(const void* input, void* output, int64_t elem_bytes, int64_t NC, int64_t IH, int64_t IW,
+                                int64_t OH, int64_t OW, int exact, double scale_h, double scale_w, void* stream);
+
+/* The six modes on channels_last tensors: input [N,IH,IW,C] -> output [N,OH,OW,C] in memory (what ATen returns for a
+ * channels_last input; resize_image preserves the format on purpose, _geometry.py:324-338).  mode: 0 nearest, 1 nearest-exact,
+ * 2 bilinear, 3 bicubic; antialias only with 2 / 3.  F32 / F16 / BF16; the nearest modes for any element size through
+ * tvmi_upsample_nearest2d_nhwc_any. */
+size_t tvmi_upsample2d_nhwc_workspace_bytes(int mode, int antialias, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                                            int align_corners, double scale_h, double scale_w);
+int tvmi_upsample2d_nhwc(const void* input, void* output, tvmi_dtype dt, int mode, int antialias, int64_t N, int64_t C,
+                         int64_t IH, int64_t IW, int64_t OH, int64_t OW, int align_corners, double scale_h, double scale_w,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int tvmi_upsample_nearest2d_nhwc_any(const void* input, void* output, int64_t elem_bytes, int64_t N, int64_t C, int64_t IH,
+                                     int64_t IW, int64_t OH, int64_t OW, int exact, double scale_h, double scale_w,
+                                     void* stream);
+
+/* Backward of the six modes above — aten::upsample_{nearest2d,bilinear2d,bicubic2d}_backward,
+ * _upsample_nearest_exact2d_backward, _upsample_{bilinear2d,bicubic2d}_aa_backward (the autograd formulas of the aten ops
+ * torchvision's resize / FPN top-down path / segmentation heads go through: ops/feature_pyramid_network.py:194,
+ * models/segmentation/_utils.py:27,33).  mode: 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic; antialias only with 2 / 3.
+ * The sizes are the FORWARD's: grad_output [NC,OH,OW] -> grad_input [NC,IH,IW], every element of grad_input written (no
+ * zero fill needed).  Gather formulation with a fixed summation order: bit-reproducible, unlike ATen's atomicAdd kernels.
+ * F32 / F16 / BF16 (fp32 accumulation, rounded once). */
+size_t tvmi_upsample2d_backward_workspace_bytes(int mode, int antialias, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                                                int align_corners, double scale_h, double scale_w);
+int tvmi_upsample2d_backward(const void* grad_output, void* grad_input, tvmi_dtype dt, int mode, int antialias, int64_t NC,
+                             int64_t IH, int64_t IW, int64_t OH, int64_t OW, int align_corners, double scale_h,
+                             double scale_w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* GeneralizedRCNNTransform.forward for a batch (models/detection/transform.py:119-255) in one
  * launch: images[i] is [C,H_i,W_i] (dt, contiguous); every output pixel of image i inside

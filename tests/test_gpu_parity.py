@@ -882,9 +882,9 @@ def test_resize_antialias_tile_kernel_shapes(mode):
 
 @pytest.mark.parametrize("mode,aa", [("nearest", False), ("nearest-exact", False), ("bilinear", False), ("bicubic", False), ("bilinear", True), ("bicubic", True)])
 def test_interpolate_gradient_matches_torch(mode, aa):
-    """vision_amd.interpolate on an input that requires grad: forward on our kernel, gradient from the matching aten
-    `upsample_*_backward` kernel — the same split autograd makes under override_aten_upsample(True).  Equal to the
-    gradient of F.interpolate on the same device tensor (the forward value of which differs by rounding only)."""
+    """vision_amd.interpolate on an input that requires grad: forward and gradient on the resize kernels of this library.
+    Equal to the gradient ATen's own CUDA kernels give F.interpolate on the same device tensor (the forward value of which
+    differs by rounding only; ATen's scatter-add sums in another order)."""
     g = gen(52)
     x = torch.rand(2, 3, 19, 23, generator=g).to(DEV)
     kw = {} if mode.startswith("nearest") else dict(align_corners=False, antialias=aa)
@@ -898,6 +898,148 @@ def test_interpolate_gradient_matches_torch(mode, aa):
         (yb * w).sum().backward()
         assert float((ya - yb).abs().max()) <= TOL
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-5)
+
+
+_BWD_CASES = [  # (in_h, in_w) -> size or scale_factor
+    ((19, 23), dict(size=(31, 40))), ((19, 23), dict(size=(11, 9))), ((19, 23), dict(size=(19, 23))), ((19, 23), dict(size=(19, 40))),
+    ((5, 7), dict(size=(64, 93))),            # > 8 outputs per input pixel and axis: the chunked column loop
+    ((200, 301), dict(size=(17, 23))),        # strong down-scale: wide anti-aliasing supports, most inputs untouched without it
+    ((37, 300), dict(size=(74, 600))),        # rows wider than one 256-lane workgroup
+    ((24, 32), dict(scale_factor=(1.7, 2.3))), ((24, 32), dict(scale_factor=0.55, recompute_scale_factor=True)),
+]
+
+
+@pytest.mark.parametrize("mode,aa", [("nearest", False), ("nearest-exact", False), ("bilinear", False), ("bicubic", False), ("bilinear", True), ("bicubic", True)])
+def test_interpolate_backward_kernels_vs_torch_cpu(mode, aa):
+    """tvmi::interpolate2d_backward (gather form of aten::upsample_*_backward, resize.hip) against the gradient installed-torch
+    CPU autograd gives F.interpolate — the arithmetic behind the reference's resize wrappers (_geometry.py:344), the FPN
+    top-down path (ops/feature_pyramid_network.py:194) and the segmentation heads (models/segmentation/_utils.py:27,33).
+    fp32 at 1e-5 of the gradient's scale; fp16 / bf16 gradients accumulate in fp32 and are rounded once.  Both align_corners
+    settings, user scale factors, identity sizes, N*C not a multiple of the plane group, and run-to-run bit equality."""
+    g = gen(61)
+    for (ih, iw), kw in _BWD_CASES:
+        for align in ((False,) if mode.startswith("nearest") else (False, True)):
+            if aa and align:
+                continue
+            extra = {} if mode.startswith("nearest") else dict(align_corners=align, antialias=aa)
+            x = torch.rand(1, 7, ih, iw, generator=g, requires_grad=True)
+            y = F.interpolate(x, mode=mode, **kw, **extra)
+            w = torch.randn(y.shape, generator=g)
+            (y * w).sum().backward()
+            xd = x.detach().to(DEV).requires_grad_(True)
+            yd = vision_amd.interpolate(xd, mode=mode, **kw, **extra)
+            assert yd.shape == y.shape
+            (yd * w.to(DEV)).sum().backward()
+            scale = max(float(x.grad.abs().max()), 1e-6)
+            err = float((xd.grad.cpu() - x.grad).abs().max()) / scale
+            assert err <= 1e-5, (mode, aa, align, (ih, iw), kw, err)
+            # the op directly, twice: bit-identical (no atomics)
+            sh, sw = -1.0, -1.0
+            if "scale_factor" in kw and not kw.get("recompute_scale_factor"):
+                sf = kw["scale_factor"]
+                sh, sw = (sf, sf) if isinstance(sf, float) else sf
+            args = (ih, iw, {"nearest": 0, "nearest-exact": 1, "bilinear": 2, "bicubic": 3}[mode], align, aa, sh, sw)
+            g1 = torch.ops.tvmi.interpolate2d_backward(w.to(DEV), *args)
+            g2 = torch.ops.tvmi.interpolate2d_backward(w.to(DEV), *args)
+            assert torch.equal(g1, g2) and torch.equal(g1, xd.grad)
+            for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+                g16 = torch.ops.tvmi.interpolate2d_backward(w.to(DEV, dt), *args)
+                x2 = x.detach().clone().requires_grad_(True)
+                (F.interpolate(x2, mode=mode, **kw, **extra) * w.to(dt).float()).sum().backward()
+                assert g16.dtype == dt
+                assert float((g16.float().cpu() - x2.grad).abs().max()) / scale <= tol, (mode, aa, dt, kw)
+
+
+def test_interpolate_backward_under_the_aten_override():
+    """With the aten override on, autograd's `upsample_*_backward` calls land in resize.hip too (call counter), grad_input
+    equal to installed-torch CPU's; float64 and channels_last gradients still reach ATen's kernels."""
+    g = gen(62)
+    x = torch.rand(2, 5, 40, 52, generator=g)
+    was = vision_amd.override_aten_upsample(True)
+    try:
+        for mode, kw in (("nearest", {}), ("nearest-exact", {}), ("bilinear", dict(align_corners=False)), ("bicubic", dict(align_corners=True)),
+                         ("bilinear", dict(align_corners=False, antialias=True)), ("bicubic", dict(align_corners=False, antialias=True))):
+            for size in ((80, 104), (23, 31)):
+                a = x.clone().requires_grad_(True)
+                ya = F.interpolate(a, size=size, mode=mode, **kw)
+                w = torch.randn(ya.shape, generator=g)
+                (ya * w).sum().backward()
+                b = x.to(DEV).requires_grad_(True)
+                c0 = int(torch.ops.tvmi.aten_upsample_calls())
+                yb = F.interpolate(b, size=size, mode=mode, **kw)
+                (yb * w.to(DEV)).sum().backward()
+                assert int(torch.ops.tvmi.aten_upsample_calls()) - c0 == 2, (mode, size)   # forward + backward
+                torch.testing.assert_close(b.grad.cpu(), a.grad, rtol=1e-5, atol=1e-5)
+        c1 = int(torch.ops.tvmi.aten_upsample_calls())
+        d = x.double().to(DEV).requires_grad_(True)
+        F.interpolate(d, size=(50, 60), mode="bilinear", align_corners=False).sum().backward()
+        assert int(torch.ops.tvmi.aten_upsample_calls()) == c1 and d.grad is not None
+    finally:
+        vision_amd.override_aten_upsample(was)
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.bool])
+def test_nearest_resize_of_integer_tensors(dtype):
+    """The nearest modes are copies: uint8 images / masks (and every other integer type) are resized without a cast, like
+    aten::upsample_nearest2d on the reference's resize path (_geometry.py:316-323).  Bit-equal to torch CPU on the types torch
+    CPU serves (uint8), and to the float round trip for the others; the aten override serves them as well."""
+    g = gen(63)
+    x = torch.randint(0, 2 if dtype == torch.bool else 100, (2, 3, 37, 53), generator=g).to(dtype)
+    for mode in ("nearest", "nearest-exact"):
+        for size in ((80, 31), (11, 120), (37, 53)):
+            ref = F.interpolate(x.float(), size=size, mode=mode).to(dtype)
+            out = vision_amd.interpolate(x.to(DEV), size=size, mode=mode)
+            assert out.dtype == dtype and torch.equal(out.cpu(), ref), (mode, size)
+            if dtype == torch.uint8:
+                assert torch.equal(out.cpu(), F.interpolate(x, size=size, mode=mode))
+    if dtype == torch.uint8:
+        was = vision_amd.override_aten_upsample(True)
+        try:
+            c0 = int(torch.ops.tvmi.aten_upsample_calls())
+            out = F.interpolate(x.to(DEV), size=(64, 64), mode="nearest")
+            assert int(torch.ops.tvmi.aten_upsample_calls()) - c0 == 1
+            assert torch.equal(out.cpu(), F.interpolate(x, size=(64, 64), mode="nearest"))
+        finally:
+            vision_amd.override_aten_upsample(was)
+        img = torch.randint(0, 256, (3, 120, 160), generator=g, dtype=torch.uint8)
+        out = vision_amd.resize(img.to(DEV), [90], interpolation="nearest-exact")
+        assert out.dtype == torch.uint8 and torch.equal(out.cpu(), F.interpolate(img[None], size=(90, 120), mode="nearest-exact")[0])
+
+
+@pytest.mark.parametrize("mode,aa", [("nearest", False), ("nearest-exact", False), ("bilinear", False), ("bicubic", False), ("bilinear", True), ("bicubic", True)])
+def test_resize_channels_last(mode, aa):
+    """channels_last in -> channels_last out without a layout copy (upsample2d_nhwc_kernel), all six modes, against torch CPU at
+    1e-4 (16-bit: the input rounded first); C = 3 images (the 1CHW case of resize_image, _geometry.py:324-338) and a 256-channel
+    map; uint8 in the nearest modes; the aten override serves the format as well."""
+    g = gen(64)
+    for shape, sizes in (((2, 3, 61, 83), ((100, 131), (23, 40), (61, 83))), ((1, 256, 25, 42), ((50, 84), (13, 20)))):
+        x = torch.rand(*shape, generator=g)
+        for size in sizes:
+            for align in ((False,) if mode.startswith("nearest") or aa else (False, True)):
+                kw = {} if mode.startswith("nearest") else dict(align_corners=align, antialias=aa)
+                ref = F.interpolate(x, size=size, mode=mode, **kw)
+                out = vision_amd.interpolate(x.to(DEV).contiguous(memory_format=torch.channels_last), size=size, mode=mode, **kw)
+                assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+                assert float((out.cpu() - ref).abs().max()) <= TOL, (mode, aa, shape, size, align)
+        x16 = x.to(torch.bfloat16)
+        kw = {} if mode.startswith("nearest") else dict(align_corners=False, antialias=aa)
+        out16 = vision_amd.interpolate(x16.to(DEV).contiguous(memory_format=torch.channels_last), size=sizes[0], mode=mode, **kw)
+        ref16 = F.interpolate(x16.float(), size=sizes[0], mode=mode, **kw)
+        assert out16.dtype == torch.bfloat16 and float((out16.float().cpu() - ref16).abs().max()) <= 1.6e-2
+    if mode.startswith("nearest"):
+        u = torch.randint(0, 256, (2, 3, 37, 53), generator=g, dtype=torch.uint8)
+        out = vision_amd.interpolate(u.to(DEV).contiguous(memory_format=torch.channels_last), size=(80, 31), mode=mode)
+        assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out.cpu(), F.interpolate(u, size=(80, 31), mode=mode))
+    was = vision_amd.override_aten_upsample(True)
+    try:
+        c0 = int(torch.ops.tvmi.aten_upsample_calls())
+        x = torch.rand(2, 8, 30, 40, generator=g)
+        kw = {} if mode.startswith("nearest") else dict(align_corners=False, antialias=aa)
+        out = F.interpolate(x.to(DEV).contiguous(memory_format=torch.channels_last), size=(45, 70), mode=mode, **kw)
+        assert int(torch.ops.tvmi.aten_upsample_calls()) - c0 == 1 and out.is_contiguous(memory_format=torch.channels_last)
+        assert float((out.cpu() - F.interpolate(x, size=(45, 70), mode=mode, **kw)).abs().max()) <= TOL
+    finally:
+        vision_amd.override_aten_upsample(was)
 
 
 def test_resize_image_wrapper_uint8():

@@ -186,12 +186,18 @@ def test_reference_python_on_the_gpu_lands_in_our_kernels(tmp_path):
             assert (got.cpu() - want).abs().max() < 1e-4, mode
         a1 = F.interpolate(img, size=(400, 533), mode="bilinear", align_corners=False)
         assert int(torch.ops.tvmi.aten_upsample_calls()) - c0 == 6 and (a0 - a1).abs().max() < 1e-4
-        # gradients still flow (aten's backward kernel) and integer / channels_last inputs fall through to ATen
+        # gradients flow through the backward override (round 5: gather kernels), channels_last inputs have their own kernel
+        # (output channels_last, like ATen's), float64 still reaches ATen
         xr = img.clone().requires_grad_(True)
-        F.interpolate(xr, scale_factor=2.0, mode="bilinear").sum().backward()
-        assert xr.grad is not None and xr.grad.shape == img.shape
         c1 = int(torch.ops.tvmi.aten_upsample_calls())
-        F.interpolate(img.contiguous(memory_format=torch.channels_last), size=(100, 100), mode="bilinear")
+        F.interpolate(xr, scale_factor=2.0, mode="bilinear").sum().backward()
+        assert xr.grad is not None and xr.grad.shape == img.shape and int(torch.ops.tvmi.aten_upsample_calls()) - c1 == 2
+        c1 = int(torch.ops.tvmi.aten_upsample_calls())
+        ycl = F.interpolate(img.contiguous(memory_format=torch.channels_last), size=(100, 100), mode="bilinear")
+        assert int(torch.ops.tvmi.aten_upsample_calls()) == c1 + 1 and ycl.is_contiguous(memory_format=torch.channels_last)
+        assert (ycl.cpu() - F.interpolate(img.cpu(), size=(100, 100), mode="bilinear")).abs().max() < 1e-4
+        c1 = int(torch.ops.tvmi.aten_upsample_calls())
+        F.interpolate(img.double(), size=(100, 100), mode="bilinear")
         assert int(torch.ops.tvmi.aten_upsample_calls()) == c1
         # a detection model of the reference end to end on this library (small input: this is a plumbing check,
         # the measured configuration is `bench.py --e2e`)

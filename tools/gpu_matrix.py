@@ -177,6 +177,30 @@ if "resize" in sections:
         t2 = tm(lambda: F.interpolate(small, size=(800, 1067), mode=mode))
         put(f"resize_3x480x640_to_800x1067_{mode}", t, aten_ms=round(t2, 4))
 
+if "resize" in sections or "resize_bwd" in sections:
+    # gradients of the resize ops (round 5: gather kernels) next to ATen's own backward kernels on the same device.
+    # shapes: the FPN top-down path of config 2/5 (nearest 2x, ops/feature_pyramid_network.py:194), a segmentation head
+    # (bilinear, models/segmentation/_utils.py:33) and the measured resize shape
+    g = torch.Generator().manual_seed(0)
+    mode_id = {"nearest": 0, "nearest-exact": 1, "bilinear": 2, "bicubic": 3}
+    aten_bwd = {("nearest", False): torch.ops.aten.upsample_nearest2d_backward, ("bilinear", False): torch.ops.aten.upsample_bilinear2d_backward,
+                ("bicubic", False): torch.ops.aten.upsample_bicubic2d_backward, ("bilinear", True): torch.ops.aten._upsample_bilinear2d_aa_backward,
+                ("bicubic", True): torch.ops.aten._upsample_bicubic2d_aa_backward}
+    for tag, ishape, osz, cases in (
+            ("fpn_4x256x100x168_to_200x336", (4, 256, 100, 168), (200, 336), (("nearest", False), ("bilinear", False))),
+            ("seg_8x21x65x65_to_520x520", (8, 21, 65, 65), (520, 520), (("bilinear", False),)),
+            ("img_8x3x1080x1920_to_800x1422", (8, 3, 1080, 1920), (800, 1422), (("bilinear", False), ("bilinear", True), ("bicubic", False), ("bicubic", True)))):
+        for dt in (torch.float32, torch.bfloat16):
+            go = torch.randn(ishape[0], ishape[1], *osz, generator=g).to(dev, dt)
+            by = go.numel() * go.element_size() * (1 + ishape[2] * ishape[3] / (osz[0] * osz[1]))
+            for mode, aa in cases:
+                t = tm(lambda: torch.ops.tvmi.interpolate2d_backward(go, ishape[2], ishape[3], mode_id[mode], False, aa, -1.0, -1.0))
+                if mode == "nearest":
+                    t2 = tm(lambda: aten_bwd[(mode, aa)](go, list(osz), list(ishape), None, None))
+                else:
+                    t2 = tm(lambda: aten_bwd[(mode, aa)](go, list(osz), list(ishape), False, None, None))
+                put(f"resize_bwd_{tag}_{mode}{'_aa' if aa else ''}_{str(dt)[6:]}", t, GBs=round(by / t / 1e6), aten_ms=round(t2, 4))
+
 if "post" in sections:
     g = torch.Generator().manual_seed(0)
     mk = torch.rand(100, 1, 28, 28, generator=g).to(dev)

@@ -143,7 +143,13 @@ def _multiscale_backward(ctx, grad):
 
 
 def _fake_interpolate2d(input, out_h, out_w, mode, align_corners, antialias, scale_h, scale_w):
-    return input.new_empty((input.size(0), input.size(1), out_h, out_w))
+    cl = not input.is_contiguous() and input.is_contiguous(memory_format=torch.channels_last)
+    return torch.empty((input.size(0), input.size(1), out_h, out_w), dtype=input.dtype, device=input.device,
+                       memory_format=torch.channels_last if cl else torch.contiguous_format)
+
+
+def _fake_interpolate2d_backward(grad_output, in_h, in_w, mode, align_corners, antialias, scale_h, scale_w):
+    return grad_output.new_empty((grad_output.size(0), grad_output.size(1), in_h, in_w))
 
 
 def _fake_pack_detections(boxes, scores, labels, image_idx, keep, num_images, max_dets):
@@ -233,6 +239,7 @@ _FAKES = {
     "tvmi::multiscale_roi_align": _fake_multiscale,
     "tvmi::multiscale_roi_align_backward": _fake_multiscale_bwd,
     "tvmi::interpolate2d": _fake_interpolate2d,
+    "tvmi::interpolate2d_backward": _fake_interpolate2d_backward,
     "torchvision::nms": _fake_nms,
     "tvmi::nms_segmented": _fake_nms_segmented,
     "torchvision::roi_align": _fake_roi_align,

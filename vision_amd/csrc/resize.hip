@@ -680,6 +680,316 @@ __global__ __launch_bounds__(kThreads) void normalize_resize_batch_kernel(XformI
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Backward of all six interpolation modes (aten::upsample_{nearest2d,bilinear2d,bicubic2d}_backward,
+// _upsample_nearest_exact2d_backward, _upsample_{bilinear2d,bicubic2d}_aa_backward; ATen/native/cuda/UpSampleBilinear2d.cu,
+// UpSampleBicubic2d.cu, UpSampleNearest2d.cu of torch 2.10).  ATen's bilinear / bicubic / anti-aliased backward kernels are
+// output-stationary and scatter with atomicAdd (non-deterministic sums; torch warns under use_deterministic_algorithms).
+// Here the gradient is GATHERED: every mode is separable, so one axis is described by the forward table
+//   output index o -> [first source index, number of taps, weights]            (bwd_axis_table_kernel / aa_table_kernel)
+// and, because the first and last source index of an output are non-decreasing in o, the outputs that touch input index i
+// form ONE contiguous range [lo(i), hi(i)) (bwd_axis_ranges_kernel, two binary searches).  A lane owns an input pixel and
+// sums wy(oy, iy) * wx(ox, ix) * grad_out[oy][ox] over its two ranges in a fixed order: deterministic, no atomics, no
+// zero-fill of grad_input, fp32 accumulation rounded once for the 16-bit types.  Taps that the forward clamps onto the
+// same border pixel have their weights added in the table (CubicAxis does the same for the forward tile kernel).
+enum { BWD_NEAREST = 0, BWD_NEAREST_EXACT = 1, BWD_BILINEAR = 2, BWD_BICUBIC = 3 };
+
+__global__ void bwd_axis_table_kernel(float* __restrict__ table, int out_size, int in_size, float scale, int kind, int taps,
+                                      int align) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= out_size) return;
+  float* row = table + (int64_t)o * (taps + 2);
+  int first = 0, n = 1;
+  float w[4] = {1.f, 0.f, 0.f, 0.f};
+  if (kind == BWD_NEAREST) {            // UpSample.h:320-343
+    first = min((int)floorf((float)o * scale), in_size - 1);
+  } else if (kind == BWD_NEAREST_EXACT) {
+    first = min((int)floorf(((float)o + 0.5f) * scale), in_size - 1);
+  } else if (kind == BWD_BILINEAR) {
+    const Lin l = linear_index(scale, o, in_size, out_size, align != 0);
+    first = l.i0;
+    n = l.i1 - l.i0 + 1;
+    w[0] = n == 1 ? l.l0 + l.l1 : l.l0;
+    w[1] = n == 1 ? 0.f : l.l1;
+  } else {  // bicubic, A = -0.75; source index not clamped at 0, taps clamped into the image (UpSample.h:400-435)
+    {
+      const float real = source_index(scale, o, align != 0, true);
+      const int ix = min((int)floorf(real), in_size - 1);
+      const float t = fminf(fmaxf(real - (float)ix, 0.f), 1.f), A = -0.75f;
+      const float c[4] = {cubic2(t + 1.f, A), cubic1(t, A), cubic1(1.f - t, A), cubic2(1.f - t + 1.f, A)};
+      first = max(min(ix - 1, in_size - 1), 0);
+      const int last = max(min(ix + 2, in_size - 1), 0);
+      n = last - first + 1;
+      w[0] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = max(min(ix - 1 + k, in_size - 1), 0) - first;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (d == q) w[q] += c[k];
+      }
+    }
+  }
+  row[0] = __int_as_float(first);
+  row[1] = __int_as_float(n);
+  for (int k = 0; k < taps; ++k) row[2 + k] = k < 4 ? w[k] : 0.f;
+}
+
+// range[i] = {first o whose taps end beyond i, first o whose taps start beyond i}
+__global__ void bwd_axis_ranges_kernel(const float* __restrict__ table, int taps, int out_size, int in_size,
+                                       int2* __restrict__ range) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in_size) return;
+  const int64_t pitch = taps + 2;
+  int lo = 0, hi = out_size;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const float* r = table + mid * pitch;
+    if (__float_as_int(r[0]) + __float_as_int(r[1]) > i) hi = mid; else lo = mid + 1;
+  }
+  const int first = lo;
+  hi = out_size;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (__float_as_int(table[mid * pitch]) > i) hi = mid; else lo = mid + 1;
+  }
+  range[i] = make_int2(first, lo);
+}
+
+__device__ __forceinline__ float bwd_weight(const float* __restrict__ table, int taps, int o, int i) {
+  const float* r = table + (int64_t)o * (taps + 2);
+  const int d = i - __float_as_int(r[0]);
+  return (d >= 0 && d < __float_as_int(r[1])) ? r[2 + d] : 0.f;
+}
+
+constexpr int kBwdPlanes = 4, kBwdCols = 8, kBwdRows = 8;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample2d_bwd_kernel(const T* __restrict__ gout, T* __restrict__ gin,
+                                                                  const float* __restrict__ ytab,
+                                                                  const float* __restrict__ xtab,
+                                                                  const int2* __restrict__ yrange,
+                                                                  const int2* __restrict__ xrange, int NC, int IH, int IW,
+                                                                  int OH, int OW, int yt, int xt, int nc_per_block) {
+  const int ix = blockIdx.x * kThreads + threadIdx.x;
+  const int iy = blockIdx.y;
+  if (ix >= IW) return;
+  const int2 yr = yrange[iy], xr = xrange[ix];
+  const int nc0 = blockIdx.z * nc_per_block, nc1 = min(NC, nc0 + nc_per_block);
+  const int64_t iplane = (int64_t)IH * IW, oplane = (int64_t)OH * OW;
+  // the weights of the first kBwdRows x kBwdCols outputs of the two ranges (all of them up to a 4x up-scale of the
+  // interpolating modes, any down-scale) are looked up once and serve every plane; longer ranges re-read the tables
+  const int cnt0 = min(kBwdCols, xr.y - xr.x), rows0 = min(kBwdRows, yr.y - yr.x);
+  float wx0[kBwdCols], wy0[kBwdRows];
+#pragma unroll
+  for (int k = 0; k < kBwdCols; ++k) wx0[k] = k < cnt0 ? bwd_weight(xtab, xt, xr.x + k, ix) : 0.f;
+#pragma unroll
+  for (int j = 0; j < kBwdRows; ++j) wy0[j] = j < rows0 ? bwd_weight(ytab, yt, yr.x + j, iy) : 0.f;
+  for (int nc = nc0; nc < nc1; nc += kBwdPlanes) {
+    const int np = min(kBwdPlanes, nc1 - nc);
+    float acc[kBwdPlanes];
+#pragma unroll
+    for (int p = 0; p < kBwdPlanes; ++p) acc[p] = 0.f;
+    for (int xc = xr.x; xc < xr.y; xc += kBwdCols) {
+      const int cnt = min(kBwdCols, xr.y - xc);
+      float wx[kBwdCols];
+      if (xc == xr.x) {
+#pragma unroll
+        for (int k = 0; k < kBwdCols; ++k) wx[k] = wx0[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kBwdCols; ++k) wx[k] = k < cnt ? bwd_weight(xtab, xt, xc + k, ix) : 0.f;
+      }
+      const T* g0 = gout + (int64_t)nc * oplane + (int64_t)yr.x * OW + xc;
+#pragma unroll
+      for (int j = 0; j < kBwdRows; ++j) {
+        if (j < rows0) {
+          const T* g = g0 + (int64_t)j * OW;
+#pragma unroll
+          for (int k = 0; k < kBwdCols; ++k) {
+            if (k < cnt) {
+              const float w = wy0[j] * wx[k];
+#pragma unroll
+              for (int p = 0; p < kBwdPlanes; ++p)
+                if (p < np) acc[p] += w * ld(g + p * oplane + k);
+            }
+          }
+        }
+      }
+      for (int oy = yr.x + kBwdRows; oy < yr.y; ++oy) {
+        const float wy = bwd_weight(ytab, yt, oy, iy);
+        const T* g = gout + (int64_t)nc * oplane + (int64_t)oy * OW + xc;
+#pragma unroll
+        for (int k = 0; k < kBwdCols; ++k) {
+          if (k < cnt) {
+            const float w = wy * wx[k];
+#pragma unroll
+            for (int p = 0; p < kBwdPlanes; ++p)
+              if (p < np) acc[p] += w * ld(g + p * oplane + k);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kBwdPlanes; ++p)
+      if (p < np) st(gin + (int64_t)(nc + p) * iplane + (int64_t)iy * IW + ix, acc[p]);
+  }
+}
+
+// The same sum with the loads of a block issued together: a block is R output rows x CC output columns (ONE CC-element load
+// per row, at element alignment) of P planes — R*P independent loads in flight per lane before the first use, where the
+// kernel above waits for every (row, column) group of 4 (its ranges differ per lane, so its loads sit under divergent
+// branches).  Loads are unconditional: a block that overhangs the range is shifted back inside the tensor / re-reads the
+// last row, and a term outside the lane's range is dropped with a select (never "multiplied by a zero weight": 0 * inf).
+// Any range length is correct (the blocks loop); the host picks (R, CC, P) from an estimate of the longest range of each axis
+// so that the common cases (2x nearest / bilinear up-scales, every down-scale) are a single block.
+template <typename T, int CC>
+struct RawVec;
+template <int CC>
+struct RawVec<float, CC> {
+  typedef float type __attribute__((ext_vector_type(CC))) __attribute__((aligned(4)));
+};
+template <int CC>
+struct RawVec<__half, CC> {
+  typedef unsigned short type __attribute__((ext_vector_type(CC))) __attribute__((aligned(2)));
+};
+template <int CC>
+struct RawVec<__hip_bfloat16, CC> {
+  typedef unsigned short type __attribute__((ext_vector_type(CC))) __attribute__((aligned(2)));
+};
+
+template <typename T, int R, int CC, int P>
+__global__ __launch_bounds__(kThreads) void upsample2d_bwd_vec_kernel(const T* __restrict__ gout, T* __restrict__ gin,
+                                                                      const float* __restrict__ ytab,
+                                                                      const float* __restrict__ xtab,
+                                                                      const int2* __restrict__ yrange,
+                                                                      const int2* __restrict__ xrange, int NC, int IH,
+                                                                      int IW, int OH, int OW, int yt, int xt,
+                                                                      int nc_per_block) {
+  typedef typename RawVec<T, CC>::type vec;
+  const int ix = blockIdx.x * kThreads + threadIdx.x;
+  const int iy = blockIdx.y;
+  if (ix >= IW) return;
+  const int2 yr = yrange[iy], xr = xrange[ix];
+  const int nc0 = blockIdx.z * nc_per_block, nc1 = min(NC, nc0 + nc_per_block);
+  const int64_t iplane = (int64_t)IH * IW, oplane = (int64_t)OH * OW;
+  // weights of the first block of each axis: looked up once for all planes (the only block up to a CC x R range)
+  float wx0[CC], wy0[R];
+  {
+    const int xs = min(xr.x, OW - CC);
+#pragma unroll
+    for (int m = 0; m < CC; ++m) wx0[m] = (xs + m >= xr.x && xs + m < min(xr.x + CC, xr.y)) ? bwd_weight(xtab, xt, xs + m, ix) : 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j) wy0[j] = yr.x + j < yr.y ? bwd_weight(ytab, yt, yr.x + j, iy) : 0.f;
+  }
+  for (int nc = nc0; nc < nc1; nc += P) {
+    float acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = 0.f;
+    const T* gp[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) gp[p] = gout + (int64_t)min(nc + p, nc1 - 1) * oplane;   // surplus planes re-read the last one
+    for (int xc = xr.x; xc < xr.y; xc += CC) {
+      const int xs = min(xc, OW - CC), xe = min(xc + CC, xr.y);
+      float wx[CC];
+      bool okx[CC];
+#pragma unroll
+      for (int m = 0; m < CC; ++m) {
+        okx[m] = xs + m >= xc && xs + m < xe;
+        wx[m] = xc == xr.x ? wx0[m] : (okx[m] ? bwd_weight(xtab, xt, xs + m, ix) : 0.f);
+      }
+      for (int yc = yr.x; yc < yr.y; yc += R) {
+        float wy[R];
+        int row[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          wy[j] = yc == yr.x ? wy0[j] : (yc + j < yr.y ? bwd_weight(ytab, yt, yc + j, iy) : 0.f);
+          row[j] = min(yc + j, yr.y - 1) * OW + xs;
+        }
+        vec v[P][R];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+          for (int j = 0; j < R; ++j) v[p][j] = *reinterpret_cast<const vec*>(gp[p] + row[j]);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const bool oky = yc + j < yr.y;
+#pragma unroll
+          for (int m = 0; m < CC; ++m) {
+            const float w = wy[j] * wx[m];
+            const bool ok = oky && okx[m];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const float t = acc[p] + w * Vec4<T>::up(v[p][j][m]);
+              acc[p] = ok ? t : acc[p];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (nc + p < nc1) st(gin + (int64_t)(nc + p) * iplane + (int64_t)iy * IW + ix, acc[p]);
+  }
+}
+
+// nearest / nearest-exact forward for any element type: a copy of B-byte elements
+template <typename U>
+__global__ __launch_bounds__(kThreads) void nearest2d_bytes_kernel(const U* __restrict__ in, U* __restrict__ out, int NC,
+                                                                   int IH, int IW, int OH, int OW, float sh, float sw,
+                                                                   int exact, int nc_per_block) {
+  const int ox = blockIdx.x * kThreads + threadIdx.x;
+  const int oy = blockIdx.y;
+  if (ox >= OW) return;
+  const int iy = exact ? min((int)floorf(((float)oy + 0.5f) * sh), IH - 1) : min((int)floorf((float)oy * sh), IH - 1);
+  const int ix = exact ? min((int)floorf(((float)ox + 0.5f) * sw), IW - 1) : min((int)floorf((float)ox * sw), IW - 1);
+  const int nc0 = blockIdx.z * nc_per_block, nc1 = min(NC, nc0 + nc_per_block);
+  const int64_t iplane = (int64_t)IH * IW, oplane = (int64_t)OH * OW;
+  const int64_t src = (int64_t)iy * IW + ix, dst = (int64_t)oy * OW + ox;
+  for (int nc = nc0; nc < nc1; ++nc) out[nc * oplane + dst] = in[nc * iplane + src];
+}
+
+// ---- channels_last (NHWC in memory) forward, all six modes: lanes run along (output column, channel) — the contiguous axis
+// of both tensors — and the two axes come from the same [first, taps, weights] tables as the backward.  ATen keeps the memory
+// format of a channels_last input (`suggest_memory_format`), the reference's resize_image goes out of its way to preserve it
+// (_geometry.py:324-338); the planar kernels would need a layout copy on either side.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample2d_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                                   const float* __restrict__ ytab,
+                                                                   const float* __restrict__ xtab, int C, int IH, int IW,
+                                                                   int OH, int OW, int yt, int xt) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;   // ox * C + c
+  const int oy = blockIdx.y, n = blockIdx.z;
+  if (e >= OW * C) return;
+  const int ox = e / C, c = e - ox * C;
+  const float* yrow = ytab + (int64_t)oy * (yt + 2);
+  const float* xrow = xtab + (int64_t)ox * (xt + 2);
+  const int y0 = __float_as_int(yrow[0]), ny = __float_as_int(yrow[1]);
+  const int x0 = __float_as_int(xrow[0]), nx = __float_as_int(xrow[1]);
+  const T* base = in + (int64_t)n * IH * IW * C + c;
+  float acc = 0.f;
+  for (int j = 0; j < ny; ++j) {
+    const T* row = base + ((int64_t)(y0 + j) * IW + x0) * C;
+    float r = 0.f;
+    for (int k = 0; k < nx; ++k) r += xrow[2 + k] * ld(row + (int64_t)k * C);
+    acc += yrow[2 + j] * r;
+  }
+  st(out + ((int64_t)n * OH + oy) * OW * C + e, acc);
+}
+
+template <typename U>
+__global__ __launch_bounds__(kThreads) void nearest2d_nhwc_bytes_kernel(const U* __restrict__ in, U* __restrict__ out, int C,
+                                                                        int IH, int IW, int OH, int OW, float sh, float sw,
+                                                                        int exact) {
+  const int e = blockIdx.x * kThreads + threadIdx.x;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  if (e >= OW * C) return;
+  const int ox = e / C, c = e - ox * C;
+  const int iy = exact ? min((int)floorf(((float)oy + 0.5f) * sh), IH - 1) : min((int)floorf((float)oy * sh), IH - 1);
+  const int ix = exact ? min((int)floorf(((float)ox + 0.5f) * sw), IW - 1) : min((int)floorf((float)ox * sw), IW - 1);
+  out[((int64_t)n * OH + oy) * OW * C + e] = in[(((int64_t)n * IH + iy) * IW + ix) * C + c];
+}
+
 struct Launch {
   dim3 grid;
   int nc_per_block;
@@ -841,6 +1151,194 @@ extern "C" int tvmi_upsample_aa2d(const void* input, void* output, tvmi_dtype dt
   });
 #undef TVMI_AA
   TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_aa2d");
+}
+
+namespace {
+struct BwdPlan {
+  int kind_y, kind_x, yt, xt;  // kind < 0: anti-aliased table of -(kind) - 1
+  float sh, sw;
+  size_t ytab_off, xtab_off, yr_off, xr_off, bytes;
+};
+// forward geometry: input [IH, IW] -> output [OH, OW]; the backward reads grad_output [OH, OW] and writes grad_input [IH, IW]
+BwdPlan bwd_plan(int mode, int antialias, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int align, double scale_h,
+                 double scale_w) {
+  BwdPlan p{};
+  const bool lin = mode >= 2;
+  p.sh = compute_scale(IH, OH, lin && align, scale_h);
+  p.sw = compute_scale(IW, OW, lin && align, scale_w);
+  if (lin && antialias) {
+    p.kind_y = p.kind_x = -(mode - 2) - 1;
+    p.yt = taps_for(mode - 2, p.sh);
+    p.xt = taps_for(mode - 2, p.sw);
+  } else {
+    p.kind_y = p.kind_x = mode;
+    p.yt = p.xt = mode == BWD_BILINEAR ? 2 : (mode == BWD_BICUBIC ? 4 : 1);
+    if (mode == BWD_BICUBIC && IH == OH && IW == OW) {  // the forward is a copy then (bicubic2d_kernel), whatever the scales say
+      p.kind_y = p.kind_x = BWD_NEAREST;
+      p.sh = p.sw = 1.f;
+    }
+  }
+  size_t f = 0;
+  p.ytab_off = f;
+  f += (size_t)OH * (p.yt + 2);
+  p.xtab_off = f;
+  f += (size_t)OW * (p.xt + 2);
+  f = (f + 1) & ~(size_t)1;  // the int2 ranges start 8-byte aligned
+  p.yr_off = f * sizeof(float);
+  p.xr_off = p.yr_off + (size_t)IH * sizeof(int2);
+  p.bytes = p.xr_off + (size_t)IW * sizeof(int2);
+  p.ytab_off *= sizeof(float);
+  p.xtab_off *= sizeof(float);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t tvmi_upsample2d_backward_workspace_bytes(int mode, int antialias, int64_t IH, int64_t IW, int64_t OH,
+                                                           int64_t OW, int align_corners, double scale_h, double scale_w) {
+  if (OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || mode < 0 || mode > 3) return 0;
+  return bwd_plan(mode, antialias, IH, IW, OH, OW, align_corners, scale_h, scale_w).bytes;
+}
+
+extern "C" int tvmi_upsample2d_backward(const void* grad_output, void* grad_input, tvmi_dtype dt, int mode, int antialias,
+                                        int64_t NC, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int align_corners,
+                                        double scale_h, double scale_w, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  if (NC * IH * IW == 0) return 0;
+  TVMI_CHECK_ARG(mode >= 0 && mode <= 3, "upsample2d_backward: mode must be 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic");
+  TVMI_CHECK_ARG(!antialias || mode >= 2, "upsample2d_backward: anti-aliasing is for the bilinear and bicubic modes");
+  TVMI_CHECK_ARG(OH > 0 && OW > 0, "upsample2d_backward: output spatial size must be positive");
+  TVMI_CHECK_ARG(grad_output && grad_input, "upsample2d_backward: null pointer");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16, "upsample2d_backward: float32 / float16 / bfloat16 only");
+  TVMI_CHECK_ARG(IH <= 65535 && IH * IW < (1ll << 31) && OH * OW < (1ll << 31), "upsample2d_backward: size too large");
+  const BwdPlan p = bwd_plan(mode, antialias, IH, IW, OH, OW, align_corners, scale_h, scale_w);
+  TVMI_CHECK_ARG(workspace && workspace_bytes >= p.bytes, "upsample2d_backward: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  float* ytab = reinterpret_cast<float*>(ws + p.ytab_off);
+  float* xtab = reinterpret_cast<float*>(ws + p.xtab_off);
+  int2* yr = reinterpret_cast<int2*>(ws + p.yr_off);
+  int2* xr = reinterpret_cast<int2*>(ws + p.xr_off);
+  const int al = (mode >= 2 && align_corners) ? 1 : 0;
+  if (p.kind_y < 0) {
+    aa_table_kernel<<<dim3((unsigned)ceil_div(OH, 128)), dim3(128), 0, s>>>(ytab, (int)OH, (int)IH, p.sh, -p.kind_y - 1, p.yt, al);
+    aa_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, p.sw, -p.kind_x - 1, p.xt, al);
+  } else {
+    bwd_axis_table_kernel<<<dim3((unsigned)ceil_div(OH, 128)), dim3(128), 0, s>>>(ytab, (int)OH, (int)IH, p.sh, p.kind_y, p.yt, al);
+    bwd_axis_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, p.sw, p.kind_x, p.xt, al);
+  }
+  bwd_axis_ranges_kernel<<<dim3((unsigned)ceil_div(IH, 128)), dim3(128), 0, s>>>(ytab, p.yt, (int)OH, (int)IH, yr);
+  bwd_axis_ranges_kernel<<<dim3((unsigned)ceil_div(IW, 128)), dim3(128), 0, s>>>(xtab, p.xt, (int)OW, (int)IW, xr);
+  const Launch L = plan(NC, IH, IW);
+  // estimated longest range per axis: outputs per input pixel = filter footprint / scale (see upsample2d_bwd_vec_kernel)
+  auto est = [&](float scale, int taps_of_mode) -> int {
+    if (antialias && mode >= 2) return scale >= 1.f ? taps_of_mode + 1 : (int)std::ceil((double)(taps_of_mode + 1) / (double)scale);
+    return scale > 0.f ? (int)std::min(4096.0, std::ceil((double)taps_of_mode / (double)scale)) : 4096;
+  };
+  const int foot = mode == BWD_BILINEAR ? 2 : (mode == BWD_BICUBIC ? 4 : 1);
+  const int ex = est(p.sw, foot), ey = est(p.sh, foot);
+#define TVMI_BWD_VEC(scalar_t, R, CC, P)                                                                                 \
+  upsample2d_bwd_vec_kernel<scalar_t, R, CC, P><<<L.grid, dim3(kThreads), 0, s>>>(                                          \
+      (const scalar_t*)grad_output, (scalar_t*)grad_input, ytab, xtab, yr, xr, (int)NC, (int)IH, (int)IW, (int)OH, (int)OW, p.yt, \
+      p.xt, L.nc_per_block)
+#define TVMI_BWD(scalar_t)                                                                                              \
+  if (OW >= 4 && ex <= 2 && ey <= 2) TVMI_BWD_VEC(scalar_t, 2, 2, 8);                                                   \
+  else if (OW >= 4 && ex <= 2) TVMI_BWD_VEC(scalar_t, 4, 2, 4);                                                         \
+  else if (OW >= 4 && ey <= 2) TVMI_BWD_VEC(scalar_t, 2, 4, 4);                                                         \
+  else if (OW >= 4) TVMI_BWD_VEC(scalar_t, 4, 4, 4);                                                                    \
+  else                                                                                                                  \
+    upsample2d_bwd_kernel<scalar_t><<<L.grid, dim3(kThreads), 0, s>>>((const scalar_t*)grad_output, (scalar_t*)grad_input, ytab, \
+                                                                      xtab, yr, xr, (int)NC, (int)IH, (int)IW, (int)OH, (int)OW,  \
+                                                                      p.yt, p.xt, L.nc_per_block)
+  if (dt == TVMI_F32) { TVMI_BWD(float); }
+  else if (dt == TVMI_F16) { TVMI_BWD(__half); }
+  else { TVMI_BWD(__hip_bfloat16); }
+#undef TVMI_BWD
+#undef TVMI_BWD_VEC
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample2d_backward");
+}
+
+extern "C" size_t tvmi_upsample2d_nhwc_workspace_bytes(int mode, int antialias, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                                                       int align_corners, double scale_h, double scale_w) {
+  if (OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || mode < 0 || mode > 3) return 0;
+  return bwd_plan(mode, antialias, IH, IW, OH, OW, align_corners, scale_h, scale_w).yr_off;   // the two tables, no ranges
+}
+
+extern "C" int tvmi_upsample2d_nhwc(const void* input, void* output, tvmi_dtype dt, int mode, int antialias, int64_t N,
+                                    int64_t C, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int align_corners,
+                                    double scale_h, double scale_w, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N * C * OH * OW == 0) return 0;
+  TVMI_CHECK_ARG(mode >= 0 && mode <= 3, "upsample2d_nhwc: mode must be 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic");
+  TVMI_CHECK_ARG(!antialias || mode >= 2, "upsample2d_nhwc: anti-aliasing is for the bilinear and bicubic modes");
+  TVMI_CHECK_ARG(input && output, "upsample2d_nhwc: null pointer");
+  TVMI_CHECK_ARG(IH > 0 && IW > 0, "upsample2d_nhwc: input spatial size must be positive");
+  TVMI_CHECK_ARG(dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16, "upsample2d_nhwc: float32 / float16 / bfloat16 only");
+  TVMI_CHECK_ARG(OH <= 65535 && N <= 65535 && OW * C < (1ll << 31) && IH * IW * C < (1ll << 40), "upsample2d_nhwc: size too large");
+  const BwdPlan p = bwd_plan(mode, antialias, IH, IW, OH, OW, align_corners, scale_h, scale_w);
+  TVMI_CHECK_ARG(workspace && workspace_bytes >= p.yr_off, "upsample2d_nhwc: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  float* ytab = reinterpret_cast<float*>(ws + p.ytab_off);
+  float* xtab = reinterpret_cast<float*>(ws + p.xtab_off);
+  const int al = (mode >= 2 && align_corners) ? 1 : 0;
+  if (p.kind_y < 0) {
+    aa_table_kernel<<<dim3((unsigned)ceil_div(OH, 128)), dim3(128), 0, s>>>(ytab, (int)OH, (int)IH, p.sh, -p.kind_y - 1, p.yt, al);
+    aa_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, p.sw, -p.kind_x - 1, p.xt, al);
+  } else {
+    bwd_axis_table_kernel<<<dim3((unsigned)ceil_div(OH, 128)), dim3(128), 0, s>>>(ytab, (int)OH, (int)IH, p.sh, p.kind_y, p.yt, al);
+    bwd_axis_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, p.sw, p.kind_x, p.xt, al);
+  }
+  const dim3 grid((unsigned)ceil_div(OW * C, kThreads), (unsigned)OH, (unsigned)N);
+#define TVMI_NHWC(scalar_t)                                                                                              \
+  upsample2d_nhwc_kernel<scalar_t><<<grid, dim3(kThreads), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)C, \
+                                                                  (int)IH, (int)IW, (int)OH, (int)OW, p.yt, p.xt)
+  if (dt == TVMI_F32) TVMI_NHWC(float);
+  else if (dt == TVMI_F16) TVMI_NHWC(__half);
+  else TVMI_NHWC(__hip_bfloat16);
+#undef TVMI_NHWC
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample2d_nhwc");
+}
+
+extern "C" int tvmi_upsample_nearest2d_nhwc_any(const void* input, void* output, int64_t elem_bytes, int64_t N, int64_t C,
+                                                int64_t IH, int64_t IW, int64_t OH, int64_t OW, int exact, double scale_h,
+                                                double scale_w, void* stream) {
+  if (N * C * OH * OW == 0) return 0;
+  TVMI_CHECK_ARG(input && output, "upsample_nearest2d_nhwc_any: null pointer");
+  TVMI_CHECK_ARG(IH > 0 && IW > 0, "upsample_nearest2d_nhwc_any: input spatial size must be positive");
+  TVMI_CHECK_ARG(OH <= 65535 && N <= 65535 && OW * C < (1ll << 31), "upsample_nearest2d_nhwc_any: size too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float sh = compute_scale(IH, OH, false, scale_h), sw = compute_scale(IW, OW, false, scale_w);
+  const dim3 grid((unsigned)ceil_div(OW * C, kThreads), (unsigned)OH, (unsigned)N);
+#define TVMI_NEAREST_NHWC(U)                                                                                           \
+  nearest2d_nhwc_bytes_kernel<U><<<grid, dim3(kThreads), 0, s>>>((const U*)input, (U*)output, (int)C, (int)IH, (int)IW, (int)OH, \
+                                                                (int)OW, sh, sw, exact)
+  switch (elem_bytes) {
+    case 1: TVMI_NEAREST_NHWC(unsigned char); break;
+    case 2: TVMI_NEAREST_NHWC(unsigned short); break;
+    case 4: TVMI_NEAREST_NHWC(unsigned int); break;
+    case 8: TVMI_NEAREST_NHWC(unsigned long long); break;
+    default: return ::tvmi::set_error(hipErrorInvalidValue, "upsample_nearest2d_nhwc_any: element size must be 1, 2, 4 or 8 bytes");
+  }
+#undef TVMI_NEAREST_NHWC
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_nearest2d_nhwc_any");
+}
+
+extern "C" int tvmi_upsample_nearest2d_any(const void* input, void* output, int64_t elem_bytes, int64_t NC, int64_t IH,
+                                           int64_t IW, int64_t OH, int64_t OW, int exact, double scale_h, double scale_w,
+                                           void* stream) {
+  TVMI_RESIZE_PROLOGUE("upsample_nearest2d_any");
+  const float sh = compute_scale(IH, OH, false, scale_h), sw = compute_scale(IW, OW, false, scale_w);
+#define TVMI_NEAREST_ANY(U)                                                                                            \
+  nearest2d_bytes_kernel<U><<<L.grid, dim3(kThreads), 0, s>>>((const U*)input, (U*)output, (int)NC, (int)IH, (int)IW, (int)OH, \
+                                                              (int)OW, sh, sw, exact, L.nc_per_block)
+  switch (elem_bytes) {
+    case 1: TVMI_NEAREST_ANY(unsigned char); break;
+    case 2: TVMI_NEAREST_ANY(unsigned short); break;
+    case 4: TVMI_NEAREST_ANY(unsigned int); break;
+    case 8: TVMI_NEAREST_ANY(unsigned long long); break;
+    default: return ::tvmi::set_error(hipErrorInvalidValue, "upsample_nearest2d_any: element size must be 1, 2, 4 or 8 bytes");
+  }
+#undef TVMI_NEAREST_ANY
+  TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample_nearest2d_any");
 }
 
 extern "C" int tvmi_paste_masks(const void* masks, const float* boxes, void* output, tvmi_dtype dt, int64_t N,

@@ -19,6 +19,12 @@
 #include <ATen/ops/upsample_bicubic2d_cuda_dispatch.h>
 #include <ATen/ops/upsample_bilinear2d_cuda_dispatch.h>
 #include <ATen/ops/upsample_nearest2d_cuda_dispatch.h>
+#include <ATen/ops/_upsample_bicubic2d_aa_backward_cuda_dispatch.h>
+#include <ATen/ops/_upsample_bilinear2d_aa_backward_cuda_dispatch.h>
+#include <ATen/ops/_upsample_nearest_exact2d_backward_cuda_dispatch.h>
+#include <ATen/ops/upsample_bicubic2d_backward_cuda_dispatch.h>
+#include <ATen/ops/upsample_bilinear2d_backward_cuda_dispatch.h>
+#include <ATen/ops/upsample_nearest2d_backward_cuda_dispatch.h>
 #include <ATen/native/Resize.h>
 #include <atomic>
 #include <climits>
@@ -619,12 +625,38 @@ at::Tensor interpolate2d(const at::Tensor& input, int64_t out_h, int64_t out_w, 
   TORCH_CHECK((input.size(2) > 0 && input.size(3) > 0) || input.numel() == 0,
               "Input and output sizes should be greater than 0");
   c10::DeviceGuard guard(input.device());
-  at::Tensor in_c = input.contiguous();
   const int64_t N = input.size(0), C = input.size(1), IH = input.size(2), IW = input.size(3);
+  void* stream = current_stream(input);
+  const auto stype = input.scalar_type();
+  const bool is_fp = stype == at::kFloat || stype == at::kDouble || stype == at::kHalf || stype == at::kBFloat16;
+  // channels_last in, channels_last out (ATen's `suggest_memory_format` rule), no layout copy: the NHWC kernels of resize.hip
+  if (!input.is_contiguous() && input.is_contiguous(at::MemoryFormat::ChannelsLast) && input.numel() > 0 && out_h > 0 && out_w > 0 &&
+      out_h <= 65535 && N <= 65535 && out_w * C < (1ll << 31) && (stype == at::kFloat || stype == at::kHalf || stype == at::kBFloat16 || (mode <= 1 && !is_fp))) {
+    at::Tensor out = at::empty({N, C, out_h, out_w}, input.options().memory_format(at::MemoryFormat::ChannelsLast));
+    if (mode <= 1 && !is_fp) {
+      check_status(tvmi_upsample_nearest2d_nhwc_any(input.const_data_ptr(), out.mutable_data_ptr(), (int64_t)input.element_size(), N, C, IH,
+                                                    IW, out_h, out_w, mode == 1, scale_h, scale_w, stream),
+                   "interpolate2d");
+      return out;
+    }
+    const size_t wb = tvmi_upsample2d_nhwc_workspace_bytes((int)mode, antialias, IH, IW, out_h, out_w, align_corners, scale_h, scale_w);
+    at::Tensor ws = at::empty({(int64_t)wb}, input.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+    check_status(tvmi_upsample2d_nhwc(input.const_data_ptr(), out.mutable_data_ptr(), dtype_of(input, "interpolate2d"), (int)mode, antialias,
+                                      N, C, IH, IW, out_h, out_w, align_corners, scale_h, scale_w, ws.mutable_data_ptr(), wb, stream),
+                 "interpolate2d");
+    return out;
+  }
+  at::Tensor in_c = input.contiguous();
   at::Tensor out = at::empty({N, C, out_h, out_w}, in_c.options());
   if (out.numel() == 0) return out;
+  if (mode <= 1 && !is_fp) {
+    // nearest / nearest-exact are copies: any element type (uint8 images and masks, _geometry.py:316-323), by element size
+    check_status(tvmi_upsample_nearest2d_any(in_c.const_data_ptr(), out.mutable_data_ptr(), (int64_t)in_c.element_size(), N * C, IH,
+                                             IW, out_h, out_w, mode == 1, scale_h, scale_w, stream),
+                 "interpolate2d");
+    return out;
+  }
   const tvmi_dtype dt = dtype_of(in_c, "interpolate2d");
-  void* stream = current_stream(input);
   int st = 0;
   if (mode <= 1) {
     st = tvmi_upsample_nearest2d(in_c.const_data_ptr(), out.mutable_data_ptr(), dt, N * C, IH, IW, out_h, out_w,
@@ -646,13 +678,40 @@ at::Tensor interpolate2d(const at::Tensor& input, int64_t out_h, int64_t out_w, 
   return out;
 }
 
+// Gradient of interpolate2d: grad_output [N,C,out_h,out_w] -> grad_input [N,C,in_h,in_w] (gather form, deterministic;
+// include/tvmi.h: tvmi_upsample2d_backward).  float32 / float16 / bfloat16.
+at::Tensor interpolate2d_backward(const at::Tensor& grad_output, int64_t in_h, int64_t in_w, int64_t mode, bool align_corners,
+                                  bool antialias, double scale_h, double scale_w) {
+  TORCH_CHECK(grad_output.is_cuda(), "grad_output must be a CUDA tensor");
+  TORCH_CHECK(grad_output.dim() == 4, "interpolate2d_backward expects a 4d tensor [N, C, H, W]");
+  TORCH_CHECK(in_h >= 0 && in_w >= 0, "input size must be non-negative");
+  TORCH_CHECK(mode >= 0 && mode <= 3, "unknown interpolation mode ", mode);
+  TORCH_CHECK(!antialias || mode >= 2, "Anti-alias option is restricted to bilinear and bicubic modes");
+  const auto t = grad_output.scalar_type();
+  TORCH_CHECK(t == at::kFloat || t == at::kHalf || t == at::kBFloat16, "interpolate2d_backward: float32 / float16 / bfloat16 only");
+  c10::DeviceGuard guard(grad_output.device());
+  at::Tensor g = grad_output.contiguous();
+  const int64_t N = g.size(0), C = g.size(1), OH = g.size(2), OW = g.size(3);
+  at::Tensor grad_input = at::empty({N, C, in_h, in_w}, g.options());
+  if (grad_input.numel() == 0) return grad_input;
+  if (g.numel() == 0) return grad_input.zero_();
+  const size_t wb = tvmi_upsample2d_backward_workspace_bytes((int)mode, antialias, in_h, in_w, OH, OW, align_corners, scale_h, scale_w);
+  at::Tensor ws = at::empty({(int64_t)wb}, g.options().dtype(at::kByte));
+  check_status(tvmi_upsample2d_backward(g.const_data_ptr(), grad_input.mutable_data_ptr(), dtype_of(g, "interpolate2d_backward"),
+                                        (int)mode, antialias, N * C, in_h, in_w, OH, OW, align_corners, scale_h, scale_w,
+                                        ws.mutable_data_ptr(), wb, current_stream(g)),
+               "interpolate2d_backward");
+  return grad_input;
+}
+
 // ---- the resize boundary of the reference: torchvision resizes through F.interpolate
 // (models/detection/transform.py:65-72, ops/feature_pyramid_network.py:194, models/detection/roi_heads.py:427,453,
 // transforms/v2/functional/_geometry.py:344-350), i.e. through aten::upsample_*.  `tvmi::override_aten_upsample(True)`
 // (opt-in; TVMI_OVERRIDE_ATEN_UPSAMPLE=1 at import) puts our kernels on the CUDA key of those aten ops, functional and
-// .out overloads, so the unchanged reference python lands in resize.hip.  Only the forward is taken over (autograd keeps
-// calling aten's *_backward); inputs our kernels do not serve (channels_last, integer dtypes, 0-sized) go to ATen's own
-// CUDA kernel through its static-dispatch entry.  The handle is dropped again by override_aten_upsample(False).
+// .out overloads, so the unchanged reference python lands in resize.hip.  Round 5: the six `*_backward` ops are taken over
+// too (gather kernels, deterministic), the nearest modes serve integer / bool tensors and channels_last inputs have their
+// own kernels; inputs our kernels do not serve (other strides, integer dtypes in the interpolating modes, float64, 0-sized)
+// go to ATen's own CUDA kernel through its static-dispatch entry.  The handle is dropped again by override_aten_upsample(False).
 namespace upsample_override {
 
 std::unique_ptr<torch::Library> g_lib;
@@ -661,15 +720,19 @@ std::atomic<int64_t> g_calls{0};  // how many aten::upsample_* calls were served
 
 // What the override serves itself.  Everything else falls through to ATen's own kernel: float64 (resize.hip computes scales,
 // weights and sums in float — fine for the 16/32-bit types, but a process-wide override must not cost fp64 callers their
-// precision, e.g. gradcheck), channels_last / strided inputs, integer types, empty tensors, and shapes beyond the limits
+// precision, e.g. gradcheck), strided inputs other than channels_last, integer types outside the nearest modes, empty tensors, and shapes beyond the limits
 // of the resize launchers (TVMI_RESIZE_PROLOGUE in resize.hip: OH <= 65535, IH*IW and OH*OW below 2^31) — those must reach
 // ATen, not raise "size too large".
-bool ours(const at::Tensor& self, at::IntArrayRef size) {
+bool ours(const at::Tensor& self, at::IntArrayRef size, bool nearest = false) {
   const auto t = self.scalar_type();
+  // nearest modes are copies: every non-complex, non-quantized element type of 1 / 2 / 4 bytes or int64 is served
+  const bool any_ok = nearest && (c10::isIntegralType(t, /*includeBool=*/true));
   if (!(self.is_cuda() && self.dim() == 4 && size.size() == 2 && self.numel() > 0 && size[0] > 0 && size[1] > 0 &&
-        (t == at::kFloat || t == at::kHalf || t == at::kBFloat16) && self.is_contiguous()))
+        (t == at::kFloat || t == at::kHalf || t == at::kBFloat16 || any_ok)))
     return false;
   const int64_t IH = self.size(2), IW = self.size(3), OH = size[0], OW = size[1];
+  if (!self.is_contiguous())   // channels_last: the NHWC kernels (output channels_last, like ATen); other strides: ATen
+    return self.is_contiguous(at::MemoryFormat::ChannelsLast) && OH <= 65535 && self.size(0) <= 65535 && OW * self.size(1) < (1ll << 31);
   return OH <= 65535 && IH * IW < (1ll << 31) && OH * OW < (1ll << 31);
 }
 
@@ -693,13 +756,13 @@ double sc(const std::optional<double>& v) { return v.has_value() ? *v : -1.0; }
   }
 #define TVMI_UPSAMPLE_NEAREST(NAME, ATEN, MODE)                                                                        \
   at::Tensor NAME(const at::Tensor& self, at::IntArrayRef size, std::optional<double> sh, std::optional<double> sw) {  \
-    if (!ours(self, size)) return at::cuda::ATEN(self, size, sh, sw);                                                  \
+    if (!ours(self, size, true)) return at::cuda::ATEN(self, size, sh, sw);                                            \
     ++g_calls;                                                                                                         \
     return interpolate2d(self, size[0], size[1], MODE, false, false, sc(sh), sc(sw));                                  \
   }                                                                                                                    \
   at::Tensor& NAME##_out(const at::Tensor& self, at::IntArrayRef size, std::optional<double> sh,                       \
                          std::optional<double> sw, at::Tensor& out) {                                                  \
-    if (!ours(self, size)) return at::cuda::ATEN##_outf(self, size, sh, sw, out);                                      \
+    if (!ours(self, size, true)) return at::cuda::ATEN##_outf(self, size, sh, sw, out);                                \
     ++g_calls;                                                                                                         \
     at::Tensor r = interpolate2d(self, size[0], size[1], MODE, false, false, sc(sh), sc(sw));                          \
     at::native::resize_output(out, r.sizes());                                                                         \
@@ -715,6 +778,60 @@ TVMI_UPSAMPLE_NEAREST(nearest, upsample_nearest2d, 0)
 TVMI_UPSAMPLE_NEAREST(nearest_exact, _upsample_nearest_exact2d, 1)
 #undef TVMI_UPSAMPLE_LINEAR
 #undef TVMI_UPSAMPLE_NEAREST
+
+// The backward ops (what autograd calls for the six forwards above): served for float32 / float16 / bfloat16 gradients of
+// 4-d problems within the launch limits (made contiguous first, grad_input contiguous), everything else reaches ATen's kernel.
+bool ours_bwd(const at::Tensor& g, at::IntArrayRef out_size, at::IntArrayRef in_size) {
+  const auto t = g.scalar_type();
+  if (!(g.is_cuda() && g.dim() == 4 && out_size.size() == 2 && in_size.size() == 4 && g.numel() > 0 &&
+        (t == at::kFloat || t == at::kHalf || t == at::kBFloat16)))   // any strides: `sum().backward()` hands an expanded grad
+    return false;
+  const int64_t IH = in_size[2], IW = in_size[3], OH = out_size[0], OW = out_size[1];
+  return g.size(0) == in_size[0] && g.size(1) == in_size[1] && g.size(2) == OH && g.size(3) == OW && IH > 0 && IW > 0 &&
+         IH <= 65535 && IH * IW < (1ll << 31) && OH * OW < (1ll << 31);
+}
+
+#define TVMI_UPSAMPLE_LINEAR_BWD(NAME, ATEN, MODE, AA)                                                                  \
+  at::Tensor NAME(const at::Tensor& g, at::IntArrayRef osz, at::IntArrayRef isz, bool align_corners,                   \
+                  std::optional<double> sh, std::optional<double> sw) {                                                \
+    if (!ours_bwd(g, osz, isz)) return at::cuda::ATEN(g, osz, isz, align_corners, sh, sw);                             \
+    ++g_calls;                                                                                                         \
+    return interpolate2d_backward(g, isz[2], isz[3], MODE, align_corners, AA, sc(sh), sc(sw));                         \
+  }                                                                                                                    \
+  at::Tensor& NAME##_out(const at::Tensor& g, at::IntArrayRef osz, at::IntArrayRef isz, bool align_corners,            \
+                         std::optional<double> sh, std::optional<double> sw, at::Tensor& grad_input) {                 \
+    if (!ours_bwd(g, osz, isz)) return at::cuda::ATEN##_outf(g, osz, isz, align_corners, sh, sw, grad_input);          \
+    ++g_calls;                                                                                                         \
+    at::Tensor r = interpolate2d_backward(g, isz[2], isz[3], MODE, align_corners, AA, sc(sh), sc(sw));                 \
+    at::native::resize_output(grad_input, r.sizes());                                                                  \
+    grad_input.copy_(r);                                                                                               \
+    return grad_input;                                                                                                 \
+  }
+#define TVMI_UPSAMPLE_NEAREST_BWD(NAME, ATEN, MODE)                                                                    \
+  at::Tensor NAME(const at::Tensor& g, at::IntArrayRef osz, at::IntArrayRef isz, std::optional<double> sh,             \
+                  std::optional<double> sw) {                                                                          \
+    if (!ours_bwd(g, osz, isz)) return at::cuda::ATEN(g, osz, isz, sh, sw);                                            \
+    ++g_calls;                                                                                                         \
+    return interpolate2d_backward(g, isz[2], isz[3], MODE, false, false, sc(sh), sc(sw));                              \
+  }                                                                                                                    \
+  at::Tensor& NAME##_out(const at::Tensor& g, at::IntArrayRef osz, at::IntArrayRef isz, std::optional<double> sh,      \
+                         std::optional<double> sw, at::Tensor& grad_input) {                                           \
+    if (!ours_bwd(g, osz, isz)) return at::cuda::ATEN##_outf(g, osz, isz, sh, sw, grad_input);                         \
+    ++g_calls;                                                                                                         \
+    at::Tensor r = interpolate2d_backward(g, isz[2], isz[3], MODE, false, false, sc(sh), sc(sw));                      \
+    at::native::resize_output(grad_input, r.sizes());                                                                  \
+    grad_input.copy_(r);                                                                                               \
+    return grad_input;                                                                                                 \
+  }
+
+TVMI_UPSAMPLE_LINEAR_BWD(bilinear_bwd, upsample_bilinear2d_backward, 2, false)
+TVMI_UPSAMPLE_LINEAR_BWD(bicubic_bwd, upsample_bicubic2d_backward, 3, false)
+TVMI_UPSAMPLE_LINEAR_BWD(bilinear_aa_bwd, _upsample_bilinear2d_aa_backward, 2, true)
+TVMI_UPSAMPLE_LINEAR_BWD(bicubic_aa_bwd, _upsample_bicubic2d_aa_backward, 3, true)
+TVMI_UPSAMPLE_NEAREST_BWD(nearest_bwd, upsample_nearest2d_backward, 0)
+TVMI_UPSAMPLE_NEAREST_BWD(nearest_exact_bwd, _upsample_nearest_exact2d_backward, 1)
+#undef TVMI_UPSAMPLE_LINEAR_BWD
+#undef TVMI_UPSAMPLE_NEAREST_BWD
 
 bool set(bool enable) {
   std::lock_guard<std::mutex> lock(g_mutex);
@@ -734,6 +851,18 @@ bool set(bool enable) {
     g_lib->impl("upsample_nearest2d.out", &nearest_out);
     g_lib->impl("_upsample_nearest_exact2d", &nearest_exact);
     g_lib->impl("_upsample_nearest_exact2d.out", &nearest_exact_out);
+    g_lib->impl("upsample_bilinear2d_backward", &bilinear_bwd);
+    g_lib->impl("upsample_bilinear2d_backward.grad_input", &bilinear_bwd_out);
+    g_lib->impl("upsample_bicubic2d_backward", &bicubic_bwd);
+    g_lib->impl("upsample_bicubic2d_backward.grad_input", &bicubic_bwd_out);
+    g_lib->impl("_upsample_bilinear2d_aa_backward", &bilinear_aa_bwd);
+    g_lib->impl("_upsample_bilinear2d_aa_backward.grad_input", &bilinear_aa_bwd_out);
+    g_lib->impl("_upsample_bicubic2d_aa_backward", &bicubic_aa_bwd);
+    g_lib->impl("_upsample_bicubic2d_aa_backward.grad_input", &bicubic_aa_bwd_out);
+    g_lib->impl("upsample_nearest2d_backward", &nearest_bwd);
+    g_lib->impl("upsample_nearest2d_backward.grad_input", &nearest_bwd_out);
+    g_lib->impl("_upsample_nearest_exact2d_backward", &nearest_exact_bwd);
+    g_lib->impl("_upsample_nearest_exact2d_backward.grad_input", &nearest_exact_bwd_out);
   } else if (!enable) {
     g_lib.reset();
   }
@@ -1327,6 +1456,9 @@ TORCH_LIBRARY(tvmi, m) {
   m.def("paste_masks(Tensor masks, Tensor boxes, int im_h, int im_w, int padding) -> Tensor");
   m.def(
       "interpolate2d(Tensor input, int out_h, int out_w, int mode, bool align_corners, bool antialias, float scale_h, float scale_w) -> Tensor");
+  // its gradient, gathered (deterministic): grad_output [N,C,OH,OW] -> grad_input [N,C,in_h,in_w]
+  m.def(
+      "interpolate2d_backward(Tensor grad_output, int in_h, int in_w, int mode, bool align_corners, bool antialias, float scale_h, float scale_w) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(torchvision, CUDA, m) {
@@ -1351,6 +1483,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("pack_detections_devcount", &pack_detections_devcount);
   m.impl("pack_detections_payload", &pack_detections_payload);
   m.impl("interpolate2d", &interpolate2d);
+  m.impl("interpolate2d_backward", &interpolate2d_backward);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
   m.impl("multiscale_roi_align_backward", &multiscale_roi_align_backward);
   m.impl("pack_detections", &pack_detections);

@@ -9,7 +9,8 @@ nearest / nearest-exact / bilinear / bicubic (+ antialias); `resize` has resize_
 meaning (size int -> shorter edge, max_size, uint8 handled as float32 + round + clamp exactly
 like the reference does on GPU tensors, _geometry.py:316-360).  CUDA tensors run on
 `tvmi::interpolate2d`; there is no fallback to ATen for the forward.  Inputs that require grad get
-ATen's `upsample_*_backward` kernels as the gradient (the same split as under the aten override).
+`tvmi::interpolate2d_backward` as the gradient (gather kernels, deterministic; float64 keeps ATen's); the nearest modes
+take any element type (uint8 images / masks stay uint8, as in the reference).
 """
 import math
 from typing import List, Optional, Sequence, Union
@@ -55,14 +56,15 @@ def interpolate(input: Tensor, size=None, scale_factor=None, mode: str = "neares
         if not recompute_scale_factor:
             scale_h, scale_w = float(sf[0]), float(sf[1])
     if input.requires_grad and torch.is_grad_enabled():
-        # forward on our kernel, backward on ATen's own `*_backward` kernels — exactly what autograd does under
-        # override_aten_upsample(True) (the resize kernels of this library are forward arithmetic)
+        # forward and backward on the resize kernels of this library
         return _Interpolate2d.apply(input, oh, ow, mode, align, bool(antialias), scale_h, scale_w)
     return torch.ops.tvmi.interpolate2d(input, oh, ow, _MODES[mode], align, bool(antialias), scale_h, scale_w)
 
 
 class _Interpolate2d(torch.autograd.Function):
-    """tvmi::interpolate2d with the gradient of the matching aten op (ATen kernel; deterministic-mode warnings are ATen's)."""
+    """tvmi::interpolate2d with tvmi::interpolate2d_backward as its gradient: the gather kernels of resize.hip (a lane owns an
+    input pixel and sums its output range in a fixed order — bit-reproducible, where ATen's bilinear / bicubic / anti-aliased
+    backward kernels scatter with atomicAdd).  float64 gradients keep ATen's `upsample_*_backward` kernels."""
 
     @staticmethod
     def forward(ctx, input, oh, ow, mode, align, antialias, scale_h, scale_w):
@@ -72,6 +74,9 @@ class _Interpolate2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         shape, oh, ow, mode, align, antialias, scale_h, scale_w = ctx.cfg
+        if grad.dtype in (torch.float32, torch.float16, torch.bfloat16):
+            gi = torch.ops.tvmi.interpolate2d_backward(grad, shape[2], shape[3], _MODES[mode], align, antialias, scale_h, scale_w)
+            return gi, None, None, None, None, None, None, None
         sh = None if scale_h <= 0 else scale_h
         sw = None if scale_w <= 0 else scale_w
         a, g = torch.ops.aten, grad.contiguous()
@@ -124,8 +129,9 @@ def resize(image: Tensor, size: Optional[Union[int, Sequence[int]]], interpolati
     if (new_h, new_w) == (old_h, old_w):
         return image
     x = image.reshape(-1, shape[-3] if image.dim() >= 3 else 1, old_h, old_w)
-    need_cast = not x.is_floating_point()
     dtype = x.dtype
+    # _geometry.py:316-342: uint8 stays uint8 in the nearest modes (the op is a copy), other integer types go through float32
+    need_cast = not (x.is_floating_point() or (dtype == torch.uint8 and interpolation in ("nearest", "nearest-exact")))
     if need_cast:
         x = x.to(torch.float32)
     align = False if interpolation in ("bilinear", "bicubic") else None
