@@ -98,6 +98,12 @@ def main():
                     "RoIAlign launch's stream; the default runs it on a second HIP stream under that launch (-3..-6 %% per step in "
                     "eight of eight round-4/5 visits once the collector stall was out of the way)")
     ap.set_defaults(overlap=True)
+    ap.add_argument("--side-priority", type=int, default=-1, help="HIP priority of the second stream (NMS + packing chain): -1 = "
+                    "high (default: its short kernels get the wave slots the RoIAlign workgroups free), 0 = normal")
+    ap.add_argument("--event-scope", type=int, default=1, help="fork / join events of the two-stream step: 1 = device-scope release "
+                    "(default), 0 = system scope, 2 = no fence from the event, -1 = torch's own wait_stream")
+    ap.add_argument("--reserve-cus", type=int, default=8, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
+                    "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD, 0 = two ordinary streams)")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -145,8 +151,27 @@ def main():
     img_idx = torch.cat([torch.full((PROPOSALS,), i, device=device, dtype=torch.int64) for i in range(BATCH)])
     counter = {"i": 0}
 
-    nms_stream = torch.cuda.Stream(device=device)
+    nms_stream = torch.cuda.Stream(device=device, priority=args.side_priority)
     overlap = {"on": args.overlap}
+    # The RoIAlign launch owns all the LDS of every CU it runs on (4 workgroups x 39 KB), so the short launches of the second
+    # stream wait in the dispatcher until it drains (kernel-trace: nms_small_seg_tiles 16 us alone, 100-195 us under it; sweep +
+    # packing behind its end) — whatever the queue priority.  The step's own stream therefore leaves `--reserve-cus` CUs alone
+    # (one per XCD for 8) and the side stream finds them empty: vision_amd/streams.py.
+    part = {"main": None, "reserved": 0, "note": None}
+    if args.overlap and args.reserve_cus > 0:
+        try:
+            part["main"], nms_stream = vision_amd.streams.partitioned_streams(args.reserve_cus, device)
+            part["reserved"] = args.reserve_cus
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            part["note"] = f"{type(exc).__name__}: {exc}"
+            print(f"[bench] CU-partitioned streams unavailable ({part['note']}); two ordinary streams", file=sys.stderr)
+
+    # fork / join of the two streams: device-scope events (vision_amd.streams.wait_stream) unless --torch-events
+    if args.event_scope >= 0:
+        vision_amd.streams.set_event_scope(args.event_scope)
+        fork_join = vision_amd.streams.wait_stream
+    else:
+        fork_join = lambda waiter, signaler: waiter.wait_stream(signaler)   # noqa: E731
 
     def device_step(which=None):
         # the whole per-rank hot path, no host synchronisation anywhere (-> hipGraph-capturable).  The two halves of the
@@ -159,7 +184,7 @@ def main():
         cur = torch.cuda.current_stream()
         side = nms_stream if overlap["on"] else cur
         if side is not cur:
-            side.wait_stream(cur)
+            fork_join(side, cur)
         with torch.cuda.stream(side):
             keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
             # padded top-MAX_DETS detections per image + the count of every image, written as the collective payload itself:
@@ -167,7 +192,7 @@ def main():
             payload = sharding.pack_kept_payload(d["all_boxes"], d["all_scores"], img_idx, keep, num, BATCH, MAX_DETS)
         pooled = pool(d["feats"], d["boxes"], image_shapes)                                 # [4000, 256, 7, 7], 1 launch
         if side is not cur:
-            cur.wait_stream(side)
+            fork_join(cur, side)
             for t in (keep, num, payload):
                 t.record_stream(cur)     # produced on the side stream, consumed (all-gather, parity check) on this one
         return pooled, num, payload, keep
@@ -231,10 +256,17 @@ def main():
     for m in marks + wm:
         m.record()                        # creates the HIP event now, not inside a timed region
     held = {"out": None}
+    host = {"enqueue_ms": None}
 
     def contract_region():
         """warm-up (= the timed loop) + pre-roll + EXACTLY K steps between two (barrier + synchronize); returns
         (seconds of the K steps, pre-roll steps run, per-step event times in step order)"""
+        if part["main"] is not None and overlap["on"] and torch.cuda.current_stream() != part["main"]:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(part["main"]):
+                r = contract_region()
+            torch.cuda.synchronize()
+            return r
         for _ in range(args.warmup):
             held["out"] = step()
             marks[1].record()
@@ -259,6 +291,7 @@ def main():
         for i in range(args.steps):
             held["out"] = step()
             marks[i + 1].record()
+        host["enqueue_ms"] = (time.perf_counter() - t0) / max(args.steps, 1) * 1e3   # host time per step before the final sync
         sync()
         dt = time.perf_counter() - t0
         return dt, preroll, [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -268,6 +301,7 @@ def main():
     gc.disable()
     gc.callbacks.append(gc_probe)
     elapsed, preroll, per_step_seq = contract_region()
+    host_enqueue_ms = host["enqueue_ms"]
     # the same K steps in the OTHER stream mode (reported next to `value`, never `value` itself)
     other_stream_ms = None
     if graph is None:
@@ -377,6 +411,7 @@ def main():
                                "argmax_step": argmax_step, "max_over_median": round(per_step[-1] / per_step[len(per_step) // 2], 3),
                                "steps_ms": [round(x, 4) for x in per_step_seq[:64]],
                                "preroll_steps": preroll, "gc_collections_in_timed_region": len(gc_seen),
+                               "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 4),
                                "how": "HIP events between consecutive steps of the timed region (rank 0), in step order; the "
                                       "collector is frozen + disabled around warm-up and region, the warm-up loop is the timed loop, "
                                       "then pairs of pre-roll steps until two consecutive steps agree within 10 %"} if per_step else None),
@@ -398,7 +433,12 @@ def main():
             "schema_ops_ms_per_step": round(schema_ms, 4),
             "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
             "rotated_input_sets": N_SETS,
-            "streams": "NMS + packing chain on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream",
+            "streams": (f"NMS + packing chain on a second HIP stream under the RoIAlign launch; the RoIAlign stream leaves "
+                        f"{part['reserved']} CUs (mask bits 0..{part['reserved'] - 1}: one per XCD and 8) to it"
+                        if args.overlap and part["reserved"] else
+                        ("NMS + packing chain on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream")),
+            "reserved_cus": part["reserved"],
+            "fork_join_events": {1: "device-scope release", 0: "system-scope release", 2: "no event fence", -1: "torch wait_stream"}[args.event_scope],
             ("one_stream_ms_per_step" if args.overlap else "two_stream_ms_per_step"): None if other_stream_ms is None else round(other_stream_ms, 4),
             "hip_graph": graph is not None,
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
@@ -451,6 +491,8 @@ def main():
             result["config5"] = c5
     if rank == 0:
         print(json.dumps(result), flush=True)
+    part["main"] = None
+    vision_amd.streams.destroy_all()          # the CU-masked streams go before the runtime (and any profiler) tears down
     if not parity_ok:
         sys.exit("bench.py: outputs differ from the CPU reference (see the parity block)")
     if args.e2e and rank == 0 and world == 1:

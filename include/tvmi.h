@@ -87,6 +87,18 @@ const char* tvmi_arch(void);
 /* Human-readable text for the last non-zero status returned on this thread. */
 const char* tvmi_last_error(void);
 
+/* A HIP stream restricted to the compute units whose bits are set in cu_mask (mask_words 32-bit words; on the multi-XCD parts
+ * the bits are dealt round-robin over the XCDs, so bits 0..7 are one CU of each XCD).  The step of this path (bench.py,
+ * vision_amd.streams.partitioned_streams) runs the chip-filling RoIAlign launch on a stream that leaves a few CUs alone and
+ * the short NMS / packing launches on a second stream that finds them empty.  *stream receives a hipStream_t. */
+int tvmi_stream_create_cu_mask(const uint32_t* cu_mask, uint32_t mask_words, void** stream);
+int tvmi_stream_destroy(void* stream);
+/* `waiter` (hipStream_t) waits for everything enqueued on `signaler` so far: torch's Stream.wait_stream with an event that
+ * releases to DEVICE scope (hipEventReleaseToDevice) instead of system scope — the fork / join of the step's two streams.
+ * tvmi_stream_event_scope: 0 system scope (torch's events), 1 device scope (default), 2 no fence from the event itself. */
+int tvmi_stream_wait_stream(void* waiter, void* signaler);
+int tvmi_stream_event_scope(int scope);
+
 /* ------------------------------------------------------------------ NMS ----------
  * Replaces: torchvision/csrc/ops/cuda/nms_kernel.cu:56-148 (nms_kernel_impl,
  * gather_keep_from_mask) and the host sequence at :166-258; semantics (and the

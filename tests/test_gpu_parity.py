@@ -806,6 +806,33 @@ def test_box_iou_rotated(tv):
     assert tv.box_iou_rotated(torch.empty(0, 5, device=DEV), b2.to(DEV)).shape == (0, 333)
 
 
+def test_box_iou_rotated_dense_tiles_and_degenerate_boxes(tv):
+    """The kernel clips the pairs that survive the circle test from a compacted per-tile list: tiles in which EVERY pair
+    survives (a cluster of overlapping boxes: the list is full, 4096 entries, 16 rounds of 256), tiles with none, identical
+    and axis-aligned boxes (the Graham scan's tie rules), zero / negative extents and a NaN — all against the C restatement of
+    cpu/box_iou_rotated_kernel.cpp, which tests/test_oracle.py pins to the reference's own kernel."""
+    gg = gen(171)
+    cluster = torch.cat([100 + torch.rand(150, 2, generator=gg) * 30, 20 + torch.rand(150, 2, generator=gg) * 60,
+                         torch.rand(150, 1, generator=gg) * 360 - 180], 1)
+    far = torch.cat([5000 + torch.rand(70, 2, generator=gg) * 9000, 2 + torch.rand(70, 2, generator=gg) * 5, torch.zeros(70, 1)], 1)
+    special = torch.tensor([[100, 100, 40, 20, 0], [100, 100, 40, 20, 0], [100, 100, 40, 20, 90], [100, 100, 40, 20, 180],
+                            [120, 100, 40, 20, 0], [100, 110, 40, 20, 0], [100, 100, 0, 20, 10], [100, 100, 40, -20, 10],
+                            [100, 100, 1e-8, 1e-8, 0], [100, 100, 40, 20, 1e-4]], dtype=torch.float32)
+    b1 = torch.cat([cluster, far, special])
+    b2 = torch.cat([special, cluster[:100], far[:30]])
+    got = tv.box_iou_rotated(b1.to(DEV), b2.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, O.box_iou_rotated(b1.numpy(), b2.numpy()), rtol=0, atol=1e-5)
+    got64 = tv.box_iou_rotated(b1.double().to(DEV), b2.double().to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got64, O.box_iou_rotated(b1.double().numpy(), b2.double().numpy()), rtol=0, atol=1e-6)
+    nan_box = b1.clone()
+    nan_box[3, 0] = float("nan")
+    got = tv.box_iou_rotated(nan_box.to(DEV), b2.to(DEV)).cpu().numpy()
+    want = O.box_iou_rotated(nan_box.numpy(), b2.numpy())
+    keep = np.ones(len(b1), bool)
+    keep[3] = False
+    np.testing.assert_allclose(got[keep], want[keep], rtol=0, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------ resize
 def test_resize_golden_and_torch_cpu(tv):
     g = golden("resize")

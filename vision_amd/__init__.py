@@ -70,3 +70,4 @@ from .integration import fuse_detection_model  # noqa: E402,F401
 from .transform import resize_boxes, resize_keypoints, resized_size, transform_images  # noqa: E402,F401
 from .transform import transform as transform_with_targets  # noqa: E402,F401
 from . import sharding  # noqa: E402,F401
+from . import streams  # noqa: E402,F401

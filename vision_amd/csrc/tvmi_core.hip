@@ -1,6 +1,9 @@
 // tvmi_core.hip — version / error plumbing of libtvmi_kernels.so.
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "tvmi_common.h"
 
 namespace tvmi {
@@ -19,3 +22,82 @@ int set_error(int code, const char* what) {
 extern "C" int tvmi_version(void) { return TVMI_ABI_VERSION; }
 extern "C" const char* tvmi_arch(void) { return "gfx950"; }
 extern "C" const char* tvmi_last_error(void) { return tvmi::g_last_error; }
+
+// A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask).  Bit i of the mask enables CU i; on the
+// multi-XCD parts the driver deals the bits round-robin over the XCDs, so clearing bits 0..7 takes ONE CU out of each of the
+// eight XCDs of an MI355X.  Use: the step's long RoIAlign launch runs on a stream that leaves a few CUs alone, the short
+// latency-bound NMS / packing chain runs on a second stream and finds those CUs empty — a chip-filling kernel that owns all the
+// LDS of every CU (4 x 39 KB workgroups) otherwise keeps the side stream's workgroups waiting until it drains (queue priorities
+// do not change that: measured, bench.py --side-priority).  *stream is a hipStream_t; destroy with tvmi_stream_destroy.
+extern "C" int tvmi_stream_create_cu_mask(const uint32_t* cu_mask, uint32_t mask_words, void** stream) {
+  if (!cu_mask || mask_words == 0 || !stream) return tvmi::set_error(hipErrorInvalidValue, "stream_create_cu_mask: null argument");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, mask_words, cu_mask);
+  if (e != hipSuccess) return tvmi::set_error((int)e, "stream_create_cu_mask: hipExtStreamCreateWithCUMask");
+  *stream = s;
+  return 0;
+}
+
+extern "C" int tvmi_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  const hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? 0 : tvmi::set_error((int)e, "stream_destroy");
+}
+
+// `waiter` waits for everything enqueued on `signaler` so far — torch's Stream.wait_stream, with an event that releases to
+// DEVICE scope (hipEventReleaseToDevice): both streams live on this device, and torch's events release to system scope (a
+// write-back + invalidate meant for host readers) on every record.  The step of this path forks and joins its two streams
+// once per step; the two hops were ~25 us of its 0.28 ms (kernel-trace: 32 us between the last RoIAlign launch of a step and
+// the first launch of the next with two streams, 8 us with one).  Events come from a per-device ring (an event may be
+// re-recorded while an older wait on it is pending: the wait took a snapshot).
+namespace tvmi {
+namespace {
+constexpr int kRing = 256, kMaxDev = 16;
+hipEvent_t g_ring[kMaxDev][kRing];
+bool g_ring_ready[kMaxDev] = {};
+std::atomic<unsigned> g_ring_next[kMaxDev];
+std::mutex g_ring_mutex;
+std::atomic<int> g_event_scope{1};   // 0 system (torch's), 1 device, 2 no fence from the event itself
+}  // namespace
+int set_stream_option(int scope) {
+  if (scope < 0 || scope > 2) return -1;
+  std::lock_guard<std::mutex> lock(g_ring_mutex);
+  for (int d = 0; d < kMaxDev; ++d)
+    if (g_ring_ready[d]) {
+      for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(g_ring[d][i]);
+      g_ring_ready[d] = false;
+    }
+  g_event_scope = scope;
+  return 0;
+}
+}  // namespace tvmi
+
+extern "C" int tvmi_stream_wait_stream(void* waiter, void* signaler) {
+  using namespace tvmi;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDev) return set_error(e != hipSuccess ? (int)e : (int)hipErrorInvalidDevice, "stream_wait_stream: device");
+  if (!g_ring_ready[dev]) {
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    if (!g_ring_ready[dev]) {
+      const int scope = g_event_scope.load();
+      const unsigned flags = hipEventDisableTiming | (scope == 1 ? hipEventReleaseToDevice : scope == 2 ? hipEventDisableSystemFence : 0u);
+      for (int i = 0; i < kRing; ++i) {
+        e = hipEventCreateWithFlags(&g_ring[dev][i], flags);
+        if (e != hipSuccess) return set_error((int)e, "stream_wait_stream: hipEventCreateWithFlags");
+      }
+      g_ring_ready[dev] = true;
+    }
+  }
+  hipEvent_t ev = g_ring[dev][g_ring_next[dev].fetch_add(1) % kRing];
+  e = hipEventRecord(ev, static_cast<hipStream_t>(signaler));
+  if (e != hipSuccess) return set_error((int)e, "stream_wait_stream: hipEventRecord");
+  e = hipStreamWaitEvent(static_cast<hipStream_t>(waiter), ev, 0);
+  if (e != hipSuccess) return set_error((int)e, "stream_wait_stream: hipStreamWaitEvent");
+  return 0;
+}
+
+// 0: events release to system scope (what torch's events do), 1 (default): device scope, 2: no fence from the event itself
+extern "C" int tvmi_stream_event_scope(int scope) {
+  return tvmi::set_stream_option(scope) == 0 ? 0 : tvmi::set_error((int)hipErrorInvalidValue, "stream_event_scope: 0, 1 or 2");
+}
