@@ -16,16 +16,14 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/
 cd $ROOTDIR
 timeout 600 python tools/gpu_matrix.py $OUT/matrix.json > $OUT/matrix.log 2>&1; tail -3 $OUT/matrix.log
 cd /tmp
-for K in roi7 roi7cl bwd7 bwd14 nms100k; do
+for K in ${TVMI_ROUND_PMC:-roi7 roi7cl bwd7 bwd14 nms100k}; do
   for C in FETCH_SIZE WRITE_SIZE; do
     TVMI_TOOL_SERIALIZED_PROFILER=1 timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_${K}_$C -o p -- python $ROOTDIR/tools/run_kernel.py $K 6 > $ROOTDIR/$OUT/pmc_${K}_$C.log 2>&1
   done
 done
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_bwd7 -o k -- python $ROOTDIR/tools/run_kernel.py bwd7 20 > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_bwd14 -o k -- python $ROOTDIR/tools/run_kernel.py bwd14 20 > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_nms100k -o k -- python $ROOTDIR/tools/run_kernel.py nms100k 10 > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_dcn_bwd -o k -- python $ROOTDIR/tools/run_kernel.py dcn_bwd 10 > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_dcn_bwd_dw -o k -- python $ROOTDIR/tools/run_kernel.py dcn_bwd_dw 10 > /dev/null 2>&1
+for K in ${TVMI_ROUND_KT:-bwd7:20 bwd14:20 nms100k:10 dcn_bwd:10 dcn_bwd_dw:10}; do
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/kt_${K%%:*} -o k -- python $ROOTDIR/tools/run_kernel.py ${K%%:*} ${K##*:} > /dev/null 2>&1
+done
 cd $ROOTDIR
 # probe binaries are not tracked: build the calibration probe here if it did not travel with the snapshot
 [ -x $ROOTDIR/tools/probe/fetch_calib ] || hipcc --offload-arch=gfx950 -O3 -o $ROOTDIR/tools/probe/fetch_calib $ROOTDIR/tools/probe/fetch_calib.hip > /dev/null 2>&1
