@@ -102,6 +102,8 @@ def main():
                     "high (default: its short kernels get the wave slots the RoIAlign workgroups free), 0 = normal")
     ap.add_argument("--event-scope", type=int, default=1, help="fork / join events of the two-stream step: 1 = device-scope release "
                     "(default), 0 = system scope, 2 = no fence from the event, -1 = torch's own wait_stream")
+    ap.add_argument("--diag-skip", choices=["fork", "join", "both"], default=None, help="DIAGNOSIS ONLY (the line is marked invalid): "
+                    "leave out the fork and / or the join of the two streams, to price the hops")
     ap.add_argument("--reserve-cus", type=int, default=8, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
                     "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD, 0 = two ordinary streams)")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
@@ -110,6 +112,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the config-5 block (Mask R-CNN img/s) of the contract line")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 and 4: NMS 100k, deform_conv2d)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, rank plumbing and the all-gather only; measures nothing")
+    ap.add_argument("--force-collective", action="store_true", help="world of one: form a 1-rank RCCL group anyway and run the step's "
+                    "all-gather as a real collective (exercises the N > 1 code path — RCCL next to the CU-partitioned streams — on a "
+                    "1-GPU box; the line says so in config.parallelism)")
     ap.add_argument("--graph", action="store_true", help="replay the per-rank chain from a captured hipGraph (measured: no gain "
                     "over eager sync-free launches on this stack, so off by default)")
     args = ap.parse_args()
@@ -126,6 +131,14 @@ def main():
                  f"{world}-GPU number as a {args.gpus}-GPU one")
     if args.dry_run:
         return dry_run(rank, world, args)
+    if world > 1 or args.force_collective:
+        # RCCL prints a version banner through C stdio on fd 1 (flushed at exit, i.e. BEHIND the JSON line): the contract is
+        # ONE JSON line on stdout, so everything written to fd 1 from here on goes to stderr, and python's own stdout — the
+        # JSON line of rank 0 — keeps the original descriptor
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real_stdout, "w")
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
     if torch.cuda.device_count() < world:
         sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one process per GPU)")
@@ -133,6 +146,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif args.force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
@@ -183,7 +200,7 @@ def main():
         counter["i"] += 1
         cur = torch.cuda.current_stream()
         side = nms_stream if overlap["on"] else cur
-        if side is not cur:
+        if side is not cur and args.diag_skip not in ("fork", "both"):
             fork_join(side, cur)
         with torch.cuda.stream(side):
             keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
@@ -192,7 +209,8 @@ def main():
             payload = sharding.pack_kept_payload(d["all_boxes"], d["all_scores"], img_idx, keep, num, BATCH, MAX_DETS)
         pooled = pool(d["feats"], d["boxes"], image_shapes)                                 # [4000, 256, 7, 7], 1 launch
         if side is not cur:
-            fork_join(cur, side)
+            if args.diag_skip not in ("join", "both"):
+                fork_join(cur, side)
             for t in (keep, num, payload):
                 t.record_stream(cur)     # produced on the side stream, consumed (all-gather, parity check) on this one
         return pooled, num, payload, keep
@@ -230,11 +248,11 @@ def main():
                 pooled, num, payload, _ = static_out[i]
             else:
                 pooled, num, payload, _ = device_step()
-            gd, gc = sharding.all_gather_payload(payload, MAX_DETS)   # the one collective (views only at world 1)
+            gd, gc = sharding.all_gather_payload(payload, MAX_DETS, always_collective=args.force_collective)   # the one collective (views only at world 1)
         return pooled, num, gd, gc
 
     def sync():
-        if world > 1:
+        if world > 1 or args.force_collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -438,10 +456,12 @@ def main():
                         if args.overlap and part["reserved"] else
                         ("NMS + packing chain on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream")),
             "reserved_cus": part["reserved"],
+            **({"INVALID_diagnosis_run": f"--diag-skip {args.diag_skip}: stream hops left out, not a measurement of the step"} if args.diag_skip else {}),
             "fork_join_events": {1: "device-scope release", 0: "system-scope release", 2: "no event fence", -1: "torch wait_stream"}[args.event_scope],
             ("one_stream_ms_per_step" if args.overlap else "two_stream_ms_per_step"): None if other_stream_ms is None else round(other_stream_ms, 4),
             "hip_graph": graph is not None,
-            "parallelism": f"images sharded over {world} GPU(s), one process per GPU",
+            "parallelism": f"images sharded over {world} GPU(s), one process per GPU"
+                           + (" (1-rank RCCL group, the all-gather run as a real collective: --force-collective)" if args.force_collective else ""),
         },
         "roofline": {
             "kernel": "roi_align_fwd_ms_dma<7,7,2>",
@@ -482,7 +502,7 @@ def main():
             result["configs"] = other_configs(device)
         except Exception as exc:  # pragma: no cover - depends on the box
             result["configs"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()          # the config-5 processes form their own group
     if not args.no_e2e:

@@ -54,7 +54,7 @@ namespace tvmi {
 namespace {
 constexpr int kRing = 256, kMaxDev = 16;
 hipEvent_t g_ring[kMaxDev][kRing];
-bool g_ring_ready[kMaxDev] = {};
+std::atomic<bool> g_ring_ready[kMaxDev];   // zero-initialised (static storage)
 std::atomic<unsigned> g_ring_next[kMaxDev];
 std::mutex g_ring_mutex;
 std::atomic<int> g_event_scope{1};   // 0 system (torch's), 1 device, 2 no fence from the event itself
@@ -63,9 +63,9 @@ int set_stream_option(int scope) {
   if (scope < 0 || scope > 2) return -1;
   std::lock_guard<std::mutex> lock(g_ring_mutex);
   for (int d = 0; d < kMaxDev; ++d)
-    if (g_ring_ready[d]) {
+    if (g_ring_ready[d].load()) {
       for (int i = 0; i < kRing; ++i) (void)hipEventDestroy(g_ring[d][i]);
-      g_ring_ready[d] = false;
+      g_ring_ready[d].store(false);
     }
   g_event_scope = scope;
   return 0;
@@ -77,16 +77,16 @@ extern "C" int tvmi_stream_wait_stream(void* waiter, void* signaler) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess || dev < 0 || dev >= kMaxDev) return set_error(e != hipSuccess ? (int)e : (int)hipErrorInvalidDevice, "stream_wait_stream: device");
-  if (!g_ring_ready[dev]) {
+  if (!g_ring_ready[dev].load(std::memory_order_acquire)) {
     std::lock_guard<std::mutex> lock(g_ring_mutex);
-    if (!g_ring_ready[dev]) {
+    if (!g_ring_ready[dev].load()) {
       const int scope = g_event_scope.load();
       const unsigned flags = hipEventDisableTiming | (scope == 1 ? hipEventReleaseToDevice : scope == 2 ? hipEventDisableSystemFence : 0u);
       for (int i = 0; i < kRing; ++i) {
         e = hipEventCreateWithFlags(&g_ring[dev][i], flags);
         if (e != hipSuccess) return set_error((int)e, "stream_wait_stream: hipEventCreateWithFlags");
       }
-      g_ring_ready[dev] = true;
+      g_ring_ready[dev].store(true, std::memory_order_release);
     }
   }
   hipEvent_t ev = g_ring[dev][g_ring_next[dev].fetch_add(1) % kRing];
