@@ -177,6 +177,25 @@ def test_roi_align_wave_kernels_stage_their_window_asynchronously(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_resize_backward_blocks_are_loaded_together(tmp_path):
+    """The gather backward of the resize modes (resize.hip, upsample2d_bwd_vec_kernel<T, R, CC, P>) beat ATen's scatter kernels on
+    up-scales only once the R x P row loads of a block were issued together as CC-element vector loads (the first version's
+    loads sat under per-lane range predicates, four in flight: FPN nearest 2x 0.172 ms against ATen's 0.095, now 0.081).
+    Guard: every instantiation loads its block rows as ONE vector load each (fp32: dwordx2 / dwordx4; 16-bit: dword / dwordx2 at
+    2-byte alignment), at least R * P of them in a loop body, nothing in scratch, within 96 VGPRs."""
+    text, res = _kernel_resources(os.path.join(CSRC, "resize.hip"), tmp_path)
+    bodies = _kernel_bodies(text, "upsample2d_bwd_vec_kernel")
+    assert len(bodies) == 12, sorted(bodies)      # {fp32, fp16, bf16} x {(2,2,8), (4,2,4), (2,4,4), (4,4,4)}
+    for name, body in bodies.items():
+        m = re.search(r"Li(\d)ELi(\d)ELi(\d)E", name)
+        R, CC, P = (int(v) for v in m.groups())
+        wide = {("f", 2): "dwordx2", ("f", 4): "dwordx4", ("h", 2): "dword", ("h", 4): "dwordx2"}[("f" if "kernelIf" in name else "h", CC)]
+        n = len(re.findall(rf"global_load_{wide} ", body))
+        assert n >= R * P, (name, wide, n)
+        assert "scratch_" not in body and res[name]["spill"] == 0 and res[name]["vgpr"] <= 96, (name, res[name])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_roi_align_backward_owner_keeps_its_prefetch_in_flight(tmp_path):
     """Round 4: the tile-owner backward lost 20-30 % to loads the compiler had made synchronous — the grads prefetch of entry
     e + 1 was `v = 0; if (inside) v = load; else if (straddles) {...}` (a phi: its copy and an s_waitcnt vmcnt(0) sat right
