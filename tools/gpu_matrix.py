@@ -177,6 +177,23 @@ if "resize" in sections:
         t2 = tm(lambda: F.interpolate(small, size=(800, 1067), mode=mode))
         put(f"resize_3x480x640_to_800x1067_{mode}", t, aten_ms=round(t2, 4))
 
+if "resize" in sections or "resize_nhwc" in sections:
+    # channels_last inputs (round 5: upsample2d_nhwc_kernel) next to ATen's channels_last kernels on the same device
+    g = torch.Generator().manual_seed(0)
+    for tag, shape, osz in (("img_8x3x1080x1920_to_800x1422", (8, 3, 1080, 1920), (800, 1422)),
+                            ("fpn_4x256x100x168_to_200x336", (4, 256, 100, 168), (200, 336))):
+        xcl = torch.rand(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        by = xcl.numel() * 4 * (1 + osz[0] * osz[1] / (shape[2] * shape[3]))
+        for mode, aa in (("nearest", False), ("bilinear", False), ("bicubic", False), ("bilinear", True)):
+            kw = {} if mode == "nearest" else dict(antialias=aa)
+            t = tm(lambda: vision_amd.interpolate(xcl, size=osz, mode=mode, **kw))
+            t2 = tm(lambda: F.interpolate(xcl, size=osz, mode=mode, **kw))
+            put(f"resize_nhwc_{tag}_{mode}{'_aa' if aa else ''}", t, GBs=round(by / t / 1e6), aten_ms=round(t2, 4))
+        x16 = xcl.to(torch.bfloat16)
+        t = tm(lambda: vision_amd.interpolate(x16, size=osz, mode="bilinear"))
+        t2 = tm(lambda: F.interpolate(x16, size=osz, mode="bilinear"))
+        put(f"resize_nhwc_{tag}_bilinear_bfloat16", t, aten_ms=round(t2, 4))
+
 if "resize" in sections or "resize_bwd" in sections:
     # gradients of the resize ops (round 5: gather kernels) next to ATen's own backward kernels on the same device.
     # shapes: the FPN top-down path of config 2/5 (nearest 2x, ops/feature_pyramid_network.py:194), a segmentation head

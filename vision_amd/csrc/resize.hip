@@ -953,28 +953,88 @@ __global__ __launch_bounds__(kThreads) void nearest2d_bytes_kernel(const U* __re
 // of both tensors — and the two axes come from the same [first, taps, weights] tables as the backward.  ATen keeps the memory
 // format of a channels_last input (`suggest_memory_format`), the reference's resize_image goes out of its way to preserve it
 // (_geometry.py:324-338); the planar kernels would need a layout copy on either side.
-template <typename T>
+// CPT channels per lane: 4 when C % 4 == 0 (one 16-byte / 8-byte load per tap), 3 for RGB images (C == 3), 1 otherwise — the axis
+// tables are looked up once per lane, not once per channel.  MAXT > 0: both axes have at most MAXT taps (nearest, bilinear,
+// bicubic without anti-aliasing) and the tap loops are unrolled with their loads issued together; MAXT == 0: any tap count.
+template <typename T, int CPT, int MAXT>
 __global__ __launch_bounds__(kThreads) void upsample2d_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                                    const float* __restrict__ ytab,
                                                                    const float* __restrict__ xtab, int C, int IH, int IW,
                                                                    int OH, int OW, int yt, int xt) {
-  const int e = blockIdx.x * kThreads + threadIdx.x;   // ox * C + c
+  const int cgs = C / CPT;                              // channel groups per pixel
+  const int e = blockIdx.x * kThreads + threadIdx.x;   // ox * cgs + channel group
   const int oy = blockIdx.y, n = blockIdx.z;
-  if (e >= OW * C) return;
-  const int ox = e / C, c = e - ox * C;
+  if (e >= OW * cgs) return;
+  const int ox = e / cgs, c0 = (e - ox * cgs) * CPT;
   const float* yrow = ytab + (int64_t)oy * (yt + 2);
   const float* xrow = xtab + (int64_t)ox * (xt + 2);
   const int y0 = __float_as_int(yrow[0]), ny = __float_as_int(yrow[1]);
   const int x0 = __float_as_int(xrow[0]), nx = __float_as_int(xrow[1]);
-  const T* base = in + (int64_t)n * IH * IW * C + c;
-  float acc = 0.f;
-  for (int j = 0; j < ny; ++j) {
-    const T* row = base + ((int64_t)(y0 + j) * IW + x0) * C;
-    float r = 0.f;
-    for (int k = 0; k < nx; ++k) r += xrow[2 + k] * ld(row + (int64_t)k * C);
-    acc += yrow[2 + j] * r;
+  const T* base = in + (int64_t)n * IH * IW * C + c0;
+  float acc[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+  auto tap = [&](const T* p, float (&v)[CPT]) {
+    if constexpr (CPT == 4) {
+      const typename RawVec<T, 4>::type q = *reinterpret_cast<const typename RawVec<T, 4>::type*>(p);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = Vec4<T>::up(q[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) v[c] = ld(p + c);
+    }
+  };
+  if constexpr (MAXT > 0) {
+    float wy[MAXT], wx[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      wy[j] = j < ny ? yrow[2 + j] : 0.f;
+      wx[j] = j < nx ? xrow[2 + j] : 0.f;
+    }
+    float v[MAXT][MAXT][CPT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k)   // taps beyond the range re-read the last one (never used: selected away below)
+        tap(base + ((int64_t)(y0 + max(min(j, ny - 1), 0)) * IW + x0 + max(min(k, nx - 1), 0)) * C, v[j][k]);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      float r[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) r[c] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) r[c] = k < nx ? r[c] + wx[k] * v[j][k][c] : r[c];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) acc[c] = j < ny ? acc[c] + wy[j] * r[c] : acc[c];
+    }
+  } else {
+    for (int j = 0; j < ny; ++j) {
+      const T* row = base + ((int64_t)(y0 + j) * IW + x0) * C;
+      float r[CPT];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) r[c] = 0.f;
+      for (int k = 0; k < nx; ++k) {
+        float v[CPT];
+        tap(row + (int64_t)k * C, v);
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) r[c] += xrow[2 + k] * v[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) acc[c] += yrow[2 + j] * r[c];
+    }
   }
-  st(out + ((int64_t)n * OH + oy) * OW * C + e, acc);
+  T* dst = out + (((int64_t)n * OH + oy) * OW + ox) * C + c0;
+  if constexpr (CPT == 4) {
+    typename RawVec<T, 4>::type q;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[c] = Vec4<T>::down(acc[c]);
+    *reinterpret_cast<typename RawVec<T, 4>::type*>(dst) = q;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) st(dst + c, acc[c]);
+  }
 }
 
 template <typename U>
@@ -1287,14 +1347,27 @@ extern "C" int tvmi_upsample2d_nhwc(const void* input, void* output, tvmi_dtype 
     bwd_axis_table_kernel<<<dim3((unsigned)ceil_div(OH, 128)), dim3(128), 0, s>>>(ytab, (int)OH, (int)IH, p.sh, p.kind_y, p.yt, al);
     bwd_axis_table_kernel<<<dim3((unsigned)ceil_div(OW, 128)), dim3(128), 0, s>>>(xtab, (int)OW, (int)IW, p.sw, p.kind_x, p.xt, al);
   }
-  const dim3 grid((unsigned)ceil_div(OW * C, kThreads), (unsigned)OH, (unsigned)N);
+  const int cpt = C % 4 == 0 ? 4 : (C == 3 ? 3 : 1);
+  const int maxt = std::max(p.yt, p.xt);   // taps of the tables: 1 nearest, 2 bilinear, 4 bicubic; anti-aliased: by scale
+  const dim3 grid((unsigned)ceil_div(OW * (C / cpt), kThreads), (unsigned)OH, (unsigned)N);
+#define TVMI_NHWC_K(scalar_t, CPT, MAXT)                                                                                 \
+  upsample2d_nhwc_kernel<scalar_t, CPT, MAXT><<<grid, dim3(kThreads), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, \
+                                                                             (int)C, (int)IH, (int)IW, (int)OH, (int)OW, p.yt, p.xt)
+#define TVMI_NHWC_T(scalar_t, CPT)                                                                                       \
+  if (maxt <= 1) TVMI_NHWC_K(scalar_t, CPT, 1);                                                                         \
+  else if (maxt <= 2) TVMI_NHWC_K(scalar_t, CPT, 2);                                                                    \
+  else if (maxt <= 4) TVMI_NHWC_K(scalar_t, CPT, 4);                                                                    \
+  else TVMI_NHWC_K(scalar_t, CPT, 0)
 #define TVMI_NHWC(scalar_t)                                                                                              \
-  upsample2d_nhwc_kernel<scalar_t><<<grid, dim3(kThreads), 0, s>>>((const scalar_t*)input, (scalar_t*)output, ytab, xtab, (int)C, \
-                                                                  (int)IH, (int)IW, (int)OH, (int)OW, p.yt, p.xt)
-  if (dt == TVMI_F32) TVMI_NHWC(float);
-  else if (dt == TVMI_F16) TVMI_NHWC(__half);
-  else TVMI_NHWC(__hip_bfloat16);
+  if (cpt == 4) { TVMI_NHWC_T(scalar_t, 4); }                                                                           \
+  else if (cpt == 3) { TVMI_NHWC_T(scalar_t, 3); }                                                                      \
+  else { TVMI_NHWC_T(scalar_t, 1); }
+  if (dt == TVMI_F32) { TVMI_NHWC(float); }
+  else if (dt == TVMI_F16) { TVMI_NHWC(__half); }
+  else { TVMI_NHWC(__hip_bfloat16); }
 #undef TVMI_NHWC
+#undef TVMI_NHWC_T
+#undef TVMI_NHWC_K
   TVMI_RETURN_LAUNCH_STATUS("tvmi_upsample2d_nhwc");
 }
 
