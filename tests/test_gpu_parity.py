@@ -1001,6 +1001,14 @@ def test_interpolate_backward_under_the_aten_override():
         d = x.double().to(DEV).requires_grad_(True)
         F.interpolate(d, size=(50, 60), mode="bilinear", align_corners=False).sum().backward()
         assert int(torch.ops.tvmi.aten_upsample_calls()) == c1 and d.grad is not None
+        # channels_last: the forward has its own kernel, a channels_last gradient keeps ATen's channels_last backward kernel
+        e = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ye = F.interpolate(e, size=(50, 60), mode="bilinear", align_corners=False)
+        ye.backward(torch.ones_like(ye))
+        assert int(torch.ops.tvmi.aten_upsample_calls()) - c1 == 1 and e.grad is not None
+        f = x.clone().requires_grad_(True)
+        F.interpolate(f, size=(50, 60), mode="bilinear", align_corners=False).sum().backward()
+        torch.testing.assert_close(e.grad.cpu(), f.grad, rtol=1e-5, atol=1e-5)
     finally:
         vision_amd.override_aten_upsample(was)
 

@@ -786,6 +786,8 @@ bool ours_bwd(const at::Tensor& g, at::IntArrayRef out_size, at::IntArrayRef in_
   if (!(g.is_cuda() && g.dim() == 4 && out_size.size() == 2 && in_size.size() == 4 && g.numel() > 0 &&
         (t == at::kFloat || t == at::kHalf || t == at::kBFloat16)))   // any strides: `sum().backward()` hands an expanded grad
     return false;
+  // channels_last gradients keep ATen's channels_last backward kernels (ours would pay a layout copy and return NCHW)
+  if (!g.is_contiguous() && g.is_contiguous(at::MemoryFormat::ChannelsLast)) return false;
   const int64_t IH = in_size[2], IW = in_size[3], OH = out_size[0], OW = out_size[1];
   return g.size(0) == in_size[0] && g.size(1) == in_size[1] && g.size(2) == OH && g.size(3) == OW && IH > 0 && IW > 0 &&
          IH <= 65535 && IH * IW < (1ll << 31) && OH * OW < (1ll << 31);
