@@ -104,6 +104,8 @@ def main():
                     "(default), 0 = system scope, 2 = no fence from the event, -1 = torch's own wait_stream")
     ap.add_argument("--diag-skip", choices=["fork", "join", "both"], default=None, help="DIAGNOSIS ONLY (the line is marked invalid): "
                     "leave out the fork and / or the join of the two streams, to price the hops")
+    ap.add_argument("--nms-small-split", type=int, default=1, help="1 (default): the small-segment batched NMS as collect + "
+                    "four-tile workgroups whose LDS fits next to the RoIAlign launch; 0: the one-launch form (21 KB of LDS)")
     ap.add_argument("--reserve-cus", type=int, default=8, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
                     "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD, 0 = two ordinary streams)")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
@@ -183,6 +185,7 @@ def main():
             part["note"] = f"{type(exc).__name__}: {exc}"
             print(f"[bench] CU-partitioned streams unavailable ({part['note']}); two ordinary streams", file=sys.stderr)
 
+    torch.ops.tvmi.set_option("nms.small_split", int(args.nms_small_split))
     # fork / join of the two streams: device-scope events (vision_amd.streams.wait_stream) unless --torch-events
     if args.event_scope >= 0:
         vision_amd.streams.set_event_scope(args.event_scope)

@@ -853,6 +853,7 @@ inline void release_handoff(int dev, hipStream_t stream) {
 // "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
 std::atomic<int64_t> g_replan_min_boxes{24576};
 std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000}, g_device_handoff{1}, g_handoff_lose_flag{0};
+std::atomic<bool> g_small_split{true};   // "nms.small_split": the small-segment path as collect + four-tile workgroups
 
 // Workspace of the large path: mask tiles | removed[CB] | keepbits[CB] | survivor offsets[CB] (int) | two score-order
 // buffers of n indices (re-planning ping-pongs between them).
@@ -1490,6 +1491,116 @@ __global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict_
   ws.tiles[((size_t)me * kSmallSegTiles + t) * 64 + lane] = mine;
 }
 
+// The same two steps as TWO launches whose workgroups fit next to a chip-filling neighbour (round 5).  nms_small_seg_tiles
+// stages a whole segment in 21 KB of LDS per 1024-lane workgroup; on a second stream under the RoIAlign forward — 4 workgroups x
+// 39 KB = 156 of the 160 KB of every CU — such a workgroup waits in the dispatcher until that launch drains (16 us alone,
+// 100-195 us there).  A: nms_small_seg_collect records the segment's members (global ranks, in score order) and
+// its size — 64 bytes of LDS.  B: nms_small_seg_tiles4, 256-lane workgroups of four tiles: a wave fetches its 64 column boxes
+// straight into registers (rank -> order -> box), the at most three row blocks of a workgroup's four consecutive tiles are
+// staged once in 3.75 KB of LDS.  Same pair arithmetic (suppression_tile), same tiles in ws.tiles, the sweep is unchanged.
+template <typename T>
+__global__ __launch_bounds__(1024) void nms_small_seg_collect(const int64_t* __restrict__ order, const int64_t* __restrict__ seg, int n,
+                                                              const int64_t* __restrict__ n_dev, int S, SmallSegWorkspace ws) {
+  __shared__ int s_wcnt[16];
+  n = live_boxes(n, n_dev);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int me = blockIdx.x;
+  int* glist = ws.glist + (size_t)me * kSmallSegBoxes;
+  int cnt = 0;
+  bool bad = false;
+  for (int base = 0; base < n; base += 1024) {
+    const int g = base + tid;
+    bool mine = false;
+    if (g < n) {
+      const int64_t sg = seg[order[g]];
+      mine = sg == me;
+      bad |= sg < 0 || sg >= S;
+    }
+    const u64 bal = __ballot(mine);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = s_wcnt[w];
+      before += w < wave ? c : 0;
+      total += c;
+    }
+    const int pos = cnt + before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (mine && pos < kSmallSegBoxes) glist[pos] = g;
+    cnt += total;
+    __syncthreads();
+  }
+  const bool any_bad = me == 0 ? __syncthreads_or(bad) : false;
+  if (tid == 0) {
+    if (cnt > kSmallSegBoxes || any_bad) ws.sync_words[1] = 1;
+    ws.gcnt[me] = min(cnt, kSmallSegBoxes);
+  }
+}
+
+constexpr int kTiles4 = 4;   // tiles (= waves) per workgroup of nms_small_seg_tiles4
+
+template <typename T>
+__global__ __launch_bounds__(kTiles4 * 64) void nms_small_seg_tiles4(const T* __restrict__ dets, const int64_t* __restrict__ order,
+                                                                     double thr, ThrBand band, SmallSegWorkspace ws) {
+  __shared__ __attribute__((aligned(16))) T s_row[3][5][64];   // the row blocks of this workgroup's tiles, component-major
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int me = blockIdx.x;
+  const int cnt = ws.gcnt[me];
+  const int nb = (cnt + 63) >> 6, ntiles = nb * (nb + 1) / 2;
+  const int t0 = blockIdx.y * kTiles4;
+  if (t0 >= ntiles) return;   // the whole workgroup: the grid is sized for the longest possible segment
+  const int* glist = ws.glist + (size_t)me * kSmallSegBoxes;
+  auto row_of = [&](int t, int& rb, int& cb) {   // tile index -> (row block, column block) of the upper triangle, row-major
+    rb = 0;
+    int rem = t;
+    while (rem >= nb - rb) {
+      rem -= nb - rb;
+      ++rb;
+    }
+    cb = rb + rem;
+  };
+  int rb0, cb0;
+  row_of(t0, rb0, cb0);
+  // four consecutive tiles span at most three row blocks (a row of the triangle has at least one tile, the last rows 3, 2, 1)
+  if (wave < 3 && rb0 + wave < nb) {
+    const int p = (rb0 + wave) * 64 + lane;
+    T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    if (p < cnt) {
+      const Box<T> b = load_box<T>(dets, order[glist[p]]);
+      x1 = b.x1;
+      y1 = b.y1;
+      x2 = b.x2;
+      y2 = b.y2;
+    }
+    s_row[wave][0][lane] = x1;
+    s_row[wave][1][lane] = y1;
+    s_row[wave][2][lane] = x2;
+    s_row[wave][3][lane] = y2;
+    s_row[wave][4][lane] = (x2 - x1) * (y2 - y1);
+  }
+  __syncthreads();
+  const int t = t0 + wave;
+  if (t >= ntiles) return;
+  int rb, cb;
+  row_of(t, rb, cb);
+  const int j = cb * 64 + lane;
+  const bool jvalid = j < cnt;
+  T jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0;
+  {
+    const Box<T> b = load_box<T>(dets, order[glist[jvalid ? j : 0]]);
+    jx1 = b.x1;
+    jy1 = b.y1;
+    jx2 = b.x2;
+    jy2 = b.y2;
+  }
+  const T jarea = (jx2 - jx1) * (jy2 - jy1);
+  const u64 mine = suppression_tile<T, 64>(&s_row[rb - rb0][0][0], nullptr, min(64, cnt - rb * 64), jx1, jy1, jx2, jy2, jarea, 0,
+                                           jvalid, cb == rb, thr, band);
+  ws.tiles[((size_t)me * kSmallSegTiles + t) * 64 + lane] = mine;
+}
+
 __global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int64_t* __restrict__ order, int n,
                                                                       const int64_t* __restrict__ n_dev,
                                                                       SmallSegWorkspace ws, int64_t* __restrict__ keep_out,
@@ -1750,10 +1861,18 @@ int set_nms_option(const char* name, int64_t value) {
     g_replan_max.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 16)), std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "nms.small_split") == 0) {   // 1 (default): collect + four-tile workgroups; 0: the one-launch form
+    g_small_split.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
   return -1;
 }
 
 int get_nms_option(const char* name, int64_t* value) {
+  if (std::strcmp(name, "nms.small_split") == 0) {
+    *value = g_small_split.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
   if (std::strcmp(name, "nms.replan_min_boxes") == 0) *value = (int64_t)g_replan_min_boxes.load(std::memory_order_relaxed);
   else if (std::strcmp(name, "nms.replan_divisor") == 0) *value = g_replan_divisor.load(std::memory_order_relaxed);
   else if (std::strcmp(name, "nms.device_handoff") == 0)
@@ -1855,7 +1974,13 @@ int nms_small_segments_entry(const void* dets, const int64_t* order, const int64
   // a segment of m boxes has ceil(m/64)*(ceil(m/64)+1)/2 tiles; m <= min(n, 1024)
   const int nbmax = (int)std::min<int64_t>(kSmallSegBlocks, ceil_div(n, 64));
   const dim3 grid((unsigned)num_segments, (unsigned)ceil_div(nbmax * (nbmax + 1) / 2, 16));
-  if (dt == TVMI_F32)
+  if (dt == TVMI_F32 && g_small_split.load(std::memory_order_relaxed)) {
+    // two launches whose workgroups fit next to a launch that owns the LDS of every CU (see nms_small_seg_collect)
+    nms_small_seg_collect<float><<<dim3((unsigned)num_segments), dim3(1024), 0, s>>>(order, seg, (int)n, n_dev, (int)num_segments, w);
+    const dim3 grid4((unsigned)num_segments, (unsigned)ceil_div(nbmax * (nbmax + 1) / 2, kTiles4));
+    nms_small_seg_tiles4<float><<<grid4, dim3(kTiles4 * 64), 0, s>>>(static_cast<const float*>(dets), order, iou_threshold,
+                                                                   thr_band(iou_threshold), w);
+  } else if (dt == TVMI_F32)
     nms_small_seg_tiles<float><<<grid, dim3(1024), 0, s>>>(static_cast<const float*>(dets), order, seg, (int)n, n_dev,
                                                            (int)num_segments, iou_threshold, thr_band(iou_threshold), w);
   else
