@@ -106,8 +106,11 @@ def main():
                     "leave out the fork and / or the join of the two streams, to price the hops")
     ap.add_argument("--nms-small-split", type=int, default=1, help="1 (default): the small-segment batched NMS as collect + "
                     "four-tile workgroups whose LDS fits next to the RoIAlign launch; 0: the one-launch form (21 KB of LDS)")
-    ap.add_argument("--reserve-cus", type=int, default=8, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
-                    "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD, 0 = two ordinary streams)")
+    ap.add_argument("--nms-sort-rank", type=int, default=1, help="1 (default): score order of <= 4096 boxes by rank counting (3 KB of "
+                    "LDS, n / 64 workgroups); 0: the one-workgroup bitonic sort (32 KB)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
+                    "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD).  0 (default) = two ordinary streams: since "
+                    "every launch of the NMS chain fits into the 4 KB of LDS the RoIAlign kernel leaves on a CU, no CU has to be kept free")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -172,10 +175,13 @@ def main():
 
     nms_stream = torch.cuda.Stream(device=device, priority=args.side_priority)
     overlap = {"on": args.overlap}
-    # The RoIAlign launch owns all the LDS of every CU it runs on (4 workgroups x 39 KB), so the short launches of the second
-    # stream wait in the dispatcher until it drains (kernel-trace: nms_small_seg_tiles 16 us alone, 100-195 us under it; sweep +
-    # packing behind its end) — whatever the queue priority.  The step's own stream therefore leaves `--reserve-cus` CUs alone
-    # (one per XCD for 8) and the side stream finds them empty: vision_amd/streams.py.
+    # The RoIAlign launch owns nearly all the LDS of every CU it runs on (4 workgroups x 39 KB of 160 KB), so a launch of the
+    # second stream that needs more than the 4 KB left waits in the dispatcher until it drains (kernel-trace of round 4's chain:
+    # nms_small_seg_tiles, 21 KB, 16 us alone, 100-195 us under it; sweep + packing behind its end) — whatever the queue
+    # priority.  Two cures, both measured: (a) the step's own stream leaves `--reserve-cus` CUs alone (one per XCD
+    # for 8, vision_amd/streams.py) and the side stream finds them empty; (b) every launch of the chain was made to fit into
+    # those 4 KB (rank-counting score sort 3 KB, collect 0.3 KB, four-tile workgroups 3.75 KB, sweep / packing 0.5 KB).  With (b)
+    # no reservation is needed and the RoIAlign launch keeps all 256 CUs: the default.
     part = {"main": None, "reserved": 0, "note": None}
     if args.overlap and args.reserve_cus > 0:
         try:
@@ -186,6 +192,7 @@ def main():
             print(f"[bench] CU-partitioned streams unavailable ({part['note']}); two ordinary streams", file=sys.stderr)
 
     torch.ops.tvmi.set_option("nms.small_split", int(args.nms_small_split))
+    torch.ops.tvmi.set_option("nms.sort_rank", int(args.nms_sort_rank))
     # fork / join of the two streams: device-scope events (vision_amd.streams.wait_stream) unless --torch-events
     if args.event_scope >= 0:
         vision_amd.streams.set_event_scope(args.event_scope)

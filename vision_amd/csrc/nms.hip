@@ -853,6 +853,7 @@ inline void release_handoff(int dev, hipStream_t stream) {
 // "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
 std::atomic<int64_t> g_replan_min_boxes{24576};
 std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000}, g_device_handoff{1}, g_handoff_lose_flag{0};
+std::atomic<bool> g_sort_rank{true};     // "nms.sort_rank": the <= 4096-score order by rank counting instead of the one-workgroup bitonic sort
 std::atomic<bool> g_small_split{true};   // "nms.small_split": the small-segment path as collect + four-tile workgroups
 
 // Workspace of the large path: mask tiles | removed[CB] | keepbits[CB] | survivor offsets[CB] (int) | two score-order
@@ -1692,6 +1693,55 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int6
 // kernel plus an index arange plus two copies (~40 us of launches for 4000 scores); this is ~half of that and has
 // no temporaries.  The unique index in the low word makes the (unstable) network produce the stable order.
 constexpr int kSortMax = 4096;
+
+// (ascending key) == (descending score, ties by ascending index): NaN is the greatest value for aten::sort, -0 == +0
+__device__ __forceinline__ u64 score_key(float f, int i) {
+  unsigned b = __builtin_bit_cast(unsigned, f);
+  unsigned d;
+  if (f != f) {
+    d = 0u;
+  } else {
+    if (f == 0.f) b = 0u;
+    const unsigned asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    d = ~asc;
+    if (d == 0u) d = 1u;  // cannot happen for non-NaN values (asc of +inf is 0xFF800000), kept for safety
+  }
+  return ((u64)d << 32) | (unsigned)i;
+}
+
+// The same order by RANK COUNTING (round 5, "nms.sort_rank", default on): the keys are unique, so the position of element i is
+// the number of keys below its own — n^2 compares (16 M at n = 4096) spread over n / 64 workgroups instead of 78 compare-exchange
+// passes of ONE workgroup over 32 KB of LDS.  Lane = element, the four waves of a workgroup count over one quarter of the keys
+// each, 64 keys at a time through a 512-byte wave-private LDS slice (built once per 64 compares, read as broadcasts).  3 KB of
+// LDS and 256 lanes per workgroup: it starts on any CU, also next to a launch that owns the CU's LDS (the bitonic kernel's 32 KB
+// do not), and it is faster on an idle chip as well.  Identical output (the rank of a unique key is exact).
+__global__ __launch_bounds__(256) void sort_scores_desc_rank(const float* __restrict__ scores, int n, int64_t* __restrict__ order) {
+  __shared__ u64 s_keys[4][64];
+  __shared__ int s_cnt[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = blockIdx.x * 64 + lane;
+  const u64 ki = i < n ? score_key(scores[i], i) : ~0ull;
+  const int per = ((n + 255) >> 8) << 6;            // keys per quarter: a multiple of 64
+  const int j_begin = wave * per, j_end = min(n, j_begin + per);
+  int cnt = 0;
+  for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+    const int j = j0 + lane;
+    s_keys[wave][lane] = j < n ? score_key(scores[j], j) : ~0ull;   // padding: above every real key, never counted
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 64; ++t) cnt += s_keys[wave][t] < ki ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  s_cnt[wave][lane] = cnt;
+  __syncthreads();
+  if (wave == 0 && i < n) order[s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane]] = i;
+}
+
 __global__ __launch_bounds__(1024) void sort_scores_desc_small(const float* __restrict__ scores, int n, int N /*pow2 >= n*/,
                                                                int64_t* __restrict__ order) {
   __shared__ u64 keys[kSortMax];
@@ -1861,6 +1911,10 @@ int set_nms_option(const char* name, int64_t value) {
     g_replan_max.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 16)), std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "nms.sort_rank") == 0) {
+    g_sort_rank.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
   if (std::strcmp(name, "nms.small_split") == 0) {   // 1 (default): collect + four-tile workgroups; 0: the one-launch form
     g_small_split.store(value != 0, std::memory_order_relaxed);
     return 0;
@@ -1871,6 +1925,10 @@ int set_nms_option(const char* name, int64_t value) {
 int get_nms_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "nms.small_split") == 0) {
     *value = g_small_split.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  if (std::strcmp(name, "nms.sort_rank") == 0) {
+    *value = g_sort_rank.load(std::memory_order_relaxed) ? 1 : 0;
     return 0;
   }
   if (std::strcmp(name, "nms.replan_min_boxes") == 0) *value = (int64_t)g_replan_min_boxes.load(std::memory_order_relaxed);
@@ -2067,6 +2125,11 @@ extern "C" int tvmi_sort_scores_desc(const float* scores, int64_t n, int64_t* or
   TVMI_CHECK_ARG(n >= 0 && n <= tvmi::kSortMax, "sort_scores_desc: 0 <= n <= 4096");
   if (n == 0) return 0;
   TVMI_CHECK_ARG(scores && order, "sort_scores_desc: null pointer");
+  if (tvmi::g_sort_rank.load(std::memory_order_relaxed) && n > 64) {
+    tvmi::sort_scores_desc_rank<<<dim3((unsigned)tvmi::ceil_div(n, 64)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(scores, (int)n,
+                                                                                                                      order);
+    TVMI_RETURN_LAUNCH_STATUS("tvmi_sort_scores_desc");
+  }
   int N = 2;
   while (N < n) N <<= 1;
   tvmi::sort_scores_desc_small<<<dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream)>>>(scores, (int)n, N, order);
