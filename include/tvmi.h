@@ -78,7 +78,12 @@ int tvmi_version(void);
  *                                recovery path above runs for real
  *   "nms.mask_lds_bytes"         dynamic LDS per mask workgroup of the large path (all chunks but the first) — an
  *                                occupancy cap that keeps wave slots free for the sweep's 16-wave workgroup
- *                                (default 36000 = four workgroups per CU; 0 = no cap) */
+ *                                (default 36000 = four workgroups per CU; 0 = no cap)
+ *   "nms.sort_rank"              1 (default) / 0: tvmi_sort_scores_desc orders its <= 4096 scores by rank counting (n / 64 workgroups
+ *                                of 256 lanes, 3 KB of LDS) instead of the one-workgroup bitonic network (32 KB); same output
+ *   "nms.small_split"            1 (default) / 0: tvmi_nms_small_segments runs its pair tests as two launches (members of a segment,
+ *                                then four tiles per 256-lane workgroup: 0.3 / 3.75 KB of LDS) instead of one that stages a
+ *                                segment in 21 KB — every launch then fits next to a kernel that owns the LDS of all CUs */
 int tvmi_set_option(const char* name, int64_t value);
 /* Current value of a switch of tvmi_set_option (0, or an error for an unknown name). */
 int tvmi_get_option(const char* name, int64_t* value);
@@ -88,9 +93,10 @@ const char* tvmi_arch(void);
 const char* tvmi_last_error(void);
 
 /* A HIP stream restricted to the compute units whose bits are set in cu_mask (mask_words 32-bit words; on the multi-XCD parts
- * the bits are dealt round-robin over the XCDs, so bits 0..7 are one CU of each XCD).  The step of this path (bench.py,
- * vision_amd.streams.partitioned_streams) runs the chip-filling RoIAlign launch on a stream that leaves a few CUs alone and
- * the short NMS / packing launches on a second stream that finds them empty.  *stream receives a hipStream_t. */
+ * the bits are dealt round-robin over the XCDs, so bits 0..7 are one CU of each XCD).  For a second stream whose launches
+ * cannot start next to a kernel that owns every CU's LDS: the chip-filling launch runs on a stream that leaves a few CUs
+ * alone (vision_amd.streams.partitioned_streams; bench.py --reserve-cus — the step itself no longer needs it, its NMS chain
+ * was slimmed down instead).  *stream receives a hipStream_t. */
 int tvmi_stream_create_cu_mask(const uint32_t* cu_mask, uint32_t mask_words, void** stream);
 int tvmi_stream_destroy(void* stream);
 /* `waiter` (hipStream_t) waits for everything enqueued on `signaler` so far: torch's Stream.wait_stream with an event that
