@@ -177,6 +177,29 @@ def test_roi_align_wave_kernels_stage_their_window_asynchronously(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_nms_chain_of_the_step_fits_next_to_the_roi_align_kernel(tmp_path):
+    """The two halves of the detection step overlap on two streams only because EVERY launch of the NMS / packing chain can start
+    on a CU that already holds four workgroups of the RoIAlign forward: 160 KB - 4 x its LDS is what is left (4 KB today), 16 of
+    the 32 wave slots are free.  Round 4's chain had a 21 KB and a 32 KB launch in it: they waited 100-195 us in the dispatcher and
+    the chain finished BEHIND the RoIAlign launch.  Guard: the rank-counting score sort, the segment collect, the
+    four-tile kernel, the sweep and the packing kernel each need at most that much LDS and at most 16 waves."""
+    _, roi = _kernel_resources(os.path.join(CSRC, "roi_align.hip"), tmp_path)
+    dma = [v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi7ELi7ELi2E" in k]
+    assert len(dma) == 1
+    left = 160 * 1024 - 4 * dma[0]["lds"]
+    assert left >= 4096, left
+    _, nms = _kernel_resources(os.path.join(CSRC, "nms.hip"), tmp_path)
+    _, post = _kernel_resources(os.path.join(CSRC, "postprocess.hip"), tmp_path)
+    want = {"sort_scores_desc_rank": nms, "nms_small_seg_collectIf": nms, "nms_small_seg_tiles4If": nms, "nms_small_seg_sweep": nms,
+            "pack_detections_kernel": post}
+    for frag, table in want.items():
+        hits = {k: v for k, v in table.items() if frag in k}
+        assert len(hits) == 1, (frag, list(hits))
+        for k, v in hits.items():
+            assert v["lds"] <= left and v["spill"] == 0 and v["scratch"] == 0 and v["vgpr"] <= 64, (k, v, left)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_resize_backward_blocks_are_loaded_together(tmp_path):
     """The gather backward of the resize modes (resize.hip, upsample2d_bwd_vec_kernel<T, R, CC, P>) beat ATen's scatter kernels on
     up-scales only once the R x P row loads of a block were issued together as CC-element vector loads (the first version's
