@@ -4,6 +4,9 @@ The RoIAlign launch of a step fills the chip: 8,000 workgroups of 39 KB of LDS e
 The NMS / packing chain next to it is ~6 short launches whose workgroups need 0.5-32 KB of LDS; on a second HIP stream they
 sit in the dispatcher until the RoIAlign kernel drains (kernel-trace of the step: `nms_small_seg_tiles` 16 us alone, 100-195 us
 under the RoIAlign launch, sweep + packing after its end), and a high-priority queue does not change that (measured).
+Two cures exist.  This module is the general one; the detection step of this library took the other (every launch of its NMS
+chain was slimmed down to the 4 KB of LDS the RoIAlign kernel leaves on a CU — rank-counting score sort, split small-segment
+kernels — so `bench.py` runs on two ordinary streams by default and `--reserve-cus 8` selects this module's pair).
 `partitioned_streams(reserve)` returns (main, side): `main` may use every CU except `reserve` of them — one per XCD for
 reserve = 8, the driver deals the mask bits round-robin over the XCDs — and `side` may use all; the short launches find
 the reserved CUs empty and the chain finishes under the RoIAlign launch instead of behind it.
