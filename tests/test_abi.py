@@ -165,3 +165,51 @@ def test_deform_conv2d_backward_workspace_plan_is_host_side_and_covers_its_buffe
     # run — a dilation-7 window does not fit its LDS, a 1 x 9 kernel is not its shape
     assert f(dt["TVMI_F32"], B, C, H, W, OC, k, k, 1, 1, 7, 7, 7, 7, 1, 1) <= g1 - 8 * n_in
     assert f(dt["TVMI_F32"], B, C, H, W, OC, 1, 9, 1, 1, 0, 4, 1, 1, 1, 1) <= g1 - 8 * n_in
+
+
+def test_resize_backward_and_channels_last_entries_host_side():
+    """The workspace queries of the round-5 resize entries are pure host arithmetic, and the launchers check their arguments
+    before anything touches a device: table sizes per mode (1 / 2 / 4 taps; the anti-aliased modes by scale), the ranges of the
+    backward on top, and the refusals (unknown mode, anti-aliasing with a nearest mode, float64, missing workspace)."""
+    import vision_amd
+
+    lib = vision_amd._loader.kernels()
+    header = open(HEADER).read()
+    dt = {k: int(re.search(rf"\b{k}\s*=\s*(\d+)", header).group(1)) for k in ("TVMI_F32", "TVMI_F64", "TVMI_F16", "TVMI_BF16")}
+    wb, wn = lib.tvmi_upsample2d_backward_workspace_bytes, lib.tvmi_upsample2d_nhwc_workspace_bytes
+    for f in (wb, wn):
+        f.restype = ctypes.c_size_t
+        f.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 4 + [ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    IH, IW, OH, OW = 100, 168, 200, 336
+    for mode, taps in ((0, 1), (1, 1), (2, 2), (3, 4)):
+        tables = 4 * (OH * (taps + 2) + OW * (taps + 2))
+        assert wn(mode, 0, IH, IW, OH, OW, 0, -1.0, -1.0) == tables                      # [first, taps, weights] per output index
+        assert wb(mode, 0, IH, IW, OH, OW, 0, -1.0, -1.0) == tables + 8 * (IH + IW)       # + one [lo, hi) range per input index
+    # anti-aliased down-scale by 2.5: support 2.5 (bilinear) -> 7 taps per output
+    aa = wn(2, 1, 250, 250, 100, 100, 0, -1.0, -1.0)
+    assert aa == 4 * 2 * 100 * (7 + 2)
+    assert wb(2, 0, 0, IW, OH, OW, 0, -1.0, -1.0) == 0 and wb(7, 0, IH, IW, OH, OW, 0, -1.0, -1.0) == 0
+    bwd = lib.tvmi_upsample2d_backward
+    bwd.restype = ctypes.c_int
+    bwd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 5 + \
+                   [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.tvmi_last_error.restype = ctypes.c_char_p
+    fake = ctypes.c_void_p(4096)    # never dereferenced: every call below is refused first
+    assert bwd(fake, fake, dt["TVMI_F32"], 0, 0, 0, IH, IW, OH, OW, 0, -1.0, -1.0, None, 0, None) == 0     # empty problem
+    assert bwd(fake, fake, dt["TVMI_F32"], 9, 0, 4, IH, IW, OH, OW, 0, -1.0, -1.0, fake, 1 << 20, None) != 0
+    assert b"mode" in lib.tvmi_last_error()
+    assert bwd(fake, fake, dt["TVMI_F32"], 0, 1, 4, IH, IW, OH, OW, 0, -1.0, -1.0, fake, 1 << 20, None) != 0
+    assert b"anti-aliasing" in lib.tvmi_last_error()
+    assert bwd(fake, fake, dt["TVMI_F64"], 2, 0, 4, IH, IW, OH, OW, 0, -1.0, -1.0, fake, 1 << 20, None) != 0
+    assert b"float32" in lib.tvmi_last_error()
+    assert bwd(fake, fake, dt["TVMI_F32"], 2, 0, 4, IH, IW, OH, OW, 0, -1.0, -1.0, None, 0, None) != 0
+    assert b"workspace" in lib.tvmi_last_error()
+    nn = lib.tvmi_upsample_nearest2d_any
+    nn.restype = ctypes.c_int
+    nn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 6 + [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    assert nn(fake, fake, 3, 4, IH, IW, OH, OW, 0, -1.0, -1.0, None) != 0 and b"element size" in lib.tvmi_last_error()
+    # stream helpers: argument checks only (no device here)
+    sc = lib.tvmi_stream_create_cu_mask
+    sc.restype = ctypes.c_int
+    assert sc(None, ctypes.c_uint32(0), None) != 0
+    assert lib.tvmi_stream_event_scope(ctypes.c_int(5)) != 0 and lib.tvmi_stream_event_scope(ctypes.c_int(1)) == 0
