@@ -1310,11 +1310,69 @@ def test_masked_segmented_nms_equals_compaction(n, nseg, live_frac):
     scores = torch.rand(n, generator=g).to(DEV)
     seg = torch.randint(0, nseg, (n,), generator=g).to(DEV)
     valid = (torch.rand(n, generator=g) < live_frac).to(DEV)
-    keep, num = torch.ops.tvmi.nms_segmented_masked(boxes, scores, seg, valid.to(torch.uint8), 0.5, nseg)
     sel = valid.nonzero()[:, 0]
     want = sel[torch.ops.tvmi.nms_segmented(boxes[sel], scores[sel], seg[sel], 0.5, nseg)] if sel.numel() else sel
-    assert int(num) == want.numel(), (int(num), want.numel())
-    assert torch.equal(keep[: int(num)], want)
+    # static per-segment bound: unknown (-1: n <= 4096 then takes the segment-major path, which cannot fail there) and the
+    # true one (small path when it is <= 1024)
+    bound = int(torch.bincount(seg, minlength=nseg).max())
+    for mx in (-1, bound):
+        keep, num = torch.ops.tvmi.nms_segmented_masked(boxes, scores, seg, valid.to(torch.uint8), 0.5, nseg, mx)
+        assert int(num) == want.numel(), (mx, int(num), want.numel())
+        assert torch.equal(keep[: int(num)], want), mx
+
+
+def test_masked_nms_limits_are_static_and_safe():
+    """ADVICE r05 (high / medium / low): the masked op used to return num = -1 for a segment above 1,024 boxes whenever
+    n <= 4096 (the same data passed at n = 4097), and the fused post-processing turned that -1 into empty detections.
+    Now (a) the small path is taken only under a static bound that fits it, (b) filter_proposals with a single-level RPN
+    and pre_nms_top_n = 2000 (2 images: n = 4000 <= 4096, 2000-box segments) equals the oracle, (c) beyond the device-count
+    limits (a segment bound above 8,192 / a grid above 1.2 M candidates) the host mirror compacts first, (d) a -1 that
+    still reaches the list-returning form raises instead of producing zeros."""
+    from vision_amd import detection_post as dp
+
+    g = gen(2000)
+    n = 4000
+    boxes = random_boxes(n, 900, 700, 8, 200, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    seg = (torch.arange(n) // 2000).to(DEV)
+    valid = torch.ones(n, dtype=torch.uint8, device=DEV)
+    want = torch.ops.tvmi.nms_segmented(boxes, scores, seg, 0.7, 2)
+    for mx in (-1, 2000, 4000):
+        keep, num = torch.ops.tvmi.nms_segmented_masked(boxes, scores, seg, valid, 0.7, 2, mx)
+        assert int(num) == want.numel() and torch.equal(keep[: int(num)], want), mx
+    # a wrong promise (bound 1000 for 2000-box segments) is reported, not silently mis-computed
+    keep, num = torch.ops.tvmi.nms_segmented_masked(boxes, scores, seg, valid, 0.7, 2, 1000)
+    assert int(num) == -1
+    with pytest.raises(RuntimeError, match="beyond its static bound"):
+        dp._split(torch.zeros(2, 5, 6, device=DEV), torch.tensor([-1, -1], device=DEV), False)
+    # (b) single-level RPN, training-size pre_nms_top_n
+    B, A = 2, 6000
+    shapes = [(600, 800), (576, 768)]
+    props = torch.stack([random_boxes(A, 800, 600, 4, 300, g) for _ in range(B)])
+    obj = torch.randn(B, A, generator=g)
+    kw = dict(pre_nms_top_n=2000, post_nms_top_n=2000, nms_thresh=0.7, score_thresh=0.0)
+    got_b, got_s = vision_amd.filter_proposals(props.to(DEV), obj.to(DEV), shapes, [A], **kw)
+    ref = O.filter_proposals(props.numpy(), obj.numpy(), shapes, [A], 2000, 2000, 0.7, 0.0, 1e-3)
+    for i, (rb, rs) in enumerate(ref):
+        assert got_b[i].shape[0] == rb.shape[0] > 200
+        np.testing.assert_allclose(got_s[i].cpu().numpy(), rs, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(got_b[i].cpu().numpy(), rb, rtol=0, atol=1e-4)
+    # (c) the compacting route (forced by lowering the limits) == the device-count route, padded form included
+    logits = torch.randn(600, 21, generator=g) * 3
+    reg = torch.randn(600, 84, generator=g) * 0.5
+    pr = [random_boxes(300, 800, 600, 8, 300, g).to(DEV) for _ in range(2)]
+    a = vision_amd.postprocess_detections(logits.to(DEV), reg.to(DEV), pr, shapes, padded=True)
+    cap, lim = dp.NMS_CAPACITY, dp.SEGMENT_LIMIT
+    try:
+        dp.NMS_CAPACITY = 1000
+        b = vision_amd.postprocess_detections(logits.to(DEV), reg.to(DEV), pr, shapes, padded=True)
+        dp.NMS_CAPACITY, dp.SEGMENT_LIMIT = cap, 100
+        c = vision_amd.postprocess_detections(logits.to(DEV), reg.to(DEV), pr, shapes, padded=True)
+    finally:
+        dp.NMS_CAPACITY, dp.SEGMENT_LIMIT = cap, lim
+    assert int(a[1].min()) > 0
+    for other in (b, c):
+        assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1])
 
 
 def test_batched_nms_partition_edge_cases():

@@ -64,6 +64,47 @@ def reference_package(scratch):
     return os.path.join(dst, "torchvision")
 
 
+TESTS_ARCHIVE = os.path.join(ROOT, "_staged", "reference_tests.tar.gz")
+# The reference's OWN tests of the hot path: test/test_ops.py (RoIOpTester, TestNMS, TestDeformConv,
+# TestRotatedBoxIou, opcheck), test/test_models.py (test_detection_model + its expect pickles), and what they import.
+TEST_FILES = ["test_ops.py", "test_models.py", "common_utils.py", "conftest.py", "_utils_internal.py", "optests_failures_dict.json", "assets/masks.tiff",
+              "assets/encode_jpeg/grace_hopper_517x606.jpg"]
+TEST_EXPECT = ("rcnn", "retinanet", "fcos", "ssd")
+
+
+def stage_tests(verbose=True):
+    """Archives the reference's own test files for the hot path (git-ignored, like the python package): they are run
+    UNCHANGED against our operator library by tests/run_reference_tests.py."""
+    src = os.path.join(REF, "test")
+    if not os.path.isdir(src):
+        return TESTS_ARCHIVE if os.path.exists(TESTS_ARCHIVE) else None
+    os.makedirs(os.path.dirname(TESTS_ARCHIVE), exist_ok=True)
+    names = list(TEST_FILES)
+    names += sorted(os.path.join("expect", f) for f in os.listdir(os.path.join(src, "expect"))
+                    if f.startswith("ModelTester.test_") and any(k in f for k in TEST_EXPECT))
+    with tarfile.open(TESTS_ARCHIVE, "w:gz") as tar:
+        for n in names:
+            tar.add(os.path.join(src, n), arcname=os.path.join("reference_tests", n))
+    if verbose:
+        print(f"[stage] {len(names)} reference test files archived in {TESTS_ARCHIVE}")
+    return TESTS_ARCHIVE
+
+
+def reference_tests(scratch):
+    """Directory holding the reference's test files: the live checkout, else the archive unpacked under `scratch`, else None."""
+    live = os.path.join(REF, "test")
+    if os.path.exists(os.path.join(live, "test_ops.py")):
+        return live
+    if not os.path.exists(TESTS_ARCHIVE):
+        return None
+    dst = os.path.join(scratch, "reference_tests")
+    if not os.path.exists(os.path.join(dst, "test_ops.py")):
+        with tarfile.open(TESTS_ARCHIVE, "r:gz") as tar:
+            tar.extractall(scratch)
+    return dst
+
+
 if __name__ == "__main__":
     stage()
+    stage_tests()
     sys.exit(0)

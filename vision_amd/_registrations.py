@@ -143,7 +143,9 @@ def _multiscale_backward(ctx, grad):
 
 
 def _fake_interpolate2d(input, out_h, out_w, mode, align_corners, antialias, scale_h, scale_w):
-    cl = not input.is_contiguous() and input.is_contiguous(memory_format=torch.channels_last)
+    # the real op: channels_last in -> channels_last out for every dtype and size (torch_shim.cpp interpolate2d)
+    cl = (not input.is_contiguous() and input.is_contiguous(memory_format=torch.channels_last) and input.numel() > 0
+          and out_h > 0 and out_w > 0)
     return torch.empty((input.size(0), input.size(1), out_h, out_w), dtype=input.dtype, device=input.device,
                        memory_format=torch.channels_last if cl else torch.contiguous_format)
 
@@ -178,7 +180,7 @@ def _fake_nms_padded(dets, scores, idxs, iou_threshold, num_segments=-1):
     return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
 
 
-def _fake_nms_masked(dets, scores, idxs, valid, iou_threshold, num_segments=-1):
+def _fake_nms_masked(dets, scores, idxs, valid, iou_threshold, num_segments=-1, max_segment_size=-1):
     return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
 
 

@@ -210,9 +210,14 @@ std::tuple<at::Tensor, at::Tensor> nms_segmented_padded(const at::Tensor& dets, 
 // (score -inf / key INT64_MAX -> behind every live candidate in both sorts; the kernels read the live count from memory), so
 // the detector post-processing needs no `nonzero` compaction and no host read between the candidate kernel and the packing
 // launch.  keep holds indices into the UNcompacted candidate list, in the reference's order (descending score, stable).
-// A segment above 8,192 live boxes (or, small form, an id outside [0, num_segments)) gives num = -1.
+// Limits (checked on the device, reported as num = -1): a segment above 8,192 live boxes on the segment-major path; an id outside
+// [0, num_segments) or a segment above 1,024 live boxes on the small path.  `max_segment_size` is the caller's STATIC bound on the
+// boxes of one segment (-1 = unknown -> n): the small path is taken only when the bound fits it, so with n <= 8192 or
+// max_segment_size <= 8192 (and ids in range) the op cannot come back with -1 (the same data used to fail at n = 4096
+// and pass at n = 4097).  `vision_amd.detection_post._masked_nms` routes anything beyond these limits to the compacting form.
 std::tuple<at::Tensor, at::Tensor> nms_segmented_masked(const at::Tensor& dets, const at::Tensor& scores, const at::Tensor& seg,
-                                                        const at::Tensor& valid, double iou_threshold, int64_t num_segments) {
+                                                        const at::Tensor& valid, double iou_threshold, int64_t num_segments,
+                                                        int64_t max_segment_size) {
   TORCH_CHECK(dets.is_cuda() && scores.is_cuda() && seg.is_cuda() && valid.is_cuda(), "nms_segmented_masked: CUDA tensors expected");
   TORCH_CHECK(dets.dim() == 2 && dets.size(1) == 4, "boxes should be a 2d tensor [N, 4]");
   const int64_t n = dets.size(0);
@@ -242,7 +247,8 @@ std::tuple<at::Tensor, at::Tensor> nms_segmented_masked(const at::Tensor& dets, 
                                              sws.mutable_data_ptr(), sb, current_stream(dets)),
                  "sort_scores_desc_large");
   }
-  if (n <= 4096 && num_segments >= 1 && num_segments <= 1024) {
+  const int64_t seg_bound = (max_segment_size < 0 || max_segment_size > n) ? n : max_segment_size;
+  if (n <= 4096 && num_segments >= 1 && num_segments <= 1024 && seg_bound <= 1024) {
     const size_t sb = tvmi_nms_small_segments_workspace_bytes(n, num_segments);
     at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
     check_status(tvmi_nms_small_segments_devcount(boxes.const_data_ptr(), order.const_data_ptr<int64_t>(), sg_m.const_data_ptr<int64_t>(),
@@ -646,6 +652,11 @@ at::Tensor interpolate2d(const at::Tensor& input, int64_t out_h, int64_t out_w, 
                  "interpolate2d");
     return out;
   }
+  // channels_last inputs the NHWC kernels do not take (float64, sizes beyond their grid limits): computed in NCHW and handed
+  // back channels_last, so the output layout depends on the input layout alone (the fake kernel promises exactly that)
+  if (!input.is_contiguous() && input.is_contiguous(at::MemoryFormat::ChannelsLast) && input.numel() > 0 && out_h > 0 && out_w > 0)
+    return interpolate2d(input.contiguous(), out_h, out_w, mode, align_corners, antialias, scale_h, scale_w)
+        .contiguous(at::MemoryFormat::ChannelsLast);
   at::Tensor in_c = input.contiguous();
   at::Tensor out = at::empty({N, C, out_h, out_w}, in_c.options());
   if (out.numel() == 0) return out;
@@ -1426,7 +1437,7 @@ TORCH_LIBRARY(tvmi, m) {
   m.def("nms_segmented(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold, int num_segments=-1) -> Tensor");
   // the same without the host sync on the result size: (keep [n] with a valid prefix, num [1] on the device)
   m.def("nms_segmented_padded(Tensor dets, Tensor scores, Tensor? idxs, float iou_threshold, int num_segments=-1) -> (Tensor, Tensor)");
-  m.def("nms_segmented_masked(Tensor dets, Tensor scores, Tensor idxs, Tensor valid, float iou_threshold, int num_segments=-1) -> (Tensor, Tensor)");
+  m.def("nms_segmented_masked(Tensor dets, Tensor scores, Tensor idxs, Tensor valid, float iou_threshold, int num_segments=-1, int max_segment_size=-1) -> (Tensor, Tensor)");
   m.def(
       "pack_detections_devcount(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, Tensor num_keep, int num_images, int max_dets) -> (Tensor, Tensor)");
   // the same launch writing the all-gather payload [B, max_dets * 6 + 1] in place (the count in the last column)

@@ -42,9 +42,32 @@ def _need_cuda(t: Tensor, what: str):
         raise RuntimeError(f"vision_amd.{what} needs device tensors (no CPU fallback in the product path)")
 
 
+# limits of the device-count NMS forms (nms.hip: capacity check of nms_segmented_entry; per-segment limit of the banded
+# segment-major sweep).  Up to these the masked op cannot fail; beyond them `_masked_nms` compacts first.
+NMS_CAPACITY = 1_200_000
+SEGMENT_LIMIT = 8192
+
+
+def _masked_nms(b: Tensor, s: Tensor, seg: Tensor, valid: Tensor, thresh: float, num_segments: int, max_per_segment: int):
+    """(keep, num) of the class/level-segmented NMS over the live candidates.  `max_per_segment`: the caller's static bound on
+    the candidates of one segment.  Within the limits of the device-count kernels this is ONE masked op with no host read;
+    beyond them (a candidate grid above 1.2 M entries — Faster R-CNN heads with ~1200 classes, 91 classes from batch 14; or a
+    segment that may exceed 8,192 boxes — rpn_pre_nms_top_n > 8192) the live candidates are compacted first (`nonzero`: one
+    host read) and the general path of tvmi::nms_segmented takes them.  Never a silently wrong list (ADVICE r05)."""
+    n = b.shape[0]
+    if n <= NMS_CAPACITY and min(n, max_per_segment) <= SEGMENT_LIMIT:
+        return torch.ops.tvmi.nms_segmented_masked(b, s, seg, valid, thresh, num_segments, int(max_per_segment))
+    live = torch.nonzero(valid).squeeze(1)
+    keep = live[torch.ops.tvmi.nms_segmented(b[live], s[live], seg[live], thresh, -1)]
+    return keep, torch.full((1,), keep.numel(), dtype=torch.int64, device=b.device)
+
+
 def _split(dets: Tensor, counts: Tensor, with_labels: bool):
     boxes, scores, labels = [], [], []
     for d, n in zip(dets, counts.tolist()):
+        if n < 0:
+            raise RuntimeError("vision_amd: the segmented NMS reported a segment beyond its static bound "
+                               "(tvmi::nms_segmented_masked returned -1); no detections were produced")
         d = d[:n]
         boxes.append(d[:, :4])
         scores.append(d[:, 4])
@@ -78,7 +101,8 @@ def filter_proposals(proposals: Tensor, objectness: Tensor, image_shapes: Sequen
         top_idx, offsets, _image_hw(image_shapes, proposals.device), BBOX_XFORM_CLIP, float(score_thresh), float(min_size))
     img = torch.arange(B, device=proposals.device, dtype=torch.int64).repeat_interleave(T)          # image of candidate i (static shape)
     b, s = boxes.reshape(-1, 4), scores.reshape(-1)
-    keep, num = torch.ops.tvmi.nms_segmented_masked(b, s, img * L + levels.reshape(-1), valid.reshape(-1), float(nms_thresh), B * L)
+    per_level = max(min(int(pre_nms_top_n), int(n)) for n in num_anchors_per_level)
+    keep, num = _masked_nms(b, s, img * L + levels.reshape(-1), valid.reshape(-1), float(nms_thresh), B * L, per_level)
     dets, counts = torch.ops.tvmi.pack_detections_devcount(b, s, None, img, keep, num, B, int(post_nms_top_n))
     return (dets, counts) if padded else _split(dets, counts, False)
 
@@ -108,7 +132,7 @@ def postprocess_detections(class_logits: Tensor, box_regression: Tensor, proposa
     labels = torch.arange(1, C, device=dev, dtype=torch.int64).repeat(R)
     img = row_image.to(torch.int64).repeat_interleave(C - 1)
     b, s = cb.reshape(-1, 4), cs.reshape(-1)
-    keep, num = torch.ops.tvmi.nms_segmented_masked(b, s, img * C + labels, cv.reshape(-1), float(nms_thresh), B * C)
+    keep, num = _masked_nms(b, s, img * C + labels, cv.reshape(-1), float(nms_thresh), B * C, max(sizes, default=0))
     dets, counts = torch.ops.tvmi.pack_detections_devcount(b, s, labels, img, keep, num, B, int(detections_per_img))
     return (dets, counts) if padded else _split(dets, counts, True)
 
@@ -153,7 +177,7 @@ def retinanet_postprocess_detections(cls_logits: Sequence[Tensor], bbox_regressi
                                                         BBOX_XFORM_CLIP, 0.0, -1.0)
     img = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(T)
     b, sc, lab = boxes.reshape(-1, 4), scores.reshape(-1), labels.reshape(-1)
-    keep, num = torch.ops.tvmi.nms_segmented_masked(b, sc, img * K + lab, ok.reshape(-1), float(nms_thresh), B * K)
+    keep, num = _masked_nms(b, sc, img * K + lab, ok.reshape(-1), float(nms_thresh), B * K, T)
     dets, counts = torch.ops.tvmi.pack_detections_devcount(b, sc, lab, img, keep, num, B, int(detections_per_img))
     if padded:
         return dets, counts

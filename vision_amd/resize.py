@@ -74,7 +74,10 @@ class _Interpolate2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         shape, oh, ow, mode, align, antialias, scale_h, scale_w = ctx.cfg
-        if grad.dtype in (torch.float32, torch.float16, torch.bfloat16):
+        # create_graph=True (grad mode on inside backward): ATen's `upsample_*_backward` ops carry a derivative formula,
+        # tvmi::interpolate2d_backward does not — double backward keeps working through them.  A channels_last
+        # grad is read through a contiguous copy and the gradient comes back NCHW-contiguous.
+        if grad.dtype in (torch.float32, torch.float16, torch.bfloat16) and not (torch.is_grad_enabled() and grad.requires_grad):
             gi = torch.ops.tvmi.interpolate2d_backward(grad, shape[2], shape[3], _MODES[mode], align, antialias, scale_h, scale_w)
             return gi, None, None, None, None, None, None, None
         sh = None if scale_h <= 0 else scale_h
