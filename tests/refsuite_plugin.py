@@ -28,7 +28,12 @@ def pytest_configure(config):
                                   if "tvmi" in line or "libtv_ref_cpu" in line})
 
 
-def pytest_report_header(config):
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    for line in _header(config):
+        terminalreporter.write_line(line)
+
+
+def _header(config):
     import torch
     import torchvision
 

@@ -9,6 +9,8 @@ the detectors their time —
     torchvision.models.detection.rpn.RegionProposalNetwork.filter_proposals  (rpn.py:242-297)
     torchvision.models.detection.retinanet.RetinaNet.postprocess_detections  (retinanet.py:509-571)
     torchvision.models.detection.transform.GeneralizedRCNNTransform.forward / .postprocess (transform.py:119-276)
+    torchvision.ops.roi_align._roi_align                                     (ops/roi_align.py:276-281: the python detour
+        under torch.use_deterministic_algorithms(True) — our backward IS deterministic, so CUDA tensors stay on the op)
 
 — for the method factories of `vision_amd.integration` (the ones `fuse_detection_model` binds to a single model).  Every
 replacement calls the reference's own method whenever the fused path does not apply (CPU tensors, training / targets,
@@ -29,8 +31,9 @@ import sys
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# module -> [(class name, method name, factory in vision_amd.integration)]
+# module -> [(class name — None for a module-level function —, method name, factory in vision_amd.integration)]
 _TARGETS = {
+    "torchvision.ops.roi_align": [(None, "_roi_align", "make_deterministic_roi_align")],
     "torchvision.ops.poolers": [("MultiScaleRoIAlign", "forward", "make_pool_forward")],
     "torchvision.models.detection.roi_heads": [("RoIHeads", "postprocess_detections", "make_postprocess_detections")],
     "torchvision.models.detection.rpn": [("RegionProposalNetwork", "filter_proposals", "make_filter_proposals")],
@@ -45,7 +48,7 @@ _state = {"finder": None}
 def _lazy_method(orig, factory_name, module):
     built = {}
 
-    def method(self, *args, **kwargs):
+    def method(*args, **kwargs):
         fn = built.get("fn")
         if fn is None:
             os.environ.setdefault("TVMI_NO_PY_REGISTRATIONS", "1")     # the reference package registered the torchvision:: fakes
@@ -59,7 +62,7 @@ def _lazy_method(orig, factory_name, module):
             else:
                 fn = factory(orig)
             built["fn"] = fn
-        return fn(self, *args, **kwargs)
+        return fn(*args, **kwargs)
 
     method.__name__ = getattr(orig, "__name__", "method")
     method.__qualname__ = getattr(orig, "__qualname__", method.__name__)
@@ -71,7 +74,7 @@ def _lazy_method(orig, factory_name, module):
 
 def _patch_module(module):
     for cls_name, meth, factory_name in _TARGETS.get(module.__name__, ()):
-        cls = getattr(module, cls_name, None)
+        cls = module if cls_name is None else getattr(module, cls_name, None)
         orig = None if cls is None else cls.__dict__.get(meth)
         if orig is None or getattr(orig, "_tvmi_autofused", False):
             continue

@@ -170,6 +170,23 @@ def make_transform_postprocess(orig):
     return postprocess
 
 
+def make_deterministic_roi_align(orig):
+    """`torchvision.ops.roi_align._roi_align` — the pure-python RoIAlign the reference detours to on GPU tensors under
+    `torch.use_deterministic_algorithms(True)` because ITS backward scatters with atomics (ops/roi_align.py:276-281,
+    cuda/roi_align_kernel.cu:304-327).  Ours is the tile-owner backward (roi_align_bwd.hip: one writer per pixel, fixed
+    summation order, bit-reproducible), so CUDA tensors of the types the op serves stay on `torchvision::roi_align`; anything
+    else (no ops loaded, other devices) keeps the reference's python."""
+    import torch
+
+    def _roi_align(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio=-1, aligned=False):
+        if (_tracing() or not input.is_cuda or not rois.is_cuda
+                or input.dtype not in (torch.float32, torch.float64, torch.float16, torch.bfloat16)):
+            return orig(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, aligned)
+        return torch.ops.torchvision.roi_align(input, rois.to(input.dtype), spatial_scale, pooled_height, pooled_width,
+                                               sampling_ratio, aligned)
+    return _roi_align
+
+
 def fuse_detection_model(model, paste_masks: bool = True, transform: bool = True):
     """Swap the fused `vision_amd` pieces into a detection model of the reference (`torchvision.models.detection`:
     Faster R-CNN / Mask R-CNN / Keypoint R-CNN = GeneralizedRCNN with RoIHeads + RPN, or RetinaNet), in place, and return it.
