@@ -647,6 +647,76 @@ def other_configs(device):
         out[f"deform_conv2d_backward_g1_{tag}"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "TFLOPs": round(2 * flops / ms / 1e9, 1),
                                                    "frac_of_mfma_peak": round(2 * flops / ms / 1e9 / peak, 4), "peak_TFLOPs": peak,
                                                    "note": "fp32 tensors on v_mfma_f32_32x32x2_f32, 16-bit tensors on v_mfma_f32_32x32x16_{bf16,f16} (round 5), fp32 accumulation; 12 calls"}
+    del cfg4, h
+    torch.cuda.empty_cache()
+    # ---- round 6: the rows north_star names that lived only in the builder's matrix
+    # BASELINE config 1 on the GPU (its CPU form is the reference's own plumbing case): 1x256x200x272 fp32 map, 1000 RoIs 7x7 + nms(1000)
+    g = torch.Generator().manual_seed(0)
+    c1 = []
+    for i in range(nsets):
+        x = torch.randn(1, 256, 200, 272, generator=g).to(device)
+        xy = torch.rand(1000, 2, generator=g) * torch.tensor([1088 - 64.0, 800 - 64.0])
+        wh = 16 + torch.rand(1000, 2, generator=g) * 284
+        r1 = torch.cat([torch.zeros(1000, 1), xy, torch.minimum(xy + wh, torch.tensor([1088.0, 800.0]))], 1).to(device)
+        c1.append((x, r1, r1[:, 1:].contiguous(), torch.rand(1000, generator=g).to(device)))
+    ms_r, mn_r = med(lambda i: tv.roi_align(c1[i % nsets][0], c1[i % nsets][1], 0.25, 7, 7, 2, False))
+    ms_n, mn_n = med(lambda i: tv.nms(c1[i % nsets][2], c1[i % nsets][3], NMS_THR))
+    c1_bytes = (256 * 200 * 272 + 1000 * 256 * 49 + 5000) * 4
+    out["config1_roi_align_1x256x200x272_1000rois_7x7"] = {"ms": round(ms_r, 4), "min_ms": round(mn_r, 4), "GBs": round(c1_bytes / ms_r / 1e6, 1),
+                                                           "frac_of_hbm_peak": round(c1_bytes / ms_r / 1e6 / HBM_PEAK_GBS, 4)}
+    out["config1_nms_1000"] = {"ms": round(ms_n, 4), "min_ms": round(mn_n, 4), "boxes_per_s_roi_align_plus_nms": round(1000 / (ms_r + ms_n) * 1e3, 1),
+                               "note": "torchvision::nms incl. the score sort and the output-size read"}
+    del c1
+    # resize (transforms/v2/functional/_geometry.py:283-362 -> F.interpolate): 8x3x1080x1920 fp32 -> 800x1422, bytes = input + output
+    big = [torch.rand(8, 3, 1080, 1920, generator=g).to(device) for _ in range(nsets)]
+    rz_bytes = (8 * 3 * 1080 * 1920 + 8 * 3 * 800 * 1422) * 4
+    for mode, aa in (("bilinear", False), ("bilinear", True), ("bicubic", False), ("bicubic", True), ("nearest", False)):
+        ms, mn = med(lambda i: vision_amd.interpolate(big[i % nsets], size=(800, 1422), mode=mode, **({} if mode == "nearest" else {"antialias": aa})), n=12)
+        out[f"resize_8x3x1080x1920_to_800x1422_{mode}{'_aa' if aa else ''}"] = {
+            "ms": round(ms, 4), "min_ms": round(mn, 4), "GBs": round(rz_bytes / ms / 1e6, 1), "frac_of_hbm_peak": round(rz_bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    go = torch.randn(8, 3, 800, 1422, device=device)
+    ms, mn = med(lambda i: torch.ops.tvmi.interpolate2d_backward(go, 1080, 1920, 2, False, False, -1.0, -1.0), n=12)
+    out["resize_bwd_8x3x800x1422_to_1080x1920_bilinear"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "GBs": round(rz_bytes / ms / 1e6, 1),
+                                                            "frac_of_hbm_peak": round(rz_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                            "note": "gather form: a lane owns an input pixel, deterministic"}
+    del big, go
+    # RoIPool (cuda/roi_pool_kernel.cu:15-78) on a config-2-shaped single-level workload: 4x256x100x168 map (stride 8), 4000 RoIs, 7x7;
+    # bytes = map + values + argmax (forward), grads + argmax read + gradient map written (backward)
+    rp = []
+    for i in range(nsets):
+        x = torch.randn(4, 256, 100, 168, generator=g).to(device)
+        xy = torch.rand(4000, 2, generator=g) * torch.tensor([1344 - 64.0, 800 - 64.0])
+        wh = 32 + torch.rand(4000, 2, generator=g) * 368
+        img = torch.arange(4).repeat_interleave(1000).float()[:, None]
+        rp.append((x, torch.cat([img, xy, torch.minimum(xy + wh, torch.tensor([1344.0, 800.0]))], 1).to(device)))
+    in_b, out_b = 4 * 256 * 100 * 168 * 4, 4000 * 256 * 49 * 4
+    ms, mn = med(lambda i: tv.roi_pool(rp[i % nsets][0], rp[i % nsets][1], 0.125, 7, 7))
+    out["roi_pool_fwd_4x256x100x168_4000rois_7x7"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "GBs": round((in_b + 2 * out_b) / ms / 1e6, 1),
+                                                      "frac_of_hbm_peak": round((in_b + 2 * out_b) / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    y, am = tv.roi_pool(rp[0][0], rp[0][1], 0.125, 7, 7)
+    gr = torch.randn_like(y)
+    ms, mn = med(lambda i: tv._roi_pool_backward(gr, rp[0][1], am, 0.125, 7, 7, 4, 256, 100, 168), n=12)
+    out["roi_pool_bwd_4x256x100x168_4000rois_7x7"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "GBs": round((in_b + 2 * out_b) / ms / 1e6, 1),
+                                                      "frac_of_hbm_peak": round((in_b + 2 * out_b) / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del rp, y, am, gr
+    # rotated IoU (csrc/ops/box_iou_rotated_utils.h:67-383): 2000 x 2000 boxes (cx, cy, w, h, angle), fp32 matrix out
+    ra, rb_ = [torch.cat([torch.rand(2000, 2, generator=g) * 800, torch.rand(2000, 2, generator=g) * 200 + 4,
+                          (torch.rand(2000, 1, generator=g) - 0.5) * 180], 1).to(device) for _ in range(2)]
+    ms, mn = med(lambda i: tv.box_iou_rotated(ra, rb_), n=12)
+    out["box_iou_rotated_2000x2000"] = {"ms": round(ms, 4), "min_ms": round(mn, 4), "Mpairs_per_s": round(4e6 / ms / 1e3, 1),
+                                        "note": "VALU-bound polygon clipping (no MFMA shape, 16 MB out): pairs/s is the figure of merit"}
+    # MFMA utilisation of the deform_conv2d kernels from the committed SQ-counter passes (like roofline.traffic: a separate
+    # rocprofv3 --pmc run, tools/prof_pmc_sq.sh + tools/pmc_summary.py -> profiles/dcn_mfma_busy.json)
+    mpath = os.path.join(ROOT, "profiles", "dcn_mfma_busy.json")
+    if os.path.exists(mpath):
+        try:
+            mj = json.load(open(mpath))
+            for key, row in mj.get("rows", {}).items():
+                if key in out:
+                    out[key]["mfma_busy_frac"] = row.get("mfma_busy_frac")
+                    out[key]["mfma_busy_source"] = row.get("source")
+        except Exception:
+            pass
     return out
 
 
@@ -729,6 +799,16 @@ def config5_block(rank, local_rank, world):
     except Exception as exc:  # pragma: no cover - depends on the box
         out["retinanet_error"] = f"{type(exc).__name__}: {exc}"
     out["wall_s"] = round(time.perf_counter() - t0, 1)
+    # where the GPU time of the fused step goes: a committed rocprofv3 --kernel-trace of tools/e2e_maskrcnn.py
+    # --variant fused, summarised by tools/kernel_share.py (a separate profiler run, like roofline.traffic)
+    kpath = os.path.join(ROOT, "profiles", "config5_kernel_share.json")
+    if os.path.exists(kpath):
+        try:
+            ks = json.load(open(kpath))
+            out["kernel_share"] = {"share_of_kernel_time": ks.get("share_of_kernel_time"), "idle_frac_of_span": ks.get("idle_frac_of_span"),
+                                   "top_kernel": (ks.get("top_kernels") or [{}])[0], "source": ks.get("source", "profiles/config5_kernel_share.json")}
+        except Exception:
+            pass
     return out
 
 

@@ -1,22 +1,66 @@
-"""Share of GPU time per kernel family from a rocprofv3 --kernel-trace --stats output directory:
-ours (namespace tvmi::) vs library kernels (MIOpen / hipBLASLt / ATen)."""
+"""Share of GPU time per kernel family from a rocprofv3 --kernel-trace [--stats] output directory:
+ours (namespace tvmi::) vs library kernels (MIOpen / Tensile / CK) vs ATen, and the idle share of the steady-state window.
+
+    python tools/kernel_share.py <dir> [out.json]
+
+Families: tvmi = our HIP kernels; conv_gemm = MIOpen / Tensile (Cijk_*) / composable_kernel / rocBLAS; aten = at::native
+elementwise / reduction / indexing / sort / copy kernels; other = the rest.  Idle = 1 - (union of kernel intervals / span) over the
+LAST HALF of the trace's dispatches (steady state: model build, first-use compilation and warm-up steps lie in the first half)."""
 import csv
 import glob
+import json
 import os
 import sys
 
-d = sys.argv[1]
-files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
-if not files:
-    sys.exit(f"no *kernel_stats.csv under {d}")
-rows = list(csv.DictReader(open(files[0])))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-ours = [r for r in rows if "tvmi::" in r["Name"]]
-t_ours = sum(float(r["TotalDurationNs"]) for r in ours)
-print(f"kernels: {len(rows)}   GPU time in kernels: {tot / 1e6:.2f} ms   in tvmi:: kernels: {t_ours / 1e6:.2f} ms = {100 * t_ours / tot:.1f} %")
-print("top 12 kernels:")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]:
-    print(f"  {100 * float(r['TotalDurationNs']) / tot:5.1f} %  calls {r['Calls']:>6}  avg {float(r['AverageNs']) / 1e3:9.1f} us  {r['Name'][:110]}")
-print("tvmi:: kernels:")
-for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
-    print(f"  {100 * float(r['TotalDurationNs']) / tot:5.2f} %  calls {r['Calls']:>6}  avg {float(r['AverageNs']) / 1e3:9.1f} us  {r['Name'][:110]}")
+
+def family(name):
+    n = name.lower()
+    if "tvmi::" in name:
+        return "tvmi"
+    if any(t in n for t in ("miopen", "cijk_", "igemm", "gridwise", "ck::", "ck_tile", "naive_conv", "rocblas", "winograd", "conv_", "gemm", "batched_transpose", "sp3asm", "gfx9_")):
+        return "conv_gemm"
+    if any(t in n for t in ("at::native", "elementwise", "vectorized", "reduce_kernel", "index", "cunn", "rocprim", "hipcub", "at::cuda", "cat_", "copy")):
+        return "aten"
+    return "other"
+
+
+def main(d, out_path=None):
+    traces = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if not traces:
+        sys.exit(f"no *kernel_trace.csv under {d}")
+    rows = []
+    for r in csv.DictReader(open(traces[0])):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    steady = rows[len(rows) // 2:]
+    span = max(e for _, e, _ in steady) - steady[0][0]
+    busy, cur_s, cur_e = 0, steady[0][0], steady[0][1]
+    for s, e, _ in steady[1:]:
+        if s > cur_e:
+            busy += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_s
+    fam, per_kernel = {}, {}
+    for s, e, n in steady:
+        f = family(n)
+        fam[f] = fam.get(f, 0) + (e - s)
+        k = per_kernel.setdefault(n, [0, 0])
+        k[0] += e - s
+        k[1] += 1
+    tot = sum(fam.values())
+    out = {"window": "last half of the dispatches of the trace (steady state)", "dispatches": len(steady), "span_ms": round(span / 1e6, 3),
+           "kernel_time_ms": round(tot / 1e6, 3), "idle_frac_of_span": round(1 - busy / span, 4),
+           "share_of_kernel_time": {f: round(v / tot, 4) for f, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+           "top_kernels": [{"share": round(v[0] / tot, 4), "calls": v[1], "avg_us": round(v[0] / v[1] / 1e3, 1), "family": family(n), "name": n[:100]}
+                           for n, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])[:14]],
+           "tvmi_kernels": [{"share": round(v[0] / tot, 4), "calls": v[1], "avg_us": round(v[0] / v[1] / 1e3, 1), "name": n[:100]}
+                            for n, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][0]) if family(n) == "tvmi"][:16]}
+    print(json.dumps(out, indent=1))
+    if out_path:
+        json.dump(out, open(out_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
