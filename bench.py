@@ -108,6 +108,8 @@ def main():
                     "four-tile workgroups whose LDS fits next to the RoIAlign launch; 0: the one-launch form (21 KB of LDS)")
     ap.add_argument("--nms-sort-rank", type=int, default=1, help="1 (default): score order of <= 4096 boxes by rank counting (3 KB of "
                     "LDS, n / 64 workgroups); 0: the one-workgroup bitonic sort (32 KB)")
+    ap.add_argument("--nms-step-fused", type=int, default=1, help="1 (default): the step's batched NMS + payload as ONE launch "
+                    "(tvmi::nms_step); 0: round 5's chain of five launches")
     ap.add_argument("--reserve-cus", type=int, default=0, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
                     "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD).  0 (default) = two ordinary streams: since "
                     "every launch of the NMS chain fits into the 4 KB of LDS the RoIAlign kernel leaves on a CU, no CU has to be kept free")
@@ -191,6 +193,12 @@ def main():
             part["note"] = f"{type(exc).__name__}: {exc}"
             print(f"[bench] CU-partitioned streams unavailable ({part['note']}); two ordinary streams", file=sys.stderr)
 
+    torch.ops.tvmi.set_option("nms.step_fused", int(args.nms_step_fused))
+    if not args.nms_step_fused:
+        def _chain(boxes_, scores_, idxs_, thr_, nseg_, img_, nimg_, maxd_):
+            k_, n_ = vision_amd.boxes.batched_nms_padded(boxes_, scores_, idxs_, thr_, nseg_)
+            return k_, n_, sharding.pack_kept_payload(boxes_, scores_, img_, k_, n_, nimg_, maxd_)
+        sharding.nms_pack_payload = _chain
     torch.ops.tvmi.set_option("nms.small_split", int(args.nms_small_split))
     torch.ops.tvmi.set_option("nms.sort_rank", int(args.nms_sort_rank))
     # fork / join of the two streams: device-scope events (vision_amd.streams.wait_stream) unless --torch-events
@@ -213,10 +221,10 @@ def main():
         if side is not cur and args.diag_skip not in ("fork", "both"):
             fork_join(side, cur)
         with torch.cuda.stream(side):
-            keep, num = vision_amd.boxes.batched_nms_padded(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH)  # per-image NMS
-            # padded top-MAX_DETS detections per image + the count of every image, written as the collective payload itself:
-            # fixed shape, ONE launch, keep length read on the device — nothing is assembled between the NMS and the all-gather
-            payload = sharding.pack_kept_payload(d["all_boxes"], d["all_scores"], img_idx, keep, num, BATCH, MAX_DETS)
+            # per-image NMS + the padded top-MAX_DETS detections per image with the count of every image, written as the
+            # collective payload itself (fixed shape, keep length read on the device): ONE launch (tvmi::nms_step, round 6;
+            # --nms-step-fused 0 = round 5's chain: score sort, collect, tiles, sweep, pack)
+            keep, num, payload = sharding.nms_pack_payload(d["all_boxes"], d["all_scores"], img_idx, NMS_THR, BATCH, img_idx, BATCH, MAX_DETS)
         pooled = pool(d["feats"], d["boxes"], image_shapes)                                 # [4000, 256, 7, 7], 1 launch
         if side is not cur:
             if args.diag_skip not in ("join", "both"):
@@ -374,9 +382,9 @@ def main():
     with torch.no_grad():
         # exactly what pool() launches, without its python-side roi formatting
         k_ms = timed(lambda i: torch.ops.tvmi.multiscale_roi_align(sets[i % N_SETS]["flist"], sets[i % N_SETS]["rois5"], scales, *ms_args))
-        # NMS alone, for the breakdown in `config`
-        nms_ms = timed(lambda i: vision_amd.boxes.batched_nms_padded(sets[i % N_SETS]["all_boxes"], sets[i % N_SETS]["all_scores"],
-                                                                      img_idx, NMS_THR, BATCH))
+        # NMS + payload alone (what the step launches), for the breakdown in `config`
+        nms_ms = timed(lambda i: sharding.nms_pack_payload(sets[i % N_SETS]["all_boxes"], sets[i % N_SETS]["all_scores"], img_idx, NMS_THR,
+                                                           BATCH, img_idx, BATCH, MAX_DETS))
         # dense variant: proposals clustered around 40 objects per image, most boxes are suppressed
         dg = torch.Generator().manual_seed(5)
         centers = torch.rand(BATCH, 40, 2, generator=dg) * torch.tensor([IMG_W - 200.0, IMG_H - 200.0])
@@ -470,6 +478,7 @@ def main():
             "fork_join_events": {1: "device-scope release", 0: "system-scope release", 2: "no event fence", -1: "torch wait_stream"}[args.event_scope],
             ("one_stream_ms_per_step" if args.overlap else "two_stream_ms_per_step"): None if other_stream_ms is None else round(other_stream_ms, 4),
             "hip_graph": graph is not None,
+            "nms_step_one_launch": bool(args.nms_step_fused),
             "parallelism": f"images sharded over {world} GPU(s), one process per GPU"
                            + (" (1-rank RCCL group, the all-gather run as a real collective: --force-collective)" if args.force_collective else ""),
         },

@@ -44,7 +44,7 @@ typedef enum {
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
  * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
-#define TVMI_ABI_VERSION 305
+#define TVMI_ABI_VERSION 306
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
@@ -205,6 +205,24 @@ int tvmi_nms_small_segments_devcount(const void* dets, const int64_t* order, con
                                      void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
                                      void* stream);
 
+/* The detector step's batched NMS (+ padded top-k payload) in ONE launch (round 6).  Replaces, on the GPU, the python chain
+ * torchvision/ops/boxes.py:57-126 (`batched_nms`: coordinate trick or per-class loop -> torchvision::nms -> index) followed
+ * by the per-image split / top-k of models/detection/roi_heads.py:716-737 — and this library's own 4-5 launch chain for the
+ * same sizes (score sort, collect, tiles, sweep, pack).
+ *   dets [n,4] / scores [n] float32, seg [n] int64 in [0, num_segments) (NULL with num_segments = 1: plain nms),
+ *   1 <= n <= 4096, num_segments <= 64, every segment <= 1024 boxes (else *num_keep_out = -1, keep_out unspecified).
+ *   keep_out [n] int64: indices of the kept boxes in descending score order over all segments (ties by index), the
+ *   reference's result; num_keep_out [1] int64 on the device.  No host synchronisation; one memset + one kernel.
+ *   payload != NULL: additionally row b of payload (row_stride floats apart) = the first max_dets kept boxes of image b as
+ *   (x1, y1, x2, y2, score, label) zero-padded, + the count behind them when count_in_row; counts [num_images] int32
+ *   optional; image_idx [n] int64 gives the image of every box (may be `seg` itself), labels optional; num_images <= 16.
+ *   The rows are what tvmi_pack_detections_payload writes from (keep_out, num_keep_out). */
+size_t tvmi_nms_step_workspace_bytes(int64_t n, int64_t num_segments);
+int tvmi_nms_step(const float* dets, const float* scores, const int64_t* seg, int64_t n, int64_t num_segments,
+                  double iou_threshold, void* workspace, size_t workspace_bytes, int64_t* keep_out, int64_t* num_keep_out,
+                  const int64_t* image_idx, const int64_t* labels, int64_t num_images, int64_t max_dets, float* payload,
+                  int64_t row_stride, int32_t* counts, int count_in_row, void* stream);
+
 /* ------------------------------------------------------------- RoIAlign ----------
  * Replaces: torchvision/csrc/ops/cuda/roi_align_kernel.cu:68-143,334-394 (forward),
  * :204-332,396-466 (backward); arithmetic follows
@@ -277,6 +295,18 @@ int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void*
                                        double canonical_scale, double canonical_level, double eps, int64_t n_stride,
                                        int64_t c_stride, int64_t h_stride, int64_t w_stride, void* workspace,
                                        size_t workspace_bytes, void* stream);
+
+/* tvmi_multiscale_roi_align_forward taking the PER-IMAGE BOX LISTS MultiScaleRoIAlign.forward receives (ops/poolers.py:289-321)
+ * instead of [K,5] rows (round 6): boxes[i] = [counts[i], 4] float32 device boxes of image i, num_images <= 64.  The rows of
+ * convert_boxes_to_roi_format (ops/_utils.py:18-25) are written to rois_out [K,5] float32 (K = sum of counts; the backward takes
+ * them) by the launch-order pre-pass of this call where that runs (7x7 / 14x14 bins with sampling_ratio 2, a multiple of 256
+ * channels, workspace given) — otherwise by tvmi_boxes_to_rois in front of the plain entry.  Same result either way. */
+int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs, const int64_t* heights, const int64_t* widths,
+                                            const double* spatial_scales, int64_t n_levels, const void* const* boxes,
+                                            const int64_t* counts, int64_t num_images, void* rois_out, void* output, tvmi_dtype dt,
+                                            int64_t N, int64_t C, int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio,
+                                            int aligned, int64_t k_min, int64_t k_max, double canonical_scale, double canonical_level,
+                                            double eps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same operation on channels_last feature maps (element (n,c,y,x) at ((n*H+y)*W+x)*C+c;
  * SURVEY.md §8f-2): lane = channel, taps are coalesced loads off a scalar base, no LDS window.

@@ -2099,3 +2099,116 @@ def test_qnms_and_qroi_align_device_kernels(tv, dtype):
         np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"{dtype} P={P} sr={sr} aligned={aligned}")
     with pytest.raises(RuntimeError, match="one image per batch"):
         tv.qroi_align(torch.cat([x, x]).to(DEV), rois.to(DEV), 0.07, zp, 0.5, 0, 1.0, 3, 3, 2, False)
+
+
+# ------------------------------------------------------------------ round 6: the detector step's NMS + payload as ONE launch
+def _step_case(n, S, B, g, kind):
+    if kind == "dense":       # clustered boxes: most are suppressed, long serial chains inside the diagonal tiles
+        centers = torch.rand(40, 2, generator=g) * 600
+        xy = centers[torch.randint(0, 40, (n,), generator=g)] + torch.randn(n, 2, generator=g) * 10
+        wh = 100 + torch.randn(n, 2, generator=g).abs() * 25
+        boxes = torch.cat([xy, xy + wh], 1)
+    else:
+        boxes = random_boxes(n, 1344, 800, 8, 300, g)
+    scores = torch.rand(n, generator=g)
+    if kind == "ties":
+        scores = (scores * 16).floor() / 16          # 17 distinct values: the order is decided by the index
+    seg = torch.randint(0, S, (n,), generator=g)
+    if kind == "by_image" or int(torch.bincount(seg, minlength=S).max()) > 1024:
+        seg = (torch.arange(n) * S // n).to(torch.int64)   # bench.py's layout: segment = image, contiguous runs (<= 1024 each)
+        if kind != "by_image":
+            seg = seg[torch.randperm(n, generator=g)]       # ... shuffled: equal-sized segments, members scattered
+    img = seg if B == S else seg % B
+    labels = torch.randint(1, 91, (n,), generator=g)
+    return boxes, scores, seg, img, labels
+
+
+@pytest.mark.parametrize("n,S,B,kind", [(4000, 4, 4, "by_image"), (4000, 4, 4, "dense"), (4096, 64, 16, "random"), (4096, 8, 2, "ties"),
+                                        (1024, 1, 1, "random"), (1000, 1, 1, "dense"), (70, 3, 3, "random"), (1, 1, 1, "random"),
+                                        (65, 2, 1, "ties"), (3000, 40, 8, "dense"), (2500, 5, 5, "ties")])
+def test_nms_step_one_launch_equals_reference_and_chain(n, S, B, kind):
+    """tvmi::nms_step (ONE launch: score order, per-segment tiles, sweeps, global-order keep list, padded top-k payload) against
+    (a) the oracle restatement of the reference's batched_nms — index list identical, bit for bit — and (b) this library's own
+    launch chain for the same sizes (nms_segmented_padded with nms.step_fused = 0, then pack_detections_payload): keep / num /
+    payload equal.  Also twice in a row: the hand-over words are re-armed by every call."""
+    g = gen(9000 + n + 7 * S + len(kind))
+    boxes, scores, seg, img, labels = _step_case(n, S, B, g, kind)
+    want = O.nms(boxes.numpy(), scores.numpy(), 0.5, seg.numpy())
+    db, ds, dg, di, dl = boxes.to(DEV), scores.to(DEV), seg.to(DEV), img.to(DEV), labels.to(DEV)
+    D = 100
+    for _ in range(2):
+        keep, num, payload = torch.ops.tvmi.nms_step(db, ds, dg, 0.5, S, di, dl, B, D)
+        assert int(num) == len(want), (int(num), len(want))
+        assert np.array_equal(keep[: int(num)].cpu().numpy(), want)
+    torch.ops.tvmi.set_option("nms.step_fused", 0)
+    try:
+        k2, n2 = torch.ops.tvmi.nms_segmented_padded(db, ds, dg, 0.5, S)
+    finally:
+        torch.ops.tvmi.set_option("nms.step_fused", 1)
+    assert int(n2) == int(num) and torch.equal(k2[: int(n2)], keep[: int(num)])
+    p2 = torch.ops.tvmi.pack_detections_payload(db, ds, dl, di, k2, n2, B, D)
+    assert torch.equal(payload, p2)
+    # the padded form now takes the one-launch kernel by itself, and so does torchvision::nms up to 1024 boxes
+    k3, n3 = torch.ops.tvmi.nms_segmented_padded(db, ds, dg, 0.5, S)
+    assert int(n3) == int(num) and torch.equal(k3[: int(n3)], keep[: int(num)])
+    if S == 1:
+        assert np.array_equal(torch.ops.torchvision.nms(db, ds, 0.5).cpu().numpy(), want)
+
+
+def test_nms_step_limits_and_special_scores():
+    """A segment above 1,024 boxes or an id outside [0, S) gives num = -1 and counts of -1 in the payload (never a wrong list); the
+    list-returning ops fall back to the general path on it; NaN / inf / -0 scores order like aten::sort (NaN first)."""
+    g = gen(424242)
+    n = 3000
+    boxes = random_boxes(n, 1000, 800, 8, 200, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    seg = torch.zeros(n, dtype=torch.int64, device=DEV)
+    seg[:100] = 1
+    keep, num, payload = torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, 2, seg, None, 2, 10)
+    assert int(num) == -1 and payload[:, -1].tolist() == [-1.0, -1.0] and not payload[:, :-1].any()
+    want = O.nms(boxes.cpu().numpy(), scores.cpu().numpy(), 0.5, seg.cpu().numpy())
+    got = torch.ops.tvmi.nms_segmented(boxes, scores, seg, 0.5, 2).cpu().numpy()
+    assert np.array_equal(got, want)
+    seg2 = torch.randint(0, 4, (n,), generator=g).to(DEV)
+    seg2[5] = 7
+    _, num, _ = torch.ops.tvmi.nms_step(boxes, scores, seg2, 0.5, 4, seg2.clamp(max=3), None, 4, 10)
+    assert int(num) == -1
+    s3 = scores.clone().cpu()
+    s3[3], s3[10], s3[11], s3[12], s3[13] = float("nan"), float("inf"), float("-inf"), -0.0, 0.0
+    seg3 = torch.randint(0, 4, (n,), generator=g)
+    want = O.nms(boxes.cpu().numpy(), s3.numpy(), 0.5, seg3.numpy())
+    keep, num, _ = torch.ops.tvmi.nms_step(boxes, s3.to(DEV), seg3.to(DEV), 0.5, 4, seg3.to(DEV), None, 4, 10)
+    assert int(num) == len(want) and np.array_equal(keep[: int(num)].cpu().numpy(), want)
+    torch.library.opcheck(torch.ops.tvmi.nms_step, args=(boxes[:200], scores[:200], seg3[:200].to(DEV), 0.5, 4, seg3[:200].to(DEV), None, 4, 10))
+
+
+@pytest.mark.parametrize("C,P,dtype", [(256, 7, torch.float32), (256, 14, torch.float32), (256, 7, torch.bfloat16), (64, 7, torch.float32),
+                                       (512, 7, torch.float16)])
+def test_multiscale_roi_align_boxes_builds_its_own_rows(C, P, dtype):
+    """tvmi::multiscale_roi_align_boxes (round 6: the [K,5] rows of convert_boxes_to_roi_format, ops/_utils.py:18-25, are written
+    by the launch-order pre-pass of the call) == tvmi::boxes_to_rois + tvmi::multiscale_roi_align, bit for bit: output, the rows it
+    returns, and the gradients of every level — with unequal and EMPTY per-image lists, on the fused route (a multiple of 256
+    channels) and on the fallback (64 channels: rows built by tvmi_boxes_to_rois inside the C entry)."""
+    g = gen(3100 + C + P)
+    B = 3
+    feats = [torch.randn(B, C, 200 // s, 304 // s, generator=g).to(DEV, dtype) for s in (1, 2, 4, 8)]
+    boxes = [random_boxes(n, 1216, 800, 6, 500, g).to(DEV) for n in (700, 0, 1301)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    tail = (P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6)
+    f1 = [f.clone().requires_grad_(True) for f in feats]
+    f2 = [f.clone().requires_grad_(True) for f in feats]
+    out, rois = torch.ops.tvmi.multiscale_roi_align_boxes(f1, boxes, scales, *tail)
+    want_rois = torch.ops.tvmi.boxes_to_rois(boxes)
+    want = torch.ops.tvmi.multiscale_roi_align(f2, want_rois, scales, *tail)
+    assert torch.equal(rois, want_rois) and rois.shape == (2001, 5)
+    assert torch.equal(out, want)
+    gr = torch.randn(out.shape, generator=g).to(DEV, dtype)
+    out.backward(gr)
+    want.backward(gr)
+    for a, b in zip(f1, f2):
+        assert torch.equal(a.grad, b.grad)
+    # the module takes the one-op route for device boxes (and still equals the per-level oracle in the baseline-size tests)
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], P, 2)
+    got = pool({str(i): f for i, f in enumerate(feats)}, boxes, [(800, 1216)] * B)
+    assert torch.equal(got, want.detach())
+    assert torch.ops.tvmi.multiscale_roi_align_boxes(feats, [b[:0] for b in boxes], scales, *tail)[0].shape == (0, C, P, P)

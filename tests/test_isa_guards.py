@@ -200,6 +200,24 @@ def test_nms_chain_of_the_step_fits_next_to_the_roi_align_kernel(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_nms_step_kernel_shape(tmp_path):
+    """The one-launch step kernel (nms_step_fused, round 6) runs ONCE per call on an otherwise idle slice of the chip: every phase
+    executes cold code, so its size is a cost (a fully unrolled first version was 22,000 instructions = 130 KB and no faster than
+    the five launches it replaced).  Guard: no spills / scratch, at most 128 VGPRs, under 32 KB of LDS, under 13,000 instructions,
+    and the counting loops compare score words with saturating subtracts (no v_cmp -> v_addc condition-code chain per key)."""
+    text, nms = _kernel_resources(os.path.join(CSRC, "nms.hip"), tmp_path)
+    hits = {k: v for k, v in nms.items() if "nms_step_fused" in k}
+    assert len(hits) == 1, list(nms)
+    (name, r), = hits.items()
+    assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128 and r["lds"] <= 32 * 1024, r
+    body = list(_kernel_bodies(text, "nms_step_fused").values())
+    assert len(body) == 1
+    insts = [ln for ln in body[0].splitlines() if ln.startswith("\t") and not ln.startswith("\t.") and not ln.strip().startswith(";")]
+    assert len(insts) < 13000, len(insts)
+    assert sum("v_sub_u32" in ln and "clamp" in ln for ln in insts) >= 8, "saturating-subtract counting loops not found"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_resize_backward_blocks_are_loaded_together(tmp_path):
     """The gather backward of the resize modes (resize.hip, upsample2d_bwd_vec_kernel<T, R, CC, P>) beat ATen's scatter kernels on
     up-scales only once the R x P row loads of a block were issued together as CC-element vector loads (the first version's

@@ -126,6 +126,33 @@ def _fake_multiscale_bwd(grad, rois, heights, widths, scales, batch_size, pooled
     return [grad.new_empty((batch_size, grad.size(1), h, w)) for h, w in zip(heights, widths)]
 
 
+def _fake_multiscale_boxes(features, boxes, scales, pooled_height, pooled_width, sampling_ratio, aligned, k_min, k_max,
+                           canonical_scale, canonical_level, eps):
+    K = sum(b.shape[0] for b in boxes)
+    f0 = features[0]
+    return f0.new_empty((K, f0.shape[1], pooled_height, pooled_width)), f0.new_empty((K, 5), dtype=torch.float32)
+
+
+def _multiscale_boxes_setup(ctx, inputs, output):
+    features = inputs[0]
+    ctx.save_for_backward(output[1])          # the [K,5] rows the pre-pass wrote
+    ctx.set_materialize_grads(False)
+    ctx.shapes = [tuple(f.shape) for f in features]
+    ctx.n_boxes = len(inputs[1])
+    ctx.params = inputs[2:]
+
+
+def _multiscale_boxes_backward(ctx, grad, _grad_rois):
+    (rois,) = ctx.saved_tensors
+    scales, ph, pw, sr, aligned, k_min, k_max, s0, lvl0, eps = ctx.params
+    if grad is None:
+        return (None, None) + (None,) * len(ctx.params)
+    grads = torch.ops.tvmi.multiscale_roi_align_backward(
+        grad, rois, [s[2] for s in ctx.shapes], [s[3] for s in ctx.shapes], scales, ctx.shapes[0][0], ph, pw, sr, aligned,
+        k_min, k_max, s0, lvl0, eps)
+    return (list(grads), [None] * ctx.n_boxes) + (None,) * len(ctx.params)
+
+
 def _multiscale_setup(ctx, inputs, output):
     features, rois = inputs[0], inputs[1]
     ctx.save_for_backward(rois)
@@ -180,6 +207,11 @@ def _fake_nms_padded(dets, scores, idxs, iou_threshold, num_segments=-1):
     return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
 
 
+def _fake_nms_step(dets, scores, idxs, iou_threshold, num_segments, image_idx, labels, num_images, max_dets):
+    return (dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64),
+            dets.new_empty((num_images, max_dets * 6 + 1), dtype=torch.float32))
+
+
 def _fake_nms_masked(dets, scores, idxs, valid, iou_threshold, num_segments=-1, max_segment_size=-1):
     return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
 
@@ -232,6 +264,7 @@ _FAKES = {
     "tvmi::box_iou_pairwise": _fake_box_iou_pairwise,
     "tvmi::nms_segmented_padded": _fake_nms_padded,
     "tvmi::nms_segmented_masked": _fake_nms_masked,
+    "tvmi::nms_step": _fake_nms_step,
     "tvmi::pack_detections_payload": _fake_pack_payload,
     "tvmi::pack_detections_devcount": _fake_pack_devcount,
     "tvmi::paste_masks": _fake_paste_masks,
@@ -239,6 +272,7 @@ _FAKES = {
     "tvmi::rpn_candidates": _fake_rpn_candidates,
     "tvmi::pack_detections": _fake_pack_detections,
     "tvmi::multiscale_roi_align": _fake_multiscale,
+    "tvmi::multiscale_roi_align_boxes": _fake_multiscale_boxes,
     "tvmi::multiscale_roi_align_backward": _fake_multiscale_bwd,
     "tvmi::interpolate2d": _fake_interpolate2d,
     "tvmi::interpolate2d_backward": _fake_interpolate2d_backward,
@@ -351,6 +385,7 @@ def register_all(torchvision_schemas: bool = True):
         if torchvision_schemas or name.startswith("tvmi::"):
             torch.library.register_fake(name, fn)
     torch.library.register_autograd("tvmi::multiscale_roi_align", _multiscale_backward, setup_context=_multiscale_setup)
+    torch.library.register_autograd("tvmi::multiscale_roi_align_boxes", _multiscale_boxes_backward, setup_context=_multiscale_boxes_setup)
     torch.library.register_autograd("tvmi::multiscale_roi_align_backward", _no_double_backward("multiscale_roi_align"))
     if not torchvision_schemas:
         return

@@ -968,10 +968,22 @@ constexpr int kOrderBuckets = 4096;
 constexpr int kOrderPerThread = 4;
 constexpr int64_t kOrderMaxRois = 1 << 16;   // beyond that one workgroup is the wrong shape: identity order
 
-template <typename R>
+// Round 6: the pre-pass can also BUILD the [K,5] RoI rows from the per-image box lists (convert_boxes_to_roi_format,
+// ops/_utils.py:18-25 — a launch of its own until now: tvmi::boxes_to_rois, 4.8 us + a launch gap in front of every
+// MultiScaleRoIAlign call): it touches every box anyway.  BOXES: row k comes from (image of k, box k - first of that image) and is
+// written to `rois_out`, which the kernels of the launch that follows read.
+constexpr int kOrderMaxImages = 64;
+struct MsBoxLists {
+  const float* ptr[kOrderMaxImages];
+  int end[kOrderMaxImages];   // exclusive prefix end of every image's boxes in the concatenation
+  int n;
+};
+
+template <typename R, bool BOXES = false>
 __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, const R* __restrict__ rois, int K, int N,
                                                                 int multiscale, int bands, int* __restrict__ perm,
-                                                                int* __restrict__ mop_counter) {
+                                                                int* __restrict__ mop_counter, MsBoxLists bl = MsBoxLists{},
+                                                                float* __restrict__ rois_out = nullptr) {
   __shared__ int hist[kOrderBuckets];
   __shared__ int wsum[kOrderThreads / 64];
   __shared__ float band_scale[kMaxLevels];   // window-top row (level pixels) -> band index
@@ -1008,9 +1020,38 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
     const int band = (yb == yb) ? min(max((int)yb, 0), bands - 1) : 0;
     return (b * L + l) * bands + band;
   };
-  auto load_key = [&](int k) {
-    const R* r = rois + (int64_t)k * 5;
-    return key_of((float)ld(r), (float)ld(r + 1), (float)ld(r + 2), (float)ld(r + 3), (float)ld(r + 4));
+  auto load_row = [&](int k, float (&v)[5], bool write) {
+    if constexpr (BOXES) {
+      int img = 0;
+      for (int i = 0; i < bl.n - 1; ++i) img += k >= bl.end[i] ? 1 : 0;
+      int first = 0;
+      const float* base = bl.ptr[0];
+#pragma unroll 1
+      for (int i = 1; i < bl.n; ++i)       // run-time index into the by-value struct would go through scratch: walk it
+        if (i == img) {
+          first = bl.end[i - 1];
+          base = bl.ptr[i];
+        }
+      const float* b = base + (int64_t)(k - first) * 4;
+      v[0] = (float)img;
+      v[1] = b[0];
+      v[2] = b[1];
+      v[3] = b[2];
+      v[4] = b[3];
+      if (write) {
+        float* r = rois_out + (int64_t)k * 5;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) r[e] = v[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 5; ++e) v[e] = (float)ld(rois + (int64_t)k * 5 + e);
+    }
+  };
+  auto load_key = [&](int k, bool write) {
+    float v[5];
+    load_row(k, v, write);
+    return key_of(v[0], v[1], v[2], v[3], v[4]);
   };
   const bool in_regs = K <= kOrderThreads * kOrderPerThread;
   int key[kOrderPerThread], rank[kOrderPerThread];
@@ -1019,8 +1060,7 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
 #pragma unroll
     for (int j = 0; j < kOrderPerThread; ++j) {       // all loads of the thread in flight together
       const int k = min(tid + j * kOrderThreads, K - 1);
-#pragma unroll
-      for (int e = 0; e < 5; ++e) v[j][e] = (float)ld(rois + (int64_t)k * 5 + e);
+      load_row(k, v[j], tid + j * kOrderThreads < K);
     }
 #pragma unroll
     for (int j = 0; j < kOrderPerThread; ++j) {
@@ -1028,7 +1068,7 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
       rank[j] = (tid + j * kOrderThreads < K) ? atomicAdd(&hist[key[j]], 1) : 0;
     }
   } else {
-    for (int k = tid; k < K; k += kOrderThreads) atomicAdd(&hist[load_key(k)], 1);
+    for (int k = tid; k < K; k += kOrderThreads) atomicAdd(&hist[load_key(k, true)], 1);
   }
   __syncthreads();
   // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, wave totals
@@ -1070,7 +1110,7 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
       if (k < K) perm[hist[key[j]] + rank[j]] = k;
     }
   } else {
-    for (int k = tid; k < K; k += kOrderThreads) perm[atomicAdd(&hist[load_key(k)], 1)] = k;
+    for (int k = tid; k < K; k += kOrderThreads) perm[atomicAdd(&hist[load_key(k, false)], 1)] = k;
   }
 }
 
@@ -1200,14 +1240,27 @@ int fill_levels(MsLevels& lv, const void* const* ptrs, const int64_t* heights, c
 
 // Decides placement and order for one launch of the DMA kernels and clears the mop-up worklist counter — in the order
 // pre-pass when that runs, with a 4-byte memset otherwise.
+// `bl` (optional): the RoI rows do not exist yet — the pre-pass writes them to `rois_out` from the box lists; the caller has
+// checked with plan_units_orders() that the pre-pass runs.
+inline bool plan_units_orders(int64_t N, int64_t L, int nchunks, const int* perm) {
+  return g_fwd_opt.pin_chunks && unit_map_can_pin(nchunks) && g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets;
+}
 template <typename R>
 int plan_units(UnitMap& um, const MsLevels& lv, const R* rois, int64_t N, int64_t K, int nchunks, int multiscale, int* mop,
-               int* perm, hipStream_t stream) {
+               int* perm, hipStream_t stream, const MsBoxLists* bl = nullptr, float* rois_out = nullptr) {
   um = UnitMap{nullptr, 0};
   um.pinned = (g_fwd_opt.pin_chunks && unit_map_can_pin(nchunks)) ? 1 : 0;
   const int64_t L = multiscale ? lv.n_levels : 1;
-  if (um.pinned && g_fwd_opt.order && perm && N >= 1 && N * L <= kOrderBuckets) {
+  if (plan_units_orders(N, L, nchunks, perm)) {
     const int bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * L)));
+    if constexpr (std::is_same<R, float>::value) {
+      if (bl) {
+        roi_fwd_order<float, true><<<dim3(1), dim3(kOrderThreads), 0, stream>>>(lv, nullptr, (int)K, (int)N, multiscale, bands, perm,
+                                                                                 mop, *bl, rois_out);
+        um.perm = perm;
+        return 0;
+      }
+    }
     roi_fwd_order<R><<<dim3(1), dim3(kOrderThreads), 0, stream>>>(lv, rois, (int)K, (int)N, multiscale, bands, perm, mop);
     um.perm = perm;
     return 0;
@@ -1438,7 +1491,7 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
 
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH,
-                  int64_t PW, int64_t sr, int aligned, int* mop, int* perm, hipStream_t stream) {
+                  int64_t PW, int64_t sr, int aligned, int* mop, int* perm, hipStream_t stream, const MsBoxLists* bl = nullptr) {
   const float* r = static_cast<const float*>(rois);
   T* out = static_cast<T*>(output);
   const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
@@ -1446,7 +1499,8 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
   const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
   UnitMap um{nullptr, 0};
   if (fast_shape && mop) {
-    const int st = plan_units<float>(um, lv, r, N, K, nchunks, /*multiscale=*/1, mop, perm, stream);
+    const int st = plan_units<float>(um, lv, r, N, K, nchunks, /*multiscale=*/1, mop, perm, stream, bl,
+                                     const_cast<float*>(r));   // with box lists `rois` is the buffer the pre-pass fills
     if (st != 0) return set_error(st, "tvmi_multiscale_roi_align_forward: clearing the worklist failed");
   }
   const dim3 dma_grid(wave_unit_grid(K, nchunks, um.pinned != 0)), grid(wave_unit_grid(K, nchunks)),
@@ -1576,6 +1630,63 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
     default:
       return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined,
                                                  perm, s);
+  }
+}
+
+// The same call taking the per-image box lists instead of [K,5] rows: where the order pre-pass runs (7x7 / 14x14 bins,
+// sampling_ratio 2, a multiple of 8 channel chunks, workspace given) it builds the rows itself; otherwise the rows are built by
+// tvmi_boxes_to_rois first.  `rois_out` [K,5] float32 receives them either way (the backward needs them).
+extern "C" int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs, const int64_t* heights, const int64_t* widths,
+                                                       const double* spatial_scales, int64_t n_levels, const void* const* boxes,
+                                                       const int64_t* counts, int64_t num_images, void* rois_out, void* output,
+                                                       tvmi_dtype dt, int64_t N, int64_t C, int64_t pooled_h, int64_t pooled_w,
+                                                       int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
+                                                       double canonical_scale, double canonical_level, double eps, void* workspace,
+                                                       size_t workspace_bytes, void* stream) {
+  TVMI_CHECK_ARG(num_images >= 0 && num_images <= tvmi::kOrderMaxImages, "multiscale_roi_align (boxes): at most 64 images per call");
+  TVMI_CHECK_ARG(num_images == 0 || (boxes && counts), "multiscale_roi_align (boxes): null pointer");
+  tvmi::MsBoxLists bl;
+  int64_t K = 0;
+  bl.n = (int)num_images;
+  for (int64_t i = 0; i < num_images; ++i) {
+    TVMI_CHECK_ARG(counts[i] >= 0 && (counts[i] == 0 || boxes[i]), "multiscale_roi_align (boxes): bad box list");
+    K += counts[i];
+    TVMI_CHECK_ARG(K < (1ll << 31), "multiscale_roi_align (boxes): too many boxes");
+    bl.ptr[i] = static_cast<const float*>(boxes[i]);
+    bl.end[i] = (int)K;
+  }
+  TVMI_CHECK_ARG(pooled_h > 0 && pooled_w > 0, "multiscale_roi_align: pooled size must be positive");
+  TVMI_CHECK_ARG(n_levels >= 1 && n_levels <= tvmi::kMaxLevels, "multiscale_roi_align: 1..8 levels supported");
+  if (K == 0) return 0;
+  TVMI_CHECK_ARG(rois_out != nullptr, "multiscale_roi_align (boxes): rois_out is null");
+  const int nchunks = (int)tvmi::ceil_div(C, tvmi::kUnitChunk);
+  int* declined = tvmi::mop_part(workspace, workspace_bytes, K);
+  int* perm = tvmi::perm_part(workspace, workspace_bytes, K);
+  const bool fast_shape = (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2) || (pooled_h == 14 && pooled_w == 14 && sampling_ratio == 2);
+  const bool fused = fast_shape && declined && K <= tvmi::kOrderMaxRois && C * pooled_h * pooled_w > 0 &&
+                     tvmi::plan_units_orders(N, n_levels, nchunks, perm) && (dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16);
+  if (!fused) {
+    const int st = tvmi_boxes_to_rois(boxes, counts, num_images, rois_out, TVMI_F32, stream);
+    if (st != 0) return st;
+    return tvmi_multiscale_roi_align_forward(inputs, heights, widths, spatial_scales, n_levels, rois_out, output, dt, N, C, K, pooled_h,
+                                             pooled_w, sampling_ratio, aligned, k_min, k_max, canonical_scale, canonical_level, eps,
+                                             workspace, workspace_bytes, stream);
+  }
+  TVMI_CHECK_ARG(inputs && heights && widths && spatial_scales && output, "multiscale_roi_align: null pointer");
+  TVMI_CHECK_ARG(K * tvmi::ceil_div(C, 32) < (1ll << 31), "multiscale_roi_align: size exceeds 32-bit launch limits");
+  for (int64_t i = 0; i < n_levels; ++i)
+    TVMI_CHECK_ARG(inputs[i] != nullptr && heights[i] * widths[i] < (1ll << 30), "multiscale_roi_align: bad level");
+  tvmi::MsLevels lv;
+  tvmi::fill_levels(lv, inputs, heights, widths, spatial_scales, n_levels, k_min, k_max, canonical_scale, canonical_level, eps);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dt) {
+    case TVMI_F32:
+      return tvmi::launch_ms_fwd<float>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s, &bl);
+    case TVMI_F16:
+      return tvmi::launch_ms_fwd<__half>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s, &bl);
+    default:
+      return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined,
+                                                 perm, s, &bl);
   }
 }
 

@@ -116,6 +116,31 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
   TORCH_CHECK(boxes.scalar_type() == at::kFloat || boxes.scalar_type() == at::kDouble,
               "nms: boxes must be a floating point tensor");
   boxes = boxes.contiguous();
+  at::Tensor seg_c;
+  const int64_t* seg_ptr = nullptr;
+  if (seg.has_value() && seg->defined()) {
+    TORCH_CHECK(seg->dim() == 1 && seg->size(0) == n, "idxs must be a 1d tensor with one entry per box");
+    seg_c = seg->to(at::kLong).contiguous();
+    seg_ptr = seg_c.const_data_ptr<int64_t>();
+  }
+  at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
+  at::Tensor num = at::empty({1}, dets.options().dtype(at::kLong));
+  // detector-step sizes: score order, per-segment tiles, sweeps and the global-order compaction as ONE launch (round 6)
+  int64_t step_on = 1;
+  tvmi_get_option("nms.step_fused", &step_on);
+  if (step_on && boxes.scalar_type() == at::kFloat && scores.scalar_type() == at::kFloat && n <= 4096 &&
+      (seg_ptr ? (num_segments >= 1 && num_segments <= 64) : n <= 1024)) {
+    at::Tensor sc = scores.contiguous();
+    const int64_t S = seg_ptr ? num_segments : 1;
+    const size_t sb = tvmi_nms_step_workspace_bytes(n, S);
+    at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
+    check_status(tvmi_nms_step(boxes.const_data_ptr<float>(), sc.const_data_ptr<float>(), seg_ptr, n, S, iou_threshold,
+                               sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(), nullptr,
+                               nullptr, 0, 0, nullptr, 0, nullptr, 0, current_stream(dets)),
+                 "nms_step");
+    if (!allow_sync || num.item<int64_t>() >= 0) return std::make_tuple(keep, num);
+    // a segment above 1024 boxes or an id outside [0, num_segments): the paths below
+  }
   at::Tensor order;
   if (scores.scalar_type() == at::kFloat && n <= 4096) {
     // detector-step sizes: the stable descending order in one launch instead of torch's sort + arange + copies
@@ -136,15 +161,6 @@ std::tuple<at::Tensor, at::Tensor> nms_impl(const at::Tensor& dets, const at::Te
   } else {
     order = std::get<1>(at::sort(scores, /*stable=*/true, /*dim=*/0, /*descending=*/true));
   }
-  at::Tensor seg_c;
-  const int64_t* seg_ptr = nullptr;
-  if (seg.has_value() && seg->defined()) {
-    TORCH_CHECK(seg->dim() == 1 && seg->size(0) == n, "idxs must be a 1d tensor with one entry per box");
-    seg_c = seg->to(at::kLong).contiguous();
-    seg_ptr = seg_c.const_data_ptr<int64_t>();
-  }
-  at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
-  at::Tensor num = at::empty({1}, dets.options().dtype(at::kLong));
   if (seg_ptr && n <= 4096 && num_segments >= 1 && num_segments <= 1024) {
     // detector-step sizes with a known id range: per-segment tiles + concurrent per-segment sweeps, no second sort
     const size_t sb = tvmi_nms_small_segments_workspace_bytes(n, num_segments);
@@ -958,6 +974,57 @@ at::Tensor multiscale_roi_align(at::TensorList features, const at::Tensor& rois,
   return output;
 }
 
+// The same op taking the per-image box lists (the argument MultiScaleRoIAlign.forward receives, ops/poolers.py:289-321): the
+// [K,5] rows of convert_boxes_to_roi_format are written by the launch-order pre-pass of the call (roi_align.hip, round 6) instead
+// of a launch of their own.  Returns (output, rois): the rows are what the backward takes.  NCHW float32 / float16 / bfloat16
+// maps and float32 boxes; everything else goes through boxes_to_rois + multiscale_roi_align in the python mirror.
+std::tuple<at::Tensor, at::Tensor> multiscale_roi_align_boxes(at::TensorList features, at::TensorList boxes, at::ArrayRef<double> scales,
+                                                              int64_t pooled_height, int64_t pooled_width, int64_t sampling_ratio,
+                                                              bool aligned, int64_t k_min, int64_t k_max, double canonical_scale,
+                                                              double canonical_level, double eps) {
+  TORCH_CHECK(features.size() >= 1 && features.size() <= 8, "multiscale_roi_align: 1..8 feature levels supported");
+  TORCH_CHECK(features.size() == scales.size(), "multiscale_roi_align: one scale per feature level");
+  TORCH_CHECK(boxes.size() >= 1 && boxes.size() <= 64, "multiscale_roi_align_boxes: 1..64 box lists (one per image)");
+  const at::Tensor& f0 = features[0];
+  TORCH_CHECK(f0.is_cuda() && f0.dim() == 4, "features must be 4d CUDA tensors");
+  c10::DeviceGuard guard(f0.device());
+  std::vector<at::Tensor> keep, bkeep;
+  std::vector<const void*> ptrs, bptrs;
+  std::vector<int64_t> hs, ws, counts;
+  int64_t K = 0;
+  for (const at::Tensor& b : boxes) {
+    TORCH_CHECK(b.is_cuda() && b.dim() == 2 && b.size(1) == 4 && b.scalar_type() == at::kFloat && b.device() == f0.device(),
+                "multiscale_roi_align_boxes: float32 CUDA boxes [n_i, 4] expected");
+    bkeep.push_back(b.contiguous());
+    bptrs.push_back(b.size(0) ? bkeep.back().const_data_ptr() : nullptr);
+    counts.push_back(b.size(0));
+    K += b.size(0);
+  }
+  for (const at::Tensor& f : features) {
+    TORCH_CHECK(f.is_cuda() && f.dim() == 4 && f.size(0) == f0.size(0) && f.size(1) == f0.size(1) &&
+                    f.scalar_type() == f0.scalar_type() && f.device() == f0.device(),
+                "multiscale_roi_align: feature levels must share device, dtype, batch and channel sizes");
+    keep.push_back(f.contiguous());
+    ptrs.push_back(keep.back().const_data_ptr());
+    hs.push_back(f.size(2));
+    ws.push_back(f.size(3));
+  }
+  const int64_t C = f0.size(1);
+  at::Tensor rois = at::empty({K, 5}, f0.options().dtype(at::kFloat));
+  at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, f0.options());
+  if (K == 0) return std::make_tuple(output, rois);
+  const size_t fwd_ws_bytes = tvmi_roi_align_forward_workspace_bytes(K, pooled_height, pooled_width, sampling_ratio);
+  at::Tensor order_ws = at::empty({(int64_t)fwd_ws_bytes}, f0.options().dtype(at::kByte));
+  check_status(tvmi_multiscale_roi_align_forward_boxes(ptrs.data(), hs.data(), ws.data(), scales.data(), (int64_t)features.size(),
+                                                       bptrs.data(), counts.data(), (int64_t)boxes.size(), rois.mutable_data_ptr(),
+                                                       output.mutable_data_ptr(), dtype_of(f0, "multiscale_roi_align"), f0.size(0), C,
+                                                       pooled_height, pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max,
+                                                       canonical_scale, canonical_level, eps, order_ws.mutable_data_ptr(), fwd_ws_bytes,
+                                                       current_stream(f0)),
+               "multiscale_roi_align_boxes");
+  return std::make_tuple(output, rois);
+}
+
 // backward of the fused multi-scale op: one launch scatters into every level's gradient map
 std::vector<at::Tensor> multiscale_roi_align_backward(const at::Tensor& grad, const at::Tensor& rois, at::IntArrayRef heights,
                                                       at::IntArrayRef widths, at::ArrayRef<double> scales, int64_t batch_size,
@@ -1192,6 +1259,42 @@ at::Tensor pack_detections_payload(const at::Tensor& boxes, const at::Tensor& sc
                                             payload.mutable_data_ptr<float>(), max_dets * 6 + 1, nullptr, current_stream(boxes)),
                "pack_detections_payload");
   return payload;
+}
+
+// The detector step's batched NMS + padded top-k payload as ONE launch (include/tvmi.h: tvmi_nms_step).  Returns
+// (keep [n] with num[0] valid entries in the reference's order, num [1] int64 on the device, payload [B, max_dets * 6 + 1]):
+// what nms_segmented_padded + pack_detections_payload return, without a host read and without the launches in between.
+std::tuple<at::Tensor, at::Tensor, at::Tensor> nms_step(const at::Tensor& dets, const at::Tensor& scores, const at::Tensor& idxs,
+                                                        double iou_threshold, int64_t num_segments, const at::Tensor& image_idx,
+                                                        const c10::optional<at::Tensor>& labels, int64_t num_images, int64_t max_dets) {
+  TORCH_CHECK(dets.is_cuda() && scores.is_cuda() && idxs.is_cuda() && image_idx.is_cuda(), "nms_step: CUDA tensors expected");
+  TORCH_CHECK(dets.dim() == 2 && dets.size(1) == 4 && dets.scalar_type() == at::kFloat && scores.scalar_type() == at::kFloat,
+              "nms_step: float32 boxes [N,4] and scores [N] expected");
+  const int64_t n = dets.size(0);
+  TORCH_CHECK(scores.dim() == 1 && scores.size(0) == n && idxs.dim() == 1 && idxs.size(0) == n && image_idx.dim() == 1 &&
+                  image_idx.size(0) == n,
+              "nms_step: scores, idxs and image_idx must have one entry per box");
+  TORCH_CHECK(n >= 1 && n <= 4096 && num_segments >= 1 && num_segments <= 64 && num_images >= 1 && num_images <= 16 && max_dets >= 1,
+              "nms_step: 1 <= n <= 4096, num_segments <= 64, num_images <= 16 (larger problems: nms_segmented_padded + pack_detections_payload)");
+  c10::DeviceGuard guard(dets.device());
+  at::Tensor b = dets.contiguous(), sc = scores.contiguous(), sg = idxs.to(at::kLong).contiguous(), ii = image_idx.to(at::kLong).contiguous();
+  at::Tensor lab;
+  const int64_t* lab_ptr = nullptr;
+  if (labels.has_value() && labels->defined()) {
+    lab = labels->to(at::kLong).contiguous();
+    lab_ptr = lab.const_data_ptr<int64_t>();
+  }
+  at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
+  at::Tensor num = at::empty({1}, dets.options().dtype(at::kLong));
+  at::Tensor payload = at::empty({num_images, max_dets * 6 + 1}, b.options());
+  const size_t sb = tvmi_nms_step_workspace_bytes(n, num_segments);
+  at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
+  check_status(tvmi_nms_step(b.const_data_ptr<float>(), sc.const_data_ptr<float>(), sg.const_data_ptr<int64_t>(), n, num_segments,
+                             iou_threshold, sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(), num.mutable_data_ptr<int64_t>(),
+                             ii.const_data_ptr<int64_t>(), lab_ptr, num_images, max_dets, payload.mutable_data_ptr<float>(),
+                             max_dets * 6 + 1, nullptr, 1, current_stream(dets)),
+               "nms_step");
+  return std::make_tuple(keep, num, payload);
 }
 
 // ---- qroi_align (quantized/cpu/qroi_align_kernel.cpp:182-231: checks and messages; :22-178: arithmetic)
@@ -1447,8 +1550,13 @@ TORCH_LIBRARY(tvmi, m) {
   // scale_* <= 0 means "not given")
   m.def(
       "pack_detections(Tensor boxes, Tensor scores, Tensor? labels, Tensor image_idx, Tensor keep, int num_images, int max_dets) -> (Tensor, Tensor)");
+  // batched NMS of a detector step + the padded top-k payload in ONE launch (n <= 4096, <= 64 segments, <= 16 images)
+  m.def(
+      "nms_step(Tensor dets, Tensor scores, Tensor idxs, float iou_threshold, int num_segments, Tensor image_idx, Tensor? labels, int num_images, int max_dets) -> (Tensor, Tensor, Tensor)");
   m.def(
       "multiscale_roi_align(Tensor[] features, Tensor rois, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor");
+  m.def(
+      "multiscale_roi_align_boxes(Tensor[] features, Tensor[] boxes, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> (Tensor, Tensor)");
   m.def(
       "multiscale_roi_align_backward(Tensor grad, Tensor rois, int[] heights, int[] widths, float[] scales, int batch_size, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor[]");
   // roi_heads.py:680-722 / rpn.py:266-286 up to the NMS, batched over images (one launch each)
@@ -1493,11 +1601,13 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("nms_segmented", &nms_segmented);
   m.impl("nms_segmented_padded", &nms_segmented_padded);
   m.impl("nms_segmented_masked", &nms_segmented_masked);
+  m.impl("nms_step", &nms_step);
   m.impl("pack_detections_devcount", &pack_detections_devcount);
   m.impl("pack_detections_payload", &pack_detections_payload);
   m.impl("interpolate2d", &interpolate2d);
   m.impl("interpolate2d_backward", &interpolate2d_backward);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
+  m.impl("multiscale_roi_align_boxes", &multiscale_roi_align_boxes);
   m.impl("multiscale_roi_align_backward", &multiscale_roi_align_backward);
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);

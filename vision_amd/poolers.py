@@ -61,11 +61,18 @@ def _multiscale_roi_align(x_filtered: List[Tensor], boxes: List[Tensor], output_
                           scales: Optional[List[float]], mapper: Optional[LevelMapper]) -> Tensor:
     if scales is None or mapper is None:
         raise ValueError("scales and mapper should not be None")
+    first = x_filtered[0]
+    if (len(x_filtered) > 1 and first.is_cuda and first.dtype in (torch.float32, torch.float16, torch.bfloat16) and first.is_contiguous()
+            and 1 <= len(boxes) <= 64 and all(b.is_cuda and b.dtype == torch.float32 and not b.requires_grad for b in boxes)):
+        # one op for the whole call: the [K,5] rows of convert_boxes_to_roi_format (ops/_utils.py:18-25) are written by the launch-order
+        # pre-pass of the multi-scale launch itself (round 6: one launch and one gap less in front of every call)
+        return torch.ops.tvmi.multiscale_roi_align_boxes(
+            list(x_filtered), list(boxes), [float(s) for s in scales], int(output_size[0]), int(output_size[1]), int(sampling_ratio),
+            False, int(mapper.k_min), int(mapper.k_max), float(mapper.s0), float(mapper.lvl0), float(mapper.eps))[0]
     rois = _convert_to_roi_format(boxes)
     if len(x_filtered) == 1:
         return roi_align(x_filtered[0], rois, output_size=output_size, spatial_scale=scales[0],
                          sampling_ratio=sampling_ratio)
-    first = x_filtered[0]
     if first.is_cuda and first.dtype in (torch.float32, torch.float16, torch.bfloat16):
         # one launch for all levels: level assignment happens in the kernel, results land
         # directly in the [K, C, PH, PW] output (no torch.where / index_put per level); the

@@ -97,6 +97,26 @@ def pack_kept_payload(boxes: Tensor, scores: Tensor, image_idx: Tensor, keep: Te
     return torch.ops.tvmi.pack_detections_payload(boxes, scores, labels, image_idx, keep, num_keep, int(num_images), int(max_dets))
 
 
+# limits of the one-launch step kernel (include/tvmi.h: tvmi_nms_step)
+STEP_MAX_BOXES, STEP_MAX_SEGMENTS, STEP_MAX_IMAGES = 4096, 64, 16
+
+
+def nms_pack_payload(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float, num_segments: int, image_idx: Tensor,
+                     num_images: int, max_dets: int, labels: Tensor = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """`boxes.batched_nms_padded` + `pack_kept_payload` of a detector step: (`keep` [N], `num` [1] on the device, `payload`
+    [num_images, max_dets * 6 + 1]).  Up to 4096 float32 boxes in <= 64 segments and <= 16 images this is ONE launch
+    (`tvmi::nms_step`: score order, per-segment suppression tiles, sweeps, the global-order keep list and the padded top-k rows are
+    phases of one grid — the reference does this with `batched_nms` + a python loop over the images, ops/boxes.py:57-126,
+    roi_heads.py:716-737); anything larger takes the two ops.  No host synchronisation either way."""
+    n = boxes.shape[0]
+    if (boxes.is_cuda and boxes.dtype == torch.float32 and scores.dtype == torch.float32 and 1 <= n <= STEP_MAX_BOXES
+            and 1 <= num_segments <= STEP_MAX_SEGMENTS and 1 <= num_images <= STEP_MAX_IMAGES):
+        return torch.ops.tvmi.nms_step(boxes, scores, idxs, float(iou_threshold), int(num_segments), image_idx, labels,
+                                       int(num_images), int(max_dets))
+    keep, num = torch.ops.tvmi.nms_segmented_padded(boxes, scores, idxs, float(iou_threshold), int(num_segments))
+    return keep, num, pack_kept_payload(boxes, scores, image_idx, keep, num, num_images, max_dets, labels)
+
+
 def split_payload(payload: Tensor, max_dets: int) -> Tuple[Tensor, Tensor]:
     """(`dets` [B, max_dets, 6], `counts` [B] float32) VIEWS of a payload — no launch, no copy."""
     return payload[:, : max_dets * DET_FIELDS].unflatten(1, (max_dets, DET_FIELDS)), payload[:, max_dets * DET_FIELDS]
