@@ -104,15 +104,10 @@ def main():
                     "(default), 0 = system scope, 2 = no fence from the event, -1 = torch's own wait_stream")
     ap.add_argument("--diag-skip", choices=["fork", "join", "both"], default=None, help="DIAGNOSIS ONLY (the line is marked invalid): "
                     "leave out the fork and / or the join of the two streams, to price the hops")
-    ap.add_argument("--nms-small-split", type=int, default=1, help="1 (default): the small-segment batched NMS as collect + "
-                    "four-tile workgroups whose LDS fits next to the RoIAlign launch; 0: the one-launch form (21 KB of LDS)")
-    ap.add_argument("--nms-sort-rank", type=int, default=1, help="1 (default): score order of <= 4096 boxes by rank counting (3 KB of "
-                    "LDS, n / 64 workgroups); 0: the one-workgroup bitonic sort (32 KB)")
     ap.add_argument("--nms-step-fused", type=int, default=1, help="1 (default): the step's batched NMS + payload as ONE launch "
                     "(tvmi::nms_step); 0: round 5's chain of five launches")
-    ap.add_argument("--reserve-cus", type=int, default=0, help="two-stream step: CUs the RoIAlign stream leaves to the NMS + packing "
-                    "stream (vision_amd.streams.partitioned_streams; 8 = one CU per XCD).  0 (default) = two ordinary streams: since "
-                    "every launch of the NMS chain fits into the 4 KB of LDS the RoIAlign kernel leaves on a CU, no CU has to be kept free")
+    ap.add_argument("--roi-inline-mop", type=int, default=None, help="roi_align.inline_mop: 1 = the units the LDS-DMA path declines take "
+                    "the wave path inside the same launch (no mop-up launch); default: the library's default")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -120,7 +115,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 3 and 4: NMS 100k, deform_conv2d)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: launcher, rank plumbing and the all-gather only; measures nothing")
     ap.add_argument("--force-collective", action="store_true", help="world of one: form a 1-rank RCCL group anyway and run the step's "
-                    "all-gather as a real collective (exercises the N > 1 code path — RCCL next to the CU-partitioned streams — on a "
+                    "all-gather as a real collective (exercises the N > 1 code path — RCCL next to the two streams — on a "
                     "1-GPU box; the line says so in config.parallelism)")
     ap.add_argument("--graph", action="store_true", help="replay the per-rank chain from a captured hipGraph (measured: no gain "
                     "over eager sync-free launches on this stack, so off by default)")
@@ -177,30 +172,17 @@ def main():
 
     nms_stream = torch.cuda.Stream(device=device, priority=args.side_priority)
     overlap = {"on": args.overlap}
-    # The RoIAlign launch owns nearly all the LDS of every CU it runs on (4 workgroups x 39 KB of 160 KB), so a launch of the
-    # second stream that needs more than the 4 KB left waits in the dispatcher until it drains (kernel-trace of round 4's chain:
-    # nms_small_seg_tiles, 21 KB, 16 us alone, 100-195 us under it; sweep + packing behind its end) — whatever the queue
-    # priority.  Two cures, both measured: (a) the step's own stream leaves `--reserve-cus` CUs alone (one per XCD
-    # for 8, vision_amd/streams.py) and the side stream finds them empty; (b) every launch of the chain was made to fit into
-    # those 4 KB (rank-counting score sort 3 KB, collect 0.3 KB, four-tile workgroups 3.75 KB, sweep / packing 0.5 KB).  With (b)
-    # no reservation is needed and the RoIAlign launch keeps all 256 CUs: the default.
-    part = {"main": None, "reserved": 0, "note": None}
-    if args.overlap and args.reserve_cus > 0:
-        try:
-            part["main"], nms_stream = vision_amd.streams.partitioned_streams(args.reserve_cus, device)
-            part["reserved"] = args.reserve_cus
-        except Exception as exc:  # pragma: no cover - depends on the runtime
-            part["note"] = f"{type(exc).__name__}: {exc}"
-            print(f"[bench] CU-partitioned streams unavailable ({part['note']}); two ordinary streams", file=sys.stderr)
-
+    # The RoIAlign launch owns nearly all the LDS of every CU it runs on (4 workgroups x 40 KB of 160 KB): a side-stream launch that
+    # needs more LDS than is left waits in the dispatcher until it drains.  The step's NMS + payload launch (tvmi::nms_step) is
+    # enqueued FIRST (the fork precedes the RoIAlign launches) and is resident before the RoIAlign grid arrives.
+    if args.roi_inline_mop is not None:
+        torch.ops.tvmi.set_option("roi_align.inline_mop", int(args.roi_inline_mop))
     torch.ops.tvmi.set_option("nms.step_fused", int(args.nms_step_fused))
     if not args.nms_step_fused:
         def _chain(boxes_, scores_, idxs_, thr_, nseg_, img_, nimg_, maxd_):
             k_, n_ = vision_amd.boxes.batched_nms_padded(boxes_, scores_, idxs_, thr_, nseg_)
             return k_, n_, sharding.pack_kept_payload(boxes_, scores_, img_, k_, n_, nimg_, maxd_)
         sharding.nms_pack_payload = _chain
-    torch.ops.tvmi.set_option("nms.small_split", int(args.nms_small_split))
-    torch.ops.tvmi.set_option("nms.sort_rank", int(args.nms_sort_rank))
     # fork / join of the two streams: device-scope events (vision_amd.streams.wait_stream) unless --torch-events
     if args.event_scope >= 0:
         vision_amd.streams.set_event_scope(args.event_scope)
@@ -297,12 +279,6 @@ def main():
     def contract_region():
         """warm-up (= the timed loop) + pre-roll + EXACTLY K steps between two (barrier + synchronize); returns
         (seconds of the K steps, pre-roll steps run, per-step event times in step order)"""
-        if part["main"] is not None and overlap["on"] and torch.cuda.current_stream() != part["main"]:
-            torch.cuda.synchronize()
-            with torch.cuda.stream(part["main"]):
-                r = contract_region()
-            torch.cuda.synchronize()
-            return r
         for _ in range(args.warmup):
             held["out"] = step()
             marks[1].record()
@@ -469,11 +445,7 @@ def main():
             "schema_ops_ms_per_step": round(schema_ms, 4),
             "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
             "rotated_input_sets": N_SETS,
-            "streams": (f"NMS + packing chain on a second HIP stream under the RoIAlign launch; the RoIAlign stream leaves "
-                        f"{part['reserved']} CUs (mask bits 0..{part['reserved'] - 1}: one per XCD and 8) to it"
-                        if args.overlap and part["reserved"] else
-                        ("NMS + packing chain on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream")),
-            "reserved_cus": part["reserved"],
+            "streams": ("NMS + payload launch on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream"),
             **({"INVALID_diagnosis_run": f"--diag-skip {args.diag_skip}: stream hops left out, not a measurement of the step"} if args.diag_skip else {}),
             "fork_join_events": {1: "device-scope release", 0: "system-scope release", 2: "no event fence", -1: "torch wait_stream"}[args.event_scope],
             ("one_stream_ms_per_step" if args.overlap else "two_stream_ms_per_step"): None if other_stream_ms is None else round(other_stream_ms, 4),
@@ -530,8 +502,6 @@ def main():
             result["config5"] = c5
     if rank == 0:
         print(json.dumps(result), flush=True)
-    part["main"] = None
-    vision_amd.streams.destroy_all()          # the CU-masked streams go before the runtime (and any profiler) tears down
     if not parity_ok:
         sys.exit("bench.py: outputs differ from the CPU reference (see the parity block)")
     if args.e2e and rank == 0 and world == 1:

@@ -79,11 +79,11 @@ int tvmi_version(void);
  *   "nms.mask_lds_bytes"         dynamic LDS per mask workgroup of the large path (all chunks but the first) — an
  *                                occupancy cap that keeps wave slots free for the sweep's 16-wave workgroup
  *                                (default 36000 = four workgroups per CU; 0 = no cap)
- *   "nms.sort_rank"              1 (default) / 0: tvmi_sort_scores_desc orders its <= 4096 scores by rank counting (n / 64 workgroups
- *                                of 256 lanes, 3 KB of LDS) instead of the one-workgroup bitonic network (32 KB); same output
- *   "nms.small_split"            1 (default) / 0: tvmi_nms_small_segments runs its pair tests as two launches (members of a segment,
- *                                then four tiles per 256-lane workgroup: 0.3 / 3.75 KB of LDS) instead of one that stages a
- *                                segment in 21 KB — every launch then fits next to a kernel that owns the LDS of all CUs */
+ *   "nms.step_fused"             1 (default) / 0: detector-step sizes (n <= 4096, <= 64 segments; plain nms up to 1024 boxes) take the
+ *                                one-launch kernel of tvmi_nms_step inside the torch glue; 0 = the launch chain (score sort, collect,
+ *                                tiles, sweep) — kept as the route for more segments / float64 and as the A/B reference
+ *   "roi_align.inline_mop"       1 (default) / 0: in the 7 x 7 multi-scale forward the units the LDS-DMA path declines take the wave path
+ *                                inside the same launch instead of a worklist + a mop-up launch */
 int tvmi_set_option(const char* name, int64_t value);
 /* Current value of a switch of tvmi_set_option (0, or an error for an unknown name). */
 int tvmi_get_option(const char* name, int64_t* value);
@@ -92,13 +92,6 @@ const char* tvmi_arch(void);
 /* Human-readable text for the last non-zero status returned on this thread. */
 const char* tvmi_last_error(void);
 
-/* A HIP stream restricted to the compute units whose bits are set in cu_mask (mask_words 32-bit words; on the multi-XCD parts
- * the bits are dealt round-robin over the XCDs, so bits 0..7 are one CU of each XCD).  For a second stream whose launches
- * cannot start next to a kernel that owns every CU's LDS: the chip-filling launch runs on a stream that leaves a few CUs
- * alone (vision_amd.streams.partitioned_streams; bench.py --reserve-cus — the step itself no longer needs it, its NMS chain
- * was slimmed down instead).  *stream receives a hipStream_t. */
-int tvmi_stream_create_cu_mask(const uint32_t* cu_mask, uint32_t mask_words, void** stream);
-int tvmi_stream_destroy(void* stream);
 /* `waiter` (hipStream_t) waits for everything enqueued on `signaler` so far: torch's Stream.wait_stream with an event that
  * releases to DEVICE scope (hipEventReleaseToDevice) instead of system scope — the fork / join of the step's two streams.
  * tvmi_stream_event_scope: 0 system scope (torch's events), 1 device scope (default), 2 no fence from the event itself. */

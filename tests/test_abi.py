@@ -209,7 +209,4 @@ def test_resize_backward_and_channels_last_entries_host_side():
     nn.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 6 + [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
     assert nn(fake, fake, 3, 4, IH, IW, OH, OW, 0, -1.0, -1.0, None) != 0 and b"element size" in lib.tvmi_last_error()
     # stream helpers: argument checks only (no device here)
-    sc = lib.tvmi_stream_create_cu_mask
-    sc.restype = ctypes.c_int
-    assert sc(None, ctypes.c_uint32(0), None) != 0
     assert lib.tvmi_stream_event_scope(ctypes.c_int(5)) != 0 and lib.tvmi_stream_event_scope(ctypes.c_int(1)) == 0

@@ -30,6 +30,9 @@ ROUTES = {
     "pinned+order": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 16},
     "pinned+order1band": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 1},
     "pinned+order64bands": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 64},
+    # round 6: the units the DMA path declines take the wave path inside the same launch (no mop-up launch; 7 x 7 multi-scale form)
+    "pinned+order+inline_mop": {"roi_align.pin_chunks": 1, "roi_align.order": 1, "roi_align.order_bands": 16, "roi_align.inline_mop": 1},
+    "ranges+inline_mop": {"roi_align.pin_chunks": 0, "roi_align.order": 0, "roi_align.inline_mop": 1},
 }
 
 
@@ -40,7 +43,9 @@ class route:
         self.opts = ROUTES[name]
 
     def __enter__(self):
-        self.saved = {k: int(torch.ops.tvmi.get_option(k)) for k in ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands")}
+        self.saved = {k: int(torch.ops.tvmi.get_option(k)) for k in ("roi_align.pin_chunks", "roi_align.order", "roi_align.order_bands",
+                                                                       "roi_align.inline_mop")}
+        torch.ops.tvmi.set_option("roi_align.inline_mop", 0)
         for k, v in self.opts.items():
             assert torch.ops.tvmi.set_option(k, v)
 

@@ -91,6 +91,12 @@ def test_occupancy_assumptions_of_the_hot_kernels(tmp_path):
     for r in dma.values():
         assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 96 and 0 < r["lds"] <= 40 * 1024, r
         assert 4 * r["lds"] <= 160 * 1024
+    # round 6: the default 7 x 7 launch carries the wave path for declined units inline — the union of both must keep four
+    # waves per SIMD (<= 128 VGPRs) and four workgroups per CU (4 x LDS <= 160 KB)
+    inl = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dma_inlIfLi7ELi7ELi2E" in k}
+    assert len(inl) == 1, list(roi)
+    for r in inl.values():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128 and 4 * r["lds"] <= 160 * 1024, r
     big = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi14ELi14ELi2E" in k}
     assert len(big) == 1 and all(v["vgpr"] <= 128 and v["spill"] == 0 and v["scratch"] == 0 for v in big.values()), big
     assert re.search(r"s_waitcnt vmcnt\(3\)", text) and re.search(r"s_waitcnt vmcnt\(4\)", text)

@@ -108,8 +108,6 @@ __global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ inpu
 }
 
 std::atomic<int> g_xcd_tiles{1};   // option "dcn.xcd_tiles": contiguous pixel-tile ranges per XCD (tile_of_block)
-std::atomic<int> g_dw_variant{1};  // option "dcn.dw_variant": 0 = the round-2..4 depthwise forward kernel, 1 = the packed one (round 5)
-std::atomic<int> g_cl_variant{1};  // option "dcn.cl_variant": 0 = the round-3 channels-last kernel, 1 = the pipelined one, 2 = its 4-wave tile
 std::atomic<int> g_cl_gather{1};  // option "dcn.channels_last_gather": the 16-bit MFMA kernel samples a [B, H*W, C] copy
 
 // ------------------------------------------------------------------ fused MFMA forward (fp32)
@@ -1699,14 +1697,6 @@ int set_dcn_option(const char* name, int64_t value) {
     g_cl_gather.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
-  if (std::strcmp(name, "dcn.cl_variant") == 0) {
-    g_cl_variant.store((int)value, std::memory_order_relaxed);
-    return 0;
-  }
-  if (std::strcmp(name, "dcn.dw_variant") == 0) {
-    g_dw_variant.store((int)value, std::memory_order_relaxed);
-    return 0;
-  }
   if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
     g_xcd_tiles.store(value != 0, std::memory_order_relaxed);
     return 0;
@@ -1717,14 +1707,6 @@ int set_dcn_option(const char* name, int64_t value) {
 int get_dcn_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "dcn.channels_last_gather") == 0) {
     *value = g_cl_gather.load(std::memory_order_relaxed) ? 1 : 0;
-    return 0;
-  }
-  if (std::strcmp(name, "dcn.cl_variant") == 0) {
-    *value = g_cl_variant.load(std::memory_order_relaxed);
-    return 0;
-  }
-  if (std::strcmp(name, "dcn.dw_variant") == 0) {
-    *value = g_dw_variant.load(std::memory_order_relaxed);
     return 0;
   }
   if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
@@ -1812,13 +1794,12 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
         (const scalar_t*)input, (scalar_t*)in_cl, (int)C, (int)(H * W));                                               \
     const scalar_t* icl = (const scalar_t*)in_cl;                                                                      \
     const scalar_t* w8 = (const scalar_t*)workspace;                                                                   \
-    const int variant = cl_bytes < ((size_t)1 << 32) ? g_cl_variant.load(std::memory_order_relaxed) : 0;  /* 32-bit lane offsets */ \
+    const bool pipelined = cl_bytes < ((size_t)1 << 32);   /* the pipelined kernel forms 32-bit lane offsets */                 \
     /* measured at config 4 (profiles/r04_dcn_variants.json): 256 x 128 tile, 8 waves of 64 x 64 — 0.098 ms against 0.125 ms   \
        for the round-3 kernel; 4 waves 0.104; 256 x 64 tiles 0.151; three stages 0.102.  OC = 128: 128 x 128 tile 0.096        \
        against 0.137 (round 3) and 0.150 (128 x 256 tile: 107 workgroups) */                                                 \
-    if (p.OCg > 128 && variant == 1) st = launch_clp16<scalar_t, 4, 2, 2, 2, 32, 2>(TVMI_CLARGS(scalar_t));            \
-    else if (p.OCg > 128 && variant == 2) st = launch_clp16<scalar_t, 4, 1, 2, 2, 32, 2>(TVMI_CLARGS(scalar_t));       \
-    else if (p.OCg > 64 && p.OCg <= 128 && variant > 0) st = launch_clp16<scalar_t, 2, 4, 2, 1, 32, 2>(TVMI_CLARGS(scalar_t)); \
+    if (p.OCg > 128 && pipelined) st = launch_clp16<scalar_t, 4, 2, 2, 2, 32, 2>(TVMI_CLARGS(scalar_t));              \
+    else if (p.OCg > 64 && p.OCg <= 128 && pipelined) st = launch_clp16<scalar_t, 2, 4, 2, 1, 32, 2>(TVMI_CLARGS(scalar_t)); \
     else                                                                                                               \
     if (p.OCg > 128) st = launch_cl16<scalar_t, 4, 2, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
     else if (p.OCg > 64) st = launch_cl16<scalar_t, 2, 4, 2, 1, 32>(icl, w8, (const scalar_t*)offset, (const scalar_t*)mask, (const scalar_t*)bias, (scalar_t*)output, p, OCg_pad, s); \
@@ -1850,7 +1831,7 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
     else TVMI_DCN16(__hip_bfloat16);
 #undef TVMI_DCN16
 #undef TVMI_DCN16_T
-  } else if (const DwGeom pg = depthwise_pk_geom(p, dt); pg.CB > 0 && g_dw_variant.load(std::memory_order_relaxed) == 1) {
+  } else if (const DwGeom pg = depthwise_pk_geom(p, dt); pg.CB > 0) {
     const dim3 grid((unsigned)(pg.ntx * pg.nty), (unsigned)(pg.csplit * p.ogroups), (unsigned)p.B);
     const size_t lds = (size_t)2 * pg.tile_sz * kDwPkCB * sizeof(float);
 #define TVMI_DWPK(scalar_t)                                                                                       \

@@ -853,8 +853,6 @@ inline void release_handoff(int dev, hipStream_t stream) {
 // "nms.replan_max" — how many times one call may re-plan; "nms.mask_lds_bytes" — dynamic LDS per mask workgroup.
 std::atomic<int64_t> g_replan_min_boxes{24576};
 std::atomic<int> g_replan_divisor{16}, g_replan_max{3}, g_mask_lds_bytes{36000}, g_device_handoff{1}, g_handoff_lose_flag{0};
-std::atomic<bool> g_sort_rank{true};     // "nms.sort_rank": the <= 4096-score order by rank counting instead of the one-workgroup bitonic sort
-std::atomic<bool> g_small_split{true};   // "nms.small_split": the small-segment path as collect + four-tile workgroups
 std::atomic<bool> g_step_fused{true};    // "nms.step_fused": detector-step sizes through the one-launch kernel (read by the glue)
 
 // Workspace of the large path: mask tiles | removed[CB] | keepbits[CB] | survivor offsets[CB] (int) | two score-order
@@ -1418,85 +1416,9 @@ inline size_t small_seg_workspace_layout(int64_t n, int64_t S, char* base, Small
   return off;
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void nms_small_seg_tiles(const T* __restrict__ dets, const int64_t* __restrict__ order,
-                                                            const int64_t* __restrict__ seg, int n,
-                                                            const int64_t* __restrict__ n_dev, int S, double thr, ThrBand band,
-                                                            SmallSegWorkspace ws) {
-  __shared__ __attribute__((aligned(16))) T s_box[5][kSmallSegBoxes];  // component-major
-  __shared__ int s_wcnt[16];
-  n = live_boxes(n, n_dev);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  const int me = blockIdx.x;
-  const bool scribe = blockIdx.y == 0;  // the workgroup of this segment that records the list
-  int* glist = ws.glist + (size_t)me * kSmallSegBoxes;
-  // ---- collect my segment, in score order
-  int cnt = 0;
-  bool bad = false;
-  for (int base = 0; base < n; base += 1024) {
-    const int g = base + tid;
-    bool mine = false;
-    int64_t oi = 0;
-    if (g < n) {
-      oi = order[g];
-      const int64_t sg = seg[oi];
-      mine = sg == me;
-      bad |= sg < 0 || sg >= S;
-    }
-    const u64 bal = __ballot(mine);
-    if (lane == 0) s_wcnt[wave] = __popcll(bal);
-    __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < 16; ++w) {
-      const int c = s_wcnt[w];
-      before += w < wave ? c : 0;
-      total += c;
-    }
-    const int pos = cnt + before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (mine && pos < kSmallSegBoxes) {
-      const Box<T> b = load_box<T>(dets, oi);
-      s_box[0][pos] = b.x1;
-      s_box[1][pos] = b.y1;
-      s_box[2][pos] = b.x2;
-      s_box[3][pos] = b.y2;
-      s_box[4][pos] = (b.x2 - b.x1) * (b.y2 - b.y1);
-      if (scribe) glist[pos] = g;
-    }
-    cnt += total;
-    __syncthreads();
-  }
-  if (scribe) {
-    // over-long segment or an id outside [0, S): the caller redoes the input on the general path
-    const bool any_bad = me == 0 ? __syncthreads_or(bad) : false;
-    if (tid == 0) {
-      if (cnt > kSmallSegBoxes || any_bad) ws.sync_words[1] = 1;
-      ws.gcnt[me] = min(cnt, kSmallSegBoxes);
-    }
-  }
-  cnt = min(cnt, kSmallSegBoxes);
-  const int nb = (cnt + 63) >> 6;
-  const int t = blockIdx.y * 16 + wave;
-  if (t >= nb * (nb + 1) / 2) return;
-  int rb = 0, rem = t;
-  while (rem >= nb - rb) {
-    rem -= nb - rb;
-    ++rb;
-  }
-  const int cb = rb + rem;
-  const int j = cb * 64 + lane;
-  const bool jvalid = j < cnt;
-  const int jj = jvalid ? j : 0;
-  const T jx1 = s_box[0][jj], jy1 = s_box[1][jj], jx2 = s_box[2][jj], jy2 = s_box[3][jj], jarea = s_box[4][jj];
-  const u64 mine = suppression_tile<T, kSmallSegBoxes>(&s_box[0][rb * 64], nullptr, min(64, cnt - rb * 64), jx1, jy1, jx2, jy2,
-                                                       jarea, 0, jvalid, cb == rb, thr, band);
-  ws.tiles[((size_t)me * kSmallSegTiles + t) * 64 + lane] = mine;
-}
-
-// The same two steps as TWO launches whose workgroups fit next to a chip-filling neighbour (round 5).  nms_small_seg_tiles
-// stages a whole segment in 21 KB of LDS per 1024-lane workgroup; on a second stream under the RoIAlign forward — 4 workgroups x
-// 39 KB = 156 of the 160 KB of every CU — such a workgroup waits in the dispatcher until that launch drains (16 us alone,
-// 100-195 us there).  A: nms_small_seg_collect records the segment's members (global ranks, in score order) and
+// Step A as TWO launches whose workgroups fit next to a chip-filling neighbour (round 5; the one-launch form that staged a whole
+// segment in 21 KB of LDS per 1024-lane workgroup — it waited 100-195 us in the dispatcher under the RoIAlign forward, which owns
+// 156 of the 160 KB of every CU — was deleted in round 6).  A1: nms_small_seg_collect records the segment's members (global ranks, in score order) and
 // its size — 64 bytes of LDS.  B: nms_small_seg_tiles4, 256-lane workgroups of four tiles: a wave fetches its 64 column boxes
 // straight into registers (rank -> order -> box), the at most three row blocks of a workgroup's four consecutive tiles are
 // staged once in 3.75 KB of LDS.  Same pair arithmetic (suppression_tile), same tiles in ws.tiles, the sweep is unchanged.
@@ -1689,10 +1611,9 @@ __global__ __launch_bounds__(kSuper * kWave) void nms_small_seg_sweep(const int6
 
 // ---------------------------------------------------------------------------------------
 // Score order for small inputs (n <= 4096, float32): order = aten::sort(scores, stable=True, descending=True)
-// indices — NaN first, ties by ascending index, -0 == +0 — as ONE single-workgroup launch (bitonic network over
-// 64-bit keys (order-preserving score bits << 32 | index) in LDS).  At these sizes torch's path is a radix-sort
-// kernel plus an index arange plus two copies (~40 us of launches for 4000 scores); this is ~half of that and has
-// no temporaries.  The unique index in the low word makes the (unstable) network produce the stable order.
+// indices — NaN first, ties by ascending index, -0 == +0 — from 64-bit keys (order-preserving score bits << 32 | index): the
+// unique index in the low word makes the rank of a key exact.  At these sizes torch's path is a radix-sort kernel plus an index
+// arange plus two copies (~40 us of launches for 4000 scores).
 constexpr int kSortMax = 4096;
 
 // (ascending key) == (descending score, ties by ascending index): NaN is the greatest value for aten::sort, -0 == +0
@@ -1710,9 +1631,9 @@ __device__ __forceinline__ u64 score_key(float f, int i) {
   return ((u64)d << 32) | (unsigned)i;
 }
 
-// The same order by RANK COUNTING (round 5, "nms.sort_rank", default on): the keys are unique, so the position of element i is
-// the number of keys below its own — n^2 compares (16 M at n = 4096) spread over n / 64 workgroups instead of 78 compare-exchange
-// passes of ONE workgroup over 32 KB of LDS.  Lane = element, the four waves of a workgroup count over one quarter of the keys
+// RANK COUNTING (round 5; the one-workgroup bitonic network over 32 KB of LDS it replaced was deleted in round 6): the keys are
+// unique, so the position of element i is the number of keys below its own — n^2 compares (16 M at n = 4096) spread over n / 64
+// workgroups instead of 78 compare-exchange passes of ONE workgroup.  Lane = element, the four waves of a workgroup count over one quarter of the keys
 // each, 64 keys at a time through a 512-byte wave-private LDS slice (built once per 64 compares, read as broadcasts).  3 KB of
 // LDS and 256 lanes per workgroup: it starts on any CU, also next to a launch that owns the CU's LDS (the bitonic kernel's 32 KB
 // do not), and it is faster on an idle chip as well.  Identical output (the rank of a unique key is exact).
@@ -1741,93 +1662,6 @@ __global__ __launch_bounds__(256) void sort_scores_desc_rank(const float* __rest
   s_cnt[wave][lane] = cnt;
   __syncthreads();
   if (wave == 0 && i < n) order[s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane]] = i;
-}
-
-__global__ __launch_bounds__(1024) void sort_scores_desc_small(const float* __restrict__ scores, int n, int N /*pow2 >= n*/,
-                                                               int64_t* __restrict__ order) {
-  __shared__ u64 keys[kSortMax];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < N; i += 1024) {
-    u64 k = ~0ull;  // padding sorts last
-    if (i < n) {
-      const float f = scores[i];
-      unsigned b = __builtin_bit_cast(unsigned, f);
-      unsigned d;  // ascending d == descending score
-      if (f != f) {
-        d = 0u;  // NaN is the greatest value for aten::sort
-      } else {
-        if (f == 0.f) b = 0u;                                  // -0 == +0
-        const unsigned asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-        d = ~asc;
-        if (d == 0u) d = 1u;  // cannot happen for non-NaN values (asc of +inf is 0xFF800000), kept for safety
-      }
-      k = ((u64)d << 32) | (unsigned)i;
-    }
-    keys[i] = k;
-  }
-  __syncthreads();
-  // Two sub-stages (j, j/2) per LDS round trip: a thread loads the quad {i, i|j/2, i|j, i|j|j/2}, does the four
-  // compare-exchanges in registers and stores it back (39 rounds instead of 78 at N = 4096).  Wave w owns quads
-  // [64w, 64w+64), i.e. the keys [256w, 256w+256): for j < 256 every quad is its own, so only the rounds with j >= 256
-  // need a workgroup barrier — LDS operations of one wave are ordered.
-  const int wave = tid >> 6, lane = tid & 63;
-  auto cmpx = [](u64& a, u64& b, bool up) {
-    if ((a > b) == up) {
-      const u64 t = a;
-      a = b;
-      b = t;
-    }
-  };
-  auto sync_round = [&](bool wide) {
-    if (wide) {
-      __syncthreads();
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  };
-  for (int k = 2; k <= N; k <<= 1) {
-    int j = k >> 1;
-    for (; j >= 2; j >>= 2) {
-      const int j2 = j >> 1;
-      const bool wide = j >= 256;
-      if (wide) __syncthreads();
-      const int q = wave * 64 + lane;  // quad index
-      if (q < (N >> 2)) {
-        // insert zero bits at positions log2(j2) and log2(j)
-        const int t1 = ((q & ~(j2 - 1)) << 1) | (q & (j2 - 1));  // zero bit at log2(j2)
-        const int i = ((t1 & ~(j - 1)) << 1) | (t1 & (j - 1));   // zero bit at log2(j)
-        u64 a = keys[i], b = keys[i | j2], c = keys[i | j], d = keys[i | j | j2];
-        const bool up = (i & k) == 0;
-        cmpx(a, c, up);
-        cmpx(b, d, up);
-        cmpx(a, b, up);
-        cmpx(c, d, up);
-        keys[i] = a;
-        keys[i | j2] = b;
-        keys[i | j] = c;
-        keys[i | j | j2] = d;
-      }
-      sync_round(wide);
-    }
-    if (j == 1) {  // odd number of sub-stages for this k: the last one alone
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int t = wave * 128 + r * 64 + lane;
-        if (t < (N >> 1)) {
-          const int i = t << 1;
-          u64 a = keys[i], b = keys[i | 1];
-          cmpx(a, b, (i & k) == 0);
-          keys[i] = a;
-          keys[i | 1] = b;
-        }
-      }
-      sync_round(false);
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += 1024) order[i] = (int64_t)(unsigned)keys[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2523,14 +2357,6 @@ int set_nms_option(const char* name, int64_t value) {
     g_replan_max.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 16)), std::memory_order_relaxed);
     return 0;
   }
-  if (std::strcmp(name, "nms.sort_rank") == 0) {
-    g_sort_rank.store(value != 0, std::memory_order_relaxed);
-    return 0;
-  }
-  if (std::strcmp(name, "nms.small_split") == 0) {   // 1 (default): collect + four-tile workgroups; 0: the one-launch form
-    g_small_split.store(value != 0, std::memory_order_relaxed);
-    return 0;
-  }
   if (std::strcmp(name, "nms.step_fused") == 0) {    // 1 (default): n <= 4096 / <= 64 segments as ONE launch (tvmi_nms_step)
     g_step_fused.store(value != 0, std::memory_order_relaxed);
     return 0;
@@ -2541,14 +2367,6 @@ int set_nms_option(const char* name, int64_t value) {
 int get_nms_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "nms.step_fused") == 0) {
     *value = g_step_fused.load(std::memory_order_relaxed) ? 1 : 0;
-    return 0;
-  }
-  if (std::strcmp(name, "nms.small_split") == 0) {
-    *value = g_small_split.load(std::memory_order_relaxed) ? 1 : 0;
-    return 0;
-  }
-  if (std::strcmp(name, "nms.sort_rank") == 0) {
-    *value = g_sort_rank.load(std::memory_order_relaxed) ? 1 : 0;
     return 0;
   }
   if (std::strcmp(name, "nms.replan_min_boxes") == 0) *value = (int64_t)g_replan_min_boxes.load(std::memory_order_relaxed);
@@ -2649,21 +2467,19 @@ int nms_small_segments_entry(const void* dets, const int64_t* order, const int64
   small_seg_workspace_layout(n, num_segments, static_cast<char*>(workspace), &w);
   hipError_t e = hipMemsetAsync(w.sync_words, 0, 2 * sizeof(int), s);
   if (e != hipSuccess) return set_error((int)e, "tvmi_nms_small_segments: memset");
-  // a segment of m boxes has ceil(m/64)*(ceil(m/64)+1)/2 tiles; m <= min(n, 1024)
+  // a segment of m boxes has ceil(m/64)*(ceil(m/64)+1)/2 tiles; m <= min(n, 1024).  Two launches whose workgroups fit next to a
+  // launch that owns the LDS of every CU (see nms_small_seg_collect)
   const int nbmax = (int)std::min<int64_t>(kSmallSegBlocks, ceil_div(n, 64));
-  const dim3 grid((unsigned)num_segments, (unsigned)ceil_div(nbmax * (nbmax + 1) / 2, 16));
-  if (dt == TVMI_F32 && g_small_split.load(std::memory_order_relaxed)) {
-    // two launches whose workgroups fit next to a launch that owns the LDS of every CU (see nms_small_seg_collect)
+  const dim3 grid4((unsigned)num_segments, (unsigned)ceil_div(nbmax * (nbmax + 1) / 2, kTiles4));
+  if (dt == TVMI_F32) {
     nms_small_seg_collect<float><<<dim3((unsigned)num_segments), dim3(1024), 0, s>>>(order, seg, (int)n, n_dev, (int)num_segments, w);
-    const dim3 grid4((unsigned)num_segments, (unsigned)ceil_div(nbmax * (nbmax + 1) / 2, kTiles4));
     nms_small_seg_tiles4<float><<<grid4, dim3(kTiles4 * 64), 0, s>>>(static_cast<const float*>(dets), order, iou_threshold,
                                                                    thr_band(iou_threshold), w);
-  } else if (dt == TVMI_F32)
-    nms_small_seg_tiles<float><<<grid, dim3(1024), 0, s>>>(static_cast<const float*>(dets), order, seg, (int)n, n_dev,
-                                                           (int)num_segments, iou_threshold, thr_band(iou_threshold), w);
-  else
-    nms_small_seg_tiles<double><<<grid, dim3(1024), 0, s>>>(static_cast<const double*>(dets), order, seg, (int)n, n_dev,
-                                                            (int)num_segments, iou_threshold, thr_band(iou_threshold), w);
+  } else {
+    nms_small_seg_collect<double><<<dim3((unsigned)num_segments), dim3(1024), 0, s>>>(order, seg, (int)n, n_dev, (int)num_segments, w);
+    nms_small_seg_tiles4<double><<<grid4, dim3(kTiles4 * 64), 0, s>>>(static_cast<const double*>(dets), order, iou_threshold,
+                                                                    thr_band(iou_threshold), w);
+  }
   nms_small_seg_sweep<<<dim3((unsigned)num_segments), dim3(kSuper * kWave), 0, s>>>(order, (int)n, n_dev, w, keep_out, num_keep_out);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_nms_small_segments");
 }
@@ -2808,13 +2624,6 @@ extern "C" int tvmi_sort_scores_desc(const float* scores, int64_t n, int64_t* or
   TVMI_CHECK_ARG(n >= 0 && n <= tvmi::kSortMax, "sort_scores_desc: 0 <= n <= 4096");
   if (n == 0) return 0;
   TVMI_CHECK_ARG(scores && order, "sort_scores_desc: null pointer");
-  if (tvmi::g_sort_rank.load(std::memory_order_relaxed) && n > 64) {
-    tvmi::sort_scores_desc_rank<<<dim3((unsigned)tvmi::ceil_div(n, 64)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(scores, (int)n,
-                                                                                                                      order);
-    TVMI_RETURN_LAUNCH_STATUS("tvmi_sort_scores_desc");
-  }
-  int N = 2;
-  while (N < n) N <<= 1;
-  tvmi::sort_scores_desc_small<<<dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream)>>>(scores, (int)n, N, order);
+  tvmi::sort_scores_desc_rank<<<dim3((unsigned)tvmi::ceil_div(n, 64)), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(scores, (int)n, order);
   TVMI_RETURN_LAUNCH_STATUS("tvmi_sort_scores_desc");
 }

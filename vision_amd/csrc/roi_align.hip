@@ -819,8 +819,10 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared<PHT>& s, const T*
   if (kStaged && staged) flush(cc - staged, staged);
 }
 
+// Returns true when the unit was left to the caller (declined == nullptr: the inline form, round 6 — the caller runs the wave
+// path for it in the same launch instead of a worklist entry for a mop-up launch).
 template <typename T, typename R, int PHT, int PWT, int SRT>
-__device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared<PHT>& s, const T* __restrict__ input,
+__device__ __forceinline__ bool roi_align_fwd_wave_dma(DmaShared<PHT>& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
                                                        int c0, int chunk, int* __restrict__ declined) {
@@ -837,12 +839,13 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared<PHT>& s, const 
   const int64_t plane_sz = (int64_t)H * W;
   const DmaWindow dw = dma_window<PHT, PWT, SRT, EPP>(g, H, W);
   if (dw.state == 2) {  // left to the mop-up launch: one worklist entry per RoI (the wave of channel chunk 0 reports it)
+    if (declined == nullptr) return true;
     if (c0 == 0 && lane == 0) declined[kMopHeader + atomicAdd(declined, 1)] = k;
-    return;
+    return false;
   }
   if (dw.state == 0) {
     for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
-    return;
+    return false;
   }
   // ---- per-lane sample set-up (registers): LDS slots of the two tap rows + separable factors
   int off[NB][NS][2];
@@ -888,6 +891,7 @@ __device__ __forceinline__ void roi_align_fwd_wave_dma(DmaShared<PHT>& s, const 
     roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
   else
     roi_align_dma_passes<T, PHT, PWT, SRT, 2 * dma_per_pass(PHT)>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+  return false;
 }
 
 template <typename T, typename R, int PHT, int PWT, int SRT>
@@ -1178,6 +1182,30 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
                                                   lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
 }
 
+// The same launch WITHOUT a mop-up launch behind it (round 6, "roi_align.inline_mop"): a unit the DMA path declines (a window
+// above 8 DMA blocks per channel, samples the reference skips: 0-2 % of the RoIs of a detector step) takes the wave path right
+// here, in the LDS of the same wave (the two per-wave images are a union: 10 KB, still four workgroups per CU).  One launch and
+// one launch gap less per call; the price is the wave path's registers in this kernel's allocation (127 instead of 73: still four
+// waves per SIMD).
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma_inl(MsLevels lv, const float* __restrict__ rois,
+                                                                     T* __restrict__ output, int C, int aligned, int nchunks,
+                                                                     int chunk, int64_t nunits, UnitMap um) {
+  union WaveLds {
+    DmaShared<PHT> d;
+    WaveShared w;
+  };
+  __shared__ WaveLds s[kThreads / 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int k, ci;
+  if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
+  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+  if (roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave].d, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                                      lv.scale[l], aligned, k, ci * chunk, chunk, nullptr))
+    roi_align_fwd_wave_fast<T, float, PHT, PWT, SRT>(s[wave].w, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                                     lv.scale[l], aligned, k, ci * chunk, chunk);
+}
+
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, const float* __restrict__ rois,
                                                                   T* __restrict__ output, int C, int PH_, int PW_,
@@ -1217,6 +1245,7 @@ struct FwdOptions {
   int pin_chunks = 1;   // "roi_align.pin_chunks": channel chunks pinned to XCDs when the chunk count allows it
   int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
   int bands = 16;       // "roi_align.order_bands": window-top bands per (image, level) in the order key
+  int inline_mop = 1;   // "roi_align.inline_mop": declined units take the wave path inside the DMA launch (multi-scale 7 x 7 entries)
 };
 FwdOptions g_fwd_opt;
 
@@ -1509,7 +1538,11 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
   roi_align_fwd_ms_dma<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, kUnitChunk, \
                                                                                nunits, mop, um)
 #define TVMI_MS(PHT, PWT, SRT)                                                                                      \
-  if (mop) {                                                                                                   \
+  if (mop && g_fwd_opt.inline_mop && PHT == 7) {   /* 14 x 14: the union of both paths needs 221 VGPRs, two waves per SIMD */ \
+    if constexpr (PHT == 7)                                                                                           \
+      roi_align_fwd_ms_dma_inl<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
+                                                                                     kUnitChunk, nunits, um);         \
+  } else if (mop) {                                                                                                   \
     TVMI_MS_DMA(PHT, PWT, SRT);                                                                                     \
     roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
                                                                             aligned, mop_nchunks, kMopChunk, mop_nunits, \
@@ -1537,6 +1570,7 @@ int set_roi_option(const char* name, int64_t value) {
   const std::string n(name);
   if (n == "roi_align.pin_chunks") g_fwd_opt.pin_chunks = value != 0;
   else if (n == "roi_align.order") g_fwd_opt.order = value != 0;
+  else if (n == "roi_align.inline_mop") g_fwd_opt.inline_mop = value != 0;
   else if (n == "roi_align.order_bands") g_fwd_opt.bands = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
   else return -1;
   return 0;
@@ -1548,6 +1582,7 @@ int get_roi_option(const char* name, int64_t* value) {
   if (n == "roi_align.pin_chunks") *value = g_fwd_opt.pin_chunks;
   else if (n == "roi_align.order") *value = g_fwd_opt.order;
   else if (n == "roi_align.order_bands") *value = g_fwd_opt.bands;
+  else if (n == "roi_align.inline_mop") *value = g_fwd_opt.inline_mop;
   else return -1;
   return 0;
 }

@@ -23,27 +23,6 @@ extern "C" int tvmi_version(void) { return TVMI_ABI_VERSION; }
 extern "C" const char* tvmi_arch(void) { return "gfx950"; }
 extern "C" const char* tvmi_last_error(void) { return tvmi::g_last_error; }
 
-// A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask).  Bit i of the mask enables CU i; on the
-// multi-XCD parts the driver deals the bits round-robin over the XCDs, so clearing bits 0..7 takes ONE CU out of each of the
-// eight XCDs of an MI355X.  Use: the step's long RoIAlign launch runs on a stream that leaves a few CUs alone, the short
-// latency-bound NMS / packing chain runs on a second stream and finds those CUs empty — a chip-filling kernel that owns all the
-// LDS of every CU (4 x 39 KB workgroups) otherwise keeps the side stream's workgroups waiting until it drains (queue priorities
-// do not change that: measured, bench.py --side-priority).  *stream is a hipStream_t; destroy with tvmi_stream_destroy.
-extern "C" int tvmi_stream_create_cu_mask(const uint32_t* cu_mask, uint32_t mask_words, void** stream) {
-  if (!cu_mask || mask_words == 0 || !stream) return tvmi::set_error(hipErrorInvalidValue, "stream_create_cu_mask: null argument");
-  hipStream_t s = nullptr;
-  const hipError_t e = hipExtStreamCreateWithCUMask(&s, mask_words, cu_mask);
-  if (e != hipSuccess) return tvmi::set_error((int)e, "stream_create_cu_mask: hipExtStreamCreateWithCUMask");
-  *stream = s;
-  return 0;
-}
-
-extern "C" int tvmi_stream_destroy(void* stream) {
-  if (!stream) return 0;
-  const hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
-  return e == hipSuccess ? 0 : tvmi::set_error((int)e, "stream_destroy");
-}
-
 // `waiter` waits for everything enqueued on `signaler` so far — torch's Stream.wait_stream, with an event that releases to
 // DEVICE scope (hipEventReleaseToDevice): both streams live on this device, and torch's events release to system scope (a
 // write-back + invalidate meant for host readers) on every record.  The step of this path forks and joins its two streams
