@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_direct(const T* __restrict__ inpu
   }
 }
 
+std::atomic<int> g_cl_pipelined{1};  // option "dcn.cl_variant": 0 forces the non-pipelined channels-last kernel — the route of copies of
+                                     // 4 GB and more (the pipelined kernel forms 32-bit lane offsets) — so that tests can reach it
 std::atomic<int> g_xcd_tiles{1};   // option "dcn.xcd_tiles": contiguous pixel-tile ranges per XCD (tile_of_block)
 std::atomic<int> g_cl_gather{1};  // option "dcn.channels_last_gather": the 16-bit MFMA kernel samples a [B, H*W, C] copy
 
@@ -1697,6 +1699,10 @@ int set_dcn_option(const char* name, int64_t value) {
     g_cl_gather.store(value != 0, std::memory_order_relaxed);
     return 0;
   }
+  if (std::strcmp(name, "dcn.cl_variant") == 0) {
+    g_cl_pipelined.store(value != 0, std::memory_order_relaxed);
+    return 0;
+  }
   if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
     g_xcd_tiles.store(value != 0, std::memory_order_relaxed);
     return 0;
@@ -1707,6 +1713,10 @@ int set_dcn_option(const char* name, int64_t value) {
 int get_dcn_option(const char* name, int64_t* value) {
   if (std::strcmp(name, "dcn.channels_last_gather") == 0) {
     *value = g_cl_gather.load(std::memory_order_relaxed) ? 1 : 0;
+    return 0;
+  }
+  if (std::strcmp(name, "dcn.cl_variant") == 0) {
+    *value = g_cl_pipelined.load(std::memory_order_relaxed);
     return 0;
   }
   if (std::strcmp(name, "dcn.xcd_tiles") == 0) {
@@ -1794,7 +1804,7 @@ extern "C" int tvmi_deform_conv2d_forward(const void* input, const void* weight,
         (const scalar_t*)input, (scalar_t*)in_cl, (int)C, (int)(H * W));                                               \
     const scalar_t* icl = (const scalar_t*)in_cl;                                                                      \
     const scalar_t* w8 = (const scalar_t*)workspace;                                                                   \
-    const bool pipelined = cl_bytes < ((size_t)1 << 32);   /* the pipelined kernel forms 32-bit lane offsets */                 \
+    const bool pipelined = cl_bytes < ((size_t)1 << 32) && g_cl_pipelined.load(std::memory_order_relaxed);   /* 32-bit lane offsets */ \
     /* measured at config 4 (profiles/r04_dcn_variants.json): 256 x 128 tile, 8 waves of 64 x 64 — 0.098 ms against 0.125 ms   \
        for the round-3 kernel; 4 waves 0.104; 256 x 64 tiles 0.151; three stages 0.102.  OC = 128: 128 x 128 tile 0.096        \
        against 0.137 (round 3) and 0.150 (128 x 256 tile: 107 workgroups) */                                                 \
