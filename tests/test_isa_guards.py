@@ -187,7 +187,7 @@ def test_nms_chain_of_the_step_fits_next_to_the_roi_align_kernel(tmp_path):
     """The two halves of the detection step overlap on two streams only because EVERY launch of the NMS / packing chain can start
     on a CU that already holds four workgroups of the RoIAlign forward: 160 KB - 4 x its LDS is what is left (4 KB today), 16 of
     the 32 wave slots are free.  Round 4's chain had a 21 KB and a 32 KB launch in it: they waited 100-195 us in the dispatcher and
-    the chain finished BEHIND the RoIAlign launch.  Guard: the rank-counting score sort, the segment collect, the
+    the chain finished BEHIND the RoIAlign launch (HISTORY.md 6.0).  Guard: the rank-counting score sort, the segment collect, the
     four-tile kernel, the sweep and the packing kernel each need at most that much LDS and at most 16 waves."""
     _, roi = _kernel_resources(os.path.join(CSRC, "roi_align.hip"), tmp_path)
     dma = [v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi7ELi7ELi2E" in k]

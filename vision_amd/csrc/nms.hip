@@ -1636,7 +1636,7 @@ __device__ __forceinline__ u64 score_key(float f, int i) {
 // workgroups instead of 78 compare-exchange passes of ONE workgroup.  Lane = element, the four waves of a workgroup count over one quarter of the keys
 // each, 64 keys at a time through a 512-byte wave-private LDS slice (built once per 64 compares, read as broadcasts).  3 KB of
 // LDS and 256 lanes per workgroup: it starts on any CU, also next to a launch that owns the CU's LDS (the bitonic kernel's 32 KB
-// do not), and it is faster on an idle chip as well.  Identical output (the rank of a unique key is exact).
+// do not; HISTORY.md 6.0), and it is faster on an idle chip as well.  Identical output (the rank of a unique key is exact).
 __global__ __launch_bounds__(256) void sort_scores_desc_rank(const float* __restrict__ scores, int n, int64_t* __restrict__ order) {
   __shared__ u64 s_keys[4][64];
   __shared__ int s_cnt[4][64];

@@ -1240,7 +1240,7 @@ inline int* perm_part(void* ws, size_t ws_bytes, int64_t K) {
 }
 
 // Process-wide switches of the forward (tvmi_set_option): measured defaults, the other settings stay reachable for the
-// variant table of DESIGN.md §4.1 and for tests that force every route.
+// variant table of HISTORY.md §4.1 and for tests that force every route.
 struct FwdOptions {
   int pin_chunks = 1;   // "roi_align.pin_chunks": channel chunks pinned to XCDs when the chunk count allows it
   int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
