@@ -239,6 +239,12 @@ def test_config2_roi_align_backward_16bit_values(tv, dtype):
                                    err_msg=f"per-level backward level {lvl}")
 
 
+# bf16 `_deform_conv2d_backward` at config 4: worst |error| / max |reference| per gradient measured on the MI355X, + 20 %
+BF16_BWD_BAR = {  # measured (round 6): g=1 3.14e-3 / 3.69e-3 / 2.27e-3 / 3.40e-3 / 2.17e-3; g=256 2.71e-3 / 2.88e-3 / 2.45e-3 / 2.44e-3 / 3.63e-3
+    1: {"grad_input": 3.8e-3, "grad_weight": 4.5e-3, "grad_offset": 2.8e-3, "grad_mask": 4.1e-3, "grad_bias": 2.7e-3},
+    256: {"grad_input": 3.3e-3, "grad_weight": 3.5e-3, "grad_offset": 3.0e-3, "grad_mask": 3.0e-3, "grad_bias": 4.4e-3}}
+
+
 @pytest.mark.parametrize("groups", [1, 256])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_config4_deform_conv2d_backward_full_size(tv, groups, dtype):
@@ -247,8 +253,8 @@ def test_config4_deform_conv2d_backward_full_size(tv, groups, dtype):
     27,200 (weights: over the pixels) products in another order, bar 1e-4 relative to the gradient's own scale.  bf16: the
     reference computes the 16-bit backward in the 16-bit type; ours is compared with the fp32 reference on the rounded
     tensors: the `columns` intermediate is a 16-bit tensor (in the reference too, cuda/deform_conv2d_kernel.cu:752-1033) and
-    the result is rounded once more, so the bar is 3e-2 of the gradient's scale (measured: 9 of 7 M elements beyond 1e-2,
-    worst 2.1e-2)."""
+    the result is rounded once more: the bar is absolute, per gradient, = the worst error measured + 20 % (BF16_BWD_BAR; round 5
+    had one 3e-2 bar with an rtol of the same size on top)."""
     g = gen(620 + groups)
     B, C, H, W, OC = 2, 256, 100, 136, 256
     x = torch.randn(B, C, H, W, generator=g).to(dtype)
@@ -264,11 +270,19 @@ def test_config4_deform_conv2d_backward_full_size(tv, groups, dtype):
         ref = torch.ops.torchvision._deform_conv2d_backward(gr.float(), x.float(), w.float(), off.float(), m.float(), b.float(),
                                                             1, 1, 1, 1, 1, 1, groups, 1, True)
         ref = [r.numpy() for r in ref]
-    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    measured = {}
     for name, a, r in zip(("grad_input", "grad_weight", "grad_offset", "grad_mask", "grad_bias"), got, ref):
         assert a.dtype == dtype, name
         scale = max(1.0, float(np.abs(r).max()))
-        np.testing.assert_allclose(a.float().cpu().numpy(), r, rtol=tol, atol=tol * scale, err_msg=f"{name} groups={groups}")
+        err = float(np.abs(a.float().cpu().numpy() - r).max()) / scale
+        measured[name] = err
+        if dtype == torch.float32:
+            np.testing.assert_allclose(a.float().cpu().numpy(), r, rtol=1e-4, atol=1e-4 * scale, err_msg=f"{name} groups={groups}")
+        else:
+            # an absolute bar only (no rtol on top), per gradient = the worst error measured on the MI355X
+            # (round 6, printed below with -s) + 20 %, in units of the gradient's largest magnitude
+            assert err <= BF16_BWD_BAR[groups][name], (name, groups, err, BF16_BWD_BAR[groups][name])
+    print(f"deform_conv2d backward {dtype} groups={groups}: max |err| / scale per gradient", {k: f"{v:.2e}" for k, v in measured.items()})
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)], ids=["bf16", "fp16"])
