@@ -455,7 +455,7 @@ def main():
                            + (" (1-rank RCCL group, the all-gather run as a real collective: --force-collective)" if args.force_collective else ""),
         },
         "roofline": {
-            "kernel": "roi_align_fwd_ms_dma<7,7,2>",
+            "kernel": "roi_align_fwd_ms_dma_inl<7,7,2>",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,

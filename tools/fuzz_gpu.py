@@ -38,11 +38,23 @@ while time.time() - t0 < 60:
         assert np.array_equal(gots, wants), ("segmented", n, S, hint, thr)
         gotb = vision_amd.batched_nms(b.to(dev), s.to(dev), idx.to(dev), thr, num_segments=hint).cpu().numpy()   # the reference's switch of arithmetic
         assert np.array_equal(gotb, O.batched_nms(b, s, idx, thr)), ("batched", n, S, hint, thr)
+    # ---- round 6: the one-launch step kernel with its payload (n <= 4096, <= 64 segments of <= 1024, <= 16 images) against the oracle
+    # and against the launch chain + pack_detections_payload
+    if n <= 4096 and int(torch.bincount(idx, minlength=S).max()) <= 1024:
+        Bi = ri(1, min(16, S)); img = (idx % Bi).to(dev); D = ri(1, 120); lab = torch.randint(0, 91, (n,), generator=g).to(dev)
+        db, ds, di = b.to(dev), s.to(dev), idx.to(dev)
+        k1, n1, p1 = torch.ops.tvmi.nms_step(db, ds, di, thr, S, img, lab, Bi, D)
+        assert int(n1) == len(wants) and np.array_equal(k1[: int(n1)].cpu().numpy(), wants), ("nms_step", n, S, thr)
+        torch.ops.tvmi.set_option("nms.step_fused", 0)
+        k2, n2 = torch.ops.tvmi.nms_segmented_padded(db, ds, di, thr, S)
+        torch.ops.tvmi.set_option("nms.step_fused", 1)
+        assert int(n2) == int(n1) and torch.equal(k2[: int(n2)], k1[: int(n1)]), ("nms chain", n, S, thr)
+        assert torch.equal(p1, torch.ops.tvmi.pack_detections_payload(db, ds, lab, img, k2, n2, Bi, D)), ("nms_step payload", n, S, Bi, D)
     # ---- RoIAlign forward NCHW vs channels_last vs oracle, backward vs oracle
     N, C, H, W = ri(1, 3), [ri(1, 70), ri(1, 70), 256, 512][ri(0, 3)], ri(2, 60), ri(4, 70)
     # launch routes of the LDS-DMA forward (C = 256 / 512: channel chunks pinned to XCDs, launch order from the pre-pass)
     torch.ops.tvmi.set_option("roi_align.pin_chunks", ri(0, 1)); torch.ops.tvmi.set_option("roi_align.order", ri(0, 1))
-    torch.ops.tvmi.set_option("roi_align.order_bands", [1, 16, 64][ri(0, 2)])
+    torch.ops.tvmi.set_option("roi_align.order_bands", [1, 16, 64][ri(0, 2)]); torch.ops.tvmi.set_option("roi_align.inline_mop", ri(0, 1))
     x = torch.rand(N, C, H, W, generator=g)
     k = ri(1, 60); scale = [1.0, 0.5, 0.25][ri(0, 2)]
     bx = torch.rand(k, 2, generator=g) * torch.tensor([W / scale, H / scale]) * 1.1 - 0.05 * W / scale

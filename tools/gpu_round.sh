@@ -4,7 +4,7 @@
 # passes (FETCH_SIZE / WRITE_SIZE in SEPARATE passes, kernel-trace only) for the dominant forward kernel, the
 # channels_last kernel, the tile-owner backward and the large-NMS mask kernel, and the FETCH/WRITE calibration probe.
 #   gpurun -- 'bash tools/gpu_round.sh <tag>'
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

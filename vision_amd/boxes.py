@@ -53,10 +53,15 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
                 # a traced / compiled graph must stay branch-free like the reference's: its own formulation,
                 # one global-order nms() of the shifted boxes — the same result, cross-category side effect included
                 return torch.ops.torchvision.nms(shifted, scores, iou_threshold)
-            keep = torch.ops.tvmi.nms_segmented(shifted, scores, idxs, iou_threshold, int(num_segments))
-            if bool(min_coordinate < -1):      # shifted categories overlap: the reference's nms() sees cross-category pairs
-                keep = torch.ops.torchvision.nms(shifted, scores, iou_threshold)
-            return keep
+            # ONE host read for both data-dependent facts (round 5 read them separately): the length of the
+            # keep list (the reference reads it too: nms returns a tensor of that size) and whether the shifted categories overlap
+            keep, num = torch.ops.tvmi.nms_segmented_padded(shifted, scores, idxs, iou_threshold, int(num_segments))
+            n, overlap = torch.stack([num[0], (min_coordinate < -1).to(torch.int64)]).tolist()
+            if overlap:                        # shifted categories overlap: the reference's nms() sees cross-category pairs
+                return torch.ops.torchvision.nms(shifted, scores, iou_threshold)
+            if n < 0:                          # beyond the limits of the device-count paths (a segment above 8192 boxes ...)
+                return torch.ops.tvmi.nms_segmented(shifted, scores, idxs, iou_threshold, int(num_segments))
+            return keep[:n]
         return torch.ops.tvmi.nms_segmented(boxes, scores, idxs, iou_threshold, int(num_segments))
     if boxes.numel() > 4000:
         return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)
