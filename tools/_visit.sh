@@ -1,2 +1,3 @@
-bash tools/gpu_round.sh r06 2>&1 | tail -30
-timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/r06/pytest_gpu_full.log 2>&1; grep -E "passed|failed" gpurun_out/r06/pytest_gpu_full.log | tail -2
+mkdir -p gpurun_out/r06
+(timeout 200 python tools/step_stress.py 90 2>&1 | tail -3) > gpurun_out/r06/stress.log; cat gpurun_out/r06/stress.log
+for seed in 21 22 23; do (timeout 200 python tools/fuzz_gpu.py $seed 2>&1 | tail -3) >> gpurun_out/r06/fuzz.log; done; cat gpurun_out/r06/fuzz.log
