@@ -2212,3 +2212,41 @@ def test_multiscale_roi_align_boxes_builds_its_own_rows(C, P, dtype):
     got = pool({str(i): f for i, f in enumerate(feats)}, boxes, [(800, 1216)] * B)
     assert torch.equal(got, want.detach())
     assert torch.ops.tvmi.multiscale_roi_align_boxes(feats, [b[:0] for b in boxes], scales, *tail)[0].shape == (0, C, P, P)
+
+
+def test_nms_step_under_graph_capture_and_on_many_streams():
+    """The hand-over words of tvmi::nms_step live in a block the library owns per (device, stream), re-armed by the kernel; a stream
+    that is being CAPTURED gets the caller's workspace words + a memset node instead (no allocation inside a capture).  Both forms
+    give the eager result: captured into a hipGraph and replayed 20 times, and eagerly on 8 streams at once."""
+    g = gen(31337)
+    n, S = 3000, 6
+    boxes = random_boxes(n, 900, 700, 8, 200, g).to(DEV)
+    scores = torch.rand(n, generator=g).to(DEV)
+    seg = (torch.arange(n) * S // n)[torch.randperm(n, generator=g)].to(DEV)
+    img = (seg % 3).contiguous()
+    want = [t.clone() for t in torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50)      # warm-up on the capture stream's pool
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50)
+    for _ in range(20):
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(out, want):
+            assert torch.equal(a, b)
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    outs = []
+    for _ in range(5):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50))
+    torch.cuda.synchronize()
+    for o in outs:
+        for a, b in zip(o, want):
+            assert torch.equal(a, b)
