@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r06
-(timeout 200 python tools/step_stress.py 90 2>&1 | tail -3) > gpurun_out/r06/stress.log; cat gpurun_out/r06/stress.log
-for seed in 21 22 23; do (timeout 200 python tools/fuzz_gpu.py $seed 2>&1 | tail -3) >> gpurun_out/r06/fuzz.log; done; cat gpurun_out/r06/fuzz.log
+python tools/dcn_fwd_timing.py dcn.channels_last_gather=0 dcn.channels_last_gather=1 dcn.channels_last_gather=0 dcn.channels_last_gather=1 2>&1 | tail -6
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_sizes.py tests/test_gpu_abi.py -q -x -m gpu -k "deform and not backward" 2>&1 | tail -3
