@@ -10,9 +10,10 @@ import vision_amd  # noqa: E402
 
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(100)
+B = int(os.environ.get("DCN_B", "2"))
 sets = []
 for i in range(3):
-    sets.append(dict(x=torch.randn(2, 256, 100, 136, generator=g).to(dev), off=torch.randn(2, 18, 100, 136, generator=g).to(dev),
+    sets.append(dict(x=torch.randn(B, 256, 100, 136, generator=g).to(dev), off=torch.randn(B, 18, 100, 136, generator=g).to(dev),
                      w=(torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(dev), b=torch.randn(256, generator=g).to(dev)))
 
 
@@ -39,6 +40,6 @@ for kv in sys.argv[1:] or ["dcn.f32_depth2=1"]:
     run = lambda i: vision_amd.deform_conv2d(sets[i % 3]["x"], sets[i % 3]["off"], sets[i % 3]["w"], sets[i % 3]["b"], padding=1)
     m, mn = med(run)
     outs.append(run(0).clone())
-    print(f"{kv}: median {m:.4f} ms  min {mn:.4f} ms   {2 * 2 * 256 * 256 * 9 * 100 * 136 / m / 1e9:.1f} TFLOP/s")
+    print(f"{kv}: median {m:.4f} ms  min {mn:.4f} ms   {2 * B * 256 * 256 * 9 * 100 * 136 / m / 1e9:.1f} TFLOP/s")
 if len(outs) > 1:
     print("bit-identical:", all(torch.equal(outs[0], o) for o in outs[1:]), " max diff", max(float((outs[0] - o).abs().max()) for o in outs[1:]))
