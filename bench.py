@@ -10,9 +10,10 @@ workload : BASELINE config 2 — a batch of 4 padded 800x1344 images per GPU, 4 
            NMS (batched_nms over the image index, IoU 0.5), packing of the padded top-100 detections of every
            image (fixed shape) and — when N > 1 — their one RCCL all-gather.  The per-rank part has no host
            synchronisation, so the launches queue back to back (--graph replays them from captured hipGraphs, one
-           per input set).  The NMS + packing chain does not depend on the RoIAlign output: it runs on a second HIP
-           stream under the RoIAlign launch (forked from and joined back into the step's stream); `--one-stream`
-           keeps it on the launch stream, and the line carries that time beside it (config.one_stream_ms_per_step).
+           per input set).  The NMS + packing does not depend on the RoIAlign output: since round 6 its workgroups ride in
+           front of the RoIAlign grid — the step is ONE launch on one stream (`--one-launch 0`: two launches, the NMS one on a
+           second HIP stream forked from and joined back into the step's stream; `--one-stream` keeps both on one stream; the
+           line carries those times beside `value`: config.two_launches_two_streams_ms_per_step, one_stream_ms_per_step).
 inputs   : synthetic (seeded), resident in HBM before the timed region.
 scaling  : weak — every rank owns its own batch of images (the path shards over images; no data-path
            collective besides the detection all-gather).  value = boxes processed by ALL ranks / time.
@@ -98,6 +99,8 @@ def main():
                     "RoIAlign launch's stream; the default runs it on a second HIP stream under that launch (-3..-6 %% per step in "
                     "eight of eight round-4/5 visits once the collector stall was out of the way)")
     ap.set_defaults(overlap=True)
+    ap.add_argument("--one-launch", type=int, default=1, help="1 (default): the step is ONE launch — the NMS workgroups ride in front of the "
+                    "RoIAlign grid (tvmi::roi_align_boxes_nms_step, round 6); 0: two launches, on two streams (or one with --one-stream)")
     ap.add_argument("--side-priority", type=int, default=-1, help="HIP priority of the second stream (NMS + packing chain): -1 = "
                     "high (default: its short kernels get the wave slots the RoIAlign workgroups free), 0 = normal")
     ap.add_argument("--event-scope", type=int, default=1, help="fork / join events of the two-stream step: 1 = device-scope release "
@@ -172,6 +175,7 @@ def main():
 
     nms_stream = torch.cuda.Stream(device=device, priority=args.side_priority)
     overlap = {"on": args.overlap}
+    mode = {"one_launch": bool(args.one_launch) and bool(args.nms_step_fused) and not args.diag_skip}
     # The RoIAlign launch owns nearly all the LDS of every CU it runs on (4 workgroups x 40 KB of 160 KB): a side-stream launch that
     # needs more LDS than is left waits in the dispatcher until it drains.  The step's NMS + payload launch (tvmi::nms_step) is
     # enqueued FIRST (the fork precedes the RoIAlign launches) and is resident before the RoIAlign grid arrives.
@@ -198,6 +202,12 @@ def main():
         # outlier seen once in round 3 has not reproduced in eight visits since).  `--one-stream` keeps one stream.
         d = sets[counter["i"] % N_SETS if which is None else which]
         counter["i"] += 1
+        if mode["one_launch"]:
+            # round 6: ONE launch for the step — the NMS workgroups (tiles, rank counting, sweeps, keep list, padded top-k payload)
+            # are the first workgroups of the RoIAlign grid: no second stream, no fork, no join
+            pooled, keep, num, payload = pool.forward_with_nms_step(d["feats"], d["boxes"], image_shapes, d["all_boxes"], d["all_scores"],
+                                                                    img_idx, NMS_THR, BATCH, img_idx, BATCH, MAX_DETS)
+            return pooled, num, payload, keep
         cur = torch.cuda.current_stream()
         side = nms_stream if overlap["on"] else cur
         if side is not cur and args.diag_skip not in ("fork", "both"):
@@ -315,11 +325,16 @@ def main():
     elapsed, preroll, per_step_seq = contract_region()
     host_enqueue_ms = host["enqueue_ms"]
     # the same K steps in the OTHER stream mode (reported next to `value`, never `value` itself)
-    other_stream_ms = None
+    other_stream_ms, other_launch_ms = None, None
     if graph is None:
+        was = mode["one_launch"]
+        mode["one_launch"] = False
+        if was:   # the step as two launches on two streams
+            other_launch_ms = contract_region()[0] / max(args.steps, 1) * 1e3
         overlap["on"] = not args.overlap
         other_stream_ms = contract_region()[0] / max(args.steps, 1) * 1e3
         overlap["on"] = args.overlap
+        mode["one_launch"] = was
     gc.callbacks.remove(gc_probe)
     gc.enable()
     gc.unfreeze()
@@ -358,6 +373,11 @@ def main():
     with torch.no_grad():
         # exactly what pool() launches, without its python-side roi formatting
         k_ms = timed(lambda i: torch.ops.tvmi.multiscale_roi_align(sets[i % N_SETS]["flist"], sets[i % N_SETS]["rois5"], scales, *ms_args))
+        roi_alone_ms = k_ms
+        if mode["one_launch"]:   # the launch the step makes: the same grid with the NMS workgroups in front (and the order pre-pass)
+            k_ms = timed(lambda i: pool.forward_with_nms_step(sets[i % N_SETS]["feats"], sets[i % N_SETS]["boxes"], image_shapes,
+                                                              sets[i % N_SETS]["all_boxes"], sets[i % N_SETS]["all_scores"], img_idx, NMS_THR,
+                                                              BATCH, img_idx, BATCH, MAX_DETS))
         # NMS + payload alone (what the step launches), for the breakdown in `config`
         nms_ms = timed(lambda i: sharding.nms_pack_payload(sets[i % N_SETS]["all_boxes"], sets[i % N_SETS]["all_scores"], img_idx, NMS_THR,
                                                            BATCH, img_idx, BATCH, MAX_DETS))
@@ -402,7 +422,7 @@ def main():
             import hashlib
 
             tj = json.load(open(tpath))
-            traffic = tj.get("roi_align_fwd_ms_dma", {}).get("hbm_bytes_per_launch")
+            traffic = tj.get("roi_align_fwd_ms_dma_inl_step" if mode["one_launch"] else "roi_align_fwd_ms_dma", {}).get("hbm_bytes_per_launch")
             h = hashlib.sha256()
             for name in ("roi_align.hip", "roi_common.h"):
                 h.update(open(os.path.join(ROOT, "vision_amd", "csrc", name), "rb").read())
@@ -436,7 +456,7 @@ def main():
             "workload": "BASELINE config 2: per GPU 4x(800x1344) images, FPN P2-P5 x256ch fp32, 1000 proposals/image; "
                         "step = MultiScaleRoIAlign 7x7 sr2 (1 launch) + per-image NMS@0.5 + all-gather of padded top-100 dets",
             "boxes_per_step_per_gpu": BATCH * PROPOSALS,
-            "roi_align_ms": round(k_ms, 4),
+            "roi_align_ms": round(roi_alone_ms, 4),
             "nms_ms": round(nms_ms, 4),
             "roi_align_channels_last_ms": round(cl_ms, 4),
             "kept_boxes": int(out[1].item()),
@@ -445,7 +465,9 @@ def main():
             "schema_ops_ms_per_step": round(schema_ms, 4),
             "schema_ops_boxes_per_s": round(BATCH * PROPOSALS / (schema_ms / 1e3), 1),
             "rotated_input_sets": N_SETS,
-            "streams": ("NMS + payload launch on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream"),
+            "streams": ("one stream, ONE launch: the NMS workgroups ride in front of the RoIAlign grid" if mode["one_launch"] else
+                        "NMS + payload launch on a second HIP stream under the RoIAlign launch" if args.overlap else "one stream, two launches"),
+            **({"two_launches_two_streams_ms_per_step": round(other_launch_ms, 4)} if other_launch_ms is not None else {}),
             **({"INVALID_diagnosis_run": f"--diag-skip {args.diag_skip}: stream hops left out, not a measurement of the step"} if args.diag_skip else {}),
             "fork_join_events": {1: "device-scope release", 0: "system-scope release", 2: "no event fence", -1: "torch wait_stream"}[args.event_scope],
             ("one_stream_ms_per_step" if args.overlap else "two_stream_ms_per_step"): None if other_stream_ms is None else round(other_stream_ms, 4),
@@ -455,7 +477,7 @@ def main():
                            + (" (1-rank RCCL group, the all-gather run as a real collective: --force-collective)" if args.force_collective else ""),
         },
         "roofline": {
-            "kernel": "roi_align_fwd_ms_dma_inl<7,7,2>",
+            "kernel": "roi_align_fwd_ms_dma_inl_step<7,7,2>" if mode["one_launch"] else "roi_align_fwd_ms_dma_inl<7,7,2>",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,

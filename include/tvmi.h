@@ -44,7 +44,7 @@ typedef enum {
  * in the owner regimes, tvmi_roi_align_backward_workspace_bytes takes (N, K, PH, PW), tvmi_box_iou_pairwise has `eps`,
  * the RoIAlign forward workspace grew (tvmi_roi_align_forward_workspace_bytes).  A caller built against a 100-series
  * header must not call this library: check TVMI_ABI_VERSION == tvmi_version(). */
-#define TVMI_ABI_VERSION 306
+#define TVMI_ABI_VERSION 307
 int tvmi_version(void);
 /* Process-wide tuning switches (thread-safe to read concurrently with launches; set them before use).  Returns 0, or an
  * error for an unknown name.
@@ -83,7 +83,9 @@ int tvmi_version(void);
  *                                one-launch kernel of tvmi_nms_step inside the torch glue; 0 = the launch chain (score sort, collect,
  *                                tiles, sweep) — kept as the route for more segments / float64 and as the A/B reference
  *   "roi_align.inline_mop"       1 (default) / 0: in the 7 x 7 multi-scale forward the units the LDS-DMA path declines take the wave path
- *                                inside the same launch instead of a worklist + a mop-up launch */
+ *                                inside the same launch instead of a worklist + a mop-up launch
+ *   "roi_align.carry_step"       1 (default) / 0: tvmi_multiscale_roi_align_forward_boxes_with_nms_step puts the NMS workgroups of the
+ *                                detector step in front of the RoIAlign grid (one launch); 0 = the two entries one after the other */
 int tvmi_set_option(const char* name, int64_t value);
 /* Current value of a switch of tvmi_set_option (0, or an error for an unknown name). */
 int tvmi_get_option(const char* name, int64_t* value);
@@ -300,6 +302,23 @@ int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs, const int
                                             int64_t N, int64_t C, int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio,
                                             int aligned, int64_t k_min, int64_t k_max, double canonical_scale, double canonical_level,
                                             double eps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The detector step as ONE call (ABI 307): tvmi_multiscale_roi_align_forward_boxes (arguments up to workspace_bytes) AND
+ * tvmi_nms_step (the arguments from nms_dets on, in that entry's order and meaning: the reference's batched_nms of
+ * ops/boxes.py:50-102 + the padded per-image top-k of models/detection/roi_heads.py:668-723 over the step's proposals) — two
+ * independent jobs of one detector step (neither reads what the other writes) that the reference issues as separate launches.
+ * Where the RoIAlign call takes its one-launch route (7x7 bins, sampling_ratio 2, a multiple of 256 channels, workspace given) the
+ * workgroups of the NMS ride in front of the RoIAlign grid: one launch on one stream, where two launches need two streams, a fork
+ * and a join to overlap (~40 us of a 265 us step on the MI355X).  Anywhere else the two entries run one after the other on
+ * `stream`.  Results are those of the two entries, bit for bit. */
+int tvmi_multiscale_roi_align_forward_boxes_with_nms_step(
+    const void* const* inputs, const int64_t* heights, const int64_t* widths, const double* spatial_scales, int64_t n_levels,
+    const void* const* boxes, const int64_t* counts, int64_t num_images, void* rois_out, void* output, tvmi_dtype dt, int64_t N, int64_t C,
+    int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max, double canonical_scale,
+    double canonical_level, double eps, void* workspace, size_t workspace_bytes, const float* nms_dets, const float* nms_scores,
+    const int64_t* nms_seg, int64_t nms_n, int64_t nms_segments, double iou_threshold, void* nms_workspace, size_t nms_workspace_bytes,
+    int64_t* keep_out, int64_t* num_keep_out, const int64_t* image_idx, const int64_t* labels, int64_t det_images, int64_t max_dets,
+    float* payload, int64_t row_stride, int32_t* det_counts, int count_in_row, void* stream);
 
 /* The same operation on channels_last feature maps (element (n,c,y,x) at ((n*H+y)*W+x)*C+c;
  * SURVEY.md §8f-2): lane = channel, taps are coalesced loads off a scalar base, no LDS window.

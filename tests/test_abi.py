@@ -54,7 +54,7 @@ def test_kernel_library_exports_every_declared_symbol():
     lib.tvmi_version.restype = ctypes.c_int
     header = open(os.path.join(ROOT, 'include', 'tvmi.h')).read()
     import re as _re
-    assert lib.tvmi_version() == int(_re.search(r'#define TVMI_ABI_VERSION (\d+)', header).group(1)) == 306   # ABI bumped with the changed entries (round 6: tvmi_nms_step)
+    assert lib.tvmi_version() == int(_re.search(r'#define TVMI_ABI_VERSION (\d+)', header).group(1)) == 307   # ABI bumped with the changed entries (round 6: tvmi_nms_step, the one-launch detector step)
     lib.tvmi_arch.restype = ctypes.c_char_p
     assert lib.tvmi_arch() == b"gfx950"
 
@@ -103,7 +103,7 @@ def test_cuda_key_has_kernels_for_every_op(tv):
             continue
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f"torchvision::{name}", "CUDA"), name
     assert tv._cuda_version() == -1
-    assert torch.ops.tvmi.abi_version() == 306
+    assert torch.ops.tvmi.abi_version() == 307
 
 
 def test_fake_kernels_give_reference_shapes(tv):

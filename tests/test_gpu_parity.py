@@ -2235,9 +2235,22 @@ def test_nms_step_under_graph_capture_and_on_many_streams():
     with torch.cuda.graph(graph):
         out = torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50)
     for _ in range(20):
-        graph.replay()
-        torch.cuda.synchronize()
+        for t in out:
+            t.fill_(-5)   # (without this the comparison passed on memory the capture's allocations inherited: a memset NODE in
+        graph.replay()    #  front of the kernel made every graph after the process's first replay correctly only once; the
+        torch.cuda.synchronize()   # capture path zeroes its words with a kernel node now — nms_step_device.h, step_zero_words)
         for a, b in zip(out, want):
+            assert torch.equal(a, b)
+    # ... and a second graph in the same process
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        out2 = torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50)
+    for _ in range(5):
+        for t in out2:
+            t.fill_(-5)
+        graph2.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(out2, want):
             assert torch.equal(a, b)
     streams = [torch.cuda.Stream() for _ in range(8)]
     outs = []
@@ -2247,6 +2260,64 @@ def test_nms_step_under_graph_capture_and_on_many_streams():
             with torch.cuda.stream(st):
                 outs.append(torch.ops.tvmi.nms_step(boxes, scores, seg, 0.5, S, img, None, 3, 50))
     torch.cuda.synchronize()
-    for o in outs:
+    for i, o in enumerate(outs):
+        assert int(o[1]) == int(want[1]), (i, int(o[1]), int(want[1]))
         for a, b in zip(o, want):
-            assert torch.equal(a, b)
+            assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("C,P,dtype,n,S,B,kind", [(256, 7, torch.float32, 4000, 4, 4, "by_image"), (256, 7, torch.bfloat16, 3000, 40, 8, "dense"),
+                                                  (512, 7, torch.float16, 70, 3, 3, "random"), (64, 7, torch.float32, 2500, 5, 5, "ties"),
+                                                  (256, 14, torch.float32, 1024, 1, 1, "random")])
+def test_one_launch_step_equals_the_two_ops(C, P, dtype, n, S, B, kind):
+    """tvmi::roi_align_boxes_nms_step — the detector step as ONE launch: the NMS workgroups ride in front of the RoIAlign grid
+    (roi_align_fwd_ms_dma_inl_step) — returns what tvmi::multiscale_roi_align_boxes and tvmi::nms_step return, bit for bit: on the
+    carrying route (7x7 bins, a multiple of 256 channels), with the carrying switched off, and on shapes that cannot carry (64
+    channels, 14x14 bins: the two entries one after the other).  Several calls in a row (the hand-over words are re-armed by every
+    launch), through the module method bench.py uses, and captured into a hipGraph."""
+    g = gen(5150 + C + P + n)
+    feats = [torch.randn(3, C, 200 // s, 304 // s, generator=g).to(DEV, dtype) for s in (1, 2, 4, 8)]
+    boxes = [random_boxes(m, 1216, 800, 6, 500, g).to(DEV) for m in (700, 0, 1301)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    tail = (P, P, 2, False, 2, 5, 224.0, 4.0, 1e-6)
+    nb, ns, nseg, nimg, nlab = (t.to(DEV) for t in _step_case(n, S, B, g, kind))
+    D = 100
+    want_out, want_rois = torch.ops.tvmi.multiscale_roi_align_boxes(feats, boxes, scales, *tail)
+    want_keep, want_num, want_pay = torch.ops.tvmi.nms_step(nb, ns, nseg, 0.5, S, nimg, nlab, B, D)
+    k = int(want_num)
+
+    def check(res):
+        out, rois, keep, num, pay = res
+        assert torch.equal(out, want_out) and torch.equal(rois, want_rois)
+        assert int(num) == k, (int(num), k)
+        assert torch.equal(keep[:k], want_keep[:k])
+        assert torch.equal(pay, want_pay)
+
+    args = (feats, boxes, scales, *tail, nb, ns, nseg, 0.5, S, nimg, nlab, B, D)
+    for _ in range(3):
+        check(torch.ops.tvmi.roi_align_boxes_nms_step(*args))
+    torch.ops.tvmi.set_option("roi_align.carry_step", 0)
+    try:
+        check(torch.ops.tvmi.roi_align_boxes_nms_step(*args))
+    finally:
+        torch.ops.tvmi.set_option("roi_align.carry_step", 1)
+    pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], P, 2)
+    pooled, keep, num, pay = pool.forward_with_nms_step({str(i): f for i, f in enumerate(feats)}, boxes, [(800, 1216)] * 3, nb, ns, nseg, 0.5, S,
+                                                        nimg, B, D, labels=nlab)
+    assert torch.equal(pooled, want_out) and int(num) == k and torch.equal(keep[:k], want_keep[:k]) and torch.equal(pay, want_pay)
+    # captured: the stream's hand-over block cannot be allocated inside a capture — the caller's words + a memset node instead
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.ops.tvmi.roi_align_boxes_nms_step(*args)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gph):
+        res = torch.ops.tvmi.roi_align_boxes_nms_step(*args)
+    for _ in range(5):
+        for t in res:
+            t.fill_(-5)
+        gph.replay()
+        torch.cuda.synchronize()
+        check(res)

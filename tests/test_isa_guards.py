@@ -97,6 +97,12 @@ def test_occupancy_assumptions_of_the_hot_kernels(tmp_path):
     assert len(inl) == 1, list(roi)
     for r in inl.values():
         assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128 and 4 * r["lds"] <= 160 * 1024, r
+    # ... and the launch that also carries the detector step's NMS workgroups (the LDS of the two jobs is one union, the NMS body
+    # must not bring static LDS of its own — __syncthreads_and / _or did: 256 bytes, three workgroups per CU instead of four)
+    step = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dma_inl_stepI" in k}
+    assert len(step) == 3, list(roi)
+    for r in step.values():
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128 and 4 * r["lds"] <= 160 * 1024, r
     big = {k: v for k, v in roi.items() if "roi_align_fwd_ms_dmaIfLi14ELi14ELi2E" in k}
     assert len(big) == 1 and all(v["vgpr"] <= 128 and v["spill"] == 0 and v["scratch"] == 0 for v in big.values()), big
     assert re.search(r"s_waitcnt vmcnt\(3\)", text) and re.search(r"s_waitcnt vmcnt\(4\)", text)

@@ -1,2 +1,2 @@
-python tools/dcn_fwd_timing.py dcn.xcd_tiles=1 dcn.xcd_tiles=1 dcn.xcd_tiles=1 2>&1 | tail -4
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_sizes.py tests/test_gpu_abi.py -q -x -m gpu -k "deform and not backward" 2>&1 | tail -3
+python tools/_dbg_step.py test_nms_100k_properties 2>&1 | grep -c "num 2481"
+for i in 1 2; do timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "one_launch_step or nms_step or multiscale_roi_align_boxes or nms" 2>&1 | grep -E "passed|failed|Error|assert" | tail -4; done

@@ -16,7 +16,7 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $ROOTDIR/$OUT/
 cd $ROOTDIR
 timeout 600 python tools/gpu_matrix.py $OUT/matrix.json > $OUT/matrix.log 2>&1; tail -3 $OUT/matrix.log
 cd /tmp
-for K in ${TVMI_ROUND_PMC:-roi7 roi7cl bwd7 bwd14 nms100k}; do
+for K in ${TVMI_ROUND_PMC:-step7 roi7 roi7cl bwd7 bwd14 nms100k}; do
   for C in FETCH_SIZE WRITE_SIZE; do
     TVMI_TOOL_SERIALIZED_PROFILER=1 timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $ROOTDIR/$OUT/pmc_${K}_$C -o p -- python $ROOTDIR/tools/run_kernel.py $K 6 > $ROOTDIR/$OUT/pmc_${K}_$C.log 2>&1
   done

@@ -21,6 +21,7 @@ import sys
 # case -> [(kernel name pattern, fetch factor, algorithmic note)]
 CASES = {
     "roi7": [("roi_align_fwd_ms_dma", 1.33)],
+    "step7": [("roi_align_fwd_ms_dma_inl_step", 1.33)],
     "roi7cl": [("roi_align_fwd_nhwc", 2.0)],
     "bwd7": [("roi_align_bwd_owner<float, 7", 2.0), ("roi_bwd_prepass", 2.0)],
     "bwd14": [("roi_align_bwd_owner<float, 14", 2.0), ("roi_bwd_prepass", 2.0)],
@@ -71,7 +72,7 @@ def main():
         note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel-trace only), KB units, per-launch mean; "
                 "fetch factor per tools/pmc_traffic.py")
         js = {}
-        for key, src in (("roi_align_fwd_ms_dma", "roi7:roi_align_fwd_ms_dma"), ("roi_align_fwd_nhwc", "roi7cl:roi_align_fwd_nhwc"),
+        for key, src in (("roi_align_fwd_ms_dma", "roi7:roi_align_fwd_ms_dma"), ("roi_align_fwd_ms_dma_inl_step", "step7:roi_align_fwd_ms_dma_inl_step"), ("roi_align_fwd_nhwc", "roi7cl:roi_align_fwd_nhwc"),
                          ("roi_align_bwd_owner_7", "bwd7:roi_align_bwd_owner<float, 7"), ("roi_align_bwd_owner_14", "bwd14:roi_align_bwd_owner<float, 14"),
                          ("nms_mask_tiles_100k", "nms100k:nms_mask_tiles")):
             if src in out:

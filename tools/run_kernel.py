@@ -20,6 +20,12 @@ with torch.no_grad():
         pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7 if which == "roi7" else 14, 2)
         for _ in range(reps):
             pool(feats, boxes, shapes)
+    elif which == "step7":   # the detector step as ONE launch: the NMS workgroups in front of the 7 x 7 RoIAlign grid (bench.py's step)
+        pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+        ab, asc = torch.cat(boxes), torch.cat(scores)
+        img = torch.arange(4, device=dev).repeat_interleave(1000)
+        for _ in range(reps):
+            pool.forward_with_nms_step(feats, boxes, shapes, ab, asc, img, 0.5, 4, img, 4, 100)
     elif which == "roi7cl":
         pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
         cl = {k: v.contiguous(memory_format=torch.channels_last) for k, v in feats.items()}

@@ -212,6 +212,13 @@ def _fake_nms_step(dets, scores, idxs, iou_threshold, num_segments, image_idx, l
             dets.new_empty((num_images, max_dets * 6 + 1), dtype=torch.float32))
 
 
+def _fake_roi_boxes_nms_step(features, boxes, scales, pooled_height, pooled_width, sampling_ratio, aligned, k_min, k_max, canonical_scale,
+                             canonical_level, eps, dets, scores, idxs, iou_threshold, num_segments, image_idx, labels, num_images, max_dets):
+    return (_fake_multiscale_boxes(features, boxes, scales, pooled_height, pooled_width, sampling_ratio, aligned, k_min, k_max,
+                                   canonical_scale, canonical_level, eps)
+            + _fake_nms_step(dets, scores, idxs, iou_threshold, num_segments, image_idx, labels, num_images, max_dets))
+
+
 def _fake_nms_masked(dets, scores, idxs, valid, iou_threshold, num_segments=-1, max_segment_size=-1):
     return dets.new_empty((dets.shape[0],), dtype=torch.int64), dets.new_empty((1,), dtype=torch.int64)
 
@@ -273,6 +280,7 @@ _FAKES = {
     "tvmi::pack_detections": _fake_pack_detections,
     "tvmi::multiscale_roi_align": _fake_multiscale,
     "tvmi::multiscale_roi_align_boxes": _fake_multiscale_boxes,
+    "tvmi::roi_align_boxes_nms_step": _fake_roi_boxes_nms_step,
     "tvmi::multiscale_roi_align_backward": _fake_multiscale_bwd,
     "tvmi::interpolate2d": _fake_interpolate2d,
     "tvmi::interpolate2d_backward": _fake_interpolate2d_backward,

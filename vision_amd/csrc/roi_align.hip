@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "roi_common.h"
+#include "nms_step_device.h"
 
 namespace tvmi {
 namespace {
@@ -920,11 +921,13 @@ struct UnitMap {
   int pinned;
 };
 
-__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const UnitMap& um, int& k, int& chunk_idx,
-                                          int wpb = kThreads / 64) {
+// (`block`: the workgroup's number within the units' grid — blockIdx.x, or blockIdx.x less the workgroups of another job that the
+// launch carries in front, a multiple of 8 so that the XCD of a unit stays what it was)
+__device__ __forceinline__ bool wave_unit_at(unsigned block, int64_t K, int nchunks, const UnitMap& um, int& k, int& chunk_idx,
+                                             int wpb = kThreads / 64) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
-  const int xcd = blockIdx.x & 7;
-  const int64_t j = blockIdx.x >> 3;
+  const int xcd = block & 7;
+  const int64_t j = block >> 3;
   const int64_t local = j * wpb + wave;
   if (um.pinned) {
     const int slot = (int)(local / K);
@@ -942,6 +945,11 @@ __device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const UnitMap&
   const int64_t kk = kstart + (local - (int64_t)chunk_idx * Kx);
   k = um.perm ? __builtin_amdgcn_readfirstlane(um.perm[kk]) : (int)kk;
   return true;
+}
+
+__device__ __forceinline__ bool wave_unit(int64_t K, int nchunks, const UnitMap& um, int& k, int& chunk_idx,
+                                          int wpb = kThreads / 64) {
+  return wave_unit_at(blockIdx.x, K, nchunks, um, k, chunk_idx, wpb);
 }
 
 __host__ __device__ inline bool unit_map_can_pin(int nchunks) { return nchunks >= 8 && nchunks % 8 == 0; }
@@ -1206,6 +1214,45 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma_inl(MsLevels lv
                                                      lv.scale[l], aligned, k, ci * chunk, chunk);
 }
 
+// The detector step in ONE launch (round 6): the workgroups of the step's NMS (nms_step_body, nms_step_device.h: tiles, rank
+// counting, sweeps, keep list and payload of <= 4096 boxes) ride in front of the RoIAlign grid.  As two launches the two jobs need
+// two streams to overlap, and the fork, the join and the second queue cost the step ~40 us more than the RoIAlign launch takes on
+// its own (bench.py: 0.265 ms against 0.220); in one grid the NMS workgroups are simply the first to be dispatched, finish within
+// the first fifth of the launch and give their slots to RoIAlign units.  `nms_blocks` is padded to a multiple of 8 (the units'
+// XCD placement keys on the workgroup number modulo 8).  The LDS of the two jobs is one union (40 KB: four workgroups per CU as
+// before), the register allocation the larger of the two.
+template <typename T, int PHT, int PWT, int SRT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void roi_align_fwd_ms_dma_inl_step(MsLevels lv, const float* __restrict__ rois,
+                                                                          T* __restrict__ output, int C, int aligned, int nchunks,
+                                                                          int chunk, int64_t nunits, UnitMap um, StepArgs na,
+                                                                          unsigned nms_blocks) {
+  static_assert(kThreads == kStepThreads, "one workgroup shape for both jobs");
+  union WaveLds {
+    DmaShared<PHT> d;
+    WaveShared w;
+  };
+  union Lds {
+    WaveLds s[kThreads / 64];
+    StepShared nms;
+  };
+  __shared__ Lds sh;
+  if (blockIdx.x < nms_blocks) {
+    const int id = (int)blockIdx.x;
+    if (id < na.S * na.gdim_y)
+      nms_step_body(sh.nms, id % na.S, id / na.S, na.gdim_y, na.dets, na.scores, na.seg, na.n, na.S, na.G, na.thr, na.band, na.ws,
+                    na.keep_out, na.num_keep, na.pk);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int k, ci;
+  if (!wave_unit_at(blockIdx.x - nms_blocks, nunits / nchunks, nchunks, um, k, ci)) return;
+  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
+  if (roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(sh.s[wave].d, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                                      lv.scale[l], aligned, k, ci * chunk, chunk, nullptr))
+    roi_align_fwd_wave_fast<T, float, PHT, PWT, SRT>(sh.s[wave].w, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
+                                                     lv.scale[l], aligned, k, ci * chunk, chunk);
+}
+
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_wave(MsLevels lv, const float* __restrict__ rois,
                                                                   T* __restrict__ output, int C, int PH_, int PW_,
@@ -1245,6 +1292,7 @@ struct FwdOptions {
   int pin_chunks = 1;   // "roi_align.pin_chunks": channel chunks pinned to XCDs when the chunk count allows it
   int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
   int bands = 16;       // "roi_align.order_bands": window-top bands per (image, level) in the order key
+  int carry_step = 1;   // "roi_align.carry_step": tvmi_multiscale_roi_align_forward_boxes_with_nms_step puts the NMS workgroups into the RoIAlign launch
   int inline_mop = 1;   // "roi_align.inline_mop": declined units take the wave path inside the DMA launch (multi-scale 7 x 7 entries)
 };
 FwdOptions g_fwd_opt;
@@ -1520,7 +1568,8 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
 
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH,
-                  int64_t PW, int64_t sr, int aligned, int* mop, int* perm, hipStream_t stream, const MsBoxLists* bl = nullptr) {
+                  int64_t PW, int64_t sr, int aligned, int* mop, int* perm, hipStream_t stream, const MsBoxLists* bl = nullptr,
+                  const StepArgs* carried = nullptr) {
   const float* r = static_cast<const float*>(rois);
   T* out = static_cast<T*>(output);
   const int nchunks = (int)ceil_div(C, kUnitChunk), mop_nchunks = (int)ceil_div(C, kMopChunk);
@@ -1539,9 +1588,16 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
                                                                                nunits, mop, um)
 #define TVMI_MS(PHT, PWT, SRT)                                                                                      \
   if (mop && g_fwd_opt.inline_mop && PHT == 7) {   /* 14 x 14: the union of both paths needs 221 VGPRs, two waves per SIMD */ \
-    if constexpr (PHT == 7)                                                                                           \
-      roi_align_fwd_ms_dma_inl<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
-                                                                                     kUnitChunk, nunits, um);         \
+    if constexpr (PHT == 7) {                                                                                         \
+      if (carried) {   /* the step's NMS workgroups in front of the grid (ms_fwd_can_carry_step) */                    \
+        const unsigned nb = (unsigned)((carried->S * carried->gdim_y + 7) & ~7);                                      \
+        roi_align_fwd_ms_dma_inl_step<T, PHT, PWT, SRT><<<dim3(dma_grid.x + nb), block, 0, stream>>>(                \
+            lv, r, out, (int)C, aligned, nchunks, kUnitChunk, nunits, um, *carried, nb);                              \
+      } else {                                                                                                        \
+        roi_align_fwd_ms_dma_inl<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
+                                                                                       kUnitChunk, nunits, um);       \
+      }                                                                                                               \
+    }                                                                                                                 \
   } else if (mop) {                                                                                                   \
     TVMI_MS_DMA(PHT, PWT, SRT);                                                                                     \
     roi_align_fwd_ms_wave<T, PHT, PWT, SRT><<<mop_grid, block, 0, stream>>>(lv, r, out, (int)C, (int)PH, (int)PW, (int)sr, \
@@ -1571,6 +1627,7 @@ int set_roi_option(const char* name, int64_t value) {
   if (n == "roi_align.pin_chunks") g_fwd_opt.pin_chunks = value != 0;
   else if (n == "roi_align.order") g_fwd_opt.order = value != 0;
   else if (n == "roi_align.inline_mop") g_fwd_opt.inline_mop = value != 0;
+  else if (n == "roi_align.carry_step") g_fwd_opt.carry_step = value != 0;
   else if (n == "roi_align.order_bands") g_fwd_opt.bands = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
   else return -1;
   return 0;
@@ -1583,6 +1640,7 @@ int get_roi_option(const char* name, int64_t* value) {
   else if (n == "roi_align.order") *value = g_fwd_opt.order;
   else if (n == "roi_align.order_bands") *value = g_fwd_opt.bands;
   else if (n == "roi_align.inline_mop") *value = g_fwd_opt.inline_mop;
+  else if (n == "roi_align.carry_step") *value = g_fwd_opt.carry_step;
   else return -1;
   return 0;
 }
@@ -1671,7 +1729,7 @@ extern "C" int tvmi_multiscale_roi_align_forward(const void* const* inputs, cons
 // The same call taking the per-image box lists instead of [K,5] rows: where the order pre-pass runs (7x7 / 14x14 bins,
 // sampling_ratio 2, a multiple of 8 channel chunks, workspace given) it builds the rows itself; otherwise the rows are built by
 // tvmi_boxes_to_rois first.  `rois_out` [K,5] float32 receives them either way (the backward needs them).
-extern "C" int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs, const int64_t* heights, const int64_t* widths,
+static int ms_fwd_boxes(const tvmi::StepArgs* carried, const void* const* inputs, const int64_t* heights, const int64_t* widths,
                                                        const double* spatial_scales, int64_t n_levels, const void* const* boxes,
                                                        const int64_t* counts, int64_t num_images, void* rois_out, void* output,
                                                        tvmi_dtype dt, int64_t N, int64_t C, int64_t pooled_h, int64_t pooled_w,
@@ -1700,6 +1758,8 @@ extern "C" int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs
   const bool fast_shape = (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2) || (pooled_h == 14 && pooled_w == 14 && sampling_ratio == 2);
   const bool fused = fast_shape && declined && K <= tvmi::kOrderMaxRois && C * pooled_h * pooled_w > 0 &&
                      tvmi::plan_units_orders(N, n_levels, nchunks, perm) && (dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16);
+  if (carried && !(fused && pooled_h == 7 && tvmi::g_fwd_opt.inline_mop))   // (the caller asked ms_fwd_boxes_carries first)
+    return tvmi::set_error((int)hipErrorInvalidValue, "multiscale_roi_align (boxes): this call cannot carry the NMS step");
   if (!fused) {
     const int st = tvmi_boxes_to_rois(boxes, counts, num_images, rois_out, TVMI_F32, stream);
     if (st != 0) return st;
@@ -1716,13 +1776,65 @@ extern "C" int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (dt) {
     case TVMI_F32:
-      return tvmi::launch_ms_fwd<float>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s, &bl);
+      return tvmi::launch_ms_fwd<float>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s, &bl, carried);
     case TVMI_F16:
-      return tvmi::launch_ms_fwd<__half>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s, &bl);
+      return tvmi::launch_ms_fwd<__half>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined, perm, s, &bl, carried);
     default:
       return tvmi::launch_ms_fwd<__hip_bfloat16>(lv, rois_out, output, N, C, K, pooled_h, pooled_w, sampling_ratio, aligned, declined,
-                                                 perm, s, &bl);
+                                                 perm, s, &bl, carried);
   }
+}
+
+
+extern "C" int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs, const int64_t* heights, const int64_t* widths,
+                                                       const double* spatial_scales, int64_t n_levels, const void* const* boxes,
+                                                       const int64_t* counts, int64_t num_images, void* rois_out, void* output,
+                                                       tvmi_dtype dt, int64_t N, int64_t C, int64_t pooled_h, int64_t pooled_w,
+                                                       int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max,
+                                                       double canonical_scale, double canonical_level, double eps, void* workspace,
+                                                       size_t workspace_bytes, void* stream) {
+  return ms_fwd_boxes(nullptr, inputs, heights, widths, spatial_scales, n_levels, boxes, counts, num_images, rois_out, output, dt, N, C,
+                      pooled_h, pooled_w, sampling_ratio, aligned, k_min, k_max, canonical_scale, canonical_level, eps, workspace,
+                      workspace_bytes, stream);
+}
+
+// The detector step as one call: MultiScaleRoIAlign over the box lists AND the step's NMS (tvmi_nms_step: same arguments, same
+// results).  Where the RoIAlign call takes the one-launch 7 x 7 route, the NMS workgroups ride in front of its grid
+// (roi_align_fwd_ms_dma_inl_step; option "roi_align.carry_step", default 1); anywhere else the two entries run one after the other on
+// `stream`.  The two jobs share nothing but the launch: neither reads what the other writes.
+extern "C" int tvmi_multiscale_roi_align_forward_boxes_with_nms_step(
+    const void* const* inputs, const int64_t* heights, const int64_t* widths, const double* spatial_scales, int64_t n_levels,
+    const void* const* boxes, const int64_t* counts, int64_t num_images, void* rois_out, void* output, tvmi_dtype dt, int64_t N, int64_t C,
+    int64_t pooled_h, int64_t pooled_w, int64_t sampling_ratio, int aligned, int64_t k_min, int64_t k_max, double canonical_scale,
+    double canonical_level, double eps, void* workspace, size_t workspace_bytes, const float* nms_dets, const float* nms_scores,
+    const int64_t* nms_seg, int64_t nms_n, int64_t nms_segments, double iou_threshold, void* nms_workspace, size_t nms_workspace_bytes,
+    int64_t* keep_out, int64_t* num_keep_out, const int64_t* image_idx, const int64_t* labels, int64_t det_images, int64_t max_dets,
+    float* payload, int64_t row_stride, int32_t* det_counts, int count_in_row, void* stream) {
+  int64_t K = 0;
+  for (int64_t i = 0; counts && i < num_images && i < tvmi::kOrderMaxImages; ++i) K += counts[i] > 0 ? counts[i] : 0;
+  const int nchunks = (int)tvmi::ceil_div(C, tvmi::kUnitChunk);
+  const bool carries = tvmi::g_fwd_opt.carry_step && tvmi::g_fwd_opt.inline_mop && pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 &&
+                       K > 0 && K <= tvmi::kOrderMaxRois && C > 0 && num_images <= tvmi::kOrderMaxImages && rois_out != nullptr &&
+                       tvmi::mop_part(workspace, workspace_bytes, K) != nullptr &&
+                       tvmi::plan_units_orders(N, n_levels, nchunks, tvmi::perm_part(workspace, workspace_bytes, K)) &&
+                       (dt == TVMI_F32 || dt == TVMI_F16 || dt == TVMI_BF16);
+  if (!carries) {
+    const int st = tvmi_nms_step(nms_dets, nms_scores, nms_seg, nms_n, nms_segments, iou_threshold, nms_workspace, nms_workspace_bytes,
+                                 keep_out, num_keep_out, image_idx, labels, det_images, max_dets, payload, row_stride, det_counts,
+                                 count_in_row, stream);
+    if (st != 0) return st;
+    return ms_fwd_boxes(nullptr, inputs, heights, widths, spatial_scales, n_levels, boxes, counts, num_images, rois_out, output, dt, N, C,
+                        pooled_h, pooled_w, sampling_ratio, aligned, k_min, k_max, canonical_scale, canonical_level, eps, workspace,
+                        workspace_bytes, stream);
+  }
+  tvmi::StepArgs a;
+  const int st = tvmi::step_prepare(&a, nms_dets, nms_scores, nms_seg, nms_n, nms_segments, iou_threshold, nms_workspace,
+                                    nms_workspace_bytes, keep_out, num_keep_out, image_idx, labels, det_images, max_dets, payload,
+                                    row_stride, det_counts, count_in_row, static_cast<hipStream_t>(stream));
+  if (st != 0) return st;
+  return ms_fwd_boxes(&a, inputs, heights, widths, spatial_scales, n_levels, boxes, counts, num_images, rois_out, output, dt, N, C,
+                      pooled_h, pooled_w, sampling_ratio, aligned, k_min, k_max, canonical_scale, canonical_level, eps, workspace,
+                      workspace_bytes, stream);
 }
 
 extern "C" int tvmi_multiscale_roi_align_forward_nhwc(const void* const* inputs, const int64_t* heights,

@@ -1297,6 +1297,81 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> nms_step(const at::Tensor& dets, 
   return std::make_tuple(keep, num, payload);
 }
 
+// The detector step as ONE call (include/tvmi.h: tvmi_multiscale_roi_align_forward_boxes_with_nms_step): multiscale_roi_align_boxes
+// and nms_step with their own arguments and their own results — (output, rois, keep, num, payload) — but where the RoIAlign call takes
+// its one-launch 7 x 7 route the NMS workgroups ride in front of its grid: one launch on one stream instead of two launches that
+// need two streams, a fork and a join to overlap.
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> roi_align_boxes_nms_step(
+    at::TensorList features, at::TensorList boxes, at::ArrayRef<double> scales, int64_t pooled_height, int64_t pooled_width,
+    int64_t sampling_ratio, bool aligned, int64_t k_min, int64_t k_max, double canonical_scale, double canonical_level, double eps,
+    const at::Tensor& dets, const at::Tensor& scores, const at::Tensor& idxs, double iou_threshold, int64_t num_segments,
+    const at::Tensor& image_idx, const c10::optional<at::Tensor>& labels, int64_t num_images, int64_t max_dets) {
+  TORCH_CHECK(features.size() >= 1 && features.size() <= 8, "multiscale_roi_align: 1..8 feature levels supported");
+  TORCH_CHECK(features.size() == scales.size(), "multiscale_roi_align: one scale per feature level");
+  TORCH_CHECK(boxes.size() >= 1 && boxes.size() <= 64, "multiscale_roi_align_boxes: 1..64 box lists (one per image)");
+  const at::Tensor& f0 = features[0];
+  TORCH_CHECK(f0.is_cuda() && f0.dim() == 4, "features must be 4d CUDA tensors");
+  TORCH_CHECK(dets.is_cuda() && scores.is_cuda() && idxs.is_cuda() && image_idx.is_cuda() && dets.device() == f0.device(),
+              "roi_align_boxes_nms_step: CUDA tensors on one device expected");
+  TORCH_CHECK(dets.dim() == 2 && dets.size(1) == 4 && dets.scalar_type() == at::kFloat && scores.scalar_type() == at::kFloat,
+              "nms_step: float32 boxes [N,4] and scores [N] expected");
+  const int64_t n = dets.size(0);
+  TORCH_CHECK(scores.dim() == 1 && scores.size(0) == n && idxs.dim() == 1 && idxs.size(0) == n && image_idx.dim() == 1 &&
+                  image_idx.size(0) == n,
+              "nms_step: scores, idxs and image_idx must have one entry per box");
+  TORCH_CHECK(n >= 1 && n <= 4096 && num_segments >= 1 && num_segments <= 64 && num_images >= 1 && num_images <= 16 && max_dets >= 1,
+              "nms_step: 1 <= n <= 4096, num_segments <= 64, num_images <= 16 (larger problems: nms_segmented_padded + pack_detections_payload)");
+  c10::DeviceGuard guard(f0.device());
+  std::vector<at::Tensor> keepalive, bkeep;
+  std::vector<const void*> ptrs, bptrs;
+  std::vector<int64_t> hs, ws, counts;
+  int64_t K = 0;
+  for (const at::Tensor& b : boxes) {
+    TORCH_CHECK(b.is_cuda() && b.dim() == 2 && b.size(1) == 4 && b.scalar_type() == at::kFloat && b.device() == f0.device(),
+                "multiscale_roi_align_boxes: float32 CUDA boxes [n_i, 4] expected");
+    bkeep.push_back(b.contiguous());
+    bptrs.push_back(b.size(0) ? bkeep.back().const_data_ptr() : nullptr);
+    counts.push_back(b.size(0));
+    K += b.size(0);
+  }
+  for (const at::Tensor& f : features) {
+    TORCH_CHECK(f.is_cuda() && f.dim() == 4 && f.size(0) == f0.size(0) && f.size(1) == f0.size(1) &&
+                    f.scalar_type() == f0.scalar_type() && f.device() == f0.device(),
+                "multiscale_roi_align: feature levels must share device, dtype, batch and channel sizes");
+    keepalive.push_back(f.contiguous());
+    ptrs.push_back(keepalive.back().const_data_ptr());
+    hs.push_back(f.size(2));
+    ws.push_back(f.size(3));
+  }
+  const int64_t C = f0.size(1);
+  at::Tensor rois = at::empty({K, 5}, f0.options().dtype(at::kFloat));
+  at::Tensor output = at::empty({K, C, pooled_height, pooled_width}, f0.options());
+  at::Tensor b = dets.contiguous(), sc = scores.contiguous(), sg = idxs.to(at::kLong).contiguous(), ii = image_idx.to(at::kLong).contiguous();
+  at::Tensor lab;
+  const int64_t* lab_ptr = nullptr;
+  if (labels.has_value() && labels->defined()) {
+    lab = labels->to(at::kLong).contiguous();
+    lab_ptr = lab.const_data_ptr<int64_t>();
+  }
+  at::Tensor keep = at::empty({n}, dets.options().dtype(at::kLong));
+  at::Tensor num = at::empty({1}, dets.options().dtype(at::kLong));
+  at::Tensor payload = at::empty({num_images, max_dets * 6 + 1}, b.options());
+  const size_t sb = tvmi_nms_step_workspace_bytes(n, num_segments);
+  at::Tensor sws = at::empty({(int64_t)sb}, dets.options().dtype(at::kByte));
+  const size_t fwd_ws_bytes = tvmi_roi_align_forward_workspace_bytes(K, pooled_height, pooled_width, sampling_ratio);
+  at::Tensor order_ws = at::empty({(int64_t)fwd_ws_bytes}, f0.options().dtype(at::kByte));
+  check_status(tvmi_multiscale_roi_align_forward_boxes_with_nms_step(
+                   ptrs.data(), hs.data(), ws.data(), scales.data(), (int64_t)features.size(), bptrs.data(), counts.data(),
+                   (int64_t)boxes.size(), rois.mutable_data_ptr(), output.mutable_data_ptr(), dtype_of(f0, "multiscale_roi_align"), f0.size(0),
+                   C, pooled_height, pooled_width, sampling_ratio, aligned ? 1 : 0, k_min, k_max, canonical_scale, canonical_level, eps,
+                   order_ws.mutable_data_ptr(), fwd_ws_bytes, b.const_data_ptr<float>(), sc.const_data_ptr<float>(),
+                   sg.const_data_ptr<int64_t>(), n, num_segments, iou_threshold, sws.mutable_data_ptr(), sb, keep.mutable_data_ptr<int64_t>(),
+                   num.mutable_data_ptr<int64_t>(), ii.const_data_ptr<int64_t>(), lab_ptr, num_images, max_dets,
+                   payload.mutable_data_ptr<float>(), max_dets * 6 + 1, nullptr, 1, current_stream(f0)),
+               "roi_align_boxes_nms_step");
+  return std::make_tuple(output, rois, keep, num, payload);
+}
+
 // ---- qroi_align (quantized/cpu/qroi_align_kernel.cpp:182-231: checks and messages; :22-178: arithmetic)
 at::Tensor qroi_align_forward(const at::Tensor& input, const at::Tensor& rois, double input_scale, int64_t input_zero_point,
                               double rois_scale, int64_t rois_zero_point, double spatial_scale, c10::SymInt pooled_height,
@@ -1558,6 +1633,8 @@ TORCH_LIBRARY(tvmi, m) {
   m.def(
       "multiscale_roi_align_boxes(Tensor[] features, Tensor[] boxes, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> (Tensor, Tensor)");
   m.def(
+      "roi_align_boxes_nms_step(Tensor[] features, Tensor[] boxes, float[] scales, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps, Tensor dets, Tensor scores, Tensor idxs, float iou_threshold, int num_segments, Tensor image_idx, Tensor? labels, int num_images, int max_dets) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def(
       "multiscale_roi_align_backward(Tensor grad, Tensor rois, int[] heights, int[] widths, float[] scales, int batch_size, int pooled_height, int pooled_width, int sampling_ratio, bool aligned, int k_min, int k_max, float canonical_scale, float canonical_level, float eps) -> Tensor[]");
   // roi_heads.py:680-722 / rpn.py:266-286 up to the NMS, batched over images (one launch each)
   m.def(
@@ -1608,6 +1685,7 @@ TORCH_LIBRARY_IMPL(tvmi, CUDA, m) {
   m.impl("interpolate2d_backward", &interpolate2d_backward);
   m.impl("multiscale_roi_align", &multiscale_roi_align);
   m.impl("multiscale_roi_align_boxes", &multiscale_roi_align_boxes);
+  m.impl("roi_align_boxes_nms_step", &roi_align_boxes_nms_step);
   m.impl("multiscale_roi_align_backward", &multiscale_roi_align_backward);
   m.impl("pack_detections", &pack_detections);
   m.impl("paste_masks", &paste_masks);

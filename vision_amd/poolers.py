@@ -113,6 +113,34 @@ class MultiScaleRoIAlign(nn.Module):
         return _multiscale_roi_align(x_filtered, boxes, self.output_size, self.sampling_ratio, self.scales,
                                      self.map_levels)
 
+    def forward_with_nms_step(self, x: Dict[str, Tensor], boxes: List[Tensor], image_shapes: List[Tuple[int, int]], dets: Tensor,
+                              scores: Tensor, idxs: Tensor, iou_threshold: float, num_segments: int, image_idx: Tensor,
+                              num_images: int, max_dets: int, labels: Optional[Tensor] = None):
+        """`forward(x, boxes, image_shapes)` AND `sharding.nms_pack_payload(dets, scores, idxs, ...)` of one detector step as ONE
+        call: (`pooled`, `keep`, `num`, `payload`).  The two jobs are independent (RoIAlign reads the maps and `boxes`, the NMS
+        `dets` / `scores`); where both take their one-launch kernels (`tvmi::roi_align_boxes_nms_step`: contiguous float32 /
+        float16 / bfloat16 CUDA maps of several levels, float32 boxes, <= 4096 float32 `dets` in <= 64 segments and <= 16 images)
+        the NMS workgroups ride in front of the RoIAlign grid — one launch on one stream instead of two streams with a fork and
+        a join.  Anything else: the two calls one after the other.  Inference only (no autograd through this entry)."""
+        from . import sharding
+        x_filtered = [v for k, v in x.items() if k in self.featmap_names]
+        if self.scales is None or self.map_levels is None:
+            self.scales, self.map_levels = _setup_scales(x_filtered, image_shapes, self.canonical_scale, self.canonical_level)
+        first, n, m = x_filtered[0], dets.shape[0], self.map_levels
+        if (len(x_filtered) > 1 and first.is_cuda and first.dtype in (torch.float32, torch.float16, torch.bfloat16)
+                and all(f.is_contiguous() and not f.requires_grad for f in x_filtered) and 1 <= len(boxes) <= 64
+                and all(b.is_cuda and b.dtype == torch.float32 and not b.requires_grad for b in boxes)
+                and dets.is_cuda and dets.dtype == torch.float32 and scores.dtype == torch.float32
+                and 1 <= n <= sharding.STEP_MAX_BOXES and 1 <= num_segments <= sharding.STEP_MAX_SEGMENTS
+                and 1 <= num_images <= sharding.STEP_MAX_IMAGES):
+            pooled, _, keep, num, payload = torch.ops.tvmi.roi_align_boxes_nms_step(
+                list(x_filtered), list(boxes), [float(s) for s in self.scales], int(self.output_size[0]), int(self.output_size[1]),
+                int(self.sampling_ratio), False, int(m.k_min), int(m.k_max), float(m.s0), float(m.lvl0), float(m.eps), dets, scores, idxs,
+                float(iou_threshold), int(num_segments), image_idx, labels, int(num_images), int(max_dets))
+            return pooled, keep, num, payload
+        keep, num, payload = sharding.nms_pack_payload(dets, scores, idxs, iou_threshold, num_segments, image_idx, num_images, max_dets, labels)
+        return self.forward(x, boxes, image_shapes), keep, num, payload
+
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(featmap_names={self.featmap_names}, "
                 f"output_size={self.output_size}, sampling_ratio={self.sampling_ratio})")
