@@ -32,7 +32,7 @@ feats, boxes, _ = bench.make_inputs(dev, 1)
 pool = vision_amd.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
 side = torch.cuda.Stream()
 bad = torch.zeros(1, dtype=torch.int64, device=dev)
-t0, calls = time.time(), 0
+t0, calls, one_launch, pooled_ref = time.time(), 0, 0, None
 while time.time() - t0 < secs:
     for it in range(50):
         b, s, seg, img, S, B, ref = cases[(calls + it) % len(cases)]
@@ -47,6 +47,14 @@ while time.time() - t0 < secs:
         if it % 2 == 0:
             with torch.no_grad():
                 pool(feats, boxes, [(bench.IMG_H, bench.IMG_W)] * 4)
+        elif it % 5 == 0:   # the one-launch step: the NMS workgroups in front of the RoIAlign grid (round 6)
+            with torch.no_grad():
+                po, k2, n2, p2 = pool.forward_with_nms_step(feats, boxes, [(bench.IMG_H, bench.IMG_W)] * 4, b, s, seg, 0.5, S, img, B, 100)
+            bad += (k2 != ref[0]).any().to(torch.int64) + (n2 != ref[1]).any().to(torch.int64) + (p2 != ref[2]).any().to(torch.int64)
+            if pooled_ref is None:
+                pooled_ref = pool(feats, boxes, [(bench.IMG_H, bench.IMG_W)] * 4).clone()
+            bad += (po != pooled_ref).any().to(torch.int64)
+            one_launch += 1
         if two:
             vision_amd.streams.wait_stream(cur, side)
             for t in (k, n, p):
@@ -56,4 +64,5 @@ while time.time() - t0 < secs:
     calls += 50
     nbad = int(bad.item())
     assert nbad == 0, f"{nbad} mismatching results after {calls} calls"
+print(f"step_stress: {one_launch} one-launch steps (RoIAlign output and NMS results compared) among them;", end=" ")
 print(f"step_stress: {calls} calls of tvmi::nms_step in {time.time() - t0:.1f} s (one and two streams, under RoIAlign launches): all results identical to the first")
