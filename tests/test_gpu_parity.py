@@ -1684,6 +1684,12 @@ def test_nms_and_fused_ops_opcheck():
     rois = torch.cat([torch.zeros(50, 1), random_boxes(50, 64, 64, 2, 40, g)], 1).to(DEV)
     torch.library.opcheck(torch.ops.tvmi.multiscale_roi_align,
                           args=(feats, rois, [1.0, 0.5], 7, 7, 2, False, 0, 1, 224.0, 4.0, 1e-6))
+    # the one-launch step (inference entry: no autograd formula, schema + fake kernel + dispatch are what is checked)
+    f2 = [f.detach() for f in feats]
+    boxes2 = [random_boxes(30, 64, 64, 2, 40, g).to(DEV)]
+    torch.library.opcheck(torch.ops.tvmi.roi_align_boxes_nms_step,
+                          args=(f2, boxes2, [1.0, 0.5], 7, 7, 2, False, 0, 1, 224.0, 4.0, 1e-6, b, s, seg3, 0.5, 3, seg3, None, 3, 10),
+                          test_utils=("test_schema", "test_faketensor"))
 
 
 def test_small_score_sort_equals_stable_descending_sort():
