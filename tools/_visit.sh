@@ -1,3 +1,1 @@
-mkdir -p gpurun_out/r06
-timeout 400 python tools/step_stress.py 240 2>&1 | tail -2 | tee gpurun_out/r06/step_stress.log
-timeout 900 python tools/fuzz_gpu.py 2>&1 | tail -3 | tee gpurun_out/r06/fuzz_tail.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_streams.py tests/test_gpu_abi.py -q -x -m gpu -k "nms or step or stream or abi" 2>&1 | grep -E "passed|failed|Error" | tail -3

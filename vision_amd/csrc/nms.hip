@@ -1482,8 +1482,10 @@ struct StepSyncBlocks {
     if (dev >= 0 && dev < 64) {
       Last& l = last[dev];
       if (l.any && l.stream != s) {   // a switch of streams: order this launch behind everything queued on the previous one
-        if (!l.ev && hipEventCreateWithFlags(&l.ev, hipEventDisableTiming) != hipSuccess) l.ev = nullptr;
-        if (l.ev && hipEventRecord(l.ev, l.stream) == hipSuccess) (void)hipStreamWaitEvent(s, l.ev, 0);
+        hipStreamCaptureStatus pst = hipStreamCaptureStatusNone;   // (never record into a capture another thread has open there)
+        const bool prev_idle = hipStreamIsCapturing(l.stream, &pst) == hipSuccess && pst == hipStreamCaptureStatusNone;
+        if (prev_idle && !l.ev && hipEventCreateWithFlags(&l.ev, hipEventDisableTiming) != hipSuccess) l.ev = nullptr;
+        if (prev_idle && l.ev && hipEventRecord(l.ev, l.stream) == hipSuccess) (void)hipStreamWaitEvent(s, l.ev, 0);
         (void)hipGetLastError();   // (a previous stream that no longer exists: nothing of it can still be running)
       }
       l.stream = s;
