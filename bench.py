@@ -111,6 +111,8 @@ def main():
                     "(tvmi::nms_step); 0: round 5's chain of five launches")
     ap.add_argument("--roi-inline-mop", type=int, default=None, help="roi_align.inline_mop: 1 = the units the LDS-DMA path declines take "
                     "the wave path inside the same launch (no mop-up launch); default: the library's default")
+    ap.add_argument("--roi-fold-order", type=int, default=None, help="roi_align.fold_order: 1 = the order pre-pass runs as a workgroup "
+                    "of the step's launch (no pre-pass launch on the critical path); default: the library's default")
     ap.add_argument("--e2e", action="store_true", help="after the contract line, also measure BASELINE config 5 (Mask R-CNN R50-FPN "
                     "inference img/s, unchanged reference python on this library, then with the fused vision_amd pieces) and print it "
                     "as a SECOND JSON object; never mixed into `value`")
@@ -181,6 +183,10 @@ def main():
     # enqueued FIRST (the fork precedes the RoIAlign launches) and is resident before the RoIAlign grid arrives.
     if args.roi_inline_mop is not None:
         torch.ops.tvmi.set_option("roi_align.inline_mop", int(args.roi_inline_mop))
+    if args.roi_fold_order is not None:
+        torch.ops.tvmi.set_option("roi_align.fold_order", int(args.roi_fold_order))
+    for kv in filter(None, os.environ.get("TVMI_SET_OPTIONS", "").split(",")):   # diagnosis: TVMI_SET_OPTIONS=name=value,...
+        torch.ops.tvmi.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     torch.ops.tvmi.set_option("nms.step_fused", int(args.nms_step_fused))
     if not args.nms_step_fused:
         def _chain(boxes_, scores_, idxs_, thr_, nseg_, img_, nimg_, maxd_):

@@ -233,3 +233,74 @@ def test_nonfinite_pixels_next_to_zero_weight_taps(tv):
         np.testing.assert_allclose(got[fin], ref[fin], rtol=0, atol=TOL, err_msg=name)
         # an interior RoI is untouched by the poisoned row / column
         np.testing.assert_allclose(got[2], clean[2], rtol=0, atol=TOL, err_msg=name)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_folded_order_prepass_changes_no_result(dtype):
+    """Round 6, roi_align.fold_order: the order pre-pass as ONE WORKGROUP of the 7x7 multi-scale launch (calls that start from box
+    lists; the first round of units runs in input order, later units wait for the sort's flag word and read their position with an
+    agent-scope load).  Only the order of the units may change: pooled output and the [K,5] rows are bit-identical with the fold
+    switched off (pre-pass launch + main launch), at box counts on both sides of the route's limits (too few RoIs for a sorted
+    part, 4096 = the register form of the 256-thread sort, 4097 = over it), on launch after launch with new boxes (every launch
+    publishes its own epoch), on eight streams at once (one flag block per stream) and against the reference CPU kernel."""
+    g = gen(6601)
+    C = 256
+    feats = [torch.randn(2, C, 96 // s, 160 // s, generator=g).to(DEV, dtype) for s in (1, 2, 4, 8)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    tail = (7, 7, 2, False, 2, 5, 224.0, 4.0, 1e-6)
+
+    def run(boxes, fold):
+        torch.ops.tvmi.set_option("roi_align.fold_order", fold)
+        try:
+            return torch.ops.tvmi.multiscale_roi_align_boxes(feats, boxes, scales, *tail)
+        finally:
+            torch.ops.tvmi.set_option("roi_align.fold_order", 1)
+
+    assert int(torch.ops.tvmi.get_option("roi_align.fold_order")) == 1
+    for rep, (m0, m1) in enumerate([(600, 415), (600, 416), (1500, 1500), (2048, 2048), (2049, 2048), (37, 5), (0, 1200), (1200, 0)] * 2):
+        boxes = [random_boxes(m, 640, 384, 4, 380, g).to(DEV) for m in (m0, m1)]
+        a_out, a_rois = run(boxes, 1)
+        b_out, b_rois = run(boxes, 0)
+        assert torch.equal(a_rois, b_rois), (m0, m1)
+        assert torch.equal(a_out, b_out), (m0, m1, rep)
+    # against the reference CPU kernel, level by level
+    boxes = [random_boxes(m, 640, 384, 4, 380, g) for m in (900, 700)]
+    out, rois = run([b.to(DEV) for b in boxes], 1)
+    r5 = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+    assert torch.equal(rois.cpu(), r5)
+    area = (r5[:, 3] - r5[:, 1]) * (r5[:, 4] - r5[:, 2])
+    lv = torch.clamp(torch.floor(4.0 + torch.log2(torch.sqrt(area) / 224.0) + 1e-6), 2, 5).long() - 2   # poolers.py:76-90
+    tol = TOL if dtype == torch.float32 else 2e-2
+    for l in range(4):
+        sel = torch.nonzero(lv == l)[:, 0]
+        if sel.numel():
+            want = _ref(feats[l].float().cpu(), r5[sel], scales[l], 7)
+            assert np.abs(out[sel].float().cpu().numpy() - want).max() < tol
+    # eight streams at once, several launches each
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    sets = [[random_boxes(m, 640, 384, 4, 380, g).to(DEV) for m in (800 + 50 * i, 900)] for i in range(8)]
+    want = [run(b, 0) for b in sets]
+    torch.cuda.synchronize()
+    got = [None] * 8
+    for _ in range(4):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                got[i] = torch.ops.tvmi.multiscale_roi_align_boxes(feats, sets[i], scales, *tail)
+    torch.cuda.synchronize()
+    for i in range(8):
+        assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1]), i
+    # captured into a hipGraph: no flag block inside a capture — the two-launch form, replayed
+    gph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.ops.tvmi.multiscale_roi_align_boxes(feats, sets[0], scales, *tail)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(gph):
+        res = torch.ops.tvmi.multiscale_roi_align_boxes(feats, sets[0], scales, *tail)
+    for _ in range(3):
+        res[0].fill_(-7)
+        gph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(res[0], want[0][0])

@@ -16,7 +16,9 @@
 //   * fp64: one thread per output element, arithmetic on the fly.
 // Multi-scale (FPN) entries pick the level of every RoI in the kernel and serve all levels with one launch.
 #include <algorithm>
+#include <mutex>
 #include <string>
+#include <vector>
 #include <type_traits>
 
 #include "roi_common.h"
@@ -979,6 +981,7 @@ constexpr int kOrderThreads = 1024;
 constexpr int kOrderBuckets = 4096;
 constexpr int kOrderPerThread = 4;
 constexpr int64_t kOrderMaxRois = 1 << 16;   // beyond that one workgroup is the wrong shape: identity order
+constexpr int kOrderMaxFold = 4096;          // RoIs the 256-thread sort inside a launch keeps in registers (16 per thread)
 
 // Round 6: the pre-pass can also BUILD the [K,5] RoI rows from the per-image box lists (convert_boxes_to_roi_format,
 // ops/_utils.py:18-25 — a launch of its own until now: tvmi::boxes_to_rois, 4.8 us + a launch gap in front of every
@@ -991,19 +994,54 @@ struct MsBoxLists {
   int n;
 };
 
-template <typename R, bool BOXES = false>
-__global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, const R* __restrict__ rois, int K, int N,
-                                                                int multiscale, int bands, int* __restrict__ perm,
-                                                                int* __restrict__ mop_counter, MsBoxLists bl = MsBoxLists{},
-                                                                float* __restrict__ rois_out = nullptr) {
-  __shared__ int hist[kOrderBuckets];
-  __shared__ int wsum[kOrderThreads / 64];
-  __shared__ float band_scale[kMaxLevels];   // window-top row (level pixels) -> band index
-  __shared__ float lvl_scale[kMaxLevels];
+// Row k of the concatenated box lists as a [K,5] RoI row (convert_boxes_to_roi_format).
+__device__ __forceinline__ void row_from_boxes(const MsBoxLists& bl, int k, float (&v)[5]) {
+  int img = 0;
+  for (int i = 0; i < bl.n - 1; ++i) img += k >= bl.end[i] ? 1 : 0;
+  int first = 0;
+  const float* base = bl.ptr[0];
+#pragma unroll 1
+  for (int i = 1; i < bl.n; ++i)       // run-time index into the by-value struct would go through scratch: walk it
+    if (i == img) {
+      first = bl.end[i - 1];
+      base = bl.ptr[i];
+    }
+  const float* b = base + (int64_t)(k - first) * 4;
+  v[0] = (float)img;
+  v[1] = b[0];
+  v[2] = b[1];
+  v[3] = b[2];
+  v[4] = b[3];
+}
+
+struct OrderShared {
+  int hist[kOrderBuckets];
+  int wsum[16];
+  float band_scale[kMaxLevels];   // window-top row (level pixels) -> band index
+  float lvl_scale[kMaxLevels];
+};
+
+// The counting sort as a workgroup body of NT threads (NT * PER >= K for the register form): the launch of its own
+// (roi_fwd_order, 1024 threads) and, round 6, ONE WORKGROUP INSIDE the 7 x 7 multi-scale launch (256 threads, "fold": see
+// FoldArgs).  n0: the first n0 RoIs keep their input position (they are not counted) and positions [n0, K) are sorted.
+// perm64 != nullptr: positions are handed to the other workgroups of the SAME launch as self-validating 64-bit entries
+// (epoch << 32 | RoI index, agent-scope stores): a reader polls ITS entry until it carries the launch's epoch.
+template <int NT, int PER, typename R, bool BOXES, int BATCH = 4>
+__device__ __forceinline__ void order_body(OrderShared& sh, const MsLevels& lv, const R* __restrict__ rois, int K, int N,
+                                           int multiscale, int bands, int* __restrict__ perm, int* __restrict__ mop_counter,
+                                           const MsBoxLists& bl, float* __restrict__ rois_out, int n0,
+                                           unsigned long long* __restrict__ perm64, int epoch) {
+  static_assert(NT % 64 == 0 && NT / 64 <= 16 && kOrderBuckets % NT == 0 && PER % BATCH == 0, "order workgroup shape");
+  // inside a launch whose other waves saturate the CU's memory path and issue slots, the one workgroup every later unit waits
+  // for goes first (measured without: the sort took ~37 us instead of 10 and the launch grew by what the pre-pass launch had cost)
+  if (perm64) __builtin_amdgcn_s_setprio(3);
+  constexpr int BPT = kOrderBuckets / NT;   // buckets per thread in the scan
+  int* hist = sh.hist;
   const int tid = threadIdx.x;
   const int L = multiscale ? lv.n_levels : 1;
   const int nb = N * L * bands;
-  for (int i = tid; i < nb; i += kOrderThreads) hist[i] = 0;
+  for (int i = tid; i < nb; i += NT) hist[i] = 0;
+  if (tid < 16) sh.wsum[tid] = 0;
   if (tid < kMaxLevels) {
     float sc = lv.scale[0];
     int Hl = lv.H[0];
@@ -1013,8 +1051,8 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
         sc = lv.scale[i];
         Hl = lv.H[i];
       }
-    lvl_scale[tid] = sc;
-    band_scale[tid] = sc * (float)bands * __builtin_amdgcn_rcpf((float)max(Hl, 1));
+    sh.lvl_scale[tid] = sc;
+    sh.band_scale[tid] = sc * (float)bands * __builtin_amdgcn_rcpf((float)max(Hl, 1));
   }
   if (tid == 0 && mop_counter) *mop_counter = 0;
   __syncthreads();
@@ -1028,29 +1066,17 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
       l = (t == t) ? min(max((int)t - lv.k_min, 0), L - 1) : 0;
     }
     const int b = (bf == bf) ? min(max((int)bf, 0), N - 1) : 0;
-    const float yb = y1 * band_scale[l];
+    const float yb = y1 * sh.band_scale[l];
     const int band = (yb == yb) ? min(max((int)yb, 0), bands - 1) : 0;
     return (b * L + l) * bands + band;
   };
   auto load_row = [&](int k, float (&v)[5], bool write) {
     if constexpr (BOXES) {
-      int img = 0;
-      for (int i = 0; i < bl.n - 1; ++i) img += k >= bl.end[i] ? 1 : 0;
-      int first = 0;
-      const float* base = bl.ptr[0];
-#pragma unroll 1
-      for (int i = 1; i < bl.n; ++i)       // run-time index into the by-value struct would go through scratch: walk it
-        if (i == img) {
-          first = bl.end[i - 1];
-          base = bl.ptr[i];
-        }
-      const float* b = base + (int64_t)(k - first) * 4;
-      v[0] = (float)img;
-      v[1] = b[0];
-      v[2] = b[1];
-      v[3] = b[2];
-      v[4] = b[3];
-      if (write) {
+      row_from_boxes(bl, k, v);
+      // (inside a launch — perm64 — the rows are written by the units themselves: every vector memory instruction of this
+      // workgroup waits a full turn of the CU's saturated texture path, and 5 row stores per RoI were 80 of its 110 per wave:
+      // the sort took ~40 us instead of 10)
+      if (write && !perm64) {
         float* r = rois_out + (int64_t)k * 5;
 #pragma unroll
         for (int e = 0; e < 5; ++e) r[e] = v[e];
@@ -1065,29 +1091,40 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
     load_row(k, v, write);
     return key_of(v[0], v[1], v[2], v[3], v[4]);
   };
-  const bool in_regs = K <= kOrderThreads * kOrderPerThread;
-  int key[kOrderPerThread], rank[kOrderPerThread];
+  auto put = [&](int pos, int k) {
+    if (perm64) st_agent64(&perm64[pos], ((unsigned long long)(unsigned)epoch << 32) | (unsigned)k);
+    else perm[pos] = k;
+  };
+  const bool in_regs = K <= NT * PER;
+  int key[PER], rank[PER];
   if (in_regs) {
-    float v[kOrderPerThread][5];
 #pragma unroll
-    for (int j = 0; j < kOrderPerThread; ++j) {       // all loads of the thread in flight together
-      const int k = min(tid + j * kOrderThreads, K - 1);
-      load_row(k, v[j], tid + j * kOrderThreads < K);
-    }
+    for (int j0 = 0; j0 < PER; j0 += BATCH) {         // BATCH rows of the thread in flight together
+      float v[BATCH][5];
 #pragma unroll
-    for (int j = 0; j < kOrderPerThread; ++j) {
-      key[j] = key_of(v[j][0], v[j][1], v[j][2], v[j][3], v[j][4]);
-      rank[j] = (tid + j * kOrderThreads < K) ? atomicAdd(&hist[key[j]], 1) : 0;
+      for (int j = 0; j < BATCH; ++j) {
+        const int k = min(tid + (j0 + j) * NT, K - 1);
+        load_row(k, v[j], tid + (j0 + j) * NT < K);
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int k = tid + (j0 + j) * NT;
+        key[j0 + j] = key_of(v[j][0], v[j][1], v[j][2], v[j][3], v[j][4]);
+        rank[j0 + j] = (k < K && k >= n0) ? atomicAdd(&hist[key[j0 + j]], 1) : 0;
+      }
     }
   } else {
-    for (int k = tid; k < K; k += kOrderThreads) atomicAdd(&hist[load_key(k, true)], 1);
+    for (int k = tid; k < K; k += NT) {
+      const int ky = load_key(k, true);
+      if (k >= n0) atomicAdd(&hist[ky], 1);
+    }
   }
   __syncthreads();
-  // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, wave totals
-  int c[4], tsum = 0;
+  // exclusive scan of the bucket counts: BPT buckets per thread, wave scan, wave totals
+  int c[BPT], tsum = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid * 4 + i;
+  for (int i = 0; i < BPT; ++i) {
+    const int idx = tid * BPT + i;
     c[i] = idx < nb ? hist[idx] : 0;
     tsum += c[i];
   }
@@ -1097,33 +1134,43 @@ __global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, cons
     const int o = __shfl_up(incl, d);
     if ((tid & 63) >= d) incl += o;
   }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  if ((tid & 63) == 63) sh.wsum[tid >> 6] = incl;
   __syncthreads();
   int wbase = 0;
   {
     const int w = tid >> 6;
-    int part = (tid & 63) < w ? wsum[tid & 15] : 0;   // the totals of the waves in front: a butterfly instead of a serial walk
+    int part = (tid & 63) < w ? sh.wsum[tid & 15] : 0;   // the totals of the waves in front: a butterfly instead of a serial walk
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
     wbase = part;
   }
-  int run = wbase + incl - tsum;
+  int run = n0 + wbase + incl - tsum;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid * 4 + i;
+  for (int i = 0; i < BPT; ++i) {
+    const int idx = tid * BPT + i;
     if (idx < nb) hist[idx] = run;
     run += c[i];
   }
   __syncthreads();
   if (in_regs) {
 #pragma unroll
-    for (int j = 0; j < kOrderPerThread; ++j) {
-      const int k = tid + j * kOrderThreads;
-      if (k < K) perm[hist[key[j]] + rank[j]] = k;
+    for (int j = 0; j < PER; ++j) {
+      const int k = tid + j * NT;
+      if (k < K) put(k >= n0 ? hist[key[j]] + rank[j] : k, k);
     }
   } else {
-    for (int k = tid; k < K; k += kOrderThreads) perm[atomicAdd(&hist[load_key(k, false)], 1)] = k;
+    for (int k = tid; k < K; k += NT) put(k >= n0 ? atomicAdd(&hist[load_key(k, false)], 1) : k, k);
   }
+}
+
+template <typename R, bool BOXES = false>
+__global__ __launch_bounds__(kOrderThreads) void roi_fwd_order(MsLevels lv, const R* __restrict__ rois, int K, int N,
+                                                                int multiscale, int bands, int* __restrict__ perm,
+                                                                int* __restrict__ mop_counter, MsBoxLists bl = MsBoxLists{},
+                                                                float* __restrict__ rois_out = nullptr) {
+  __shared__ OrderShared sh;
+  order_body<kOrderThreads, kOrderPerThread, R, BOXES>(sh, lv, rois, K, N, multiscale, bands, perm, mop_counter, bl, rois_out, 0,
+                                                       nullptr, 0);
 }
 
 // Mop-up launch: a FIXED small grid whose waves walk the worklist the DMA launch filled (RoI x channel chunk units).
@@ -1190,6 +1237,112 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
                                                   lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
 }
 
+// Round 6, "fold": the order pre-pass INSIDE the launch (roi_align.fold_order, calls that start from box lists).  One workgroup in
+// front of the units' grid runs the counting sort (order_body, 256 threads) while the units of the launch's FIRST ROUND — positions
+// below n0 = what the chip holds at once — take the RoIs in input order straight from the box lists; a unit at a later position
+// polls ITS 64-bit entry of the order (written long before the unit is dispatched: the sort takes ~10 us, a unit ~25) with an
+// agent-scope load until the entry carries this launch's epoch, and takes its RoI index from the same word: no flag word, no
+// second dependent load, nothing to reset — epochs come from one host counter and are never reused, so an entry an earlier launch
+// left in the buffer cannot be mistaken for this launch's.  Saves the pre-pass launch and the gap behind it on the critical path
+// of every detector step for ~1/8 of the units in input order.  Not used under graph capture (the epoch would be frozen into the
+// node and a replay could read the entries of the replay before it): the two-launch form runs there.
+// Only the ORDER of the units depends on any of this — never a result.
+struct FoldArgs {
+  unsigned long long* perm64;   // nullptr: no fold — positions come from um.perm (the pre-pass launch), rows from `rois`
+  int epoch, n0, bands, N;
+  float* rois_out;
+  MsBoxLists bl;
+};
+constexpr unsigned kFoldBlocks = 8;   // workgroups in front of the units (one sorts, seven leave): a multiple of 8 keeps the units' XCDs
+
+template <int PHT>
+union MsWaveLds {
+  DmaShared<PHT> d;
+  WaveShared w;
+};
+
+template <typename T, int PHT, int PWT, int SRT>
+__device__ __forceinline__ void ms_inl_unit(MsWaveLds<PHT>& s, const MsLevels& lv, const float* __restrict__ rois,
+                                            T* __restrict__ output, int C, int aligned, int nchunks, int chunk, int64_t nunits,
+                                            const UnitMap& um, const FoldArgs& fa, unsigned block) {
+  constexpr int PHW = PHT * PWT;
+  int k, ci;
+  float row[5];
+  if (fa.perm64) {
+    int kk;
+    if (!wave_unit_at(block, nunits / nchunks, nchunks, UnitMap{nullptr, 1}, kk, ci)) return;
+    k = kk;
+    if (kk >= fa.n0) {
+      // fast path: a SCALAR load (the vector path queues behind the CU's window DMAs, ~1 us).  An entry that carries this launch's
+      // epoch IS this launch's entry whatever cache it came from (epochs are never reused); anything else — not written yet, or a
+      // line some cache took before it was written — falls back to the agent-scope poll, which no cache can satisfy
+      unsigned long long e;
+      const unsigned long long* ep = fa.perm64 + kk;
+      asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(e) : "s"(ep) : "memory");
+      if ((int)(e >> 32) != fa.epoch) e = ld_agent64(fa.perm64 + kk);
+      for (int polls = 0; (int)(e >> 32) != fa.epoch; ++polls) {
+        __builtin_amdgcn_s_sleep(8);
+        if (polls > (1 << 22)) __builtin_trap();   // the sort workgroup is resident before any unit: seconds of polling mean a broken launch
+        e = ld_agent64(fa.perm64 + kk);
+      }
+      k = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+    }
+    {   // the wave-uniform form of row_from_boxes: the box as one scalar load
+      int img = 0;
+      for (int i = 0; i < fa.bl.n - 1; ++i) img += k >= fa.bl.end[i] ? 1 : 0;
+      int first = 0;
+      const float* base = fa.bl.ptr[0];
+#pragma unroll 1
+      for (int i = 1; i < fa.bl.n; ++i)
+        if (i == img) {
+          first = fa.bl.end[i - 1];
+          base = fa.bl.ptr[i];
+        }
+      const float* bp = base + (int64_t)(k - first) * 4;
+      unsigned long long b01, b23;
+      asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x8\n\ts_waitcnt lgkmcnt(0)" : "=&s"(b01), "=&s"(b23) : "s"(bp) : "memory");
+      row[0] = (float)img;
+      row[1] = __builtin_bit_cast(float, (unsigned)b01);
+      row[2] = __builtin_bit_cast(float, (unsigned)(b01 >> 32));
+      row[3] = __builtin_bit_cast(float, (unsigned)b23);
+      row[4] = __builtin_bit_cast(float, (unsigned)(b23 >> 32));
+      if (ci == 0) {   // the [K,5] row the caller asked for (the backward reads it): one store by the unit of channel chunk 0
+        const int lane = threadIdx.x & 63;
+        const float v = lane == 0 ? row[0] : lane == 1 ? row[1] : lane == 2 ? row[2] : lane == 3 ? row[3] : row[4];
+        if (lane < 5) fa.rois_out[(int64_t)k * 5 + lane] = v;
+      }
+    }
+  } else {
+    // position -> RoI index -> row as SCALAR loads (both wave-uniform, both written by the launch in front): the vector path
+    // queues a load behind the window DMAs of the 15 other waves of the CU (~1 us each under this kernel's own traffic, twice in
+    // a row at the start of every unit); the scalar cache has its own path to L2
+    int kk;
+    if (!wave_unit_at(block, nunits / nchunks, nchunks, UnitMap{nullptr, um.pinned}, kk, ci)) return;
+    k = kk;
+    if (um.perm) {
+      const int* pp = um.perm + kk;
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k) : "s"(pp) : "memory");
+    }
+    const float* rp = rois + (int64_t)k * 5;
+    // (64-bit pairs, not one dwordx4: element extracts of a 4-vector inline-asm result in SGPRs all came back as element 0)
+    unsigned long long r01, r23;
+    int r4;
+    asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dword %2, %3, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r01), "=&s"(r23), "=&s"(r4) : "s"(rp) : "memory");
+    row[0] = __builtin_bit_cast(float, (unsigned)r01);
+    row[1] = __builtin_bit_cast(float, (unsigned)(r01 >> 32));
+    row[2] = __builtin_bit_cast(float, (unsigned)r23);
+    row[3] = __builtin_bit_cast(float, (unsigned)(r23 >> 32));
+    row[4] = __builtin_bit_cast(float, r4);
+  }
+  const int l = fpn_level<float>(row, lv);
+  T* outk = output + (int64_t)k * C * PHW;
+  if (roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s.d, static_cast<const T*>(lv.ptr[l]), row, outk, C, lv.H[l], lv.W[l],
+                                                      lv.scale[l], aligned, 0, ci * chunk, chunk, nullptr))
+    roi_align_fwd_wave_fast<T, float, PHT, PWT, SRT>(s.w, static_cast<const T*>(lv.ptr[l]), row, outk, C, lv.H[l], lv.W[l],
+                                                     lv.scale[l], aligned, 0, ci * chunk, chunk);
+}
+
 // The same launch WITHOUT a mop-up launch behind it (round 6, "roi_align.inline_mop"): a unit the DMA path declines (a window
 // above 8 DMA blocks per channel, samples the reference skips: 0-2 % of the RoIs of a detector step) takes the wave path right
 // here, in the LDS of the same wave (the two per-wave images are a union: 10 KB, still four workgroups per CU).  One launch and
@@ -1198,20 +1351,24 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
 template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma_inl(MsLevels lv, const float* __restrict__ rois,
                                                                      T* __restrict__ output, int C, int aligned, int nchunks,
-                                                                     int chunk, int64_t nunits, UnitMap um) {
-  union WaveLds {
-    DmaShared<PHT> d;
-    WaveShared w;
+                                                                     int chunk, int64_t nunits, UnitMap um, FoldArgs fa) {
+  union Lds {
+    MsWaveLds<PHT> s[kThreads / 64];
+    OrderShared order;
   };
-  __shared__ WaveLds s[kThreads / 64];
+  __shared__ Lds sh;
+  unsigned block = blockIdx.x;
+  if (fa.perm64) {
+    if (block < kFoldBlocks) {
+      if (block == 0)
+        order_body<kThreads, kOrderMaxFold / kThreads, float, true, 8>(sh.order, lv, nullptr, (int)(nunits / nchunks), fa.N, 1, fa.bands,
+                                                                    nullptr, nullptr, fa.bl, fa.rois_out, fa.n0, fa.perm64, fa.epoch);
+      return;
+    }
+    block -= kFoldBlocks;
+  }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  int k, ci;
-  if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
-  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  if (roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave].d, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                                      lv.scale[l], aligned, k, ci * chunk, chunk, nullptr))
-    roi_align_fwd_wave_fast<T, float, PHT, PWT, SRT>(s[wave].w, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                                     lv.scale[l], aligned, k, ci * chunk, chunk);
+  ms_inl_unit<T, PHT, PWT, SRT>(sh.s[wave], lv, rois, output, C, aligned, nchunks, chunk, nunits, um, fa, block);
 }
 
 // The detector step in ONE launch (round 6): the workgroups of the step's NMS (nms_step_body, nms_step_device.h: tiles, rank
@@ -1225,15 +1382,12 @@ template <typename T, int PHT, int PWT, int SRT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void roi_align_fwd_ms_dma_inl_step(MsLevels lv, const float* __restrict__ rois,
                                                                           T* __restrict__ output, int C, int aligned, int nchunks,
                                                                           int chunk, int64_t nunits, UnitMap um, StepArgs na,
-                                                                          unsigned nms_blocks) {
+                                                                          unsigned nms_blocks, FoldArgs fa) {
   static_assert(kThreads == kStepThreads, "one workgroup shape for both jobs");
-  union WaveLds {
-    DmaShared<PHT> d;
-    WaveShared w;
-  };
   union Lds {
-    WaveLds s[kThreads / 64];
+    MsWaveLds<PHT> s[kThreads / 64];
     StepShared nms;
+    OrderShared order;
   };
   __shared__ Lds sh;
   if (blockIdx.x < nms_blocks) {
@@ -1243,14 +1397,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))
                     na.keep_out, na.num_keep, na.pk);
     return;
   }
+  unsigned block = blockIdx.x - nms_blocks;
+  if (fa.perm64) {
+    if (block < kFoldBlocks) {
+      if (block == 0)
+        order_body<kThreads, kOrderMaxFold / kThreads, float, true, 8>(sh.order, lv, nullptr, (int)(nunits / nchunks), fa.N, 1, fa.bands,
+                                                                    nullptr, nullptr, fa.bl, fa.rois_out, fa.n0, fa.perm64, fa.epoch);
+      return;
+    }
+    block -= kFoldBlocks;
+  }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  int k, ci;
-  if (!wave_unit_at(blockIdx.x - nms_blocks, nunits / nchunks, nchunks, um, k, ci)) return;
-  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  if (roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(sh.s[wave].d, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                                      lv.scale[l], aligned, k, ci * chunk, chunk, nullptr))
-    roi_align_fwd_wave_fast<T, float, PHT, PWT, SRT>(sh.s[wave].w, static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l], lv.W[l],
-                                                     lv.scale[l], aligned, k, ci * chunk, chunk);
+  ms_inl_unit<T, PHT, PWT, SRT>(sh.s[wave], lv, rois, output, C, aligned, nchunks, chunk, nunits, um, fa, block);
 }
 
 template <typename T, int PHT, int PWT, int SRT>
@@ -1293,6 +1451,8 @@ struct FwdOptions {
   int order = 1;        // "roi_align.order": launch order from roi_fwd_order (needs the pinned placement + workspace)
   int bands = 16;       // "roi_align.order_bands": window-top bands per (image, level) in the order key
   int carry_step = 1;   // "roi_align.carry_step": tvmi_multiscale_roi_align_forward_boxes_with_nms_step puts the NMS workgroups into the RoIAlign launch
+  int fold_pct = 100;   // "roi_align.fold_first_round_pct": positions left in input order, in percent of what the chip holds at once
+  int fold_order = 1;   // "roi_align.fold_order": the order pre-pass as a workgroup of the 7 x 7 multi-scale launch (calls from box lists)
   int inline_mop = 1;   // "roi_align.inline_mop": declined units take the wave path inside the DMA launch (multi-scale 7 x 7 entries)
 };
 FwdOptions g_fwd_opt;
@@ -1566,6 +1726,29 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward_nhwc");
 }
 
+// Epochs of the folded order pre-pass (FoldArgs): one host counter, never reused (2^31 launches, then from 1 again).  A capturing
+// stream gets none (the epoch would be frozen into the graph node): the caller takes the two-launch form.
+inline bool fold_epoch(hipStream_t s, int* epoch, int* resident_wgs) {
+  static std::mutex mu;
+  static int next = 0, resident = 0;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (resident == 0) {   // workgroups of the 7 x 7 kernels the chip holds at once (4 per CU)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    resident = 4 * cus;
+  }
+  next = next == 0x7fffffff ? 1 : next + 1;
+  *epoch = next;
+  *resident_wgs = resident;
+  return true;
+}
+
 template <typename T>
 int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int64_t N, int64_t C, int64_t K, int64_t PH,
                   int64_t PW, int64_t sr, int aligned, int* mop, int* perm, hipStream_t stream, const MsBoxLists* bl = nullptr,
@@ -1576,7 +1759,31 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
   const int64_t nunits = K * nchunks, mop_nunits = K * mop_nchunks;
   const bool fast_shape = (PH == 7 && PW == 7 && sr == 2) || (PH == 14 && PW == 14 && sr == 2);
   UnitMap um{nullptr, 0};
-  if (fast_shape && mop) {
+  FoldArgs fa{};
+  unsigned front = carried ? (unsigned)((carried->S * carried->gdim_y + 7) & ~7) : 0u;   // workgroups in front of the units
+  if (fast_shape && mop && bl && PH == 7 && g_fwd_opt.inline_mop && g_fwd_opt.fold_order && K <= kOrderMaxFold &&
+      plan_units_orders(N, lv.n_levels, nchunks, perm)) {
+    // the order pre-pass as a workgroup of the launch: worth it when the sorted part is most of the RoIs.  The 64-bit entries
+    // take the worklist + order parts of the workspace ([4 + K][K] ints, contiguous: the inline form needs no worklist)
+    int epoch = 0, resident = 0;
+    unsigned long long* p64 = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(mop) + 7) & ~(uintptr_t)7);
+    const bool room = reinterpret_cast<char*>(p64 + K) <= reinterpret_cast<char*>(perm + K);
+    if (room && fold_epoch(stream, &epoch, &resident)) {
+      const int64_t n0 = 4 * (std::max<int64_t>(0, ((int64_t)resident - front - kFoldBlocks) / 8) * g_fwd_opt.fold_pct / 100);   // positions of the first round
+      if (2 * n0 <= K) {
+        fa.perm64 = p64;
+        fa.epoch = epoch;
+        fa.n0 = (int)n0;
+        fa.bands = (int)std::max<int64_t>(1, std::min<int64_t>(g_fwd_opt.bands, kOrderBuckets / (N * lv.n_levels)));
+        fa.N = (int)N;
+        fa.rois_out = const_cast<float*>(r);
+        fa.bl = *bl;
+        um = UnitMap{nullptr, 1};
+        front += kFoldBlocks;
+      }
+    }
+  }
+  if (fast_shape && mop && !fa.perm64) {
     const int st = plan_units<float>(um, lv, r, N, K, nchunks, /*multiscale=*/1, mop, perm, stream, bl,
                                      const_cast<float*>(r));   // with box lists `rois` is the buffer the pre-pass fills
     if (st != 0) return set_error(st, "tvmi_multiscale_roi_align_forward: clearing the worklist failed");
@@ -1591,11 +1798,11 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
     if constexpr (PHT == 7) {                                                                                         \
       if (carried) {   /* the step's NMS workgroups in front of the grid (ms_fwd_can_carry_step) */                    \
         const unsigned nb = (unsigned)((carried->S * carried->gdim_y + 7) & ~7);                                      \
-        roi_align_fwd_ms_dma_inl_step<T, PHT, PWT, SRT><<<dim3(dma_grid.x + nb), block, 0, stream>>>(                \
-            lv, r, out, (int)C, aligned, nchunks, kUnitChunk, nunits, um, *carried, nb);                              \
+        roi_align_fwd_ms_dma_inl_step<T, PHT, PWT, SRT><<<dim3(dma_grid.x + front), block, 0, stream>>>(             \
+            lv, r, out, (int)C, aligned, nchunks, kUnitChunk, nunits, um, *carried, nb, fa);                          \
       } else {                                                                                                        \
-        roi_align_fwd_ms_dma_inl<T, PHT, PWT, SRT><<<dma_grid, block, 0, stream>>>(lv, r, out, (int)C, aligned, nchunks, \
-                                                                                       kUnitChunk, nunits, um);       \
+        roi_align_fwd_ms_dma_inl<T, PHT, PWT, SRT><<<dim3(dma_grid.x + front), block, 0, stream>>>(                  \
+            lv, r, out, (int)C, aligned, nchunks, kUnitChunk, nunits, um, fa);                                        \
       }                                                                                                               \
     }                                                                                                                 \
   } else if (mop) {                                                                                                   \
@@ -1628,6 +1835,8 @@ int set_roi_option(const char* name, int64_t value) {
   else if (n == "roi_align.order") g_fwd_opt.order = value != 0;
   else if (n == "roi_align.inline_mop") g_fwd_opt.inline_mop = value != 0;
   else if (n == "roi_align.carry_step") g_fwd_opt.carry_step = value != 0;
+  else if (n == "roi_align.fold_order") g_fwd_opt.fold_order = value != 0;
+  else if (n == "roi_align.fold_first_round_pct") g_fwd_opt.fold_pct = (int)std::max<int64_t>(0, std::min<int64_t>(value, 400));
   else if (n == "roi_align.order_bands") g_fwd_opt.bands = (int)std::max<int64_t>(1, std::min<int64_t>(value, 64));
   else return -1;
   return 0;
@@ -1641,6 +1850,8 @@ int get_roi_option(const char* name, int64_t* value) {
   else if (n == "roi_align.order_bands") *value = g_fwd_opt.bands;
   else if (n == "roi_align.inline_mop") *value = g_fwd_opt.inline_mop;
   else if (n == "roi_align.carry_step") *value = g_fwd_opt.carry_step;
+  else if (n == "roi_align.fold_order") *value = g_fwd_opt.fold_order;
+  else if (n == "roi_align.fold_first_round_pct") *value = g_fwd_opt.fold_pct;
   else return -1;
   return 0;
 }
