@@ -1,4 +1,8 @@
-for cfg in "0 100" "1 100" "1 200" "1 150" "0 100" "1 200" "1 300"; do
-set -- $cfg
-TVMI_SET_OPTIONS=roi_align.fold_first_round_pct=$2 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-e2e --no-configs --roi-fold-order $1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fold=$1 pct=$2', d['value'], d['ms_per_step'], d.get('roofline',{}).get('launch_ms'))"
+timeout 900 python -m pytest tests/test_gpu_roi_routes.py tests/test_gpu_baseline_sizes.py -q -x -m gpu -k "roi or multiscale or routes or fold" 2>&1 | tail -3
+rm -rf _variants/*.o
+for v in head new head new; do
+  cp _variants/libtvmi_kernels_$v.so vision_amd/_lib/libtvmi_kernels.so
+  for a in "14" "7 bf16" "14 bf16"; do python tools/roi_knock.py $v $a 2>&1 | tail -1; done
+  python tools/nhwc_timing.py 2>&1 | grep -E "order 1|nhwc bf16|bits"
 done
+cp _variants/libtvmi_kernels_new.so vision_amd/_lib/libtvmi_kernels.so

@@ -5,6 +5,8 @@ import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, vision_amd, bench
+for kv in filter(None, os.environ.get("TVMI_SET_OPTIONS", "").split(",")):   # e.g. TVMI_SET_OPTIONS=roi_align.fold_order=0
+    torch.ops.tvmi.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda:0")
 sets = [bench.make_inputs(dev, 1000 + 97 * i) for i in range(4)]
 shapes = [(800, 1344)] * 4

@@ -828,7 +828,7 @@ template <typename T, typename R, int PHT, int PWT, int SRT>
 __device__ __forceinline__ bool roi_align_fwd_wave_dma(DmaShared<PHT>& s, const T* __restrict__ input,
                                                        const R* __restrict__ rois, T* __restrict__ output,
                                                        int C, int H, int W, float spatial_scale, int aligned, int k,
-                                                       int c0, int chunk, int* __restrict__ declined) {
+                                                       int c0, int chunk, int* __restrict__ declined, int k_id = -1) {
   constexpr int PHW = PHT * PWT;
   constexpr int NB = (PHW + 63) / 64;
   constexpr int NS = SRT * SRT;
@@ -843,7 +843,7 @@ __device__ __forceinline__ bool roi_align_fwd_wave_dma(DmaShared<PHT>& s, const 
   const DmaWindow dw = dma_window<PHT, PWT, SRT, EPP>(g, H, W);
   if (dw.state == 2) {  // left to the mop-up launch: one worklist entry per RoI (the wave of channel chunk 0 reports it)
     if (declined == nullptr) return true;
-    if (c0 == 0 && lane == 0) declined[kMopHeader + atomicAdd(declined, 1)] = k;
+    if (c0 == 0 && lane == 0) declined[kMopHeader + atomicAdd(declined, 1)] = k_id >= 0 ? k_id : k;   // (k_id: `rois` is the row itself)
     return false;
   }
   if (dw.state == 0) {
@@ -923,6 +923,28 @@ struct UnitMap {
   int pinned;
 };
 
+// Position -> RoI index and the [5] row of a float RoI list as SCALAR loads (wave-uniform addresses, data of the launch in front):
+// a vector load of a unit's first instructions queues behind the window DMAs of the CU's other waves (~1 us under these
+// kernels' own traffic) — twice in a row for position -> index -> row; the scalar cache has its own path to L2.
+__device__ __forceinline__ int perm_at(const int* __restrict__ perm, int64_t kk) {
+  int k;
+  const int* pp = perm + kk;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k) : "s"(pp) : "memory");
+  return k;
+}
+// (64-bit pairs, not one dwordx4: element extracts of a 4-vector inline-asm result in SGPRs all came back as element 0)
+__device__ __forceinline__ void roi_row_scalar(const float* __restrict__ rp, float (&row)[5]) {
+  unsigned long long r01, r23;
+  int r4;
+  asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dword %2, %3, 0x10\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(r01), "=&s"(r23), "=&s"(r4) : "s"(rp) : "memory");
+  row[0] = __builtin_bit_cast(float, (unsigned)r01);
+  row[1] = __builtin_bit_cast(float, (unsigned)(r01 >> 32));
+  row[2] = __builtin_bit_cast(float, (unsigned)r23);
+  row[3] = __builtin_bit_cast(float, (unsigned)(r23 >> 32));
+  row[4] = __builtin_bit_cast(float, r4);
+}
+
 // (`block`: the workgroup's number within the units' grid — blockIdx.x, or blockIdx.x less the workgroups of another job that the
 // launch carries in front, a multiple of 8 so that the XCD of a unit stays what it was)
 __device__ __forceinline__ bool wave_unit_at(unsigned block, int64_t K, int nchunks, const UnitMap& um, int& k, int& chunk_idx,
@@ -936,7 +958,7 @@ __device__ __forceinline__ bool wave_unit_at(unsigned block, int64_t K, int nchu
     chunk_idx = xcd + 8 * slot;
     if (chunk_idx >= nchunks) return false;
     const int64_t kk = local - (int64_t)slot * K;
-    k = um.perm ? __builtin_amdgcn_readfirstlane(um.perm[kk]) : (int)kk;
+    k = um.perm ? perm_at(um.perm, kk) : (int)kk;
     return true;
   }
   const int64_t kbase = K >> 3, krem = K & 7;
@@ -945,7 +967,7 @@ __device__ __forceinline__ bool wave_unit_at(unsigned block, int64_t K, int nchu
   if (local >= Kx * nchunks) return false;
   chunk_idx = (int)(local / Kx);
   const int64_t kk = kstart + (local - (int64_t)chunk_idx * Kx);
-  k = um.perm ? __builtin_amdgcn_readfirstlane(um.perm[kk]) : (int)kk;
+  k = um.perm ? perm_at(um.perm, kk) : (int)kk;
   return true;
 }
 
@@ -1232,9 +1254,11 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: keep unit math scalar
   int k, ci;
   if (!wave_unit(nunits / nchunks, nchunks, um, k, ci)) return;
-  const int l = fpn_level<float>(rois + (int64_t)k * 5, lv);
-  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), rois, output, C, lv.H[l],
-                                                  lv.W[l], lv.scale[l], aligned, k, ci * chunk, chunk, mop);
+  float row[5];
+  roi_row_scalar(rois + (int64_t)k * 5, row);
+  const int l = fpn_level<float>(row, lv);
+  roi_align_fwd_wave_dma<T, float, PHT, PWT, SRT>(s[wave], static_cast<const T*>(lv.ptr[l]), row, output + (int64_t)k * C * (PHT * PWT), C,
+                                                  lv.H[l], lv.W[l], lv.scale[l], aligned, 0, ci * chunk, chunk, mop, k);
 }
 
 // Round 6, "fold": the order pre-pass INSIDE the launch (roi_align.fold_order, calls that start from box lists).  One workgroup in
@@ -1264,13 +1288,13 @@ union MsWaveLds {
 template <typename T, int PHT, int PWT, int SRT>
 __device__ __forceinline__ void ms_inl_unit(MsWaveLds<PHT>& s, const MsLevels& lv, const float* __restrict__ rois,
                                             T* __restrict__ output, int C, int aligned, int nchunks, int chunk, int64_t nunits,
-                                            const UnitMap& um, const FoldArgs& fa, unsigned block) {
+                                            const UnitMap& um, const FoldArgs& fa, unsigned block, int wpb = kThreads / 64) {
   constexpr int PHW = PHT * PWT;
   int k, ci;
   float row[5];
   if (fa.perm64) {
     int kk;
-    if (!wave_unit_at(block, nunits / nchunks, nchunks, UnitMap{nullptr, 1}, kk, ci)) return;
+    if (!wave_unit_at(block, nunits / nchunks, nchunks, UnitMap{nullptr, 1}, kk, ci, wpb)) return;
     k = kk;
     if (kk >= fa.n0) {
       // fast path: a SCALAR load (the vector path queues behind the CU's window DMAs, ~1 us).  An entry that carries this launch's
@@ -1313,27 +1337,8 @@ __device__ __forceinline__ void ms_inl_unit(MsWaveLds<PHT>& s, const MsLevels& l
       }
     }
   } else {
-    // position -> RoI index -> row as SCALAR loads (both wave-uniform, both written by the launch in front): the vector path
-    // queues a load behind the window DMAs of the 15 other waves of the CU (~1 us each under this kernel's own traffic, twice in
-    // a row at the start of every unit); the scalar cache has its own path to L2
-    int kk;
-    if (!wave_unit_at(block, nunits / nchunks, nchunks, UnitMap{nullptr, um.pinned}, kk, ci)) return;
-    k = kk;
-    if (um.perm) {
-      const int* pp = um.perm + kk;
-      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(k) : "s"(pp) : "memory");
-    }
-    const float* rp = rois + (int64_t)k * 5;
-    // (64-bit pairs, not one dwordx4: element extracts of a 4-vector inline-asm result in SGPRs all came back as element 0)
-    unsigned long long r01, r23;
-    int r4;
-    asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dword %2, %3, 0x10\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(r01), "=&s"(r23), "=&s"(r4) : "s"(rp) : "memory");
-    row[0] = __builtin_bit_cast(float, (unsigned)r01);
-    row[1] = __builtin_bit_cast(float, (unsigned)(r01 >> 32));
-    row[2] = __builtin_bit_cast(float, (unsigned)r23);
-    row[3] = __builtin_bit_cast(float, (unsigned)(r23 >> 32));
-    row[4] = __builtin_bit_cast(float, r4);
+    if (!wave_unit_at(block, nunits / nchunks, nchunks, um, k, ci, wpb)) return;
+    roi_row_scalar(rois + (int64_t)k * 5, row);
   }
   const int l = fpn_level<float>(row, lv);
   T* outk = output + (int64_t)k * C * PHW;
@@ -1371,6 +1376,9 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma_inl(MsLevels lv
   ms_inl_unit<T, PHT, PWT, SRT>(sh.s[wave], lv, rois, output, C, aligned, nchunks, chunk, nunits, um, fa, block);
 }
 
+// (Measured and removed, round 6: the same units as ONE-WAVE workgroups — a slot refilled when its own unit ends instead of when
+// the slowest of four ends — 0.2494 against 0.2452 ms for the op on one box: the coupling of the four waves costs less than four
+// times the dispatches.)
 // The detector step in ONE launch (round 6): the workgroups of the step's NMS (nms_step_body, nms_step_device.h: tiles, rank
 // counting, sweeps, keep list and payload of <= 4096 boxes) ride in front of the RoIAlign grid.  As two launches the two jobs need
 // two streams to overlap, and the fork, the join and the second queue cost the step ~40 us more than the RoIAlign launch takes on
@@ -1596,9 +1604,11 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_nhwc(MsLevels lv, cons
   if (!wave_unit_nhwc(nunits / ngroups, ngroups, perm, k, gi)) return;
   const int c0 = gi * GC;
   // level / batch index are wave-uniform: say so, the tap base then lives in SGPRs
-  const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(rois + (int64_t)k * 5, lv));
+  float row[5];
+  roi_row_scalar(rois + (int64_t)k * 5, row);
+  const int l = __builtin_amdgcn_readfirstlane(fpn_level<float>(row, lv));
   const int H = lv.H[l], W = lv.W[l];
-  const RoiGeom<float> g = roi_geom<float, float>(rois + (int64_t)k * 5, lv.scale[l], PHT, PWT, SRT, aligned != 0);
+  const RoiGeom<float> g = roi_geom<float, float>(row, lv.scale[l], PHT, PWT, SRT, aligned != 0);
   const int batch = __builtin_amdgcn_readfirstlane(g.batch);
   // ---- per-RoI sample tables, one sample per lane: element offset of the low tap + the two factors
   // y: the reference's (low, high) rows (high = low on the bottom edge); x: shifted pairs + a legacy multiply for the
