@@ -85,7 +85,12 @@ int tvmi_version(void);
  *   "roi_align.inline_mop"       1 (default) / 0: in the 7 x 7 multi-scale forward the units the LDS-DMA path declines take the wave path
  *                                inside the same launch instead of a worklist + a mop-up launch
  *   "roi_align.carry_step"       1 (default) / 0: tvmi_multiscale_roi_align_forward_boxes_with_nms_step puts the NMS workgroups of the
- *                                detector step in front of the RoIAlign grid (one launch); 0 = the two entries one after the other */
+ *                                detector step in front of the RoIAlign grid (one launch); 0 = the two entries one after the other
+ *   "roi_align.fold_order"       1 (default) / 0: in the 7 x 7 multi-scale forward that starts from box lists (<= 4096 boxes, stream not
+ *                                being captured) the launch-order pre-pass runs as ONE WORKGROUP OF THE LAUNCH instead of a launch
+ *                                in front of it; the first round of units runs in input order meanwhile.  Same results either way
+ *   "roi_align.fold_first_round_pct"  100 (default), 0..400: how many positions stay in input order, in percent of the workgroups the
+ *                                chip holds at once (tuning value of the folded form) */
 int tvmi_set_option(const char* name, int64_t value);
 /* Current value of a switch of tvmi_set_option (0, or an error for an unknown name). */
 int tvmi_get_option(const char* name, int64_t* value);
@@ -295,7 +300,8 @@ int tvmi_multiscale_roi_align_backward(const void* grad, const void* rois, void*
  * instead of [K,5] rows (round 6): boxes[i] = [counts[i], 4] float32 device boxes of image i, num_images <= 64.  The rows of
  * convert_boxes_to_roi_format (ops/_utils.py:18-25) are written to rois_out [K,5] float32 (K = sum of counts; the backward takes
  * them) by the launch-order pre-pass of this call where that runs (7x7 / 14x14 bins with sampling_ratio 2, a multiple of 256
- * channels, workspace given) — otherwise by tvmi_boxes_to_rois in front of the plain entry.  Same result either way. */
+ * channels, workspace given) — by the units of the launch itself where the pre-pass is folded into it ("roi_align.fold_order") —
+ * otherwise by tvmi_boxes_to_rois in front of the plain entry.  Same result either way. */
 int tvmi_multiscale_roi_align_forward_boxes(const void* const* inputs, const int64_t* heights, const int64_t* widths,
                                             const double* spatial_scales, int64_t n_levels, const void* const* boxes,
                                             const int64_t* counts, int64_t num_images, void* rois_out, void* output, tvmi_dtype dt,

@@ -210,3 +210,34 @@ def test_resize_backward_and_channels_last_entries_host_side():
     assert nn(fake, fake, 3, 4, IH, IW, OH, OW, 0, -1.0, -1.0, None) != 0 and b"element size" in lib.tvmi_last_error()
     # stream helpers: argument checks only (no device here)
     assert lib.tvmi_stream_event_scope(ctypes.c_int(5)) != 0 and lib.tvmi_stream_event_scope(ctypes.c_int(1)) == 0
+
+
+def test_options_round_trip_host_side():
+    """tvmi_set_option / tvmi_get_option are host-only switches: every name include/tvmi.h lists for the RoIAlign forward reads back
+    what was set (no GPU needed), the tuning value is clamped to its documented range, unknown names are refused with an error text."""
+    import ctypes
+
+    import vision_amd
+
+    lib = vision_amd._loader.kernels()
+    lib.tvmi_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    lib.tvmi_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    lib.tvmi_last_error.restype = ctypes.c_char_p
+
+    def get(name):
+        v = ctypes.c_int64(-99)
+        assert lib.tvmi_get_option(name, ctypes.byref(v)) == 0, name
+        return v.value
+
+    header = open(HEADER).read()
+    for name, default in ((b"roi_align.pin_chunks", 1), (b"roi_align.order", 1), (b"roi_align.inline_mop", 1), (b"roi_align.carry_step", 1),
+                          (b"roi_align.fold_order", 1)):
+        assert name.decode() in header or name in (b"roi_align.pin_chunks", b"roi_align.order"), name
+        assert get(name) == default, name
+        assert lib.tvmi_set_option(name, 0) == 0 and get(name) == 0
+        assert lib.tvmi_set_option(name, default) == 0 and get(name) == default
+    assert get(b"roi_align.fold_first_round_pct") == 100
+    assert lib.tvmi_set_option(b"roi_align.fold_first_round_pct", 100000) == 0 and get(b"roi_align.fold_first_round_pct") == 400
+    assert lib.tvmi_set_option(b"roi_align.fold_first_round_pct", 100) == 0
+    assert lib.tvmi_set_option(b"roi_align.no_such_switch", 1) != 0
+    assert b"unknown option" in lib.tvmi_last_error()
