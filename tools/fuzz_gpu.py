@@ -76,6 +76,37 @@ while time.time() - t0 < 60:
         gi = tv._roi_align_backward(gr.to(dev), rois.to(dev), scale, 14, 14, N, C, H, W, 2, aligned)
         refb = O.roi_align_backward(gr.numpy(), rois.numpy(), scale, 14, 14, N, C, H, W, 2, aligned)
         assert np.abs(gi.cpu().numpy() - refb).max() < 1e-4 * max(1.0, float(np.abs(refb).max())), ("roi bwd14", N, C, H, W)
+    # ---- round 6: multi-scale RoIAlign from box lists with the order pre-pass FOLDED INTO THE LAUNCH (one workgroup sorts, the first
+    # round of units runs in input order, later units wait for their order entries) against the two-launch form: same bits, same rows
+    if ri(0, 2) == 0:
+        nim = ri(1, 6); L = ri(2, 4); Hm, Wm = ri(24, 80), ri(32, 120)
+        total = [ri(1, 900), ri(900, 1100), ri(1100, 4096), ri(4090, 4200)][ri(0, 3)]
+        cuts = sorted(ri(0, total) for _ in range(nim - 1)); cnts = [b_ - a_ for a_, b_ in zip([0] + cuts, cuts + [total])]
+        fm = [torch.randn(nim, 256, max(Hm >> l, 2), max(Wm >> l, 4), generator=g).to(dev) for l in range(L)]
+        bl = []
+        for m in cnts:
+            o = torch.rand(m, 2, generator=g) * torch.tensor([Wm * 4.0, Hm * 4.0]) - 8.0
+            e = torch.rand(m, 2, generator=g) * [16.0, 120.0, 500.0][ri(0, 2)]
+            bb = torch.cat([o, o + e], 1)
+            if m and ri(0, 3) == 0: bb[::3, 2:] = bb[::3, :2]                      # zero-area boxes
+            if m and ri(0, 4) == 0: bb[ri(0, m - 1)] = float("nan")
+            if m and ri(0, 4) == 0: bb[ri(0, m - 1), 2:] = bb[ri(0, m - 1), :2] - 3.0
+            bl.append(bb.to(dev))
+        sc = [0.25 / (1 << l) for l in range(L)]; tail = (7, 7, 2, bool(ri(0, 1)), 2, 1 + L, 224.0, 4.0, 1e-6)
+        torch.ops.tvmi.set_option("roi_align.pin_chunks", 1); torch.ops.tvmi.set_option("roi_align.order", 1); torch.ops.tvmi.set_option("roi_align.inline_mop", 1)
+        torch.ops.tvmi.set_option("roi_align.fold_first_round_pct", [0, 50, 100, 200][ri(0, 3)])
+        torch.ops.tvmi.set_option("roi_align.fold_order", 1); fo, fr = torch.ops.tvmi.multiscale_roi_align_boxes(fm, bl, sc, *tail)
+        torch.ops.tvmi.set_option("roi_align.fold_order", 0); uo, ur = torch.ops.tvmi.multiscale_roi_align_boxes(fm, bl, sc, *tail)
+        torch.ops.tvmi.set_option("roi_align.fold_order", 1); torch.ops.tvmi.set_option("roi_align.fold_first_round_pct", 100)
+        if not torch.equal(fr.view(torch.int32), ur.view(torch.int32)):
+            want = torch.cat([torch.cat([torch.full((b_.shape[0], 1), float(i_), device=dev), b_], 1) for i_, b_ in enumerate(bl)])
+            rb = (fr.view(torch.int32) != ur.view(torch.int32)).any(1).nonzero()[:, 0]
+            print("fold rows differ:", rb.numel(), rb[:8].tolist(), "fold-vs-want", int((fr.view(torch.int32) != want.view(torch.int32)).any(1).sum()),
+                  "unfold-vs-want", int((ur.view(torch.int32) != want.view(torch.int32)).any(1).sum()), "fold", fr[int(rb[0])].tolist(), "unfold", ur[int(rb[0])].tolist(),
+                  "want", want[int(rb[0])].tolist(), flush=True)
+        assert torch.equal(fr.view(torch.int32), ur.view(torch.int32)), ("fold rows", cnts)
+        assert torch.equal(fo.view(torch.int32), uo.view(torch.int32)), ("fold out", cnts, L, Hm, Wm)
+        cases += 1
     # ---- RoIPool 7x7 (column kernel): value and argmax bit-exact, ties from rounded values
     C2 = [ri(1, 40), ri(40, 130), ri(250, 300)][ri(0, 2)]
     xp = (torch.randn(N, C2, H, W, generator=g) * 2).round()
@@ -165,6 +196,6 @@ while time.time() - t0 < 60:
             assert min(abs(float(iou[i_, j_]) - o) for o in outs) < 2e-5, ("rotated", n1, n2, spread, float(iou[i_, j_]), sorted(set(round(o, 5) for o in outs)))
         unstable_pairs += len(off)
     cases += 1
-print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, roi_align NCHW + channels_last + backward + generic-shape wave kernels, roi_pool fwd + bwd, "
+print(f"fuzz ok: {cases} random cases (each: nms, 2x batched nms, the folded multi-scale RoIAlign launch against the two-launch form in a third of the cases, roi_align NCHW + channels_last + backward + generic-shape wave kernels, roi_pool fwd + bwd, "
       f"ps_roi_align / ps_roi_pool fwd + bwd, resize fwd / channels_last / bwd in a random mode, rotated IoU); rotated pairs on which the "
       f"reference's own float32 arithmetic is unstable (accepted when equal to a value the reference gives within 2 ulps of the inputs): {unstable_pairs}")

@@ -1266,8 +1266,8 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_ms_dma(MsLevels lv, co
 // below n0 = what the chip holds at once — take the RoIs in input order straight from the box lists; a unit at a later position
 // polls ITS 64-bit entry of the order (written long before the unit is dispatched: the sort takes ~10 us, a unit ~25) with an
 // agent-scope load until the entry carries this launch's epoch, and takes its RoI index from the same word: no flag word, no
-// second dependent load, nothing to reset — epochs come from one host counter and are never reused, so an entry an earlier launch
-// left in the buffer cannot be mistaken for this launch's.  Saves the pre-pass launch and the gap behind it on the critical path
+// second dependent load, nothing to reset — the entries live in a block only these sort workgroups write (FoldBlocks, per stream)
+// and the block's epoch only grows, so an entry an earlier launch left there cannot be mistaken for this launch's.  Saves the pre-pass launch and the gap behind it on the critical path
 // of every detector step for ~1/8 of the units in input order.  Not used under graph capture (the epoch would be frozen into the
 // node and a replay could read the entries of the replay before it): the two-launch form runs there.
 // Only the ORDER of the units depends on any of this — never a result.
@@ -1736,27 +1736,65 @@ int launch_ms_fwd_nhwc(const MsLevels& lv, const void* rois, void* output, int64
   TVMI_RETURN_LAUNCH_STATUS("tvmi_multiscale_roi_align_forward_nhwc");
 }
 
-// Epochs of the folded order pre-pass (FoldArgs): one host counter, never reused (2^31 launches, then from 1 again).  A capturing
-// stream gets none (the epoch would be frozen into the graph node): the caller takes the two-launch form.
-inline bool fold_epoch(hipStream_t s, int* epoch, int* resident_wgs) {
-  static std::mutex mu;
-  static int next = 0, resident = 0;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return false;
+// Order entries of the folded pre-pass (FoldArgs): a block of kOrderMaxFold 64-bit words the LIBRARY owns, one per (device,
+// stream), zeroed once on that stream, and an epoch per block that only grows.  The block is written by nothing but the sort
+// workgroups of launches on that stream — `epoch << 32 | RoI` — and launches of a stream run one after the other, so a word that
+// carries this launch's epoch can only be this launch's entry.  (The first version kept the entries in the CALLER's workspace:
+// recycled memory holds arbitrary bits, and the fuzzer produced a leftover pair of ints whose upper half happened to equal the
+// epoch — one RoI pooled twice, another never.  A tag cannot vouch for memory other writers touch.)  At the wrap of the epoch
+// (2^31 launches) the block is zeroed again.  A capturing stream gets no block (the epoch would be frozen into the graph node):
+// the caller takes the two-launch form.
+struct FoldBlocks {
+  std::mutex mu;
+  struct Block {
+    int dev;
+    hipStream_t stream;
+    unsigned long long* words;
+    int epoch;
+  };
+  std::vector<Block> blocks;
+  int resident = 0;   // workgroups of the 7 x 7 kernels the chip holds at once (4 per CU)
+  bool take(hipStream_t s, unsigned long long** words, int* epoch, int* resident_wgs) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return false;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (resident == 0) {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      resident = 4 * cus;
+    }
+    *resident_wgs = resident;
+    constexpr size_t kBytes = (size_t)kOrderMaxFold * sizeof(unsigned long long);
+    for (auto& b : blocks)
+      if (b.dev == dev && b.stream == s) {
+        if (b.epoch == 0x7fffffff) {
+          if (hipMemsetAsync(b.words, 0, kBytes, s) != hipSuccess) return false;
+          b.epoch = 0;
+        }
+        *words = b.words;
+        *epoch = ++b.epoch;
+        return true;
+      }
+    unsigned long long* p = nullptr;
+    // zeroed ON THE STREAM of the launches that will use it (hipMemset on the null stream may return before the fill has run)
+    if (hipMalloc(reinterpret_cast<void**>(&p), kBytes) != hipSuccess || hipMemsetAsync(p, 0, kBytes, s) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    blocks.push_back(Block{dev, s, p, 1});
+    *words = p;
+    *epoch = 1;
+    return true;
   }
-  std::lock_guard<std::mutex> lock(mu);
-  if (resident == 0) {   // workgroups of the 7 x 7 kernels the chip holds at once (4 per CU)
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    resident = 4 * cus;
-  }
-  next = next == 0x7fffffff ? 1 : next + 1;
-  *epoch = next;
-  *resident_wgs = resident;
-  return true;
+};
+inline FoldBlocks& fold_blocks() {
+  static FoldBlocks* f = new FoldBlocks();   // never destroyed: the runtime may be gone at exit
+  return *f;
 }
 
 template <typename T>
@@ -1773,12 +1811,10 @@ int launch_ms_fwd(const tvmi::MsLevels& lv, const void* rois, void* output, int6
   unsigned front = carried ? (unsigned)((carried->S * carried->gdim_y + 7) & ~7) : 0u;   // workgroups in front of the units
   if (fast_shape && mop && bl && PH == 7 && g_fwd_opt.inline_mop && g_fwd_opt.fold_order && K <= kOrderMaxFold &&
       plan_units_orders(N, lv.n_levels, nchunks, perm)) {
-    // the order pre-pass as a workgroup of the launch: worth it when the sorted part is most of the RoIs.  The 64-bit entries
-    // take the worklist + order parts of the workspace ([4 + K][K] ints, contiguous: the inline form needs no worklist)
+    // the order pre-pass as a workgroup of the launch: worth it when the sorted part is most of the RoIs
     int epoch = 0, resident = 0;
-    unsigned long long* p64 = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(mop) + 7) & ~(uintptr_t)7);
-    const bool room = reinterpret_cast<char*>(p64 + K) <= reinterpret_cast<char*>(perm + K);
-    if (room && fold_epoch(stream, &epoch, &resident)) {
+    unsigned long long* p64 = nullptr;
+    if (fold_blocks().take(stream, &p64, &epoch, &resident)) {
       const int64_t n0 = 4 * (std::max<int64_t>(0, ((int64_t)resident - front - kFoldBlocks) / 8) * g_fwd_opt.fold_pct / 100);   // positions of the first round
       if (2 * n0 <= K) {
         fa.perm64 = p64;
