@@ -656,13 +656,13 @@ __device__ __forceinline__ void unpack_word(unsigned w, float (&v)[4 / (int)size
 // (Measured and removed, round 4: a tap pair as ONE ds_read_b64 at 4-byte alignment — or one 2-byte-aligned ds_read_b32 for
 // the 16-bit types — is correct on gfx950 but 2.6x slower for the whole launch, 0.68 vs 0.26 ms: misaligned LDS reads are
 // replayed; profiles/r04_roi_variants_v1.json.)
-template <typename T, int PHT, int PWT, int SRT, int NRG>
+// `setup(off, fy, fx)`: the per-lane tap set-up of the unit (LDS slots of the tap rows, separable factors).  It runs AFTER the first
+// pass of DMAs has been issued (round 6): in-kernel stamps (profiles/r06_roi_fwd_bound/stamps.patch) put a unit's first DMA 3.4 us
+// after its start and the first pass's latency at 1.2 us — the taps are not needed before the pass has landed.
+template <typename T, int PHT, int PWT, int SRT, int NRG, typename Setup>
 __device__ __forceinline__ void roi_align_dma_passes(DmaShared<PHT>& s, const T* __restrict__ in0, T* __restrict__ out,
                                                      int64_t plane_sz, int cc, int H, int W, const DmaWindow& dw,
-                                                     const RoiGeom<float>& g,
-                                                     const int (&off)[(PHT * PWT + 63) / 64][SRT * SRT][2],
-                                                     const float (&fy)[(PHT * PWT + 63) / 64][SRT][2],
-                                                     const float (&fx)[(PHT * PWT + 63) / 64][SRT][2]) {
+                                                     const RoiGeom<float>& g, Setup&& setup) {
   constexpr int PHW = PHT * PWT;
   constexpr int NB = (PHW + 63) / 64;
   constexpr int NS = SRT * SRT;
@@ -692,6 +692,10 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared<PHT>& s, const T*
     }
     goff[rg] = min(y, H - 1) * W + gx;
   }
+  if (kDouble) dma_issue_pass<T, NRG, kDmaPerPass>(in0, plane_sz, min(G, cc), goff, bytes);
+  int off[NB][NS][2];
+  float fy[NB][SRT][2], fx[NB][SRT][2];
+  setup(off, fy, fx);
   // Output rows are parked in LDS and leave SC channels at a time: the [channel][bin] block of a wave unit is contiguous
   // in the NCHW output, so 8 channels of 7 x 7 bins (1568 B) are two full-width 16-byte store instructions instead of eight
   // 49-lane dword stores — the texture path charges ~20 cycles per wave instruction whatever its width, and the stores were
@@ -792,7 +796,6 @@ __device__ __forceinline__ void roi_align_dma_passes(DmaShared<PHT>& s, const T*
     }
   };
   const int npass = (cc + G - 1) / G;
-  if (kDouble) dma_issue_pass<T, NRG, kDmaPerPass>(in0, plane_sz, min(G, cc), goff, bytes);
   for (int p = 0; p < npass; ++p) {
     const int cg = p * G;
     const int gc = min(G, cc - cg);
@@ -850,9 +853,9 @@ __device__ __forceinline__ bool roi_align_fwd_wave_dma(DmaShared<PHT>& s, const 
     for (int o = lane; o < cc * PHW; o += 64) st(out + o, 0.f);
     return false;
   }
-  // ---- per-lane sample set-up (registers): LDS slots of the two tap rows + separable factors
-  int off[NB][NS][2];
-  float fy[NB][SRT][2], fx[NB][SRT][2];
+  // ---- per-lane sample set-up (registers): LDS slots of the two tap rows + separable factors; run by roi_align_dma_passes
+  // once the first DMAs are on their way
+  auto setup = [&](int (&off)[NB][NS][2], float (&fy)[NB][SRT][2], float (&fx)[NB][SRT][2]) {
   const int rstride = EPP * dw.lpr;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -884,16 +887,17 @@ __device__ __forceinline__ bool roi_align_fwd_wave_dma(DmaShared<PHT>& s, const 
         off[b][iy * SRT + ix][1] = rlo[iy][1] + xlo[ix];
       }
   }
+  };
   if (dw.nrg <= 1)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 1>(s, in0, out, plane_sz, cc, H, W, dw, g, setup);
   else if (dw.nrg <= 2)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2>(s, in0, out, plane_sz, cc, H, W, dw, g, setup);
   else if (dw.nrg <= 3)   // 28 sampled rows of <= 5 pieces: three DMA instructions per channel, not four
-    roi_align_dma_passes<T, PHT, PWT, SRT, 3>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 3>(s, in0, out, plane_sz, cc, H, W, dw, g, setup);
   else if (dw.nrg <= 4)
-    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 4>(s, in0, out, plane_sz, cc, H, W, dw, g, setup);
   else
-    roi_align_dma_passes<T, PHT, PWT, SRT, 2 * dma_per_pass(PHT)>(s, in0, out, plane_sz, cc, H, W, dw, g, off, fy, fx);
+    roi_align_dma_passes<T, PHT, PWT, SRT, 2 * dma_per_pass(PHT)>(s, in0, out, plane_sz, cc, H, W, dw, g, setup);
   return false;
 }
 
