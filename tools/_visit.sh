@@ -1,1 +1,1 @@
-echo "see tools/gpu_round.sh; this file is the scratch script of single GPU visits"
+echo "scratch script of single GPU visits (see tools/gpu_round.sh)"
